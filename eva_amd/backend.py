@@ -1,0 +1,319 @@
+"""ctypes binding of libeva_hip.so (include/eva_hip.h) — the MI355X CKKS evaluation backend.
+
+This is the drop-in for the seal::Evaluator calls of EVA's SEALExecutor
+(/root/reference/eva/seal/seal_executor.h:114-243).  There is no CPU fallback: if the HIP
+library is missing or no device is present, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libeva_hip.so")
+
+KEY_RELIN = 0
+KEY_GALOIS = 1
+
+
+class EvaHipError(RuntimeError):
+    pass
+
+
+_u64p = C.POINTER(C.c_uint64)
+_vp = C.c_void_p
+_vpp = C.POINTER(C.c_void_p)
+
+# name -> (argtypes); every function returns int status unless listed in _VOID / _OTHER
+_SIGS = {
+    "evah_device_count": [C.POINTER(C.c_int)],
+    "evah_ctx_create": [C.c_uint32, C.c_uint32, _u64p, C.c_int, _vpp],
+    "evah_ctx_set_stream": [_vp, _vp],
+    "evah_ctx_sync": [_vp],
+    "evah_ctx_mem_info": [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
+    "evah_key_upload": [_vp, C.c_int, C.c_uint32, C.c_uint32, _u64p],
+    "evah_galois_elt_from_step": [_vp, C.c_int32, C.POINTER(C.c_uint32)],
+    "evah_ct_upload": [_vp, C.c_uint32, C.c_uint32, C.c_double, _u64p, _vpp],
+    "evah_ct_info": [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double)],
+    "evah_ct_download": [_vp, _vp, _u64p],
+    "evah_pt_upload": [_vp, C.c_uint32, C.c_double, _u64p, _vpp],
+    "evah_pt_upload_coeff": [_vp, C.c_uint32, C.c_double, _u64p, _vpp],
+    "evah_pt_uniform": [_vp, C.c_uint32, C.c_double, _u64p, _vpp],
+    "evah_pt_info": [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_double)],
+    "evah_pt_download": [_vp, _vp, _u64p],
+    "evah_add": [_vp, _vp, _vp, _vpp],
+    "evah_sub": [_vp, _vp, _vp, _vpp],
+    "evah_add_plain": [_vp, _vp, _vp, _vpp],
+    "evah_sub_plain": [_vp, _vp, _vp, _vpp],
+    "evah_negate": [_vp, _vp, _vpp],
+    "evah_multiply": [_vp, _vp, _vp, _vpp],
+    "evah_square": [_vp, _vp, _vpp],
+    "evah_multiply_plain": [_vp, _vp, _vp, _vpp],
+    "evah_relinearize": [_vp, _vp, _vpp],
+    "evah_rotate": [_vp, _vp, C.c_int32, _vpp],
+    "evah_rescale": [_vp, _vp, C.c_uint32, _vpp],
+    "evah_mod_switch": [_vp, _vp, _vpp],
+    "evah_test_ntt": [_vp, C.c_uint32, C.c_int, _u64p],
+    "evah_timer_start": [_vp],
+    "evah_timer_stop": [_vp, C.POINTER(C.c_float)],
+}
+_VOID = {
+    "evah_ctx_destroy": [_vp],
+    "evah_ct_free": [_vp, _vp],
+    "evah_pt_free": [_vp, _vp],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGS) + list(_VOID) + ["evah_last_error", "evah_abi_version"])
+
+_lib = None
+
+
+def load():
+    """Load libeva_hip.so (once).  Raises EvaHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EvaHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the MI355X backend has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    for name, args in _VOID.items():
+        fn = getattr(lib, name)
+        fn.restype = None
+        fn.argtypes = args
+    lib.evah_last_error.restype = C.c_char_p
+    lib.evah_last_error.argtypes = []
+    lib.evah_abi_version.restype = C.c_int
+    lib.evah_abi_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise EvaHipError(_lib.evah_last_error().decode())
+
+
+def _p(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_u64p)
+
+
+def device_count():
+    lib = load()
+    n = C.c_int(0)
+    _chk(lib.evah_device_count(C.byref(n)))
+    return n.value
+
+
+class Ciphertext:
+    """Device-resident ciphertext handle (evah_ct)."""
+
+    __slots__ = ("ctx", "h")
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def info(self):
+        s, l, sc = C.c_uint32(), C.c_uint32(), C.c_double()
+        _chk(_lib.evah_ct_info(self.h, C.byref(s), C.byref(l), C.byref(sc)))
+        return s.value, l.value, sc.value
+
+    size = property(lambda self: self.info()[0])
+    limbs = property(lambda self: self.info()[1])
+    scale = property(lambda self: self.info()[2])
+
+    def download(self):
+        s, l, _ = self.info()
+        out = np.empty((s, l, self.ctx.N), dtype=np.uint64)
+        _chk(_lib.evah_ct_download(self.ctx.h, self.h, _p(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            _lib.evah_ct_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.free()
+        except Exception:
+            pass
+
+
+class Plaintext:
+    """Device-resident plaintext handle (evah_pt)."""
+
+    __slots__ = ("ctx", "h")
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def info(self):
+        l, sc = C.c_uint32(), C.c_double()
+        _chk(_lib.evah_pt_info(self.h, C.byref(l), C.byref(sc)))
+        return l.value, sc.value
+
+    limbs = property(lambda self: self.info()[0])
+    scale = property(lambda self: self.info()[1])
+
+    def download(self):
+        l, _ = self.info()
+        out = np.empty((l, self.ctx.N), dtype=np.uint64)
+        _chk(_lib.evah_pt_download(self.ctx.h, self.h, _p(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            _lib.evah_pt_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """evah_ctx: N, key-level prime chain (special prime last), tables and keys on one GPU."""
+
+    def __init__(self, N, primes, device=0):
+        load()
+        self.N = int(N)
+        self.primes = [int(p) for p in primes]
+        self.k = len(self.primes)
+        arr = np.array(self.primes, dtype=np.uint64)
+        h = C.c_void_p()
+        self.h = None
+        _chk(_lib.evah_ctx_create(self.N, self.k, _p(arr), int(device), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            _lib.evah_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing
+    def set_stream(self, stream_ptr):
+        _chk(_lib.evah_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def sync(self):
+        _chk(_lib.evah_ctx_sync(self.h))
+
+    def mem_info(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        _chk(_lib.evah_ctx_mem_info(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def timer_start(self):
+        _chk(_lib.evah_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _chk(_lib.evah_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- keys and values
+    def upload_relin_key(self, key):
+        key = np.ascontiguousarray(key, dtype=np.uint64)
+        assert key.shape[1:] == (2, self.k, self.N)
+        _chk(_lib.evah_key_upload(self.h, KEY_RELIN, 0, key.shape[0], _p(key)))
+
+    def upload_galois_key(self, elt, key):
+        key = np.ascontiguousarray(key, dtype=np.uint64)
+        assert key.shape[1:] == (2, self.k, self.N)
+        _chk(_lib.evah_key_upload(self.h, KEY_GALOIS, int(elt), key.shape[0], _p(key)))
+
+    def galois_elt_from_step(self, steps):
+        e = C.c_uint32()
+        _chk(_lib.evah_galois_elt_from_step(self.h, int(steps), C.byref(e)))
+        return e.value
+
+    def upload_ct(self, data, scale):
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        size, limbs, n = data.shape
+        assert n == self.N
+        h = C.c_void_p()
+        _chk(_lib.evah_ct_upload(self.h, size, limbs, float(scale), _p(data), C.byref(h)))
+        return Ciphertext(self, h)
+
+    def upload_pt(self, data, scale, coeff_form=False):
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        limbs, n = data.shape
+        assert n == self.N
+        h = C.c_void_p()
+        fn = _lib.evah_pt_upload_coeff if coeff_form else _lib.evah_pt_upload
+        _chk(fn(self.h, limbs, float(scale), _p(data), C.byref(h)))
+        return Plaintext(self, h)
+
+    def uniform_pt(self, values, scale):
+        values = np.ascontiguousarray(values, dtype=np.uint64)
+        h = C.c_void_p()
+        _chk(_lib.evah_pt_uniform(self.h, values.shape[0], float(scale), _p(values), C.byref(h)))
+        return Plaintext(self, h)
+
+    # ---- evaluator (one method per SEAL call in SEALExecutor)
+    def _ct2(self, fn, a, b):
+        h = C.c_void_p()
+        _chk(fn(self.h, a.h, b.h, C.byref(h)))
+        return Ciphertext(self, h)
+
+    def _ct1(self, fn, a, *extra):
+        h = C.c_void_p()
+        _chk(fn(self.h, a.h, *extra, C.byref(h)))
+        return Ciphertext(self, h)
+
+    def add(self, a, b):
+        return self._ct2(_lib.evah_add, a, b)
+
+    def sub(self, a, b):
+        return self._ct2(_lib.evah_sub, a, b)
+
+    def add_plain(self, a, pt):
+        return self._ct2(_lib.evah_add_plain, a, pt)
+
+    def sub_plain(self, a, pt):
+        return self._ct2(_lib.evah_sub_plain, a, pt)
+
+    def multiply(self, a, b):
+        return self._ct2(_lib.evah_multiply, a, b)
+
+    def multiply_plain(self, a, pt):
+        return self._ct2(_lib.evah_multiply_plain, a, pt)
+
+    def negate(self, a):
+        return self._ct1(_lib.evah_negate, a)
+
+    def square(self, a):
+        return self._ct1(_lib.evah_square, a)
+
+    def relinearize(self, a):
+        return self._ct1(_lib.evah_relinearize, a)
+
+    def rotate(self, a, steps):
+        return self._ct1(_lib.evah_rotate, a, C.c_int32(int(steps)))
+
+    def rescale(self, a, divisor_bits):
+        return self._ct1(_lib.evah_rescale, a, C.c_uint32(int(divisor_bits)))
+
+    def mod_switch(self, a):
+        return self._ct1(_lib.evah_mod_switch, a)
+
+    # ---- test hook
+    def test_ntt(self, prime_idx, x, inverse=False):
+        y = np.ascontiguousarray(x, dtype=np.uint64).copy()
+        _chk(_lib.evah_test_ntt(self.h, int(prime_idx), 1 if inverse else 0, _p(y)))
+        return y

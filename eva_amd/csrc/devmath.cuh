@@ -1,0 +1,92 @@
+// devmath.cuh — 64-bit modular arithmetic for gfx950 (CDNA4).
+//
+// All ciphertext data are residues < q < 2^61.  CDNA4 has no 64x64->128 multiply; every
+// product below lowers to v_mad_u64_u32 / v_mul_hi_u32 chains, so the instruction budget is
+// counted in 32-bit multiplies: Shoup mulmod = 10, lazy 128-bit MAC term = 4, Barrett-128 = 18.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace evah {
+
+typedef unsigned long long u64;
+
+struct u128_t {
+  u64 lo, hi;
+};
+
+// Per-prime constants, device resident (one 64-byte record per RNS prime).
+struct DevPrime {
+  u64 q;        // modulus
+  u64 brt;      // floor(2^64 / q)            (64-bit Barrett)
+  u64 r0, r1;   // floor(2^128 / q) lo, hi    (128-bit Barrett)
+  u64 ninv;     // N^-1 mod q
+  u64 ninv_s;   // Shoup quotient of ninv
+  u64 w0ninv;   // irp[1] * N^-1 mod q  (last inverse stage twiddle with the scaling folded in)
+  u64 w0ninv_s;
+};
+
+// Device-side view of a context (passed by value to kernels).
+struct DevCtx {
+  const DevPrime *primes;      // [k]
+  const ulonglong2 *tw_fwd;    // [k][N]  (w, floor(w*2^64/q)), heap order: stage m group i -> [m+i]
+  const ulonglong2 *tw_inv;    // [k][N]  inverses, same indexing
+  const ulonglong2 *invq;      // [k][k]  invq[a*k+b] = (q_a^-1 mod q_b, Shoup quotient)
+  const u64 *halfmod;          // [k][k]  (q_a >> 1) mod q_b
+  uint32_t N, logN, k;
+};
+
+__device__ __forceinline__ u128_t mul128(u64 a, u64 b) {
+  u128_t r;
+  r.lo = a * b;
+  r.hi = __umul64hi(a, b);
+  return r;
+}
+__device__ __forceinline__ void acc128(u128_t &acc, u64 a, u64 b) {
+  u64 lo = a * b, hi = __umul64hi(a, b);
+  u64 s = acc.lo + lo;
+  acc.hi += hi + (s < lo);
+  acc.lo = s;
+}
+
+__device__ __forceinline__ u64 addmod(u64 a, u64 b, u64 q) {
+  u64 s = a + b;
+  return s >= q ? s - q : s;
+}
+__device__ __forceinline__ u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+__device__ __forceinline__ u64 negmod(u64 a, u64 q) { return a ? q - a : 0; }
+
+// x*w mod q in [0, 2q), any 64-bit x, ws = floor(w*2^64/q)   (Shoup / Harvey)
+__device__ __forceinline__ u64 mul_shoup_lazy(u64 x, u64 w, u64 ws, u64 q) {
+  return x * w - __umul64hi(x, ws) * q;
+}
+__device__ __forceinline__ u64 mul_shoup(u64 x, u64 w, u64 ws, u64 q) {
+  u64 r = mul_shoup_lazy(x, w, ws, q);
+  return r >= q ? r - q : r;
+}
+
+// x mod q for any 64-bit x; brt = floor(2^64/q)
+__device__ __forceinline__ u64 barrett64(u64 x, u64 q, u64 brt) {
+  u64 r = x - __umul64hi(x, brt) * q;
+  return r >= q ? r - q : r;
+}
+
+// (hi:lo) mod q for any 128-bit input, q < 2^62; (r1:r0) = floor(2^128/q)
+__device__ __forceinline__ u64 barrett128(u128_t x, const DevPrime &m) {
+  u64 carry = __umul64hi(x.lo, m.r0);
+  u64 t_lo = x.lo * m.r1, t_hi = __umul64hi(x.lo, m.r1);
+  u64 tmp1 = t_lo + carry;
+  u64 tmp3 = t_hi + (tmp1 < carry);
+  u64 s_lo = x.hi * m.r0, s_hi = __umul64hi(x.hi, m.r0);
+  u64 tmp1b = tmp1 + s_lo;
+  carry = s_hi + (tmp1b < tmp1);
+  u64 qhat = x.hi * m.r1 + tmp3 + carry;
+  u64 r = x.lo - qhat * m.q;
+  r = r >= m.q ? r - m.q : r;
+  return r >= m.q ? r - m.q : r;
+}
+__device__ __forceinline__ u64 mulmod(u64 a, u64 b, const DevPrime &m) {
+  return barrett128(mul128(a, b), m);
+}
+
+}  // namespace evah

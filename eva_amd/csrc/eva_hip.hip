@@ -1,0 +1,893 @@
+// eva_hip.hip — libeva_hip.so: C-ABI + HIP kernels of the MI355X CKKS evaluation backend.
+//
+// Replaces, for EVA's execute() hot path, every seal::Evaluator call made by
+// SEALExecutor::operator() (/root/reference/eva/seal/seal_executor.h:279-404) — see
+// include/eva_hip.h for the per-entry-point mapping.  gfx950 only; no CPU fallback: every entry
+// point needs a HIP device and fails with an error otherwise.
+#include "../../include/eva_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "hostmath.h"
+#include "ntt.cuh"
+
+namespace evah {
+
+static thread_local std::string g_err;
+
+#define HIPCHK(x)                                                                                \
+  do {                                                                                           \
+    hipError_t e_ = (x);                                                                         \
+    if (e_ != hipSuccess)                                                                        \
+      throw std::runtime_error(std::string(#x) + " failed: " + hipGetErrorString(e_));          \
+  } while (0)
+
+// ------------------------------------------------------------------------------- kernels
+
+// 2 coefficients per thread (16-byte accesses); grid = (N/512, limbs, polys)
+#define EW_SETUP                                                                                 \
+  const uint32_t p = blockIdx.z, i = blockIdx.y;                                                 \
+  const size_t off = (size_t)i * cx.N + 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);    \
+  const DevPrime pm = cx.primes[i];                                                              \
+  (void)p;
+
+__device__ __forceinline__ ulonglong2 ld2(const u64 *p) { return *reinterpret_cast<const ulonglong2 *>(p); }
+__device__ __forceinline__ void st2(u64 *p, ulonglong2 v) { *reinterpret_cast<ulonglong2 *>(p) = v; }
+
+// K1/K2: add / sub / add_plain / sub_plain.  Common polys combined, extra
+// polys of the longer operand copied (or negated when it is the subtrahend).
+__global__ void __launch_bounds__(256)
+k_addsub(DevCtx cx, const u64 *a, size_t a_ps, uint32_t sa, const u64 *b, size_t b_ps, uint32_t sb,
+         u64 *out, size_t o_ps, int sub) {
+  EW_SETUP
+  ulonglong2 r;
+  if (p < sa && p < sb) {
+    ulonglong2 x = ld2(a + p * a_ps + off), y = ld2(b + p * b_ps + off);
+    r.x = sub ? submod(x.x, y.x, pm.q) : addmod(x.x, y.x, pm.q);
+    r.y = sub ? submod(x.y, y.y, pm.q) : addmod(x.y, y.y, pm.q);
+  } else if (p < sa) {
+    r = ld2(a + p * a_ps + off);
+  } else {
+    r = ld2(b + p * b_ps + off);
+    if (sub) { r.x = negmod(r.x, pm.q); r.y = negmod(r.y, pm.q); }
+  }
+  st2(out + p * o_ps + off, r);
+}
+
+// K3: negate
+__global__ void __launch_bounds__(256)
+k_negate(DevCtx cx, const u64 *a, size_t a_ps, u64 *out, size_t o_ps) {
+  EW_SETUP
+  ulonglong2 r = ld2(a + p * a_ps + off);
+  r.x = negmod(r.x, pm.q);
+  r.y = negmod(r.y, pm.q);
+  st2(out + p * o_ps + off, r);
+}
+
+// K4: multiply 2x2 -> 3: (a0b0, a0b1 + a1b0, a1b1); grid.z = 1
+__global__ void __launch_bounds__(256)
+k_mul22(DevCtx cx, const u64 *a, size_t a_ps, const u64 *b, size_t b_ps, u64 *out, size_t o_ps) {
+  EW_SETUP
+  ulonglong2 a0 = ld2(a + off), a1 = ld2(a + a_ps + off);
+  ulonglong2 b0 = ld2(b + off), b1 = ld2(b + b_ps + off);
+  ulonglong2 d0, d1, d2;
+  d0.x = mulmod(a0.x, b0.x, pm);
+  d0.y = mulmod(a0.y, b0.y, pm);
+  d2.x = mulmod(a1.x, b1.x, pm);
+  d2.y = mulmod(a1.y, b1.y, pm);
+  u128_t t = mul128(a0.x, b1.x);
+  acc128(t, a1.x, b0.x);
+  d1.x = barrett128(t, pm);
+  t = mul128(a0.y, b1.y);
+  acc128(t, a1.y, b0.y);
+  d1.y = barrett128(t, pm);
+  st2(out + off, d0);
+  st2(out + o_ps + off, d1);
+  st2(out + 2 * o_ps + off, d2);
+}
+
+// K5: square 2 -> 3: (a0^2, 2 a0 a1, a1^2)
+__global__ void __launch_bounds__(256)
+k_square(DevCtx cx, const u64 *a, size_t a_ps, u64 *out, size_t o_ps) {
+  EW_SETUP
+  ulonglong2 a0 = ld2(a + off), a1 = ld2(a + a_ps + off);
+  ulonglong2 d0, d1, d2;
+  d0.x = mulmod(a0.x, a0.x, pm);
+  d0.y = mulmod(a0.y, a0.y, pm);
+  d2.x = mulmod(a1.x, a1.x, pm);
+  d2.y = mulmod(a1.y, a1.y, pm);
+  u64 x = mulmod(a0.x, a1.x, pm), y = mulmod(a0.y, a1.y, pm);
+  d1.x = addmod(x, x, pm.q);
+  d1.y = addmod(y, y, pm.q);
+  st2(out + off, d0);
+  st2(out + o_ps + off, d1);
+  st2(out + 2 * o_ps + off, d2);
+}
+
+// K6: multiply_plain, every poly x pt
+__global__ void __launch_bounds__(256)
+k_mul_plain(DevCtx cx, const u64 *a, size_t a_ps, const u64 *pt, u64 *out, size_t o_ps) {
+  EW_SETUP
+  ulonglong2 x = ld2(a + p * a_ps + off), y = ld2(pt + off), r;
+  r.x = mulmod(x.x, y.x, pm);
+  r.y = mulmod(x.y, y.y, pm);
+  st2(out + p * o_ps + off, r);
+}
+
+// K8: NTT-domain Galois automorphism out[p][i][n] = in[p][i][perm[n]]
+__global__ void __launch_bounds__(256)
+k_galois_perm(DevCtx cx, const u64 *a, size_t a_ps, const uint32_t *perm, u64 *out, size_t o_ps) {
+  EW_SETUP
+  const uint32_t n = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+  const uint2 pi = *reinterpret_cast<const uint2 *>(perm + n);
+  const u64 *src = a + p * a_ps + (size_t)i * cx.N;
+  ulonglong2 r;
+  r.x = src[pi.x];
+  r.y = src[pi.y];
+  st2(out + p * o_ps + off, r);
+}
+
+// per-limb constant fill (uniform-constant plaintexts)
+__global__ void __launch_bounds__(256) k_fill_limbs(DevCtx cx, const u64 *vals, u64 *out) {
+  EW_SETUP
+  ulonglong2 r;
+  r.x = r.y = vals[i];
+  st2(out + off, r);
+}
+
+// K9 inner product: prod[K][I] = sum_J op(I,J) * key[J][K][kappa(I)],
+// op(I,J) = target[J] when I == J, else scratch[I][J].  128-bit lazy accumulation, one Barrett
+// reduction at the end.  grid = (N/512, l+1).
+__global__ void __launch_bounds__(256)
+k_ks_mac(DevCtx cx, const u64 *target, const u64 *scratch, const u64 *key, u64 *prod, uint32_t l) {
+  const uint32_t I = blockIdx.y;
+  const uint32_t kap = (I == l) ? cx.k - 1 : I;
+  const size_t n = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
+  const DevPrime pm = cx.primes[kap];
+  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
+  u128_t a0x = {0, 0}, a0y = {0, 0}, a1x = {0, 0}, a1y = {0, 0};
+  for (uint32_t J = 0; J < l; J++) {
+    const u64 *op = (I == J) ? target + (size_t)J * N : scratch + ((size_t)I * l + J) * N;
+    const ulonglong2 o = ld2(op + n);
+    const u64 *kp = key + J * key_digit + (size_t)kap * N + n;
+    const ulonglong2 k0 = ld2(kp), k1 = ld2(kp + (size_t)cx.k * N);
+    acc128(a0x, o.x, k0.x);
+    acc128(a0y, o.y, k0.y);
+    acc128(a1x, o.x, k1.x);
+    acc128(a1y, o.y, k1.y);
+  }
+  ulonglong2 r0, r1;
+  r0.x = barrett128(a0x, pm);
+  r0.y = barrett128(a0y, pm);
+  r1.x = barrett128(a1x, pm);
+  r1.y = barrett128(a1y, pm);
+  st2(prod + (size_t)I * N + n, r0);
+  st2(prod + ((size_t)(l + 1) + I) * N + n, r1);
+}
+
+// ------------------------------------------------------------------------------- host state
+
+struct Pool {
+  std::map<size_t, std::vector<void *>> free_;
+  size_t in_use = 0, cached = 0;
+  void *alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = free_.find(bytes);
+    void *p = nullptr;
+    if (it != free_.end() && !it->second.empty()) {
+      p = it->second.back();
+      it->second.pop_back();
+      cached -= bytes;
+    } else {
+      hipError_t e = hipMalloc(&p, bytes);
+      if (e != hipSuccess) {
+        release_cached();
+        HIPCHK(hipMalloc(&p, bytes));
+      }
+    }
+    in_use += bytes;
+    return p;
+  }
+  void free(void *p, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    free_[bytes].push_back(p);
+    in_use -= bytes;
+    cached += bytes;
+  }
+  void release_cached() {
+    for (auto &kv : free_)
+      for (void *p : kv.second) (void)hipFree(p);
+    free_.clear();
+    cached = 0;
+  }
+};
+
+struct Buffer {
+  u64 *d;
+  size_t bytes;
+  int refs;
+};
+
+struct KeyDev {
+  u64 *d = nullptr;
+  uint32_t n_digits = 0;
+  size_t bytes = 0;
+};
+
+} // namespace evah
+
+using namespace evah;
+
+struct evah_ct {
+  Buffer *buf;
+  u64 *d;
+  uint32_t size, limbs;
+  size_t ps; // poly stride in elements
+  double scale;
+};
+struct evah_pt {
+  Buffer *buf;
+  u64 *d;
+  uint32_t limbs;
+  double scale;
+};
+
+struct evah_ctx {
+  int device = 0;
+  uint32_t N = 0, logN = 0, k = 0;
+  std::vector<u64> primes;
+  std::vector<int> total_bits; // total_bits[l] = bit length of prod primes[0..l)
+  DevCtx dev{};
+  void *d_tables = nullptr;
+  hipStream_t own = nullptr, stream = nullptr;
+  Pool pool;
+  KeyDev relin;
+  std::map<uint32_t, KeyDev> galois;
+  std::map<uint32_t, uint32_t *> perms;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace evah {
+
+static void use(evah_ctx *c) { HIPCHK(hipSetDevice(c->device)); }
+
+static Buffer *buf_new(evah_ctx *c, size_t elems) {
+  Buffer *b = new Buffer;
+  b->bytes = elems * sizeof(u64);
+  b->d = (u64 *)c->pool.alloc(b->bytes);
+  b->refs = 1;
+  return b;
+}
+static void buf_unref(evah_ctx *c, Buffer *b) {
+  if (b && --b->refs == 0) {
+    c->pool.free(b->d, b->bytes);
+    delete b;
+  }
+}
+static evah_ct *ct_new(evah_ctx *c, uint32_t size, uint32_t limbs, double scale) {
+  evah_ct *t = new evah_ct;
+  t->buf = buf_new(c, (size_t)size * limbs * c->N);
+  t->d = t->buf->d;
+  t->size = size;
+  t->limbs = limbs;
+  t->ps = (size_t)limbs * c->N;
+  t->scale = scale;
+  return t;
+}
+static evah_pt *pt_new(evah_ctx *c, uint32_t limbs, double scale) {
+  evah_pt *t = new evah_pt;
+  t->buf = buf_new(c, (size_t)limbs * c->N);
+  t->d = t->buf->d;
+  t->limbs = limbs;
+  t->scale = scale;
+  return t;
+}
+
+struct Scratch { // pool-backed temporary, returned on scope exit (stream-ordered reuse)
+  evah_ctx *c;
+  u64 *d;
+  size_t bytes;
+  Scratch(evah_ctx *c_, size_t elems) : c(c_), bytes(elems * sizeof(u64)) {
+    d = (u64 *)c->pool.alloc(bytes);
+  }
+  ~Scratch() { c->pool.free(d, bytes); }
+};
+
+static dim3 ew_grid(evah_ctx *c, uint32_t limbs, uint32_t polys) {
+  return dim3(c->N / 512, limbs, polys);
+}
+
+// ---- NTT launch plumbing
+template <int P, bool STRIDED, bool INVERSE, class Op>
+static void launch_pass(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  const uint32_t tile = c->N < (uint32_t)NTT_TILE ? c->N : (uint32_t)NTT_TILE;
+  const int logC = (int)ilog2(tile) - P;
+  const size_t lds = ((size_t)1 << logC) * lds_sub_stride<P>() * sizeof(u64);
+  dim3 grid(c->N / tile, jobs), block(tile / NTT_R);
+  hipLaunchKernelGGL((ntt_pass_kernel<P, STRIDED, INVERSE, Op>), grid, block, lds, c->stream, c->dev,
+                     prm, logC);
+  HIPCHK(hipGetLastError());
+}
+
+template <bool STRIDED, bool INVERSE, class Op>
+static void launch_pass_p(evah_ctx *c, int P, const typename Op::Params &prm, uint32_t jobs) {
+  switch (P) {
+  case 5: launch_pass<5, STRIDED, INVERSE, Op>(c, prm, jobs); break;
+  case 6: launch_pass<6, STRIDED, INVERSE, Op>(c, prm, jobs); break;
+  case 7: launch_pass<7, STRIDED, INVERSE, Op>(c, prm, jobs); break;
+  case 8: launch_pass<8, STRIDED, INVERSE, Op>(c, prm, jobs); break;
+  case 9:
+    if constexpr (STRIDED) { launch_pass<9, STRIDED, INVERSE, Op>(c, prm, jobs); break; }
+    [[fallthrough]];
+  default: throw std::runtime_error("unsupported poly_modulus_degree for the NTT kernels");
+  }
+}
+
+template <class Op> static void ntt_forward(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  const int a = (c->logN + 1) / 2, b = c->logN / 2;
+  launch_pass_p<true, false, Op>(c, a, prm, jobs);
+  launch_pass_p<false, false, Op>(c, b, prm, jobs);
+}
+template <class Op> static void ntt_inverse(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  const int a = (c->logN + 1) / 2, b = c->logN / 2;
+  launch_pass_p<false, true, Op>(c, b, prm, jobs);
+  launch_pass_p<true, true, Op>(c, a, prm, jobs);
+}
+
+// SEAL Evaluator::switch_key_inplace, device version.
+//   out[K] = (add && K < add_polys ? add[K] : 0) + keyswitch(target)[K],  K in {0,1}
+static void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev &key, const u64 *add,
+                       size_t add_ps, uint32_t add_polys, u64 *out, size_t out_ps) {
+  const size_t N = c->N;
+  if (key.n_digits < l) throw std::runtime_error("key switching key has too few digits");
+  Scratch t(c, (size_t)l * N);                 // coefficient-form digits
+  Scratch sc(c, (size_t)(l + 1) * l * N);      // converted digits, NTT form per output limb
+  Scratch prod(c, (size_t)2 * (l + 1) * N);    // [K][l+1][N]
+  // 1. digits to coefficient form
+  OpPlain::Params ip{target, t.d, 0, 0, l, 0, 0};
+  ntt_inverse<OpPlain>(c, ip, l);
+  // 2a. base-convert + NTT every digit under every output prime
+  OpKsDigit::Params dp{t.d, sc.d, l};
+  ntt_forward<OpKsDigit>(c, dp, (l + 1) * l);
+  // 2b. inner product with the key
+  hipLaunchKernelGGL(k_ks_mac, dim3(c->N / 512, l + 1), dim3(256), 0, c->stream, c->dev, target, sc.d,
+                     key.d, prod.d, l);
+  HIPCHK(hipGetLastError());
+  // 3. mod-down by the special prime: INTT(special limb) + P/2, then per-limb NTT + combine
+  Scratch r(c, 2 * N);
+  OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1};
+  ntt_inverse<OpPlain>(c, sp, 2);
+  OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, add, add_ps, add_polys, out, out_ps,
+                       c->k - 1, l};
+  ntt_forward<OpModDown>(c, mp, 2 * l);
+}
+
+static int bitlen_of_product(const std::vector<u64> &primes, uint32_t count) {
+  std::vector<u64> w{1};
+  for (uint32_t i = 0; i < count; i++) {
+    u64 carry = 0;
+    for (auto &x : w) {
+      u128 t = (u128)x * primes[i] + carry;
+      x = (u64)t;
+      carry = (u64)(t >> 64);
+    }
+    if (carry) w.push_back(carry);
+  }
+  int bits = (int)(w.size() - 1) * 64;
+  u64 top = w.back();
+  while (top) { bits++; top >>= 1; }
+  return bits;
+}
+
+static void check_scale(evah_ctx *c, double scale, uint32_t limbs) {
+  // SEAL is_scale_within_bounds: 0 < scale, log2(scale) < total coeff modulus bits at the level
+  if (!(scale > 0) || (int)std::log2(scale) >= c->total_bits[limbs])
+    throw std::invalid_argument("scale out of bounds");
+}
+static bool same_scale(double a, double b) {
+  // SEAL util::are_close<double>
+  double scale_factor = std::max({std::fabs(a), std::fabs(b), 1.0});
+  return std::fabs(a - b) < 2.220446049250313e-16 * scale_factor;
+}
+
+} // namespace evah
+
+// ------------------------------------------------------------------------------- C-ABI
+
+#define API_BEGIN try {
+#define API_END                                                                                  \
+  g_err.clear();                                                                                 \
+  return 0;                                                                                      \
+  }                                                                                              \
+  catch (const std::exception &e) {                                                              \
+    g_err = e.what();                                                                            \
+    return 1;                                                                                    \
+  }                                                                                              \
+  catch (...) {                                                                                  \
+    g_err = "unknown error";                                                                     \
+    return 1;                                                                                    \
+  }
+
+extern "C" {
+
+const char *evah_last_error(void) { return g_err.c_str(); }
+int evah_abi_version(void) { return 1; }
+
+int evah_device_count(int *count) {
+  API_BEGIN
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  API_END
+}
+
+int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, evah_ctx **out) {
+  API_BEGIN
+  if (N < 1024 || N > 131072 || (N & (N - 1))) throw std::invalid_argument("poly_modulus_degree must be a power of two in [1024, 131072]");
+  if (k < 2 || k > 62) throw std::invalid_argument("need at least one data prime and one special prime");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    throw std::runtime_error("libeva_hip: no HIP device available (this backend has no CPU fallback)");
+  if (device < 0 || device >= ndev) throw std::invalid_argument("invalid device index");
+  auto *c = new evah_ctx;
+  try {
+    c->device = device;
+    c->N = N;
+    c->logN = ilog2(N);
+    c->k = k;
+    c->primes.assign(primes, primes + k);
+    for (u64 q : c->primes)
+      if (q >= ((u64)1 << 61) || (q - 1) % (2ull * N) || !is_prime(q))
+        throw std::invalid_argument("coeff modulus primes must be < 2^61, prime and 1 mod 2N");
+    for (uint32_t l = 0; l <= k; l++) c->total_bits.push_back(l ? bitlen_of_product(c->primes, l) : 0);
+    use(c);
+    HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
+    c->stream = c->own;
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    // ---- tables: [primes k][tw_fwd k*N][tw_inv k*N][invq k*k][halfmod k*k]
+    const size_t sz_pr = sizeof(DevPrime) * k, sz_tw = sizeof(ulonglong2) * (size_t)k * N,
+                 sz_iq = sizeof(ulonglong2) * (size_t)k * k, sz_hm = sizeof(u64) * (size_t)k * k;
+    const size_t total = sz_pr + 2 * sz_tw + sz_iq + sz_hm;
+    std::vector<unsigned char> host(total);
+    auto *hp = reinterpret_cast<DevPrime *>(host.data());
+    auto *hf = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr);
+    auto *hi = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr + sz_tw);
+    auto *hq = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr + 2 * sz_tw);
+    auto *hh = reinterpret_cast<u64 *>(host.data() + sz_pr + 2 * sz_tw + sz_iq);
+    for (uint32_t i = 0; i < k; i++) {
+      const u64 q = c->primes[i];
+      const u64 psi = minimal_primitive_root(N, q), psi_inv = invmod(psi, q);
+      std::vector<u64> rp = root_power_table(N, q, psi), irp = root_power_table(N, q, psi_inv);
+      for (uint32_t j = 0; j < N; j++) {
+        hf[(size_t)i * N + j] = make_ulonglong2(rp[j], shoup(rp[j], q));
+        hi[(size_t)i * N + j] = make_ulonglong2(irp[j], shoup(irp[j], q));
+      }
+      DevPrime &d = hp[i];
+      d.q = q;
+      d.brt = (u64)((((u128)1) << 64) / q);
+      u128 ratio = (~(u128)0) / q;
+      d.r0 = (u64)ratio;
+      d.r1 = (u64)(ratio >> 64);
+      d.ninv = invmod(N % q, q);
+      d.ninv_s = shoup(d.ninv, q);
+      d.w0ninv = mulmod(irp[1], d.ninv, q);
+      d.w0ninv_s = shoup(d.w0ninv, q);
+      for (uint32_t a = 0; a < k; a++) {
+        const u64 qa = c->primes[a];
+        if (a == i) {
+          hq[a * k + i] = make_ulonglong2(0, 0);
+          hh[a * k + i] = 0;
+        } else {
+          u64 inv = invmod(qa % q, q);
+          hq[a * k + i] = make_ulonglong2(inv, shoup(inv, q));
+          hh[a * k + i] = (qa >> 1) % q;
+        }
+      }
+    }
+    HIPCHK(hipMalloc(&c->d_tables, total));
+    HIPCHK(hipMemcpy(c->d_tables, host.data(), total, hipMemcpyHostToDevice));
+    auto *base = reinterpret_cast<unsigned char *>(c->d_tables);
+    c->dev.primes = reinterpret_cast<const DevPrime *>(base);
+    c->dev.tw_fwd = reinterpret_cast<const ulonglong2 *>(base + sz_pr);
+    c->dev.tw_inv = reinterpret_cast<const ulonglong2 *>(base + sz_pr + sz_tw);
+    c->dev.invq = reinterpret_cast<const ulonglong2 *>(base + sz_pr + 2 * sz_tw);
+    c->dev.halfmod = reinterpret_cast<const u64 *>(base + sz_pr + 2 * sz_tw + sz_iq);
+    c->dev.N = N;
+    c->dev.logN = c->logN;
+    c->dev.k = k;
+  } catch (...) {
+    evah_ctx_destroy(c);
+    throw;
+  }
+  *out = c;
+  API_END
+}
+
+void evah_ctx_destroy(evah_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->relin.d) (void)hipFree(c->relin.d);
+  for (auto &kv : c->galois) (void)hipFree(kv.second.d);
+  for (auto &kv : c->perms) (void)hipFree(kv.second);
+  c->pool.release_cached();
+  if (c->d_tables) (void)hipFree(c->d_tables);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own) (void)hipStreamDestroy(c->own);
+  delete c;
+}
+
+int evah_ctx_set_stream(evah_ctx *c, void *s) {
+  API_BEGIN
+  use(c);
+  HIPCHK(hipStreamSynchronize(c->stream)); // pool reuse is ordered per stream
+  c->stream = s ? (hipStream_t)s : c->own;
+  API_END
+}
+
+int evah_ctx_sync(evah_ctx *c) {
+  API_BEGIN
+  use(c);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  API_END
+}
+
+int evah_ctx_mem_info(evah_ctx *c, size_t *in_use, size_t *cached) {
+  API_BEGIN
+  *in_use = c->pool.in_use;
+  *cached = c->pool.cached;
+  API_END
+}
+
+int evah_galois_elt_from_step(evah_ctx *c, int32_t steps, uint32_t *elt) {
+  API_BEGIN
+  const uint32_t N = c->N, m = 2 * N;
+  if (steps == 0) {
+    *elt = m - 1;
+  } else {
+    uint32_t pos = steps < 0 ? (uint32_t)(-(int64_t)steps) : (uint32_t)steps;
+    if (pos >= (N >> 1)) throw std::invalid_argument("step count too large");
+    uint32_t s = steps < 0 ? (N >> 1) - pos : pos, e = 1;
+    for (uint32_t i = 0; i < s; i++) e = (e * 3u) & (m - 1);
+    *elt = e;
+  }
+  API_END
+}
+
+int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digits, const uint64_t *data) {
+  API_BEGIN
+  use(c);
+  if (n_digits == 0 || n_digits > c->k - 1) throw std::invalid_argument("invalid key digit count");
+  KeyDev kd;
+  kd.n_digits = n_digits;
+  kd.bytes = sizeof(u64) * (size_t)n_digits * 2 * c->k * c->N;
+  HIPCHK(hipMalloc(&kd.d, kd.bytes));
+  HIPCHK(hipMemcpy(kd.d, data, kd.bytes, hipMemcpyHostToDevice));
+  if (kind == EVAH_KEY_RELIN) {
+    if (c->relin.d) (void)hipFree(c->relin.d);
+    c->relin = kd;
+  } else if (kind == EVAH_KEY_GALOIS) {
+    if (!(galois_elt & 1) || galois_elt >= 2 * c->N) {
+      (void)hipFree(kd.d);
+      throw std::invalid_argument("Galois element is not valid");
+    }
+    auto it = c->galois.find(galois_elt);
+    if (it != c->galois.end()) (void)hipFree(it->second.d);
+    c->galois[galois_elt] = kd;
+  } else {
+    (void)hipFree(kd.d);
+    throw std::invalid_argument("unknown key kind");
+  }
+  API_END
+}
+
+int evah_ct_upload(evah_ctx *c, uint32_t size, uint32_t limbs, double scale, const uint64_t *data, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
+  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
+  evah_ct *t = ct_new(c, size, limbs, scale);
+  HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)size * limbs * c->N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = t;
+  API_END
+}
+
+int evah_ct_info(const evah_ct *ct, uint32_t *size, uint32_t *limbs, double *scale) {
+  API_BEGIN
+  if (size) *size = ct->size;
+  if (limbs) *limbs = ct->limbs;
+  if (scale) *scale = ct->scale;
+  API_END
+}
+
+int evah_ct_download(evah_ctx *c, const evah_ct *ct, uint64_t *out) {
+  API_BEGIN
+  use(c);
+  const size_t row = sizeof(u64) * (size_t)ct->limbs * c->N;
+  HIPCHK(hipMemcpy2DAsync(out, row, ct->d, sizeof(u64) * ct->ps, row, ct->size, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  API_END
+}
+
+void evah_ct_free(evah_ctx *c, evah_ct *ct) {
+  if (!ct) return;
+  buf_unref(c, ct->buf);
+  delete ct;
+}
+
+int evah_pt_upload(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *data, evah_pt **out) {
+  API_BEGIN
+  use(c);
+  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
+  evah_pt *t = pt_new(c, limbs, scale);
+  HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)limbs * c->N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = t;
+  API_END
+}
+
+int evah_pt_upload_coeff(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *data, evah_pt **out) {
+  API_BEGIN
+  use(c);
+  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
+  evah_pt *t = pt_new(c, limbs, scale);
+  HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)limbs * c->N, hipMemcpyHostToDevice, c->stream));
+  OpPlain::Params p{t->d, t->d, 0, 0, limbs, 0, 0};
+  ntt_forward<OpPlain>(c, p, limbs);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = t;
+  API_END
+}
+
+int evah_pt_uniform(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *value, evah_pt **out) {
+  API_BEGIN
+  use(c);
+  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
+  evah_pt *t = pt_new(c, limbs, scale);
+  Scratch v(c, limbs);
+  HIPCHK(hipMemcpyAsync(v.d, value, sizeof(u64) * limbs, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_fill_limbs, ew_grid(c, limbs, 1), dim3(256), 0, c->stream, c->dev, v.d, t->d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = t;
+  API_END
+}
+
+int evah_pt_info(const evah_pt *pt, uint32_t *limbs, double *scale) {
+  API_BEGIN
+  if (limbs) *limbs = pt->limbs;
+  if (scale) *scale = pt->scale;
+  API_END
+}
+
+int evah_pt_download(evah_ctx *c, const evah_pt *pt, uint64_t *out) {
+  API_BEGIN
+  use(c);
+  HIPCHK(hipMemcpyAsync(out, pt->d, sizeof(u64) * (size_t)pt->limbs * c->N, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  API_END
+}
+
+void evah_pt_free(evah_ctx *c, evah_pt *pt) {
+  if (!pt) return;
+  buf_unref(c, pt->buf);
+  delete pt;
+}
+
+// ---- evaluator
+
+static int addsub_impl(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct **out, int sub) {
+  API_BEGIN
+  use(c);
+  if (a->limbs != b->limbs) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+  if (!same_scale(a->scale, b->scale)) throw std::invalid_argument("scale mismatch");
+  const uint32_t s = std::max(a->size, b->size);
+  evah_ct *o = ct_new(c, s, a->limbs, a->scale);
+  hipLaunchKernelGGL(k_addsub, ew_grid(c, a->limbs, s), dim3(256), 0, c->stream, c->dev, a->d, a->ps, a->size,
+                     b->d, b->ps, b->size, o->d, o->ps, sub);
+  HIPCHK(hipGetLastError());
+  *out = o;
+  API_END
+}
+int evah_add(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct **out) { return addsub_impl(c, a, b, out, 0); }
+int evah_sub(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct **out) { return addsub_impl(c, a, b, out, 1); }
+
+static int addsub_plain_impl(evah_ctx *c, const evah_ct *a, const evah_pt *b, evah_ct **out, int sub) {
+  API_BEGIN
+  use(c);
+  if (a->limbs != b->limbs) throw std::invalid_argument("encrypted and plain parameter mismatch");
+  if (!same_scale(a->scale, b->scale)) throw std::invalid_argument("scale mismatch");
+  evah_ct *o = ct_new(c, a->size, a->limbs, a->scale);
+  hipLaunchKernelGGL(k_addsub, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps,
+                     a->size, b->d, (size_t)0, 1u, o->d, o->ps, sub);
+  HIPCHK(hipGetLastError());
+  *out = o;
+  API_END
+}
+int evah_add_plain(evah_ctx *c, const evah_ct *a, const evah_pt *b, evah_ct **out) { return addsub_plain_impl(c, a, b, out, 0); }
+int evah_sub_plain(evah_ctx *c, const evah_ct *a, const evah_pt *b, evah_ct **out) { return addsub_plain_impl(c, a, b, out, 1); }
+
+int evah_negate(evah_ctx *c, const evah_ct *a, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  evah_ct *o = ct_new(c, a->size, a->limbs, a->scale);
+  hipLaunchKernelGGL(k_negate, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps, o->d, o->ps);
+  HIPCHK(hipGetLastError());
+  *out = o;
+  API_END
+}
+
+int evah_multiply(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (a->limbs != b->limbs) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+  if (a->size != 2 || b->size != 2) throw std::invalid_argument("multiply supports size-2 operands only (relinearize first)");
+  const double ns = a->scale * b->scale;
+  check_scale(c, ns, a->limbs);
+  evah_ct *o = ct_new(c, 3, a->limbs, ns);
+  hipLaunchKernelGGL(k_mul22, ew_grid(c, a->limbs, 1), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, b->ps, o->d, o->ps);
+  HIPCHK(hipGetLastError());
+  *out = o;
+  API_END
+}
+
+int evah_square(evah_ctx *c, const evah_ct *a, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (a->size != 2) throw std::invalid_argument("square supports size-2 operands only (relinearize first)");
+  const double ns = a->scale * a->scale;
+  check_scale(c, ns, a->limbs);
+  evah_ct *o = ct_new(c, 3, a->limbs, ns);
+  hipLaunchKernelGGL(k_square, ew_grid(c, a->limbs, 1), dim3(256), 0, c->stream, c->dev, a->d, a->ps, o->d, o->ps);
+  HIPCHK(hipGetLastError());
+  *out = o;
+  API_END
+}
+
+int evah_multiply_plain(evah_ctx *c, const evah_ct *a, const evah_pt *b, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (a->limbs != b->limbs) throw std::invalid_argument("encrypted and plain parameter mismatch");
+  const double ns = a->scale * b->scale;
+  check_scale(c, ns, a->limbs);
+  evah_ct *o = ct_new(c, a->size, a->limbs, ns);
+  hipLaunchKernelGGL(k_mul_plain, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, o->d, o->ps);
+  HIPCHK(hipGetLastError());
+  *out = o;
+  API_END
+}
+
+int evah_relinearize(evah_ctx *c, const evah_ct *a, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (a->size != 3) throw std::invalid_argument("relinearize expects a size-3 ciphertext");
+  if (!c->relin.d) throw std::invalid_argument("relinearization key not present");
+  evah_ct *o = ct_new(c, 2, a->limbs, a->scale);
+  try {
+    switch_key(c, a->limbs, a->d + 2 * a->ps, c->relin, a->d, a->ps, 2, o->d, o->ps);
+  } catch (...) {
+    evah_ct_free(c, o);
+    throw;
+  }
+  *out = o;
+  API_END
+}
+
+int evah_rotate(evah_ctx *c, const evah_ct *a, int32_t steps, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
+  const size_t N = c->N;
+  if (steps == 0) { // SEAL rotate_internal: no-op
+    evah_ct *o = ct_new(c, 2, a->limbs, a->scale);
+    const size_t row = sizeof(u64) * (size_t)a->limbs * N;
+    HIPCHK(hipMemcpy2DAsync(o->d, sizeof(u64) * o->ps, a->d, sizeof(u64) * a->ps, row, 2, hipMemcpyDeviceToDevice, c->stream));
+    *out = o;
+  } else {
+    uint32_t elt = 0;
+    if (evah_galois_elt_from_step(c, steps, &elt)) throw std::invalid_argument(g_err);
+    auto kit = c->galois.find(elt);
+    if (kit == c->galois.end()) throw std::invalid_argument("Galois key not present");
+    auto pit = c->perms.find(elt);
+    if (pit == c->perms.end()) {
+      std::vector<uint32_t> tab(N);
+      for (uint32_t i = 0; i < N; i++) {
+        uint32_t reversed = bitrev((uint32_t)N + i, c->logN + 1);
+        u64 raw = (((u64)elt * reversed) >> 1) & (u64)(N - 1);
+        tab[i] = bitrev((uint32_t)raw, c->logN);
+      }
+      uint32_t *d = nullptr;
+      HIPCHK(hipMalloc(&d, sizeof(uint32_t) * N));
+      HIPCHK(hipMemcpy(d, tab.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+      pit = c->perms.emplace(elt, d).first;
+    }
+    Scratch perm(c, (size_t)2 * a->limbs * N); // [c0 permuted][c1 permuted = key-switch target]
+    const size_t pps = (size_t)a->limbs * N;
+    hipLaunchKernelGGL(k_galois_perm, ew_grid(c, a->limbs, 2), dim3(256), 0, c->stream, c->dev, a->d, a->ps,
+                       pit->second, perm.d, pps);
+    HIPCHK(hipGetLastError());
+    evah_ct *o = ct_new(c, 2, a->limbs, a->scale);
+    try {
+      switch_key(c, a->limbs, perm.d + pps, kit->second, perm.d, pps, 1, o->d, o->ps);
+    } catch (...) {
+      evah_ct_free(c, o);
+      throw;
+    }
+    *out = o;
+  }
+  API_END
+}
+
+int evah_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bits, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (a->limbs < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  const uint32_t l = a->limbs;
+  const size_t N = c->N;
+  evah_ct *o = ct_new(c, a->size, l - 1, a->scale / std::pow(2.0, (double)divisor_bits));
+  Scratch r(c, (size_t)a->size * N);
+  OpPlain::Params ip{a->d + (size_t)(l - 1) * N, r.d, a->ps, N, 1, l - 1, 1};
+  ntt_inverse<OpPlain>(c, ip, a->size);
+  OpModDown::Params mp{r.d, N, a->d, a->ps, nullptr, 0, 0, o->d, o->ps, l - 1, l - 1};
+  ntt_forward<OpModDown>(c, mp, a->size * (l - 1));
+  *out = o;
+  API_END
+}
+
+int evah_mod_switch(evah_ctx *c, const evah_ct *a, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (a->limbs < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  check_scale(c, a->scale, a->limbs - 1);
+  // dropping the last limb is a view: same buffer, same poly stride, one limb fewer
+  evah_ct *o = new evah_ct(*a);
+  o->limbs = a->limbs - 1;
+  o->buf->refs++;
+  *out = o;
+  API_END
+}
+
+int evah_test_ntt(evah_ctx *c, uint32_t prime_idx, int inverse, uint64_t *host) {
+  API_BEGIN
+  use(c);
+  if (prime_idx >= c->k) throw std::invalid_argument("prime index out of range");
+  Scratch s(c, c->N);
+  HIPCHK(hipMemcpyAsync(s.d, host, sizeof(u64) * c->N, hipMemcpyHostToDevice, c->stream));
+  OpPlain::Params p{s.d, s.d, 0, 0, 1, prime_idx, 0};
+  if (inverse) ntt_inverse<OpPlain>(c, p, 1);
+  else ntt_forward<OpPlain>(c, p, 1);
+  HIPCHK(hipMemcpyAsync(host, s.d, sizeof(u64) * c->N, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  API_END
+}
+
+int evah_timer_start(evah_ctx *c) {
+  API_BEGIN
+  use(c);
+  HIPCHK(hipEventRecord(c->ev0, c->stream));
+  API_END
+}
+int evah_timer_stop(evah_ctx *c, float *ms) {
+  API_BEGIN
+  use(c);
+  HIPCHK(hipEventRecord(c->ev1, c->stream));
+  HIPCHK(hipEventSynchronize(c->ev1));
+  HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  API_END
+}
+
+} // extern "C"

@@ -1,0 +1,323 @@
+// ntt.cuh — two-pass negacyclic NTT / INTT over 64-bit RNS primes for gfx950.
+//
+// Replaces SEAL's ntt_negacyclic_harvey / inverse_ntt_negacyclic_harvey as reached from
+// /root/reference/eva/seal/seal_executor.h:200 (relinearize), :181/:188 (rotate_vector) and
+// :213 (rescale_to_next).  Same mathematical transform (psi = minimal primitive 2N-th root,
+// natural -> bit-reversed order forward, Gentleman-Sande inverse scaled by N^-1), so outputs
+// are the same canonical residues.
+//
+// Decomposition (N = 2^logN, logN = a + b, a = ceil(logN/2)):
+//   forward  pass 1 "strided": stages 0..a-1   — N/2^a... independent 2^a-point column NTTs
+//            pass 2 "contig" : stages a..logN-1 — 2^a independent contiguous 2^b-point NTTs
+//   inverse  pass 1 "contig" : stages logN-1..a, pass 2 "strided": stages a-1..0 (+ N^-1)
+// The twiddle table is a binary heap (stage m, group i -> index m+i), so a sub-transform
+// rooted at heap node `node` uses tw[(node << s) + v] at its local stage s: both passes share
+// one table and no re-indexing is needed.
+//
+// One workgroup owns a tile of up to 4096 coefficients in LDS (32 KiB + padding); each thread
+// keeps 16 coefficients in registers per round and runs up to 4 butterfly stages on them
+// (radix-16 worth of work per LDS round trip).  Harvey lazy butterflies: forward values live
+// in [0,4q), inverse in [0,2q); only the value finally stored is canonical.
+//
+// The first pass reads through Op::load and the second writes through Op::store, which is how
+// the digit base-conversion, the rescale / mod-down combine and the +q/2 rounding offset are
+// fused into the transforms instead of being separate HBM round trips.
+#pragma once
+#include "devmath.cuh"
+
+namespace evah {
+
+constexpr int NTT_R = 16;      // coefficients per thread
+constexpr int NTT_TILE = 4096; // coefficients per workgroup (max)
+
+template <int P> struct Rounds {
+  static constexpr int NR = (P + 3) / 4;
+  static constexpr int bits(int i) { return P / NR + (i < P % NR ? 1 : 0); }
+  static constexpr int lo(int i) {
+    int l = P;
+    for (int j = 0; j <= i; j++) l -= bits(j);
+    return l;
+  }
+};
+
+__device__ __forceinline__ int lds_pad(int e) { return e + (e >> 4); }
+template <int P> constexpr int lds_sub_stride() { return (1 << P) + ((1 << P) >> 4) + 1; }
+
+// forward Cooley-Tukey butterfly, X,Y in [0,4q) -> [0,4q)
+__device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 q, u64 q2) {
+  u64 x = X - (X >= q2 ? q2 : 0);
+  u64 t = mul_shoup_lazy(Y, w.x, w.y, q);
+  X = x + t;
+  Y = x + q2 - t;
+}
+// inverse Gentleman-Sande butterfly, X,Y in [0,2q) -> [0,2q)
+__device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 q, u64 q2) {
+  u64 s = X + Y;
+  u64 d = X + q2 - Y;
+  X = s - (s >= q2 ? q2 : 0);
+  Y = mul_shoup_lazy(d, w.x, w.y, q);
+}
+
+// One register round: RB stages over bit range [LO, LO+RB) of the P-bit local index.
+template <int P, int RB, int LO, bool INVERSE, bool STRIDED>
+__device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
+                                          const ulonglong2 *__restrict__ tw, const DevPrime &pm) {
+  constexpr int S = 1 << P, TPS = S / NTT_R, G = NTT_R >> RB, NU = 1 << RB;
+  constexpr int S0 = P - LO - RB; // local stages above this round
+  const u64 q = pm.q, q2 = pm.q << 1;
+  u64 x[NTT_R];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const int o = g * TPS + tid;
+    const int o_lo = o & ((1 << LO) - 1), o_hi = o >> LO;
+    const int ebase = (o_hi << (LO + RB)) | o_lo;
+#pragma unroll
+    for (int u = 0; u < NU; u++) x[g * NU + u] = sub_lds[lds_pad(ebase | (u << LO))];
+    const uint32_t node = STRIDED ? ((1u << S0) | (uint32_t)o_hi)
+                                  : ((1u << (pre + S0)) | (h << S0) | (uint32_t)o_hi);
+    if (!INVERSE) {
+#pragma unroll
+      for (int s = 0; s < RB; s++) {
+        const int half = 1 << (RB - 1 - s);
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+          if (u & half) continue;
+          const int v = u >> (RB - s);
+          const ulonglong2 w = tw[((size_t)node << s) + v];
+          bfly_fwd(x[g * NU + u], x[g * NU + u + half], w, q, q2);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = RB - 1; s >= 0; s--) {
+        const int half = 1 << (RB - 1 - s);
+        // the very last stage of the whole inverse transform folds in N^-1
+        const bool last = STRIDED && (S0 == 0) && (s == 0);
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+          if (u & half) continue;
+          u64 &X = x[g * NU + u], &Y = x[g * NU + u + half];
+          if (last) {
+            u64 sum = X + Y, d = X + q2 - Y;
+            X = mul_shoup(sum, pm.ninv, pm.ninv_s, q);
+            Y = mul_shoup(d, pm.w0ninv, pm.w0ninv_s, q);
+          } else {
+            const int v = u >> (RB - s);
+            const ulonglong2 w = tw[((size_t)node << s) + v];
+            bfly_inv(X, Y, w, q, q2);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; u++) sub_lds[lds_pad(ebase | (u << LO))] = x[g * NU + u];
+  }
+}
+
+template <int P, int I, bool INVERSE, bool STRIDED> struct RoundSeq {
+  // forward: rounds 0..NR-1 (top bits first); inverse: NR-1..0 (low bits first)
+  static __device__ __forceinline__ void run(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
+                                             const ulonglong2 *tw, const DevPrime &pm) {
+    using RS = Rounds<P>;
+    constexpr int idx = INVERSE ? (RS::NR - 1 - I) : I;
+    ntt_round<P, RS::bits(idx), RS::lo(idx), INVERSE, STRIDED>(sub_lds, tid, h, pre, tw, pm);
+    if constexpr (I + 1 < RS::NR) {
+      __syncthreads();
+      RoundSeq<P, I + 1, INVERSE, STRIDED>::run(sub_lds, tid, h, pre, tw, pm);
+    }
+  }
+};
+
+// One pass.  grid.x = N / tile, grid.y = jobs, block = tile / 16 threads.
+template <int P, bool STRIDED, bool INVERSE, class Op>
+__global__ void __launch_bounds__(256)
+ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
+  constexpr bool FIRST = (STRIDED != INVERSE);
+  typename Op::Job jb;
+  if (!Op::setup(cx, prm, blockIdx.y, jb)) return; // block-uniform
+  const DevPrime pm = cx.primes[jb.prime];
+  const ulonglong2 *tw = (INVERSE ? cx.tw_inv : cx.tw_fwd) + (size_t)jb.prime * cx.N;
+  const int C = 1 << logC, T = blockDim.x;
+  const uint32_t pre = STRIDED ? 0u : (cx.logN - P);
+  const uint32_t stride_log = cx.logN - P; // strided pass: distance between local elements
+
+  // ---- tile -> LDS
+  uint32_t gbase, sub0 = 0;
+  if (STRIDED) gbase = blockIdx.x << logC; // column c0 (pre = 0 => single prefix)
+  else { sub0 = blockIdx.x << logC; gbase = sub0 << P; }
+#pragma unroll
+  for (int it = 0; it < NTT_R; it++) {
+    const int idx = threadIdx.x + it * T;
+    uint32_t n;
+    int l;
+    if (STRIDED) {
+      const int c = idx & (C - 1), e = idx >> logC;
+      n = gbase + ((uint32_t)e << stride_log) + c;
+      l = c * SP + lds_pad(e);
+    } else {
+      const int sub = idx >> P, e = idx & (S - 1);
+      n = gbase + idx;
+      l = sub * SP + lds_pad(e);
+    }
+    lds[l] = FIRST ? Op::load(cx, jb, pm, n) : jb.dst[n];
+  }
+  __syncthreads();
+
+  // ---- register rounds
+  {
+    const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
+    RoundSeq<P, 0, INVERSE, STRIDED>::run(lds + sub * SP, tid, sub0 + sub, pre, tw, pm);
+  }
+  __syncthreads();
+
+  // ---- LDS -> global
+  const u64 q = pm.q, q2 = pm.q << 1;
+#pragma unroll
+  for (int it = 0; it < NTT_R; it++) {
+    const int idx = threadIdx.x + it * T;
+    uint32_t n;
+    int l;
+    if (STRIDED) {
+      const int c = idx & (C - 1), e = idx >> logC;
+      n = gbase + ((uint32_t)e << stride_log) + c;
+      l = c * SP + lds_pad(e);
+    } else {
+      const int sub = idx >> P, e = idx & (S - 1);
+      n = gbase + idx;
+      l = sub * SP + lds_pad(e);
+    }
+    u64 v = lds[l];
+    if (FIRST) {
+      jb.dst[n] = v; // lazy intermediate
+    } else {
+      if (!INVERSE) { // forward final: [0,4q) -> canonical
+        v -= (v >= q2 ? q2 : 0);
+        v -= (v >= q ? q : 0);
+      }
+      Op::store(cx, jb, pm, n, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ fused load/store ops
+
+// Plain batched transform over limbs.  job -> (poly p = job / jl, limb i = job % jl),
+// prime = prime0 + i.  addhalf: x <- x + floor(q/2) mod q on store (rounding offset of
+// rescale / key-switch mod-down).
+struct OpPlain {
+  struct Params {
+    const u64 *src;
+    u64 *dst;
+    size_t src_ps, dst_ps; // poly strides (elements)
+    uint32_t jl, prime0;
+    int addhalf;
+  };
+  struct Job {
+    uint32_t prime;
+    const u64 *src;
+    u64 *dst;
+    int addhalf;
+  };
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job,
+                                               Job &j) {
+    const uint32_t pp = job / p.jl, i = job % p.jl;
+    j.prime = p.prime0 + i;
+    j.src = p.src + pp * p.src_ps + (size_t)i * cx.N;
+    j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
+    j.addhalf = p.addhalf;
+    return true;
+  }
+  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &,
+                                             uint32_t n) {
+    return j.src[n];
+  }
+  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm,
+                                               uint32_t n, u64 v) {
+    if (j.addhalf) v = addmod(v, pm.q >> 1, pm.q);
+    j.dst[n] = v;
+  }
+};
+
+// Key-switch digit conversion: job -> (I = job / l, J = job % l);
+// scratch[I][J] = NTT_{kappa(I)}( t[J] mod q_kappa(I) ), I == J skipped (NTT form reused).
+struct OpKsDigit {
+  struct Params {
+    const u64 *t;   // [l][N] coefficient-form digits
+    u64 *scratch;   // [l+1][l][N]
+    uint32_t l;
+  };
+  struct Job {
+    uint32_t prime;
+    const u64 *src;
+    u64 *dst;
+  };
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job,
+                                               Job &j) {
+    const uint32_t I = job / p.l, J = job % p.l;
+    if (I == J) return false;
+    j.prime = (I == p.l) ? cx.k - 1 : I;
+    j.src = p.t + (size_t)J * cx.N;
+    j.dst = p.scratch + ((size_t)I * p.l + J) * cx.N;
+    return true;
+  }
+  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm,
+                                             uint32_t n) {
+    return barrett64(j.src[n], pm.q, pm.brt);
+  }
+  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &,
+                                               uint32_t n, u64 v) {
+    j.dst[n] = v;
+  }
+};
+
+// Divide-and-round by prime a (rescale: a = last data prime; key-switch: a = special prime).
+// job -> (p = job / jl, i = job % jl).  r[p] is INTT(limb a) + floor(q_a/2) in coefficient form.
+//   load : u = (r mod q_i) - (floor(q_a/2) mod q_i)
+//   store: v = (c[p][i] - NTT(u)) * q_a^-1 mod q_i ;  dst = add ? add + v : v
+struct OpModDown {
+  struct Params {
+    const u64 *r;
+    size_t r_ps;
+    const u64 *c;
+    size_t c_ps;
+    const u64 *add; // nullable; applies to polys p < add_polys
+    size_t add_ps;
+    uint32_t add_polys;
+    u64 *dst;
+    size_t dst_ps;
+    uint32_t a, jl;
+  };
+  struct Job {
+    uint32_t prime;
+    const u64 *src, *c, *add;
+    u64 *dst;
+    u64 halfm;
+    ulonglong2 inv;
+  };
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job,
+                                               Job &j) {
+    const uint32_t pp = job / p.jl, i = job % p.jl;
+    j.prime = i;
+    j.src = p.r + pp * p.r_ps;
+    j.c = p.c + pp * p.c_ps + (size_t)i * cx.N;
+    j.add = (p.add && pp < p.add_polys) ? p.add + pp * p.add_ps + (size_t)i * cx.N : nullptr;
+    j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
+    j.halfm = cx.halfmod[p.a * cx.k + i];
+    j.inv = cx.invq[p.a * cx.k + i];
+    return true;
+  }
+  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm,
+                                             uint32_t n) {
+    return submod(barrett64(j.src[n], pm.q, pm.brt), j.halfm, pm.q);
+  }
+  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm,
+                                               uint32_t n, u64 U) {
+    u64 v = mul_shoup(submod(j.c[n], U, pm.q), j.inv.x, j.inv.y, pm.q);
+    if (j.add) v = addmod(j.add[n], v, pm.q);
+    j.dst[n] = v;
+  }
+};
+
+} // namespace evah

@@ -1,0 +1,122 @@
+/*
+ * eva_hip.h — C-ABI of libeva_hip.so: the MI355X (gfx950) CKKS evaluation backend that
+ * replaces the SEAL Evaluator calls behind EVA's execute() path.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * /root/reference).  Conventions:
+ *   - every function returns 0 on success, non-zero on error; evah_last_error() gives the
+ *     message (the reference throws C++ exceptions: seal_executor.h:130,146,171,402 and SEAL's
+ *     invalid_argument / logic_error; the host wrapper rethrows std::runtime_error).
+ *   - handles are opaque; device memory is owned by the backend; uploads and downloads copy.
+ *   - a ciphertext is `size` polynomials x `limbs` RNS limbs x N uint64 residues in NTT form,
+ *     poly-major / limb-major / coefficient-contiguous (SEAL's layout); limb i is mod primes[i].
+ *     limbs = (k-1) - level, where level is EVA's EncodeAtLevelAttribute / signature level
+ *     (seal_executor.h:221-224, seal.cpp:59-62).
+ *   - one evah_ctx is driven from one host thread at a time; distinct contexts are independent.
+ */
+#ifndef EVA_HIP_H
+#define EVA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct evah_ctx evah_ctx; /* replaces seal::SEALContext + seal::Evaluator (seal.h:58-66) */
+typedef struct evah_ct evah_ct;   /* replaces seal::Ciphertext in SEALExecutor::Objects (seal_executor.h:32-42) */
+typedef struct evah_pt evah_pt;   /* replaces seal::Plaintext  in SEALExecutor::Objects */
+
+/* Last error message of the calling thread ("" if none). */
+const char *evah_last_error(void);
+/* ABI version of this header. */
+int evah_abi_version(void);
+/* Number of visible HIP devices. */
+int evah_device_count(int *count);
+
+/* ---- context -------------------------------------------------------------------------------
+ * Replaces getSEALContext(params) + seal::Evaluator(context) (seal.cpp:148-172, seal.h:52).
+ * primes: the key-level chain in CoeffModulus::Create order, special prime last (seal.cpp:181).
+ * The backend derives psi (minimal primitive 2N-th root) and all NTT tables itself. */
+int evah_ctx_create(uint32_t poly_degree, uint32_t n_primes, const uint64_t *primes, int device,
+                    evah_ctx **out);
+void evah_ctx_destroy(evah_ctx *ctx);
+/* Launch on an external HIP stream (hipStream_t as void*); NULL restores the context's own. */
+int evah_ctx_set_stream(evah_ctx *ctx, void *hip_stream);
+/* Block until all work issued on the context's stream has finished. */
+int evah_ctx_sync(evah_ctx *ctx);
+/* Bytes currently held in the context's device pool (in use + cached). */
+int evah_ctx_mem_info(evah_ctx *ctx, size_t *in_use, size_t *cached);
+
+/* ---- keys ----------------------------------------------------------------------------------
+ * Replaces the seal::RelinKeys / seal::GaloisKeys members of SEALPublic (seal.h:62-63).
+ * data: [n_digits][2][n_primes][N] uint64, NTT form (one size-2 key-level ciphertext per digit;
+ * SEAL KSwitchKeys layout).  galois_elt is ignored for the relinearization key. */
+#define EVAH_KEY_RELIN 0
+#define EVAH_KEY_GALOIS 1
+int evah_key_upload(evah_ctx *ctx, int kind, uint32_t galois_elt, uint32_t n_digits,
+                    const uint64_t *data);
+/* Galois element used by evah_rotate for `steps` (SEAL GaloisTool::get_elt_from_step). */
+int evah_galois_elt_from_step(evah_ctx *ctx, int32_t steps, uint32_t *elt);
+
+/* ---- values --------------------------------------------------------------------------------
+ * Replace SEALExecutor::setInputs / getOutputs / free (seal_executor.h:264-277,420-435,406-418). */
+int evah_ct_upload(evah_ctx *ctx, uint32_t size, uint32_t limbs, double scale,
+                   const uint64_t *data /* [size][limbs][N] */, evah_ct **out);
+int evah_ct_info(const evah_ct *ct, uint32_t *size, uint32_t *limbs, double *scale);
+int evah_ct_download(evah_ctx *ctx, const evah_ct *ct, uint64_t *out /* [size][limbs][N] */);
+void evah_ct_free(evah_ctx *ctx, evah_ct *ct);
+/* data in NTT form */
+int evah_pt_upload(evah_ctx *ctx, uint32_t limbs, double scale, const uint64_t *data /* [limbs][N] */,
+                   evah_pt **out);
+/* data in coefficient form (output of the host FP64 encoder); the backend runs the per-limb
+ * forward NTT — the device half of CKKSEncoder::encode (seal_executor.h:242). */
+int evah_pt_upload_coeff(evah_ctx *ctx, uint32_t limbs, double scale, const uint64_t *data,
+                         evah_pt **out);
+/* plaintext whose every slot is the same residue per limb: encode of a uniform constant
+ * (Program::makeUniformConstant, program.h:58-60) — value[i] = round(c*scale) mod primes[i]. */
+int evah_pt_uniform(evah_ctx *ctx, uint32_t limbs, double scale, const uint64_t *value /* [limbs] */,
+                    evah_pt **out);
+int evah_pt_info(const evah_pt *pt, uint32_t *limbs, double *scale);
+int evah_pt_download(evah_ctx *ctx, const evah_pt *pt, uint64_t *out /* [limbs][N] */);
+void evah_pt_free(evah_ctx *ctx, evah_pt *pt);
+
+/* ---- evaluator ops: one per SEAL call made by SEALExecutor::operator() ---------------------- */
+/* evaluator.add (seal_executor.h:124); sizes may differ (2/3), limbs and scale must match */
+int evah_add(evah_ctx *ctx, const evah_ct *a, const evah_ct *b, evah_ct **out);
+/* evaluator.sub (seal_executor.h:140) */
+int evah_sub(evah_ctx *ctx, const evah_ct *a, const evah_ct *b, evah_ct **out);
+/* evaluator.add_plain (seal_executor.h:127) */
+int evah_add_plain(evah_ctx *ctx, const evah_ct *a, const evah_pt *b, evah_ct **out);
+/* evaluator.sub_plain (seal_executor.h:143) */
+int evah_sub_plain(evah_ctx *ctx, const evah_ct *a, const evah_pt *b, evah_ct **out);
+/* evaluator.negate (seal_executor.h:194) */
+int evah_negate(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
+/* evaluator.multiply, both operands size 2 (seal_executor.h:164) */
+int evah_multiply(evah_ctx *ctx, const evah_ct *a, const evah_ct *b, evah_ct **out);
+/* evaluator.square, operand size 2 (seal_executor.h:162) */
+int evah_square(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
+/* evaluator.multiply_plain (seal_executor.h:168) */
+int evah_multiply_plain(evah_ctx *ctx, const evah_ct *a, const evah_pt *b, evah_ct **out);
+/* evaluator.relinearize, size 3 -> 2 (seal_executor.h:200); needs the relin key */
+int evah_relinearize(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
+/* evaluator.rotate_vector(a, steps) (seal_executor.h:181; rightRotate passes -steps, :188);
+ * steps == 0 copies; needs the Galois key for exactly this step's element */
+int evah_rotate(evah_ctx *ctx, const evah_ct *a, int32_t steps, evah_ct **out);
+/* evaluator.rescale_to_next + scale fix-up out.scale = a.scale / 2^divisor_bits
+ * (seal_executor.h:213-214) */
+int evah_rescale(evah_ctx *ctx, const evah_ct *a, uint32_t divisor_bits, evah_ct **out);
+/* evaluator.mod_switch_to_next (seal_executor.h:206) */
+int evah_mod_switch(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
+
+/* ---- test / measurement hooks -------------------------------------------------------------- */
+/* in-place negacyclic NTT (inverse=0) or INTT (inverse=1) of one host polynomial mod primes[i] */
+int evah_test_ntt(evah_ctx *ctx, uint32_t prime_idx, int inverse, uint64_t *host_inout);
+/* HIP-event timing on the context's stream: start, stop -> elapsed milliseconds */
+int evah_timer_start(evah_ctx *ctx);
+int evah_timer_stop(evah_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
