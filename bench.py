@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's metric on MI355X: homomorphic op-triples/s
+(multiply + relinearize + rescale) at N = 2^16, L = 10 data limbs (k = 11 key primes).
+
+One "step" = one batch of --batch independent op-triples through the C-ABI of libeva_hip.so
+(evah_multiply -> evah_relinearize -> evah_rescale), inputs and the relinearization key already
+resident in HBM.  One process per GPU; ranks run independent batches (the path shards over
+independent ciphertexts — no data-path collective), `value` = triples of all ranks / max time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline     — dominant kernel class by HIP-event time measured live in the timed region
+  cpu_baseline — the CPU oracle (kind "port") timed on one host core on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def class_bytes(N, l, k):
+    """Compulsory HBM bytes (distinct inputs read once + outputs written once) per launch of each
+    kernel class inside one op-triple (relinearize at l limbs, rescale l -> l-1); DESIGN.md §5."""
+    W = 8 * N
+    relin = {
+        "intt_pass1": [2 * l * W, 2 * 2 * W],            # digits; special limbs of prod
+        "intt_pass2": [2 * l * W, 2 * 2 * W],
+        "ksdigit_pass1": [(l + l * l) * W],
+        "ksdigit_pass2": [2 * l * l * W],
+        "ks_mac": [(2 * l * (l + 1) + l * l + l + 2 * (l + 1)) * W],
+        "moddown_pass1": [(2 + 2 * l) * W],
+        "moddown_pass2": [(2 * l + 2 * l + 2 * l + 2 * l) * W],   # interm + prod + add + out
+    }
+    resc = {
+        "intt_pass1": [2 * 2 * W],
+        "intt_pass2": [2 * 2 * W],
+        "moddown_pass1": [(2 + 2 * (l - 1)) * W],
+        "moddown_pass2": [(3 * 2 * (l - 1)) * W],
+    }
+    out = {"elementwise": [7 * l * W]}
+    for d in (relin, resc):
+        for kk, v in d.items():
+            out.setdefault(kk, []).extend(v)
+    return {kk: sum(v) / len(v) for kk, v in out.items()}
+
+
+def triple_bytes(N, l):
+    """multiply 7P + relinearize 5P + 2l(l+1)N8 + rescale 2P + 2(l-1)N8."""
+    P = l * N * 8
+    return 7 * P + 5 * P + 2 * l * (l + 1) * N * 8 + 2 * P + 2 * (l - 1) * N * 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="independent op-triples per step")
+    ap.add_argument("--logn", type=int, default=16)
+    ap.add_argument("--limbs", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # first: the HIP runtime torch bundles must be the one every library shares
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
+                         "the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+
+    from eva_amd import backend
+    from eva_amd.hostref import coeff_modulus_create
+
+    N, l = 1 << args.logn, args.limbs
+    k = l + 1
+    primes = coeff_modulus_create(N, [60] * k)
+    g = backend.Context(N, primes, device=local)
+
+    # synthetic inputs: uniform residues; 4 distinct operand pairs per rank
+    rng = np.random.default_rng(0xE7A + rank)
+
+    def rand(prefix, nl):
+        return np.stack([rng.integers(0, primes[i], size=prefix + (N,), dtype=np.uint64)
+                         for i in range(nl)], axis=len(prefix))
+
+    key_host = rand((l, 2), k)
+    g.upload_relin_key(key_host)
+    npairs = 4
+    host_pairs = [(rand((2,), l), rand((2,), l)) for _ in range(npairs)]
+    pairs = [(g.upload_ct(a, 2.0 ** 40), g.upload_ct(b, 2.0 ** 40)) for a, b in host_pairs]
+
+    PROF_EVERY = 8  # HIP-event brackets on every 8th triple only: keeps the timed region honest
+
+    def step(profile=False):
+        for i in range(args.batch):
+            a, b = pairs[i % npairs]
+            sample = profile and (i % PROF_EVERY == 0)
+            if sample:
+                g.profile(True)
+            m = g.multiply(a, b)
+            r = g.relinearize(m)
+            o = g.rescale(r, 60)
+            if sample:
+                g.profile(False)
+            m.free(); r.free(); o.free()
+
+    def barrier():
+        g.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    g.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(profile=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = g.profile_get()
+
+    triples = args.steps * args.batch * world
+    value = triples / dt
+
+    if rank == 0:
+        cb = class_bytes(N, l, k)
+        dom = max(prof, key=lambda c: prof[c][1])
+        n_l, ms = prof[dom]
+        avg_us = ms * 1e3 / max(n_l, 1)
+        ach = cb[dom] / (avg_us * 1e-6) / 1e9 if dom in cb and n_l else 0.0
+        kern_total_ms = sum(v[1] for v in prof.values())
+        roofline = {
+            "bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+            "avg_launch_us": round(avg_us, 2), "launches_sampled": n_l,
+            "sampling": f"HIP events around every launch of 1 in {PROF_EVERY} triples inside the timed region",
+            "bytes_per_launch": int(cb.get(dom, 0)),
+            "op_level": {  # SURVEY.md §8(d) figure: 198.2 MB per op-triple at N=2^16, l=10
+                "bytes_per_triple": triple_bytes(N, l),
+                "achieved": round(triple_bytes(N, l) * value / world / 1e9, 1),
+                "frac": round(triple_bytes(N, l) * value / world / 1e9 / HBM_PEAK_GBPS, 4)},
+            "by_class_us": {c: round(v[1] * 1e3 / max(v[0], 1), 2) for c, v in prof.items() if v[0]},
+            "by_class_share": {c: round(v[1] / kern_total_ms, 3) for c, v in prof.items() if v[0]},
+        }
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import pyoracle as po  # checker / reported baseline only
+            o = po.Oracle(N, primes)
+            a, b = host_pairs[0]
+            t1 = time.perf_counter()
+            o.op_triple(a, b, key_host)
+            one = time.perf_counter() - t1
+            n = max(1, min(50, int(args.cpu_seconds / max(one, 1e-3))))
+            t1 = time.perf_counter()
+            for i in range(n):
+                a, b = host_pairs[i % npairs]
+                o.op_triple(a, b, key_host)
+            cdt = time.perf_counter() - t1
+            cpu = {"value": round(n / cdt, 3), "unit": "op-triples/s", "cores": 1, "kind": "port",
+                   "sample": f"{n} op-triples (multiply+relinearize+rescale) at N=2^{args.logn}, "
+                             f"L={l}, same inputs/key as the GPU run, oracle/libeva_oracle.so, "
+                             f"1 thread of {os.cpu_count()} host cores"}
+        line = {
+            "metric": "homomorphic ops/sec (mul+rescale+relin) at N=2^16, L=10; execute() wall-time",
+            "value": round(value, 2), "unit": "op-triples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"op-triple multiply+relinearize+rescale, N=2^{args.logn}, "
+                                   f"L={l} data limbs + 1 special prime (60-bit), "
+                                   f"{args.batch} independent triples per step per GPU",
+                       "poly_modulus_degree": N, "limbs": l, "batch_per_gpu": args.batch,
+                       "parallelism": f"independent ciphertexts sharded over {world} GPU(s), no collective"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

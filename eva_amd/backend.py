@@ -54,6 +54,9 @@ _SIGS = {
     "evah_rescale": [_vp, _vp, C.c_uint32, _vpp],
     "evah_mod_switch": [_vp, _vp, _vpp],
     "evah_test_ntt": [_vp, C.c_uint32, C.c_int, _u64p],
+    "evah_profile_enable": [_vp, C.c_int],
+    "evah_profile_reset": [_vp],
+    "evah_profile_get": [_vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
     "evah_timer_start": [_vp],
     "evah_timer_stop": [_vp, C.POINTER(C.c_float)],
 }
@@ -62,7 +65,8 @@ _VOID = {
     "evah_ct_free": [_vp, _vp],
     "evah_pt_free": [_vp, _vp],
 }
-EXPORTED_SYMBOLS = sorted(list(_SIGS) + list(_VOID) + ["evah_last_error", "evah_abi_version"])
+EXPORTED_SYMBOLS = sorted(list(_SIGS) + list(_VOID) + [
+    "evah_last_error", "evah_abi_version", "evah_profile_classes", "evah_profile_class_name"])
 
 _lib = None
 
@@ -89,6 +93,10 @@ def load():
     lib.evah_last_error.argtypes = []
     lib.evah_abi_version.restype = C.c_int
     lib.evah_abi_version.argtypes = []
+    lib.evah_profile_classes.restype = C.c_int
+    lib.evah_profile_classes.argtypes = []
+    lib.evah_profile_class_name.restype = C.c_char_p
+    lib.evah_profile_class_name.argtypes = [C.c_int]
     _lib = lib
     return lib
 
@@ -225,6 +233,21 @@ class Context:
         ms = C.c_float()
         _chk(_lib.evah_timer_stop(self.h, C.byref(ms)))
         return ms.value
+
+    def profile(self, on):
+        _chk(_lib.evah_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        _chk(_lib.evah_profile_reset(self.h))
+
+    def profile_get(self):
+        """{kernel class: (launches, total_ms)} measured with HIP events around each launch"""
+        out = {}
+        for i in range(_lib.evah_profile_classes()):
+            n, ms = C.c_uint64(), C.c_double()
+            _chk(_lib.evah_profile_get(self.h, i, C.byref(n), C.byref(ms)))
+            out[_lib.evah_profile_class_name(i).decode()] = (n.value, ms.value)
+        return out
 
     # ---- keys and values
     def upload_relin_key(self, key):

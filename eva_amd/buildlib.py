@@ -1,0 +1,79 @@
+"""In-tree build of the native pieces (explicit hipcc / g++; no JIT cache).
+
+  eva_amd/lib/libeva_hip.so   — HIP kernels + C-ABI (hipcc --offload-arch=gfx950)
+  eva_amd/_eva*.so            — host module (pybind11, g++), built when its sources exist
+"""
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+HIP_LIB = os.path.join(LIBDIR, "libeva_hip.so")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm to build the gfx950 backend)")
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in ("eva_hip.hip", "ntt.cuh", "devmath.cuh", "hostmath.h")]
+    srcs.append(os.path.join(os.path.dirname(HERE), "include", "eva_hip.h"))
+    if not force and not _newer(HIP_LIB, srcs):
+        return HIP_LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", HIP_LIB, os.path.join(CSRC, "eva_hip.hip")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def host_module_path():
+    ext = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+    return os.path.join(HERE, "_eva" + ext)
+
+
+def build_host(force=False, verbose=False):
+    hdir = os.path.join(HERE, "host")
+    main = os.path.join(hdir, "module.cpp")
+    if not os.path.exists(main):
+        return None
+    srcs = [os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith((".cpp", ".h"))]
+    srcs += [os.path.join(CSRC, "hostmath.h"), os.path.join(os.path.dirname(HERE), "include", "eva_hip.h")]
+    out = host_module_path()
+    if not force and not _newer(out, srcs):
+        return out
+    import pybind11
+    cpps = [s for s in srcs if s.endswith(".cpp")]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-march=x86-64-v3",
+           "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
+           "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", CSRC, "-I", hdir,
+           "-o", out] + cpps + ["-L", LIBDIR, "-leva_hip", "-Wl,-rpath,$ORIGIN/lib", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
+def build_all(force=False, verbose=False):
+    build_hip(force, verbose)
+    build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

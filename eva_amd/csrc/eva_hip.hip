@@ -215,6 +215,29 @@ struct Buffer {
   int refs;
 };
 
+// Kernel classes for the optional per-launch HIP-event profile (bench.py's roofline leg).
+enum KClass {
+  KC_EW = 0,        // elementwise add/sub/negate/mul/square/mul_plain/perm/fill
+  KC_INTT_A,        // inverse pass 1 (contig)
+  KC_INTT_B,        // inverse pass 2 (strided)
+  KC_KSDIGIT_A,     // key-switch digit conversion, forward pass 1 (strided, fused base conversion)
+  KC_KSDIGIT_B,     // key-switch digit conversion, forward pass 2 (contig)
+  KC_KSMAC,         // key-switch inner product
+  KC_MODDOWN_A,     // rescale / mod-down forward pass 1 (fused reduce - half)
+  KC_MODDOWN_B,     // rescale / mod-down forward pass 2 (fused combine)
+  KC_NTT_A,         // plain forward pass 1
+  KC_NTT_B,         // plain forward pass 2
+  KC_COUNT
+};
+static const char *const kclass_names[KC_COUNT] = {
+    "elementwise", "intt_pass1", "intt_pass2", "ksdigit_pass1", "ksdigit_pass2", "ks_mac",
+    "moddown_pass1", "moddown_pass2", "ntt_pass1", "ntt_pass2"};
+
+struct ProfRec {
+  hipEvent_t e0, e1;
+  int cls;
+};
+
 struct KeyDev {
   u64 *d = nullptr;
   uint32_t n_digits = 0;
@@ -252,11 +275,59 @@ struct evah_ctx {
   std::map<uint32_t, KeyDev> galois;
   std::map<uint32_t, uint32_t *> perms;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // per-launch profile
+  bool prof_on = false;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> prof_free;
+  double prof_ms[KC_COUNT] = {0};
+  uint64_t prof_n[KC_COUNT] = {0};
 };
 
 namespace evah {
 
 static void use(evah_ctx *c) { HIPCHK(hipSetDevice(c->device)); }
+
+static hipEvent_t prof_event(evah_ctx *c) {
+  if (!c->prof_free.empty()) {
+    hipEvent_t e = c->prof_free.back();
+    c->prof_free.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIPCHK(hipEventCreate(&e));
+  return e;
+}
+static void prof_drain(evah_ctx *c) {
+  for (auto &r : c->prof_recs) {
+    float ms = 0;
+    HIPCHK(hipEventSynchronize(r.e1));
+    HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
+    c->prof_ms[r.cls] += ms;
+    c->prof_n[r.cls]++;
+    c->prof_free.push_back(r.e0);
+    c->prof_free.push_back(r.e1);
+  }
+  c->prof_recs.clear();
+}
+struct ProfScope { // brackets one kernel launch with HIP events on the launch stream
+  evah_ctx *c;
+  int cls;
+  hipEvent_t e0 = nullptr;
+  ProfScope(evah_ctx *c_, int cls_) : c(c_), cls(cls_) {
+    if (c->prof_on) {
+      if (c->prof_recs.size() >= 8192) prof_drain(c);
+      e0 = prof_event(c);
+      HIPCHK(hipEventRecord(e0, c->stream));
+    }
+  }
+  ~ProfScope() {
+    if (e0) {
+      hipEvent_t e1 = prof_event(c);
+      (void)hipEventRecord(e1, c->stream);
+      c->prof_recs.push_back({e0, e1, cls});
+    }
+  }
+};
 
 static Buffer *buf_new(evah_ctx *c, size_t elems) {
   Buffer *b = new Buffer;
@@ -305,8 +376,15 @@ static dim3 ew_grid(evah_ctx *c, uint32_t limbs, uint32_t polys) {
 }
 
 // ---- NTT launch plumbing
+template <class Op> struct OpClass;
+template <> struct OpClass<OpPlain> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
+template <> struct OpClass<OpKsDigit> { static constexpr int fwd_a = KC_KSDIGIT_A, fwd_b = KC_KSDIGIT_B; };
+template <> struct OpClass<OpModDown> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
+
 template <int P, bool STRIDED, bool INVERSE, class Op>
 static void launch_pass(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  ProfScope ps(c, INVERSE ? (STRIDED ? KC_INTT_B : KC_INTT_A)
+                          : (STRIDED ? OpClass<Op>::fwd_a : OpClass<Op>::fwd_b));
   const uint32_t tile = c->N < (uint32_t)NTT_TILE ? c->N : (uint32_t)NTT_TILE;
   const int logC = (int)ilog2(tile) - P;
   const size_t lds = ((size_t)1 << logC) * lds_sub_stride<P>() * sizeof(u64);
@@ -357,8 +435,11 @@ static void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev 
   OpKsDigit::Params dp{t.d, sc.d, l};
   ntt_forward<OpKsDigit>(c, dp, (l + 1) * l);
   // 2b. inner product with the key
+  {
+  ProfScope ps(c, KC_KSMAC);
   hipLaunchKernelGGL(k_ks_mac, dim3(c->N / 512, l + 1), dim3(256), 0, c->stream, c->dev, target, sc.d,
                      key.d, prod.d, l);
+  }
   HIPCHK(hipGetLastError());
   // 3. mod-down by the special prime: INTT(special limb) + P/2, then per-limb NTT + combine
   Scratch r(c, 2 * N);
@@ -401,6 +482,7 @@ static bool same_scale(double a, double b) {
 
 // ------------------------------------------------------------------------------- C-ABI
 
+#define EW_LAUNCH(...) do { ProfScope ps_(c, KC_EW); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 #define API_BEGIN try {
 #define API_END                                                                                  \
   g_err.clear();                                                                                 \
@@ -524,6 +606,8 @@ void evah_ctx_destroy(evah_ctx *c) {
   for (auto &kv : c->perms) (void)hipFree(kv.second);
   c->pool.release_cached();
   if (c->d_tables) (void)hipFree(c->d_tables);
+  for (auto &r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto e : c->prof_free) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own) (void)hipStreamDestroy(c->own);
@@ -660,7 +744,7 @@ int evah_pt_uniform(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *v
   evah_pt *t = pt_new(c, limbs, scale);
   Scratch v(c, limbs);
   HIPCHK(hipMemcpyAsync(v.d, value, sizeof(u64) * limbs, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_fill_limbs, ew_grid(c, limbs, 1), dim3(256), 0, c->stream, c->dev, v.d, t->d);
+  EW_LAUNCH(k_fill_limbs, ew_grid(c, limbs, 1), dim3(256), 0, c->stream, c->dev, v.d, t->d);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   *out = t;
@@ -697,7 +781,7 @@ static int addsub_impl(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct 
   if (!same_scale(a->scale, b->scale)) throw std::invalid_argument("scale mismatch");
   const uint32_t s = std::max(a->size, b->size);
   evah_ct *o = ct_new(c, s, a->limbs, a->scale);
-  hipLaunchKernelGGL(k_addsub, ew_grid(c, a->limbs, s), dim3(256), 0, c->stream, c->dev, a->d, a->ps, a->size,
+  EW_LAUNCH(k_addsub, ew_grid(c, a->limbs, s), dim3(256), 0, c->stream, c->dev, a->d, a->ps, a->size,
                      b->d, b->ps, b->size, o->d, o->ps, sub);
   HIPCHK(hipGetLastError());
   *out = o;
@@ -712,7 +796,7 @@ static int addsub_plain_impl(evah_ctx *c, const evah_ct *a, const evah_pt *b, ev
   if (a->limbs != b->limbs) throw std::invalid_argument("encrypted and plain parameter mismatch");
   if (!same_scale(a->scale, b->scale)) throw std::invalid_argument("scale mismatch");
   evah_ct *o = ct_new(c, a->size, a->limbs, a->scale);
-  hipLaunchKernelGGL(k_addsub, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps,
+  EW_LAUNCH(k_addsub, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps,
                      a->size, b->d, (size_t)0, 1u, o->d, o->ps, sub);
   HIPCHK(hipGetLastError());
   *out = o;
@@ -725,7 +809,7 @@ int evah_negate(evah_ctx *c, const evah_ct *a, evah_ct **out) {
   API_BEGIN
   use(c);
   evah_ct *o = ct_new(c, a->size, a->limbs, a->scale);
-  hipLaunchKernelGGL(k_negate, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps, o->d, o->ps);
+  EW_LAUNCH(k_negate, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps, o->d, o->ps);
   HIPCHK(hipGetLastError());
   *out = o;
   API_END
@@ -739,7 +823,7 @@ int evah_multiply(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct **out
   const double ns = a->scale * b->scale;
   check_scale(c, ns, a->limbs);
   evah_ct *o = ct_new(c, 3, a->limbs, ns);
-  hipLaunchKernelGGL(k_mul22, ew_grid(c, a->limbs, 1), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, b->ps, o->d, o->ps);
+  EW_LAUNCH(k_mul22, ew_grid(c, a->limbs, 1), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, b->ps, o->d, o->ps);
   HIPCHK(hipGetLastError());
   *out = o;
   API_END
@@ -752,7 +836,7 @@ int evah_square(evah_ctx *c, const evah_ct *a, evah_ct **out) {
   const double ns = a->scale * a->scale;
   check_scale(c, ns, a->limbs);
   evah_ct *o = ct_new(c, 3, a->limbs, ns);
-  hipLaunchKernelGGL(k_square, ew_grid(c, a->limbs, 1), dim3(256), 0, c->stream, c->dev, a->d, a->ps, o->d, o->ps);
+  EW_LAUNCH(k_square, ew_grid(c, a->limbs, 1), dim3(256), 0, c->stream, c->dev, a->d, a->ps, o->d, o->ps);
   HIPCHK(hipGetLastError());
   *out = o;
   API_END
@@ -765,7 +849,7 @@ int evah_multiply_plain(evah_ctx *c, const evah_ct *a, const evah_pt *b, evah_ct
   const double ns = a->scale * b->scale;
   check_scale(c, ns, a->limbs);
   evah_ct *o = ct_new(c, a->size, a->limbs, ns);
-  hipLaunchKernelGGL(k_mul_plain, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, o->d, o->ps);
+  EW_LAUNCH(k_mul_plain, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, o->d, o->ps);
   HIPCHK(hipGetLastError());
   *out = o;
   API_END
@@ -817,7 +901,7 @@ int evah_rotate(evah_ctx *c, const evah_ct *a, int32_t steps, evah_ct **out) {
     }
     Scratch perm(c, (size_t)2 * a->limbs * N); // [c0 permuted][c1 permuted = key-switch target]
     const size_t pps = (size_t)a->limbs * N;
-    hipLaunchKernelGGL(k_galois_perm, ew_grid(c, a->limbs, 2), dim3(256), 0, c->stream, c->dev, a->d, a->ps,
+    EW_LAUNCH(k_galois_perm, ew_grid(c, a->limbs, 2), dim3(256), 0, c->stream, c->dev, a->d, a->ps,
                        pit->second, perm.d, pps);
     HIPCHK(hipGetLastError());
     evah_ct *o = ct_new(c, 2, a->limbs, a->scale);
@@ -872,6 +956,32 @@ int evah_test_ntt(evah_ctx *c, uint32_t prime_idx, int inverse, uint64_t *host) 
   else ntt_forward<OpPlain>(c, p, 1);
   HIPCHK(hipMemcpyAsync(host, s.d, sizeof(u64) * c->N, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  API_END
+}
+
+int evah_profile_enable(evah_ctx *c, int on) {
+  API_BEGIN
+  use(c);
+  prof_drain(c);
+  c->prof_on = on != 0;
+  API_END
+}
+int evah_profile_reset(evah_ctx *c) {
+  API_BEGIN
+  use(c);
+  prof_drain(c);
+  for (int i = 0; i < KC_COUNT; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+  API_END
+}
+int evah_profile_classes(void) { return KC_COUNT; }
+const char *evah_profile_class_name(int cls) { return (cls >= 0 && cls < KC_COUNT) ? kclass_names[cls] : ""; }
+int evah_profile_get(evah_ctx *c, int cls, uint64_t *launches, double *total_ms) {
+  API_BEGIN
+  use(c);
+  if (cls < 0 || cls >= KC_COUNT) throw std::invalid_argument("kernel class out of range");
+  prof_drain(c);
+  *launches = c->prof_n[cls];
+  *total_ms = c->prof_ms[cls];
   API_END
 }
 

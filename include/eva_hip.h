@@ -112,6 +112,13 @@ int evah_mod_switch(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
 /* ---- test / measurement hooks -------------------------------------------------------------- */
 /* in-place negacyclic NTT (inverse=0) or INTT (inverse=1) of one host polynomial mod primes[i] */
 int evah_test_ntt(evah_ctx *ctx, uint32_t prime_idx, int inverse, uint64_t *host_inout);
+/* Per-launch HIP-event profile by kernel class (events are recorded on the launch stream around
+ * every kernel launch while enabled); used by bench.py for the roofline of the dominant kernel. */
+int evah_profile_enable(evah_ctx *ctx, int on);
+int evah_profile_reset(evah_ctx *ctx);
+int evah_profile_classes(void);
+const char *evah_profile_class_name(int cls);
+int evah_profile_get(evah_ctx *ctx, int cls, uint64_t *launches, double *total_ms);
 /* HIP-event timing on the context's stream: start, stop -> elapsed milliseconds */
 int evah_timer_start(evah_ctx *ctx);
 int evah_timer_stop(evah_ctx *ctx, float *ms);
