@@ -1,0 +1,205 @@
+// module.cpp — pybind11 module eva_amd._eva: the same Python-visible surface as the reference's
+// eva._eva (/root/reference/python/eva/wrapper.cpp:26-246) over the arena IR, the CKKS compiler
+// and the MI355X executor.  Submodules: _ckks (compiler), _seal (backend; the name is kept so
+// `from eva.seal import generate_keys` keeps working — the backend behind it is libeva_hip.so).
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "executor.h"
+
+namespace py = pybind11;
+using namespace evahost;
+
+namespace {
+
+struct PyTerm {
+  Program *prog;
+  TermId id;
+  py::object owner; // keeps the owning Program alive while a handle exists
+};
+
+std::vector<TermId> ids_of(const std::vector<PyTerm> &v) {
+  std::vector<TermId> out;
+  for (auto &t : v) out.push_back(t.id);
+  return out;
+}
+
+py::array_t<uint64_t> to_numpy(const std::vector<u64> &v, std::vector<py::ssize_t> shape) {
+  py::array_t<uint64_t> a(shape);
+  std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(u64));
+  return a;
+}
+
+static int g_num_threads = 1;
+
+} // namespace
+
+PYBIND11_MODULE(_eva, m) {
+  m.doc() = "MI355X-native EVA: Python wrapper";
+
+  py::enum_<Op>(m, "Op")
+      .value("Undef", Op::Undef).value("Input", Op::Input).value("Output", Op::Output).value("Constant", Op::Constant)
+      .value("Negate", Op::Negate).value("Add", Op::Add).value("Sub", Op::Sub).value("Mul", Op::Mul)
+      .value("RotateLeftConst", Op::RotateLeftConst).value("RotateRightConst", Op::RotateRightConst)
+      .value("Relinearize", Op::Relinearize).value("ModSwitch", Op::ModSwitch).value("Rescale", Op::Rescale)
+      .value("Encode", Op::Encode);
+  py::enum_<Type>(m, "Type")
+      .value("Undef", Type::Undef).value("Cipher", Type::Cipher).value("Raw", Type::Raw).value("Plain", Type::Plain);
+
+  py::class_<PyTerm>(m, "Term", "Native Term handle")
+      .def_property_readonly("op", [](const PyTerm &t) { return t.prog->at(t.id).op; }, "The operation performed by this term")
+      .def_property_readonly("index", [](const PyTerm &t) { return t.id; });
+
+  py::class_<Program>(m, "Program", "Native Program class")
+      .def(py::init<std::string, uint64_t>(), py::arg("name"), py::arg("vec_size"))
+      .def_property("name", &Program::name, &Program::set_name, "The name of this program")
+      .def_property_readonly("vec_size", &Program::vec_size, "The number of elements for all vectors in this program")
+      .def_property_readonly("inputs", [](py::object self) {
+        Program &p = self.cast<Program &>();
+        std::unordered_map<std::string, PyTerm> out;
+        for (auto &kv : p.inputs()) out.emplace(kv.first, PyTerm{&p, kv.second, self});
+        return out;
+      }, "A dictionary from input names to terms")
+      .def_property_readonly("outputs", [](py::object self) {
+        Program &p = self.cast<Program &>();
+        std::unordered_map<std::string, PyTerm> out;
+        for (auto &kv : p.outputs()) out.emplace(kv.first, PyTerm{&p, kv.second, self});
+        return out;
+      }, "A dictionary from output names to terms")
+      .def("set_output_ranges", [](Program &p, uint32_t range) {
+        for (auto &kv : p.outputs()) { p.at(kv.second).has_range = true; p.at(kv.second).range = range; }
+      }, py::arg("range"), "Sets the range (in bits) all outputs must accommodate")
+      .def("set_input_scales", [](Program &p, uint32_t scale) {
+        for (TermId s : p.sources()) { p.at(s).has_encode_scale = true; p.at(s).encode_scale = scale; }
+      }, py::arg("scale"), "Sets the scale (in bits) all inputs and constants are encoded at")
+      .def("to_DOT", &Program::to_dot)
+      .def("_make_term", [](py::object self, Op op, const std::vector<PyTerm> &operands) { Program &p = self.cast<Program &>(); return PyTerm{&p, p.make_term(op, ids_of(operands)), self}; })
+      .def("_make_left_rotation", [](py::object self, const PyTerm &t, int32_t s) { Program &p = self.cast<Program &>(); return PyTerm{&p, p.make_left_rotation(t.id, s), self}; })
+      .def("_make_right_rotation", [](py::object self, const PyTerm &t, int32_t s) { Program &p = self.cast<Program &>(); return PyTerm{&p, p.make_right_rotation(t.id, s), self}; })
+      .def("_make_dense_constant", [](py::object self, std::vector<double> v) { Program &p = self.cast<Program &>(); return PyTerm{&p, p.make_dense_constant(std::move(v)), self}; })
+      .def("_make_uniform_constant", [](py::object self, double v) { Program &p = self.cast<Program &>(); return PyTerm{&p, p.make_uniform_constant(v), self}; })
+      .def("_make_input", [](py::object self, const std::string &name, Type t) { Program &p = self.cast<Program &>(); return PyTerm{&p, p.make_input(name, t), self}; })
+      .def("_make_output", [](py::object self, const std::string &name, const PyTerm &t) { Program &p = self.cast<Program &>(); return PyTerm{&p, p.make_output(name, t.id), self}; })
+      // introspection used by the parity tests: the live DAG in topological order
+      .def("_dump", [](Program &p) {
+        py::list out;
+        for (TermId t : p.topo_order()) {
+          const Term &x = p.at(t);
+          py::dict d;
+          d["id"] = t;
+          d["op"] = x.op;
+          d["operands"] = x.operands;
+          if (x.has_rotation) d["rotation"] = x.rotation;
+          if (x.has_rescale_divisor) d["rescale_divisor"] = x.rescale_divisor;
+          if (x.has_type) d["type"] = x.type_attr;
+          if (x.has_range) d["range"] = x.range;
+          if (x.has_encode_scale) d["encode_scale"] = x.encode_scale;
+          if (x.has_encode_level) d["encode_level"] = x.encode_level;
+          if (x.constant) d["constant"] = x.constant->values;
+          out.append(d);
+        }
+        return out;
+      });
+
+  m.def("evaluate", &evaluate, py::arg("program"), py::arg("inputs"), "Evaluate the program without homomorphic encryption (reference semantics)");
+  m.def("set_num_threads", [](int n) { if (n < 1) throw std::invalid_argument("num_threads must be positive"); g_num_threads = n; }, py::arg("num_threads"),
+        "Kept for API compatibility: node-level parallelism is HIP streams on the GPU, not host threads");
+  struct GaloisGuard {};
+  py::class_<GaloisGuard>(m, "_GaloisGuard").def(py::init());
+
+  // ---- CKKS compiler
+  py::module mckks = m.def_submodule("_ckks", "CKKS compiler");
+  py::class_<CKKSCompiler>(mckks, "CKKSCompiler")
+      .def(py::init(), "Create a compiler with the default config")
+      .def(py::init([](const std::unordered_map<std::string, std::string> &cfg) { return CKKSCompiler(CKKSConfig(cfg)); }), py::arg("config"))
+      .def("compile", [](CKKSCompiler &c, Program &p) {
+        auto r = c.compile(p);
+        return py::make_tuple(py::cast(std::move(std::get<0>(r))), std::get<1>(r), std::get<2>(r));
+      }, py::arg("program"));
+  py::class_<CKKSParameters>(mckks, "CKKSParameters", "Abstract encryption parameters for CKKS")
+      .def(py::init([](std::vector<uint32_t> bits, std::set<int> rot, uint32_t n) { CKKSParameters p; p.prime_bits = bits; p.rotations = rot; p.poly_modulus_degree = n; return p; }),
+           py::arg("prime_bits"), py::arg("rotations"), py::arg("poly_modulus_degree"))
+      .def_readwrite("prime_bits", &CKKSParameters::prime_bits)
+      .def_readwrite("rotations", &CKKSParameters::rotations)
+      .def_readwrite("poly_modulus_degree", &CKKSParameters::poly_modulus_degree);
+  py::class_<CKKSEncodingInfo>(mckks, "CKKSEncodingInfo")
+      .def_readonly("input_type", &CKKSEncodingInfo::input_type)
+      .def_readonly("scale", &CKKSEncodingInfo::scale)
+      .def_readonly("level", &CKKSEncodingInfo::level);
+  py::class_<CKKSSignature>(mckks, "CKKSSignature")
+      .def_readonly("vec_size", &CKKSSignature::vec_size)
+      .def_readonly("inputs", &CKKSSignature::inputs);
+
+  // ---- backend
+  py::module mseal = m.def_submodule("_seal", "MI355X CKKS execution backend (drop-in for eva._eva._seal)");
+  mseal.def("generate_keys", [](const CKKSParameters &p, uint64_t seed) { return generate_keys(p, seed); }, py::arg("abstract_params"), py::arg("seed") = 0);
+  py::class_<HipValuation>(mseal, "SEALValuation", "Inputs or outputs of execute(): ciphertexts, plaintexts or raw vectors")
+      .def(py::init<>())
+      .def("_set_cipher", [](HipValuation &v, const std::string &name, py::array_t<uint64_t, py::array::c_style | py::array::forcecast> data, double scale) {
+        if (data.ndim() != 3) throw std::invalid_argument("cipher data must be [size][limbs][N]");
+        HostCipher c;
+        c.size = (uint32_t)data.shape(0);
+        c.limbs = (uint32_t)data.shape(1);
+        c.scale = scale;
+        c.data.assign((const u64 *)data.data(), (const u64 *)data.data() + data.size());
+        v.values[name] = std::move(c);
+      })
+      .def("_set_plain", [](HipValuation &v, const std::string &name, py::array_t<uint64_t, py::array::c_style | py::array::forcecast> data, double scale) {
+        if (data.ndim() != 2) throw std::invalid_argument("plain data must be [limbs][N]");
+        HostPlain p;
+        p.limbs = (uint32_t)data.shape(0);
+        p.scale = scale;
+        p.data.assign((const u64 *)data.data(), (const u64 *)data.data() + data.size());
+        v.values[name] = std::move(p);
+      })
+      .def("_set_raw", [](HipValuation &v, const std::string &name, std::vector<double> data) { v.values[name] = std::move(data); })
+      .def("names", [](const HipValuation &v) { std::vector<std::string> n; for (auto &kv : v.values) n.push_back(kv.first); return n; })
+      // (kind, size, limbs, scale, data) — raw residues for the bit-exact parity tests
+      .def("get", [](const HipValuation &v, const std::string &name) -> py::object {
+        auto it = v.values.find(name);
+        if (it == v.values.end()) throw std::out_of_range("No value named " + name);
+        if (auto *c = std::get_if<HostCipher>(&it->second)) {
+          py::ssize_t n = (py::ssize_t)(c->data.size() / ((size_t)c->size * c->limbs));
+          return py::make_tuple("cipher", c->size, c->limbs, c->scale, to_numpy(c->data, {(py::ssize_t)c->size, (py::ssize_t)c->limbs, n}));
+        }
+        if (auto *p = std::get_if<HostPlain>(&it->second)) {
+          py::ssize_t n = (py::ssize_t)(p->data.size() / p->limbs);
+          return py::make_tuple("plain", 1, p->limbs, p->scale, to_numpy(p->data, {(py::ssize_t)p->limbs, n}));
+        }
+        return py::make_tuple("raw", 0, 0, 1.0, py::cast(std::get<std::vector<double>>(it->second)));
+      });
+  py::class_<HipPublic, std::shared_ptr<HipPublic>>(mseal, "SEALPublic", "Public context: encryption and execution on the MI355X")
+      .def("encrypt", &HipPublic::encrypt, py::arg("inputs"), py::arg("signature"))
+      .def("execute", &HipPublic::execute, py::arg("program"), py::arg("inputs"))
+      .def_readwrite("device", &HipPublic::device)
+      .def_readwrite("free_eagerly", &HipPublic::free_eagerly)
+      .def_property_readonly("poly_modulus_degree", [](const HipPublic &p) { return p.host->N; })
+      .def_property_readonly("primes", [](const HipPublic &p) { return std::vector<uint64_t>(p.host->primes.begin(), p.host->primes.end()); })
+      // host FP64 encoder + host NTT: the plaintext an Encode node produces (tests pin the
+      // integer path "from the encoded plaintext onward")
+      .def("_encode", [](const HipPublic &p, const std::vector<double> &values, uint32_t scale_bits, uint32_t level) {
+        const HostContext &h = *p.host;
+        const size_t slots = h.N / 2;
+        if (values.empty() || slots % values.size()) throw std::runtime_error("Size must exactly divide slots");
+        if (level >= h.k - 1) throw std::runtime_error("Encode level exceeds the modulus chain");
+        const uint32_t limbs = h.k - 1 - level;
+        std::vector<double> vec;
+        for (size_t r = slots / values.size(); r > 0; --r) vec.insert(vec.end(), values.begin(), values.end());
+        std::vector<u64> out((size_t)limbs * h.N);
+        h.encode_coeff(vec.data(), std::pow(2.0, (double)scale_bits), limbs, out.data());
+        for (uint32_t i = 0; i < limbs; i++) h.ntt(i, out.data() + (size_t)i * h.N);
+        return to_numpy(out, {(py::ssize_t)limbs, (py::ssize_t)h.N});
+      }, py::arg("values"), py::arg("scale_bits"), py::arg("level"))
+      .def("relin_key", [](const HipPublic &p) {
+        return to_numpy(p.relin.data, {(py::ssize_t)p.relin.n_digits, 2, (py::ssize_t)p.host->k, (py::ssize_t)p.host->N});
+      })
+      .def("galois_keys", [](const HipPublic &p) {
+        py::dict d;
+        for (auto &kv : p.galois)
+          d[py::int_(kv.first)] = to_numpy(kv.second.data, {(py::ssize_t)kv.second.n_digits, 2, (py::ssize_t)p.host->k, (py::ssize_t)p.host->N});
+        return d;
+      });
+  py::class_<HipSecret, std::shared_ptr<HipSecret>>(mseal, "SEALSecret", "Secret context: decryption. Holds the secret key.")
+      .def("decrypt", &HipSecret::decrypt, py::arg("enc_outputs"), py::arg("signature"));
+}

@@ -1,0 +1,111 @@
+"""Test-side restatement of SEALExecutor's dispatch over the CPU oracle
+(/root/reference/eva/seal/seal_executor.h:279-404): walks a compiled program's term list and
+calls one oracle op per node.  Used to check execute() on the GPU bit-for-bit at the DAG level.
+Test infrastructure only."""
+import numpy as np
+
+from oracle import pyoracle as po
+
+
+class Cipher:
+    def __init__(self, data, scale):
+        self.data, self.scale = data, scale
+
+
+class Plain:
+    def __init__(self, data, scale):
+        self.data, self.scale = data, scale
+
+
+def _rot(v, s, left):
+    n = len(v)
+    s %= n
+    return v[s:] + v[:s] if left else v[n - s:] + v[:n - s]
+
+
+class OracleExecutor:
+    def __init__(self, public_ctx):
+        self.pub = public_ctx
+        self.N = public_ctx.poly_modulus_degree
+        self.primes = list(public_ctx.primes)
+        self.k = len(self.primes)
+        self.o = po.Oracle(self.N, self.primes)
+        self.relin = public_ctx.relin_key()
+        self.galois = public_ctx.galois_keys()
+
+    def execute(self, program, enc_inputs):
+        vals = {}
+        inputs = {name: t.index for name, t in program.inputs.items()}
+        for name in enc_inputs.names():
+            kind, size, limbs, scale, data = enc_inputs.get(name)
+            t = inputs[name]
+            if kind == "cipher":
+                vals[t] = Cipher(data, scale)
+            elif kind == "plain":
+                vals[t] = Plain(data, scale)
+            else:
+                vals[t] = list(data) * (program.vec_size // len(data))
+        from eva_amd import Op
+        for d in program._dump():
+            t, op, a = d["id"], d["op"], d["operands"]
+            if op == Op.Input:
+                continue
+            if op == Op.Constant:
+                c = d["constant"]
+                vals[t] = list(c) * (program.vec_size // len(c))
+            elif op == Op.Encode:
+                data = self.pub._encode(vals[a[0]], d["encode_scale"], d["encode_level"])
+                vals[t] = Plain(data, 2.0 ** d["encode_scale"])
+            elif op in (Op.Add, Op.Sub, Op.Mul):
+                x, y = vals[a[0]], vals[a[1]]
+                if isinstance(x, list) and isinstance(y, list):
+                    f = {Op.Add: lambda u, v: u + v, Op.Sub: lambda u, v: u - v, Op.Mul: lambda u, v: u * v}[op]
+                    vals[t] = [f(u, v) for u, v in zip(x, y)]
+                elif op == Op.Add:
+                    if not isinstance(x, Cipher):
+                        x, y = y, x
+                    if isinstance(y, Cipher):
+                        vals[t] = Cipher(self.o.add(x.data, y.data), x.scale)
+                    else:
+                        vals[t] = Cipher(self.o.add_plain(x.data, y.data), x.scale)
+                elif op == Op.Sub:
+                    if isinstance(y, Cipher):
+                        vals[t] = Cipher(self.o.sub(x.data, y.data), x.scale)
+                    else:
+                        vals[t] = Cipher(self.o.sub_plain(x.data, y.data), x.scale)
+                else:
+                    same = a[0] == a[1]
+                    if not isinstance(x, Cipher):
+                        x, y = y, x
+                    if isinstance(y, Cipher):
+                        out = self.o.square(x.data) if same else self.o.multiply(x.data, y.data)
+                    else:
+                        out = self.o.multiply_plain(x.data, y.data)
+                    vals[t] = Cipher(out, x.scale * y.scale)
+            elif op in (Op.RotateLeftConst, Op.RotateRightConst):
+                x = vals[a[0]]
+                if isinstance(x, list):
+                    vals[t] = _rot(x, d["rotation"], op == Op.RotateLeftConst)
+                else:
+                    steps = d["rotation"] if op == Op.RotateLeftConst else -d["rotation"]
+                    key = None
+                    if steps != 0:
+                        key = self.galois[po.galois_elt_from_step(self.N, steps)]
+                    vals[t] = Cipher(self.o.rotate(x.data, steps, key), x.scale)
+            elif op == Op.Negate:
+                x = vals[a[0]]
+                vals[t] = [-u for u in x] if isinstance(x, list) else Cipher(self.o.negate(x.data), x.scale)
+            elif op == Op.Relinearize:
+                x = vals[a[0]]
+                vals[t] = Cipher(self.o.relinearize(x.data, self.relin), x.scale)
+            elif op == Op.ModSwitch:
+                x = vals[a[0]]
+                vals[t] = Cipher(self.o.mod_switch(x.data), x.scale)
+            elif op == Op.Rescale:
+                x = vals[a[0]]
+                vals[t] = Cipher(self.o.rescale(x.data), x.scale / 2.0 ** d["rescale_divisor"])
+            elif op == Op.Output:
+                vals[t] = vals[a[0]]
+            else:
+                raise RuntimeError(f"Unhandled op {op}")
+        return {name: vals[t.index] for name, t in program.outputs.items()}

@@ -1,0 +1,211 @@
+"""GPU end-to-end: the reference's own test programs (tests/features.py, large_programs.py,
+bug_fixes.py, std.py; examples/image_processing.py) through compile -> generate_keys -> encrypt ->
+public_ctx.execute (MI355X) -> decrypt, with the reference's thresholds (tests/common.py:25,34)
+and, where marked, the output ciphertexts compared bit-for-bit with the CPU oracle walking the
+same compiled DAG on the same encrypted inputs and keys."""
+import math
+
+import pytest
+
+from eva import EvaProgram, Input, Output
+from eva.std.numeric import horizontal_sum
+from evatest import compile_and_check
+from test_compiler import _sobel
+
+pytestmark = pytest.mark.gpu
+
+
+def test_readme_polynomial_bit_exact():
+    """BASELINE config 1 (README.md:120-150)"""
+    poly = EvaProgram('Polynomial', vec_size=1024)
+    with poly:
+        x = Input('x')
+        Output('y', 3 * x ** 2 + 5 * x - 2)
+    poly.set_output_ranges(30)
+    poly.set_input_scales(30)
+    compile_and_check(poly, {'x': [i / 64.0 for i in range(1024)]}, check_bit_exact=True)
+
+
+def test_bin_ops():
+    for binop in (lambda a, b: a + b, lambda a, b: a - b, lambda a, b: a * b):
+        for enc1 in (False, True):
+            for enc2 in (False, True):
+                prog = EvaProgram('BinOp', vec_size=64)
+                with prog:
+                    a = Input('a', enc1)
+                    b = Input('b', enc2)
+                    Output('y', binop(a, b))
+                prog.set_output_ranges(20)
+                prog.set_input_scales(30)
+                compile_and_check(prog, check_bit_exact=True)
+
+
+def test_unary_ops():
+    for unop in (lambda x: x, lambda x: -x, lambda x: x ** 3, lambda x: 42):
+        for enc in (False, True):
+            prog = EvaProgram('UnOp', vec_size=64)
+            with prog:
+                x = Input('x', enc)
+                Output('y', unop(x))
+            prog.set_output_ranges(20)
+            prog.set_input_scales(30)
+            compile_and_check(prog, check_bit_exact=True)
+
+
+def test_rotations():
+    for rotop in (lambda x, r: x << r, lambda x, r: x >> r):
+        for rot in range(-2, 2):
+            prog = EvaProgram('RotOp', vec_size=8)
+            with prog:
+                x = Input('x')
+                Output('y', rotop(x, rot))
+            prog.set_output_ranges(20)
+            prog.set_input_scales(30)
+            compile_and_check(prog, check_bit_exact=True)
+
+
+def test_unencrypted_computation():
+    for enc1 in (False, True):
+        for enc2 in (False, True):
+            prog = EvaProgram('UnencryptedInputs', vec_size=128)
+            with prog:
+                x1 = Input('x1', enc1)
+                x2 = Input('x2', enc2)
+                Output('y', pow(x2, 3) + x1 * x2)
+            prog.set_output_ranges(20)
+            prog.set_input_scales(30)
+            compile_and_check(prog)
+
+
+def test_transparent_ciphertext():
+    prog = EvaProgram('Transparent', vec_size=4096)
+    with prog:
+        x = Input('x')
+        Output('y', x - x + x * 0)
+    prog.set_output_ranges(20)
+    prog.set_input_scales(30)
+    compile_and_check(prog, check_bit_exact=True)
+
+
+def test_x1x1x2_scale60():
+    prog = EvaProgram('prog', vec_size=128)
+    with prog:
+        x1, x2 = Input('x1'), Input('x2')
+        Output('y', x1 * x1 * x2)
+    prog.set_output_ranges(20)
+    prog.set_input_scales(60)
+    compile_and_check(prog, check_bit_exact=True)
+
+
+@pytest.mark.parametrize("enc", [True, False])
+def test_horizontal_sum(enc):
+    prog = EvaProgram('HorizontalSum', vec_size=2048)
+    with prog:
+        x = Input('x', is_encrypted=enc)
+        Output('y', horizontal_sum(x))
+    prog.set_output_ranges(25)
+    prog.set_input_scales(33)
+    compile_and_check(prog, check_bit_exact=enc)
+
+
+@pytest.mark.parametrize("rescaler", ['lazy_waterline', 'eager_waterline', 'always'])
+@pytest.mark.parametrize("balance", ['true', 'false'])
+def test_sobel_configs(rescaler, balance):
+    """tests/large_programs.py:10-53 — Sobel on a 90x90 image padded to vec 8192"""
+    sobel = _sobel(90, 90, 2 ** math.ceil(math.log(90 * 90, 2)))
+    sobel.set_input_scales(45)
+    sobel.set_output_ranges(20)
+    compile_and_check(sobel, config={'rescaler': rescaler, 'balance_reductions': balance},
+                      check_bit_exact=(rescaler == 'lazy_waterline' and balance == 'true'))
+
+
+def _image(n):
+    return {'image': [((37 * i) % 256) / 255.0 for i in range(n)]}
+
+
+def test_sobel_example_n8192_bit_exact():
+    """BASELINE config 2: examples/image_processing.py Sobel 64x64, N = 2^13"""
+    sobel = _sobel(64, 64, 4096)
+    sobel.set_input_scales(25)
+    sobel.set_output_ranges(10)
+    compiled, params, _ = compile_and_check(sobel, _image(4096), check_bit_exact=True)
+    assert params.poly_modulus_degree == 8192
+
+
+def _harris():
+    h = w = 64
+
+    def convolution(image, width, filt):
+        for i in range(3):
+            for j in range(3):
+                partial = (image << i * width + j) * filt[i][j]
+                convolved = partial if (i == 0 and j == 0) else convolved + partial
+        return convolved
+
+    def convolutionXY(image, width, filt):
+        for i in range(3):
+            for j in range(3):
+                rotated = image << (i * width + j)
+                hz, vt = rotated * filt[i][j], rotated * filt[j][i]
+                if i == 0 and j == 0:
+                    Ix, Iy = hz, vt
+                else:
+                    Ix += hz
+                    Iy += vt
+        return Ix, Iy
+
+    harris = EvaProgram('harris', vec_size=h * w)
+    with harris:
+        image = Input('image')
+        sobel_filter = [[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]]
+        pool = [[1, 1, 1], [1, 1, 1], [1, 1, 1]]
+        c = 0.04
+        Ix, Iy = convolutionXY(image, w, sobel_filter)
+        Ixx, Iyy, Ixy = Ix ** 2, Iy ** 2, Ix * Iy
+        Sxx, Syy, Sxy = convolution(Ixx, w, pool), convolution(Iyy, w, pool), convolution(Ixy, w, pool)
+        det = Sxx * Syy - Sxy * Sxy
+        trace = Sxx + Syy
+        Output('image', det - trace ** 2 * c)
+    harris.set_input_scales(30)
+    harris.set_output_ranges(20)
+    return harris
+
+
+def test_harris_example():
+    """BASELINE config 3: examples/image_processing.py Harris 64x64 (N as selected by the compiler)"""
+    compiled, params, _ = compile_and_check(_harris(), _image(4096), check_bit_exact=True)
+    assert params.poly_modulus_degree >= 16384
+
+
+def test_regression_programs():
+    """tests/large_programs.py:55-146 — deterministic inputs"""
+    linreg = EvaProgram('linear_regression', vec_size=2048)
+    with linreg:
+        p = 63
+        x = [Input(f'x{i}') for i in range(p)]
+        e = Input('e')
+        y = e + 6.56
+        for i in range(p):
+            y += x[i] * (i * 0.732)
+        Output('y', y)
+    linreg.set_input_scales(40)
+    linreg.set_output_ranges(30)
+    inputs = {'e': [(2048 - i) * 0.001 for i in range(2048)]}
+    for i in range(63):
+        inputs[f'x{i}'] = [i * j * 0.01 for j in range(2048)]
+    compile_and_check(linreg, inputs)
+
+    polyreg = EvaProgram('polynomial_regression', vec_size=4096)
+    with polyreg:
+        x, e = Input('x'), Input('e')
+        y = e + 6.56
+        for i in range(4):
+            x_i = x
+            for j in range(i):
+                x_i = x_i * x
+            y += x_i * (i * 0.732)
+        Output('y', y)
+    polyreg.set_input_scales(40)
+    polyreg.set_output_ranges(30)
+    compile_and_check(polyreg, {'x': [i * 0.01 for i in range(4096)],
+                                'e': [(4096 - i) * 0.001 for i in range(4096)]})

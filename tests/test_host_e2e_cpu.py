@@ -1,0 +1,64 @@
+"""CPU end-to-end: compiler + host crypto (keygen / encode / encrypt / decrypt) with the compiled
+DAG walked over the CPU oracle — the reference's statistical oracle (MSE < 0.01,
+/root/reference/tests/common.py:34) on the reference's own programs, without a GPU.  Also pins the
+oracle's evaluator semantics end to end (rotation direction, rescale, relinearize decrypt right)."""
+import numpy as np
+import pytest
+
+from eva import EvaProgram, Input, Output
+from eva.std.numeric import horizontal_sum
+from evatest import compile_and_check
+
+
+def test_readme_polynomial():
+    poly = EvaProgram('Polynomial', vec_size=1024)
+    with poly:
+        x = Input('x')
+        Output('y', 3 * x ** 2 + 5 * x - 2)
+    poly.set_output_ranges(30)
+    poly.set_input_scales(30)
+    compile_and_check(poly, {'x': [i / 64.0 for i in range(1024)]}, executor="oracle")
+
+
+@pytest.mark.parametrize("rot", [-2, -1, 0, 1])
+@pytest.mark.parametrize("left", [True, False])
+def test_rotations_small(rot, left):
+    prog = EvaProgram('RotOp', vec_size=8)
+    with prog:
+        x = Input('x')
+        Output('y', (x << rot) if left else (x >> rot))
+    prog.set_output_ranges(20)
+    prog.set_input_scales(30)
+    compile_and_check(prog, executor="oracle")
+
+
+def test_mixed_raw_cipher_and_cube():
+    for enc1 in (False, True):
+        prog = EvaProgram('UnencryptedInputs', vec_size=128)
+        with prog:
+            x1 = Input('x1', enc1)
+            x2 = Input('x2', True)
+            Output('y', pow(x2, 3) + x1 * x2)
+        prog.set_output_ranges(20)
+        prog.set_input_scales(30)
+        compile_and_check(prog, executor="oracle")
+
+
+def test_horizontal_sum_small():
+    prog = EvaProgram('HorizontalSum', vec_size=64)
+    with prog:
+        x = Input('x')
+        Output('y', horizontal_sum(x))
+    prog.set_output_ranges(25)
+    prog.set_input_scales(25)
+    compile_and_check(prog, executor="oracle")
+
+
+def test_transparent_ciphertext():
+    prog = EvaProgram('Transparent', vec_size=512)
+    with prog:
+        x = Input('x')
+        Output('y', x - x + x * 0)
+    prog.set_output_ranges(20)
+    prog.set_input_scales(30)
+    compile_and_check(prog, executor="oracle")
