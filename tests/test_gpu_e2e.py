@@ -128,8 +128,9 @@ def test_sobel_example_n8192_bit_exact():
     sobel = _sobel(64, 64, 4096)
     sobel.set_input_scales(25)
     sobel.set_output_ranges(10)
-    compiled, params, _ = compile_and_check(sobel, _image(4096), check_bit_exact=True)
-    assert params.poly_modulus_degree == 8192
+    def force(params):  # N forced to 2^13 (legal: seal.cpp:169 uses sec_level none)
+        params.poly_modulus_degree = 8192
+    compile_and_check(sobel, _image(4096), check_bit_exact=True, params_hook=force)
 
 
 def _harris():
@@ -172,9 +173,11 @@ def _harris():
 
 
 def test_harris_example():
-    """BASELINE config 3: examples/image_processing.py Harris 64x64 (N as selected by the compiler)"""
-    compiled, params, _ = compile_and_check(_harris(), _image(4096), check_bit_exact=True)
-    assert params.poly_modulus_degree >= 16384
+    """BASELINE config 3: examples/image_processing.py Harris 64x64, N forced to 2^15"""
+    def force(params):
+        params.poly_modulus_degree = 32768
+    compiled, params, _ = compile_and_check(_harris(), _image(4096), check_bit_exact=True, params_hook=force)
+    assert list(params.prime_bits) == [60] * 5 and len(params.rotations) == 9
 
 
 def test_regression_programs():
