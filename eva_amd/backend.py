@@ -28,12 +28,18 @@ _vpp = C.POINTER(C.c_void_p)
 _SIGS = {
     "evah_device_count": [C.POINTER(C.c_int)],
     "evah_ctx_create": [C.c_uint32, C.c_uint32, _u64p, C.c_int, _vpp],
+    "evah_ctx_fork": [_vp, _vpp],
     "evah_ctx_set_stream": [_vp, _vp],
     "evah_ctx_sync": [_vp],
     "evah_ctx_mem_info": [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "evah_key_upload": [_vp, C.c_int, C.c_uint32, C.c_uint32, _u64p],
     "evah_galois_elt_from_step": [_vp, C.c_int32, C.POINTER(C.c_uint32)],
     "evah_ct_upload": [_vp, C.c_uint32, C.c_uint32, C.c_double, _u64p, _vpp],
+    "evah_ct_write": [_vp, _vp, _u64p],
+    "evah_pt_write": [_vp, _vp, _u64p],
+    "evah_capture_begin": [_vp, _vpp, C.c_uint32],
+    "evah_capture_end": [_vp, _vpp, C.c_uint32, _vpp],
+    "evah_graph_launch": [_vp, _vp],
     "evah_ct_info": [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double)],
     "evah_ct_download": [_vp, _vp, _u64p],
     "evah_pt_upload": [_vp, C.c_uint32, C.c_double, _u64p, _vpp],
@@ -64,6 +70,7 @@ _VOID = {
     "evah_ctx_destroy": [_vp],
     "evah_ct_free": [_vp, _vp],
     "evah_pt_free": [_vp, _vp],
+    "evah_graph_free": [_vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + list(_VOID) + [
     "evah_last_error", "evah_abi_version", "evah_profile_classes", "evah_profile_class_name"])
@@ -202,6 +209,15 @@ class Context:
         self.h = None
         _chk(_lib.evah_ctx_create(self.N, self.k, _p(arr), int(device), C.byref(h)))
         self.h = h
+
+    def fork(self):
+        """Another issue queue (own stream + pool) sharing this context's tables and keys."""
+        child = Context.__new__(Context)
+        child.N, child.primes, child.k, child.h = self.N, self.primes, self.k, None
+        h = C.c_void_p()
+        _chk(_lib.evah_ctx_fork(self.h, C.byref(h)))
+        child.h = h
+        return child
 
     def close(self):
         if self.h:

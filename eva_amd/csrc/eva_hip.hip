@@ -8,9 +8,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -134,11 +137,15 @@ k_galois_perm(DevCtx cx, const u64 *a, size_t a_ps, const uint32_t *perm, u64 *o
   st2(out + p * o_ps + off, r);
 }
 
-// per-limb constant fill (uniform-constant plaintexts)
-__global__ void __launch_bounds__(256) k_fill_limbs(DevCtx cx, const u64 *vals, u64 *out) {
+// per-limb constant fill (uniform-constant plaintexts); the per-limb values travel as a
+// kernel argument so the call needs no host->device copy and no synchronisation
+struct LimbVals {
+  u64 v[64];
+};
+__global__ void __launch_bounds__(256) k_fill_limbs(DevCtx cx, LimbVals vals, u64 *out) {
   EW_SETUP
   ulonglong2 r;
-  r.x = r.y = vals[i];
+  r.x = r.y = vals.v[i];
   st2(out + off, r);
 }
 
@@ -213,6 +220,11 @@ struct Buffer {
   u64 *d;
   size_t bytes;
   int refs;
+  Pool *pool;                       // owning queue's pool (handles may be freed through any fork)
+  evah_ctx *owner;                  // queue whose stream produced / will recycle this buffer
+  bool ready_everywhere;            // contents were synchronised with the host (uploads)
+  std::vector<evah_ctx *> synced;   // foreign queues that already wait for the producer
+  std::vector<evah_ctx *> readers;  // foreign queues that have enqueued reads
 };
 
 // Kernel classes for the optional per-launch HIP-event profile (bench.py's roofline leg).
@@ -261,20 +273,43 @@ struct evah_pt {
   uint32_t limbs;
   double scale;
 };
+struct evah_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+// Device state shared by a context and its forks: tables, keys, permutation tables.
+struct SharedDev {
+  int device = 0;
+  void *d_tables = nullptr;
+  KeyDev relin;
+  std::map<uint32_t, KeyDev> galois;
+  std::map<uint32_t, uint32_t *> perms;
+  ~SharedDev() {
+    (void)hipSetDevice(device);
+    if (relin.d) (void)hipFree(relin.d);
+    for (auto &kv : galois) (void)hipFree(kv.second.d);
+    for (auto &kv : perms) (void)hipFree(kv.second);
+    if (d_tables) (void)hipFree(d_tables);
+  }
+};
 
 struct evah_ctx {
+  std::shared_ptr<SharedDev> sh;
   int device = 0;
   uint32_t N = 0, logN = 0, k = 0;
   std::vector<u64> primes;
   std::vector<int> total_bits; // total_bits[l] = bit length of prod primes[0..l)
   DevCtx dev{};
-  void *d_tables = nullptr;
   hipStream_t own = nullptr, stream = nullptr;
   Pool pool;
-  KeyDev relin;
-  std::map<uint32_t, KeyDev> galois;
-  std::map<uint32_t, uint32_t *> perms;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool capturing = false;              // inside evah_capture_begin/end: no syncs, no profiling events
+  std::vector<hipEvent_t> capture_events; // events consumed by the capture in progress
+  std::vector<hipEvent_t> sync_events; // recycled events for cross-queue ordering
+  int ntt_lr = 3; // log2(coefficients per thread) in the NTT kernels (EVAH_NTT_LR=3|4)
+  bool fuse_mac = true; // key-switch: fuse the inner product into the digit NTTs' second pass
+  int ks_threads = 256; // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS)
   // per-launch profile
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
@@ -314,7 +349,7 @@ struct ProfScope { // brackets one kernel launch with HIP events on the launch s
   int cls;
   hipEvent_t e0 = nullptr;
   ProfScope(evah_ctx *c_, int cls_) : c(c_), cls(cls_) {
-    if (c->prof_on) {
+    if (c->prof_on && !c->capturing) {
       if (c->prof_recs.size() >= 8192) prof_drain(c);
       e0 = prof_event(c);
       HIPCHK(hipEventRecord(e0, c->stream));
@@ -334,11 +369,48 @@ static Buffer *buf_new(evah_ctx *c, size_t elems) {
   b->bytes = elems * sizeof(u64);
   b->d = (u64 *)c->pool.alloc(b->bytes);
   b->refs = 1;
+  b->pool = &c->pool;
+  b->owner = c;
+  b->ready_everywhere = false;
   return b;
 }
+static hipEvent_t sync_event(evah_ctx *c) {
+  if (!c->capturing && !c->sync_events.empty()) {
+    hipEvent_t e = c->sync_events.back();
+    c->sync_events.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return e;
+}
+// make `waiter`'s stream wait for everything enqueued so far on `signaller`'s stream
+static void stream_wait(evah_ctx *waiter, evah_ctx *signaller) {
+  if (waiter == signaller || waiter->stream == signaller->stream) return;
+  hipEvent_t e = sync_event(waiter);
+  HIPCHK(hipEventRecord(e, signaller->stream));
+  HIPCHK(hipStreamWaitEvent(waiter->stream, e, 0));
+  // eager mode: the wait captured this record, so the event can be re-recorded right away.
+  // While capturing, an event is used for exactly one record/wait pair of the graph (re-recording
+  // one inside a capture has produced cyclic graphs with the ROCm 7.2 runtime).
+  if (waiter->capturing || signaller->capturing) waiter->capture_events.push_back(e);
+  else waiter->sync_events.push_back(e);
+}
+// Called before queue `c` enqueues a read of `b`: orders the read after the producer and
+// remembers the reader so the buffer is not recycled under it.
+static void acquire(evah_ctx *c, Buffer *b) {
+  if (!b || b->owner == c) return;
+  if (!b->ready_everywhere && std::find(b->synced.begin(), b->synced.end(), c) == b->synced.end()) {
+    stream_wait(c, b->owner);
+    b->synced.push_back(c);
+  }
+  if (std::find(b->readers.begin(), b->readers.end(), c) == b->readers.end()) b->readers.push_back(c);
+}
 static void buf_unref(evah_ctx *c, Buffer *b) {
+  (void)c;
   if (b && --b->refs == 0) {
-    c->pool.free(b->d, b->bytes);
+    for (evah_ctx *r : b->readers) stream_wait(b->owner, r); // recycle only after foreign reads
+    b->pool->free(b->d, b->bytes);
     delete b;
   }
 }
@@ -381,30 +453,58 @@ template <> struct OpClass<OpPlain> { static constexpr int fwd_a = KC_NTT_A, fwd
 template <> struct OpClass<OpKsDigit> { static constexpr int fwd_a = KC_KSDIGIT_A, fwd_b = KC_KSDIGIT_B; };
 template <> struct OpClass<OpModDown> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 
-template <int P, bool STRIDED, bool INVERSE, class Op>
+template <int P, int LR, bool STRIDED, bool INVERSE, class Op>
 static void launch_pass(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
   ProfScope ps(c, INVERSE ? (STRIDED ? KC_INTT_B : KC_INTT_A)
                           : (STRIDED ? OpClass<Op>::fwd_a : OpClass<Op>::fwd_b));
-  const uint32_t tile = c->N < (uint32_t)NTT_TILE ? c->N : (uint32_t)NTT_TILE;
+  const uint32_t max_tile = (uint32_t)NTT_THREADS << LR;
+  const uint32_t tile = c->N < max_tile ? c->N : max_tile;
   const int logC = (int)ilog2(tile) - P;
   const size_t lds = ((size_t)1 << logC) * lds_sub_stride<P>() * sizeof(u64);
-  dim3 grid(c->N / tile, jobs), block(tile / NTT_R);
-  hipLaunchKernelGGL((ntt_pass_kernel<P, STRIDED, INVERSE, Op>), grid, block, lds, c->stream, c->dev,
+  dim3 grid(c->N / tile, jobs), block(tile >> LR);
+  hipLaunchKernelGGL((ntt_pass_kernel<P, LR, STRIDED, INVERSE, Op>), grid, block, lds, c->stream, c->dev,
                      prm, logC);
   HIPCHK(hipGetLastError());
 }
 
-template <bool STRIDED, bool INVERSE, class Op>
-static void launch_pass_p(evah_ctx *c, int P, const typename Op::Params &prm, uint32_t jobs) {
+template <int LR, bool STRIDED, bool INVERSE, class Op>
+static void launch_pass_lr(evah_ctx *c, int P, const typename Op::Params &prm, uint32_t jobs) {
   switch (P) {
-  case 5: launch_pass<5, STRIDED, INVERSE, Op>(c, prm, jobs); break;
-  case 6: launch_pass<6, STRIDED, INVERSE, Op>(c, prm, jobs); break;
-  case 7: launch_pass<7, STRIDED, INVERSE, Op>(c, prm, jobs); break;
-  case 8: launch_pass<8, STRIDED, INVERSE, Op>(c, prm, jobs); break;
+  case 5: launch_pass<5, LR, STRIDED, INVERSE, Op>(c, prm, jobs); break;
+  case 6: launch_pass<6, LR, STRIDED, INVERSE, Op>(c, prm, jobs); break;
+  case 7: launch_pass<7, LR, STRIDED, INVERSE, Op>(c, prm, jobs); break;
+  case 8: launch_pass<8, LR, STRIDED, INVERSE, Op>(c, prm, jobs); break;
   case 9:
-    if constexpr (STRIDED) { launch_pass<9, STRIDED, INVERSE, Op>(c, prm, jobs); break; }
+    if constexpr (STRIDED) { launch_pass<9, LR, STRIDED, INVERSE, Op>(c, prm, jobs); break; }
     [[fallthrough]];
   default: throw std::runtime_error("unsupported poly_modulus_degree for the NTT kernels");
+  }
+}
+template <bool STRIDED, bool INVERSE, class Op>
+static void launch_pass_p(evah_ctx *c, int P, const typename Op::Params &prm, uint32_t jobs) {
+  if (c->ntt_lr == 4) launch_pass_lr<4, STRIDED, INVERSE, Op>(c, P, prm, jobs);
+  else launch_pass_lr<3, STRIDED, INVERSE, Op>(c, P, prm, jobs);
+}
+
+template <int P, int LR>
+static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scratch, const u64 *key, u64 *prod, uint32_t l) {
+  ProfScope ps(c, KC_KSMAC);
+  const uint32_t max_tile = (uint32_t)c->ks_threads << LR;
+  const uint32_t tile = c->N < max_tile ? c->N : max_tile;
+  const int logC = (int)ilog2(tile) - P;
+  if (logC < 0) throw std::runtime_error("ks_inner tile smaller than one sub-transform");
+  const size_t lds = ((size_t)1 << logC) * lds_sub_stride<P>() * sizeof(u64);
+  hipLaunchKernelGGL((ks_inner_kernel<P, LR>), dim3(c->N / tile, l + 1), dim3(tile >> LR), lds, c->stream, c->dev,
+                     target, scratch, key, prod, l, logC);
+  HIPCHK(hipGetLastError());
+}
+static void launch_ks_inner(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const u64 *key, u64 *prod, uint32_t l) {
+  switch (P) {
+  case 5: launch_ks_inner_plr<5, 3>(c, target, scratch, key, prod, l); break;
+  case 6: launch_ks_inner_plr<6, 3>(c, target, scratch, key, prod, l); break;
+  case 7: launch_ks_inner_plr<7, 3>(c, target, scratch, key, prod, l); break;
+  case 8: launch_ks_inner_plr<8, 3>(c, target, scratch, key, prod, l); break;
+  default: throw std::runtime_error("unsupported poly_modulus_degree for the key-switch kernel");
   }
 }
 
@@ -431,16 +531,21 @@ static void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev 
   // 1. digits to coefficient form
   OpPlain::Params ip{target, t.d, 0, 0, l, 0, 0};
   ntt_inverse<OpPlain>(c, ip, l);
-  // 2a. base-convert + NTT every digit under every output prime
   OpKsDigit::Params dp{t.d, sc.d, l};
-  ntt_forward<OpKsDigit>(c, dp, (l + 1) * l);
-  // 2b. inner product with the key
-  {
-  ProfScope ps(c, KC_KSMAC);
-  hipLaunchKernelGGL(k_ks_mac, dim3(c->N / 512, l + 1), dim3(256), 0, c->stream, c->dev, target, sc.d,
-                     key.d, prod.d, l);
+  if (c->fuse_mac) {
+    // 2a. base-convert + first (strided) NTT pass of every digit under every output prime
+    const int a = (c->logN + 1) / 2, b = c->logN / 2;
+    launch_pass_p<true, false, OpKsDigit>(c, a, dp, (l + 1) * l);
+    // 2b. second (contiguous) pass fused with the inner product with the key
+    launch_ks_inner(c, b, target, sc.d, key.d, prod.d, l);
+  } else {
+    // unfused reference path (EVAH_FUSE_MAC=0): full digit NTTs, then a separate MAC kernel
+    ntt_forward<OpKsDigit>(c, dp, (l + 1) * l);
+    ProfScope ps(c, KC_KSMAC);
+    hipLaunchKernelGGL(k_ks_mac, dim3(c->N / 512, l + 1), dim3(256), 0, c->stream, c->dev, target, sc.d,
+                       key.d, prod.d, l);
+    HIPCHK(hipGetLastError());
   }
-  HIPCHK(hipGetLastError());
   // 3. mod-down by the special prime: INTT(special limb) + P/2, then per-limb NTT + combine
   Scratch r(c, 2 * N);
   OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1};
@@ -529,6 +634,12 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     c->logN = ilog2(N);
     c->k = k;
     c->primes.assign(primes, primes + k);
+    if (const char *e = std::getenv("EVAH_NTT_LR")) c->ntt_lr = std::atoi(e) == 4 ? 4 : 3;
+    if (const char *e = std::getenv("EVAH_FUSE_MAC")) c->fuse_mac = std::atoi(e) != 0;
+    if (const char *e = std::getenv("EVAH_KS_THREADS")) {
+      int t = std::atoi(e);
+      if (t == 64 || t == 128 || t == 256) c->ks_threads = t;
+    }
     for (u64 q : c->primes)
       if (q >= ((u64)1 << 61) || (q - 1) % (2ull * N) || !is_prime(q))
         throw std::invalid_argument("coeff modulus primes must be < 2^61, prime and 1 mod 2N");
@@ -578,9 +689,11 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
         }
       }
     }
-    HIPCHK(hipMalloc(&c->d_tables, total));
-    HIPCHK(hipMemcpy(c->d_tables, host.data(), total, hipMemcpyHostToDevice));
-    auto *base = reinterpret_cast<unsigned char *>(c->d_tables);
+    c->sh = std::make_shared<SharedDev>();
+    c->sh->device = device;
+    HIPCHK(hipMalloc(&c->sh->d_tables, total));
+    HIPCHK(hipMemcpy(c->sh->d_tables, host.data(), total, hipMemcpyHostToDevice));
+    auto *base = reinterpret_cast<unsigned char *>(c->sh->d_tables);
     c->dev.primes = reinterpret_cast<const DevPrime *>(base);
     c->dev.tw_fwd = reinterpret_cast<const ulonglong2 *>(base + sz_pr);
     c->dev.tw_inv = reinterpret_cast<const ulonglong2 *>(base + sz_pr + sz_tw);
@@ -597,17 +710,44 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
   API_END
 }
 
+int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
+  API_BEGIN
+  use(parent);
+  auto *c = new evah_ctx;
+  try {
+    c->sh = parent->sh;
+    c->device = parent->device;
+    c->N = parent->N;
+    c->logN = parent->logN;
+    c->k = parent->k;
+    c->primes = parent->primes;
+    c->total_bits = parent->total_bits;
+    c->dev = parent->dev;
+    c->ntt_lr = parent->ntt_lr;
+    c->fuse_mac = parent->fuse_mac;
+    c->ks_threads = parent->ks_threads;
+    HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
+    c->stream = c->own;
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+  } catch (...) {
+    evah_ctx_destroy(c);
+    throw;
+  }
+  *out = c;
+  API_END
+}
+
 void evah_ctx_destroy(evah_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->relin.d) (void)hipFree(c->relin.d);
-  for (auto &kv : c->galois) (void)hipFree(kv.second.d);
-  for (auto &kv : c->perms) (void)hipFree(kv.second);
   c->pool.release_cached();
-  if (c->d_tables) (void)hipFree(c->d_tables);
+  c->sh.reset(); // tables and keys go when the last fork goes
   for (auto &r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : c->prof_free) (void)hipEventDestroy(e);
+  for (auto e : c->sync_events) (void)hipEventDestroy(e);
+  for (auto e : c->capture_events) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own) (void)hipStreamDestroy(c->own);
@@ -654,6 +794,7 @@ int evah_galois_elt_from_step(evah_ctx *c, int32_t steps, uint32_t *elt) {
 int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digits, const uint64_t *data) {
   API_BEGIN
   use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
   if (n_digits == 0 || n_digits > c->k - 1) throw std::invalid_argument("invalid key digit count");
   KeyDev kd;
   kd.n_digits = n_digits;
@@ -661,16 +802,16 @@ int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digit
   HIPCHK(hipMalloc(&kd.d, kd.bytes));
   HIPCHK(hipMemcpy(kd.d, data, kd.bytes, hipMemcpyHostToDevice));
   if (kind == EVAH_KEY_RELIN) {
-    if (c->relin.d) (void)hipFree(c->relin.d);
-    c->relin = kd;
+    if (c->sh->relin.d) (void)hipFree(c->sh->relin.d);
+    c->sh->relin = kd;
   } else if (kind == EVAH_KEY_GALOIS) {
     if (!(galois_elt & 1) || galois_elt >= 2 * c->N) {
       (void)hipFree(kd.d);
       throw std::invalid_argument("Galois element is not valid");
     }
-    auto it = c->galois.find(galois_elt);
-    if (it != c->galois.end()) (void)hipFree(it->second.d);
-    c->galois[galois_elt] = kd;
+    auto it = c->sh->galois.find(galois_elt);
+    if (it != c->sh->galois.end()) (void)hipFree(it->second.d);
+    c->sh->galois[galois_elt] = kd;
   } else {
     (void)hipFree(kd.d);
     throw std::invalid_argument("unknown key kind");
@@ -681,13 +822,93 @@ int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digit
 int evah_ct_upload(evah_ctx *c, uint32_t size, uint32_t limbs, double scale, const uint64_t *data, evah_ct **out) {
   API_BEGIN
   use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
   if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
   if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
   evah_ct *t = ct_new(c, size, limbs, scale);
   HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)size * limbs * c->N, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  t->buf->ready_everywhere = true;
   *out = t;
   API_END
+}
+
+int evah_ct_write(evah_ctx *c, evah_ct *ct, const uint64_t *data) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("evah_ct_write cannot be captured into a graph");
+  if (ct->ps != (size_t)ct->limbs * c->N) throw std::invalid_argument("cannot write into a mod-switched view");
+  acquire(c, ct->buf);
+  HIPCHK(hipMemcpyAsync(ct->d, data, sizeof(u64) * (size_t)ct->size * ct->limbs * c->N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream)); // pageable source: the caller may reuse it after return
+  API_END
+}
+
+int evah_pt_write(evah_ctx *c, evah_pt *pt, const uint64_t *data) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("evah_pt_write cannot be captured into a graph");
+  acquire(c, pt->buf);
+  HIPCHK(hipMemcpyAsync(pt->d, data, sizeof(u64) * (size_t)pt->limbs * c->N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  API_END
+}
+
+int evah_capture_begin(evah_ctx *q0, evah_ctx **others, uint32_t n_others) {
+  API_BEGIN
+  use(q0);
+  HIPCHK(hipStreamSynchronize(q0->stream));
+  for (uint32_t i = 0; i < n_others; i++) HIPCHK(hipStreamSynchronize(others[i]->stream));
+  HIPCHK(hipStreamBeginCapture(q0->stream, hipStreamCaptureModeRelaxed));
+  q0->capturing = true;
+  for (uint32_t i = 0; i < n_others; i++) { // fork: every queue joins the capture
+    stream_wait(others[i], q0);
+    others[i]->capturing = true;
+  }
+  API_END
+}
+
+int evah_capture_end(evah_ctx *q0, evah_ctx **others, uint32_t n_others, evah_graph **out) {
+  API_BEGIN
+  use(q0);
+  for (uint32_t i = 0; i < n_others; i++) { // join
+    stream_wait(q0, others[i]);
+    others[i]->capturing = false;
+  }
+  q0->capturing = false;
+  auto *g = new evah_graph;
+  hipError_t e = hipStreamEndCapture(q0->stream, &g->graph);
+  if (e != hipSuccess) {
+    delete g;
+    throw std::runtime_error(std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
+  }
+  for (uint32_t i = 0; i <= n_others; i++) { // events of this capture may be recycled now
+    evah_ctx *q = i ? others[i - 1] : q0;
+    q->sync_events.insert(q->sync_events.end(), q->capture_events.begin(), q->capture_events.end());
+    q->capture_events.clear();
+  }
+  e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    throw std::runtime_error(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e));
+  }
+  *out = g;
+  API_END
+}
+
+int evah_graph_launch(evah_ctx *q0, evah_graph *g) {
+  API_BEGIN
+  use(q0);
+  HIPCHK(hipGraphLaunch(g->exec, q0->stream));
+  API_END
+}
+
+void evah_graph_free(evah_graph *g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
 }
 
 int evah_ct_info(const evah_ct *ct, uint32_t *size, uint32_t *limbs, double *scale) {
@@ -701,6 +922,8 @@ int evah_ct_info(const evah_ct *ct, uint32_t *size, uint32_t *limbs, double *sca
 int evah_ct_download(evah_ctx *c, const evah_ct *ct, uint64_t *out) {
   API_BEGIN
   use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  acquire(c, ct->buf);
   const size_t row = sizeof(u64) * (size_t)ct->limbs * c->N;
   HIPCHK(hipMemcpy2DAsync(out, row, ct->d, sizeof(u64) * ct->ps, row, ct->size, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -716,10 +939,12 @@ void evah_ct_free(evah_ctx *c, evah_ct *ct) {
 int evah_pt_upload(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *data, evah_pt **out) {
   API_BEGIN
   use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
   if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
   evah_pt *t = pt_new(c, limbs, scale);
   HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)limbs * c->N, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  t->buf->ready_everywhere = true;
   *out = t;
   API_END
 }
@@ -727,12 +952,14 @@ int evah_pt_upload(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *da
 int evah_pt_upload_coeff(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *data, evah_pt **out) {
   API_BEGIN
   use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
   if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
   evah_pt *t = pt_new(c, limbs, scale);
   HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)limbs * c->N, hipMemcpyHostToDevice, c->stream));
   OpPlain::Params p{t->d, t->d, 0, 0, limbs, 0, 0};
   ntt_forward<OpPlain>(c, p, limbs);
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream)); // the pageable host buffer may go away after return
+  t->buf->ready_everywhere = true;
   *out = t;
   API_END
 }
@@ -741,12 +968,12 @@ int evah_pt_uniform(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *v
   API_BEGIN
   use(c);
   if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
+  if (limbs > 64) throw std::invalid_argument("too many limbs");
   evah_pt *t = pt_new(c, limbs, scale);
-  Scratch v(c, limbs);
-  HIPCHK(hipMemcpyAsync(v.d, value, sizeof(u64) * limbs, hipMemcpyHostToDevice, c->stream));
-  EW_LAUNCH(k_fill_limbs, ew_grid(c, limbs, 1), dim3(256), 0, c->stream, c->dev, v.d, t->d);
+  LimbVals lv;
+  for (uint32_t i = 0; i < limbs; i++) lv.v[i] = value[i];
+  EW_LAUNCH(k_fill_limbs, ew_grid(c, limbs, 1), dim3(256), 0, c->stream, c->dev, lv, t->d);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
   *out = t;
   API_END
 }
@@ -761,6 +988,8 @@ int evah_pt_info(const evah_pt *pt, uint32_t *limbs, double *scale) {
 int evah_pt_download(evah_ctx *c, const evah_pt *pt, uint64_t *out) {
   API_BEGIN
   use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  acquire(c, pt->buf);
   HIPCHK(hipMemcpyAsync(out, pt->d, sizeof(u64) * (size_t)pt->limbs * c->N, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   API_END
@@ -777,6 +1006,8 @@ void evah_pt_free(evah_ctx *c, evah_pt *pt) {
 static int addsub_impl(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct **out, int sub) {
   API_BEGIN
   use(c);
+  acquire(c, a->buf);
+  acquire(c, b->buf);
   if (a->limbs != b->limbs) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
   if (!same_scale(a->scale, b->scale)) throw std::invalid_argument("scale mismatch");
   const uint32_t s = std::max(a->size, b->size);
@@ -793,6 +1024,8 @@ int evah_sub(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct **out) { r
 static int addsub_plain_impl(evah_ctx *c, const evah_ct *a, const evah_pt *b, evah_ct **out, int sub) {
   API_BEGIN
   use(c);
+  acquire(c, a->buf);
+  acquire(c, b->buf);
   if (a->limbs != b->limbs) throw std::invalid_argument("encrypted and plain parameter mismatch");
   if (!same_scale(a->scale, b->scale)) throw std::invalid_argument("scale mismatch");
   evah_ct *o = ct_new(c, a->size, a->limbs, a->scale);
@@ -808,6 +1041,7 @@ int evah_sub_plain(evah_ctx *c, const evah_ct *a, const evah_pt *b, evah_ct **ou
 int evah_negate(evah_ctx *c, const evah_ct *a, evah_ct **out) {
   API_BEGIN
   use(c);
+  acquire(c, a->buf);
   evah_ct *o = ct_new(c, a->size, a->limbs, a->scale);
   EW_LAUNCH(k_negate, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps, o->d, o->ps);
   HIPCHK(hipGetLastError());
@@ -818,6 +1052,8 @@ int evah_negate(evah_ctx *c, const evah_ct *a, evah_ct **out) {
 int evah_multiply(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct **out) {
   API_BEGIN
   use(c);
+  acquire(c, a->buf);
+  acquire(c, b->buf);
   if (a->limbs != b->limbs) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
   if (a->size != 2 || b->size != 2) throw std::invalid_argument("multiply supports size-2 operands only (relinearize first)");
   const double ns = a->scale * b->scale;
@@ -832,6 +1068,7 @@ int evah_multiply(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct **out
 int evah_square(evah_ctx *c, const evah_ct *a, evah_ct **out) {
   API_BEGIN
   use(c);
+  acquire(c, a->buf);
   if (a->size != 2) throw std::invalid_argument("square supports size-2 operands only (relinearize first)");
   const double ns = a->scale * a->scale;
   check_scale(c, ns, a->limbs);
@@ -845,6 +1082,8 @@ int evah_square(evah_ctx *c, const evah_ct *a, evah_ct **out) {
 int evah_multiply_plain(evah_ctx *c, const evah_ct *a, const evah_pt *b, evah_ct **out) {
   API_BEGIN
   use(c);
+  acquire(c, a->buf);
+  acquire(c, b->buf);
   if (a->limbs != b->limbs) throw std::invalid_argument("encrypted and plain parameter mismatch");
   const double ns = a->scale * b->scale;
   check_scale(c, ns, a->limbs);
@@ -858,11 +1097,12 @@ int evah_multiply_plain(evah_ctx *c, const evah_ct *a, const evah_pt *b, evah_ct
 int evah_relinearize(evah_ctx *c, const evah_ct *a, evah_ct **out) {
   API_BEGIN
   use(c);
+  acquire(c, a->buf);
   if (a->size != 3) throw std::invalid_argument("relinearize expects a size-3 ciphertext");
-  if (!c->relin.d) throw std::invalid_argument("relinearization key not present");
+  if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
   evah_ct *o = ct_new(c, 2, a->limbs, a->scale);
   try {
-    switch_key(c, a->limbs, a->d + 2 * a->ps, c->relin, a->d, a->ps, 2, o->d, o->ps);
+    switch_key(c, a->limbs, a->d + 2 * a->ps, c->sh->relin, a->d, a->ps, 2, o->d, o->ps);
   } catch (...) {
     evah_ct_free(c, o);
     throw;
@@ -874,6 +1114,7 @@ int evah_relinearize(evah_ctx *c, const evah_ct *a, evah_ct **out) {
 int evah_rotate(evah_ctx *c, const evah_ct *a, int32_t steps, evah_ct **out) {
   API_BEGIN
   use(c);
+  acquire(c, a->buf);
   if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
   const size_t N = c->N;
   if (steps == 0) { // SEAL rotate_internal: no-op
@@ -884,10 +1125,10 @@ int evah_rotate(evah_ctx *c, const evah_ct *a, int32_t steps, evah_ct **out) {
   } else {
     uint32_t elt = 0;
     if (evah_galois_elt_from_step(c, steps, &elt)) throw std::invalid_argument(g_err);
-    auto kit = c->galois.find(elt);
-    if (kit == c->galois.end()) throw std::invalid_argument("Galois key not present");
-    auto pit = c->perms.find(elt);
-    if (pit == c->perms.end()) {
+    auto kit = c->sh->galois.find(elt);
+    if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
+    auto pit = c->sh->perms.find(elt);
+    if (pit == c->sh->perms.end()) {
       std::vector<uint32_t> tab(N);
       for (uint32_t i = 0; i < N; i++) {
         uint32_t reversed = bitrev((uint32_t)N + i, c->logN + 1);
@@ -897,7 +1138,7 @@ int evah_rotate(evah_ctx *c, const evah_ct *a, int32_t steps, evah_ct **out) {
       uint32_t *d = nullptr;
       HIPCHK(hipMalloc(&d, sizeof(uint32_t) * N));
       HIPCHK(hipMemcpy(d, tab.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
-      pit = c->perms.emplace(elt, d).first;
+      pit = c->sh->perms.emplace(elt, d).first;
     }
     Scratch perm(c, (size_t)2 * a->limbs * N); // [c0 permuted][c1 permuted = key-switch target]
     const size_t pps = (size_t)a->limbs * N;
@@ -919,6 +1160,7 @@ int evah_rotate(evah_ctx *c, const evah_ct *a, int32_t steps, evah_ct **out) {
 int evah_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bits, evah_ct **out) {
   API_BEGIN
   use(c);
+  acquire(c, a->buf);
   if (a->limbs < 2) throw std::invalid_argument("end of modulus switching chain reached");
   const uint32_t l = a->limbs;
   const size_t N = c->N;
@@ -948,6 +1190,7 @@ int evah_mod_switch(evah_ctx *c, const evah_ct *a, evah_ct **out) {
 int evah_test_ntt(evah_ctx *c, uint32_t prime_idx, int inverse, uint64_t *host) {
   API_BEGIN
   use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
   if (prime_idx >= c->k) throw std::invalid_argument("prime index out of range");
   Scratch s(c, c->N);
   HIPCHK(hipMemcpyAsync(s.d, host, sizeof(u64) * c->N, hipMemcpyHostToDevice, c->stream));

@@ -27,11 +27,12 @@
 
 namespace evah {
 
-constexpr int NTT_R = 16;      // coefficients per thread
-constexpr int NTT_TILE = 4096; // coefficients per workgroup (max)
+constexpr int NTT_THREADS = 256; // threads per workgroup (max); tile = NTT_THREADS << LR coefficients
 
-template <int P> struct Rounds {
-  static constexpr int NR = (P + 3) / 4;
+// LR = log2(coefficients per thread): 4 -> 16 coefficients / up to 4 stages per LDS round trip,
+// 3 -> 8 coefficients / 3 stages (half the registers, twice the waves in flight)
+template <int P, int LR> struct Rounds {
+  static constexpr int NR = (P + LR - 1) / LR;
   static constexpr int bits(int i) { return P / NR + (i < P % NR ? 1 : 0); }
   static constexpr int lo(int i) {
     int l = P;
@@ -59,9 +60,10 @@ __device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 q, u6
 }
 
 // One register round: RB stages over bit range [LO, LO+RB) of the P-bit local index.
-template <int P, int RB, int LO, bool INVERSE, bool STRIDED>
+template <int P, int LR, int RB, int LO, bool INVERSE, bool STRIDED>
 __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
                                           const ulonglong2 *__restrict__ tw, const DevPrime &pm) {
+  constexpr int NTT_R = 1 << LR;
   constexpr int S = 1 << P, TPS = S / NTT_R, G = NTT_R >> RB, NU = 1 << RB;
   constexpr int S0 = P - LO - RB; // local stages above this round
   const u64 q = pm.q, q2 = pm.q << 1;
@@ -114,25 +116,26 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
   }
 }
 
-template <int P, int I, bool INVERSE, bool STRIDED> struct RoundSeq {
+template <int P, int LR, int I, bool INVERSE, bool STRIDED> struct RoundSeq {
   // forward: rounds 0..NR-1 (top bits first); inverse: NR-1..0 (low bits first)
   static __device__ __forceinline__ void run(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
                                              const ulonglong2 *tw, const DevPrime &pm) {
-    using RS = Rounds<P>;
+    using RS = Rounds<P, LR>;
     constexpr int idx = INVERSE ? (RS::NR - 1 - I) : I;
-    ntt_round<P, RS::bits(idx), RS::lo(idx), INVERSE, STRIDED>(sub_lds, tid, h, pre, tw, pm);
+    ntt_round<P, LR, RS::bits(idx), RS::lo(idx), INVERSE, STRIDED>(sub_lds, tid, h, pre, tw, pm);
     if constexpr (I + 1 < RS::NR) {
       __syncthreads();
-      RoundSeq<P, I + 1, INVERSE, STRIDED>::run(sub_lds, tid, h, pre, tw, pm);
+      RoundSeq<P, LR, I + 1, INVERSE, STRIDED>::run(sub_lds, tid, h, pre, tw, pm);
     }
   }
 };
 
-// One pass.  grid.x = N / tile, grid.y = jobs, block = tile / 16 threads.
-template <int P, bool STRIDED, bool INVERSE, class Op>
-__global__ void __launch_bounds__(256)
+// One pass.  grid.x = N / tile, grid.y = jobs, block = tile >> LR threads.
+template <int P, int LR, bool STRIDED, bool INVERSE, class Op>
+__global__ void __launch_bounds__(NTT_THREADS)
 ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  constexpr int NTT_R = 1 << LR;
   constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
   constexpr bool FIRST = (STRIDED != INVERSE);
   typename Op::Job jb;
@@ -168,7 +171,7 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
   // ---- register rounds
   {
     const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
-    RoundSeq<P, 0, INVERSE, STRIDED>::run(lds + sub * SP, tid, sub0 + sub, pre, tw, pm);
+    RoundSeq<P, LR, 0, INVERSE, STRIDED>::run(lds + sub * SP, tid, sub0 + sub, pre, tw, pm);
   }
   __syncthreads();
 
@@ -198,6 +201,91 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
       }
       Op::store(cx, jb, pm, n, v);
     }
+  }
+}
+
+// Key-switch inner product fused with the second (contiguous) pass of the digit NTTs
+// (SURVEY.md A.6 step 2).  One workgroup owns output limb I = blockIdx.y and one tile of
+// coefficient positions; it walks the digits J, finishing NTT_kappa(t_J) for its tile in LDS
+// (or taking target[J] as is when I == J) and multiply-accumulating with key[J][0/1][kappa] into
+// 128-bit register accumulators.  The l^2 N converted digits are therefore never written back:
+// HBM sees the pass-1 intermediates once, the key once and prod[2][l+1][N] once.
+template <int P, int LR>
+__global__ void __launch_bounds__(NTT_THREADS)
+ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target, const u64 *__restrict__ scratch,
+                const u64 *__restrict__ key, u64 *__restrict__ prod, uint32_t l, int logC) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  constexpr int NTT_R = 1 << LR, NPAIR = NTT_R / 2;
+  constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
+  const uint32_t I = blockIdx.y;
+  const uint32_t kap = (I == l) ? cx.k - 1 : I;
+  const DevPrime pm = cx.primes[kap];
+  const ulonglong2 *tw = cx.tw_fwd + (size_t)kap * cx.N;
+  const int T = blockDim.x;
+  const uint32_t pre = cx.logN - P;
+  const uint32_t sub0 = blockIdx.x << logC, gbase = sub0 << P;
+  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
+  const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
+
+  u128_t acc0[NTT_R], acc1[NTT_R];
+#pragma unroll
+  for (int i = 0; i < NTT_R; i++) { acc0[i] = {0, 0}; acc1[i] = {0, 0}; }
+
+  for (uint32_t J = 0; J < l; J++) {
+    u64 val[NTT_R];
+    if (I == J) { // already in NTT form mod q_J: use the key-switch target directly
+      const u64 *src = target + (size_t)J * N + gbase;
+#pragma unroll
+      for (int it = 0; it < NPAIR; it++) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + 2 * (threadIdx.x + it * T));
+        val[2 * it] = v.x;
+        val[2 * it + 1] = v.y;
+      }
+    } else {
+      const u64 *src = scratch + ((size_t)I * l + J) * N + gbase;
+      __syncthreads(); // previous iteration's LDS reads are done
+#pragma unroll
+      for (int it = 0; it < NPAIR; it++) {
+        const int idx = 2 * (threadIdx.x + it * T);
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + idx);
+        const int sb = idx >> P, e = idx & (S - 1);
+        lds[sb * SP + lds_pad(e)] = v.x;
+        lds[sb * SP + lds_pad(e + 1)] = v.y;
+      }
+      __syncthreads();
+      RoundSeq<P, LR, 0, false, false>::run(lds + sub * SP, tid, sub0 + sub, pre, tw, pm);
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NPAIR; it++) {
+        const int idx = 2 * (threadIdx.x + it * T);
+        const int sb = idx >> P, e = idx & (S - 1);
+        val[2 * it] = lds[sb * SP + lds_pad(e)];       // lazy [0,4q): fine for the 128-bit MAC
+        val[2 * it + 1] = lds[sb * SP + lds_pad(e + 1)];
+      }
+    }
+    const u64 *kp = key + J * key_digit + (size_t)kap * N + gbase;
+#pragma unroll
+    for (int it = 0; it < NPAIR; it++) {
+      const int idx = 2 * (threadIdx.x + it * T);
+      const ulonglong2 k0 = *reinterpret_cast<const ulonglong2 *>(kp + idx);
+      const ulonglong2 k1 = *reinterpret_cast<const ulonglong2 *>(kp + (size_t)cx.k * N + idx);
+      acc128(acc0[2 * it], val[2 * it], k0.x);
+      acc128(acc0[2 * it + 1], val[2 * it + 1], k0.y);
+      acc128(acc1[2 * it], val[2 * it], k1.x);
+      acc128(acc1[2 * it + 1], val[2 * it + 1], k1.y);
+    }
+  }
+  u64 *p0 = prod + (size_t)I * N + gbase, *p1 = prod + ((size_t)(l + 1) + I) * N + gbase;
+#pragma unroll
+  for (int it = 0; it < NPAIR; it++) {
+    const int idx = 2 * (threadIdx.x + it * T);
+    ulonglong2 r0, r1;
+    r0.x = barrett128(acc0[2 * it], pm);
+    r0.y = barrett128(acc0[2 * it + 1], pm);
+    r1.x = barrett128(acc1[2 * it], pm);
+    r1.y = barrett128(acc1[2 * it + 1], pm);
+    *reinterpret_cast<ulonglong2 *>(p0 + idx) = r0;
+    *reinterpret_cast<ulonglong2 *>(p1 + idx) = r1;
   }
 }
 

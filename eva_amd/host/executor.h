@@ -12,7 +12,10 @@
 // There is no CPU evaluator behind execute(): every Cipher/Plain node goes to the GPU library and
 // a missing device is an error.
 #pragma once
+#include <array>
+#include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <functional>
 #include <memory>
 #include <random>
@@ -126,9 +129,19 @@ struct PtHandle {
 // Per-term dispatcher: Term -> one libeva_hip call (SEALExecutor::operator(), :279-404)
 class HipExecutor {
 public:
-  using RuntimeValue = std::variant<std::monostate, std::shared_ptr<CtHandle>, std::shared_ptr<PtHandle>, std::vector<double>>;
+  // An Encode node is materialised lazily on the queue of its first consumer.
+  struct LazyPlain {
+    TermId src;
+    uint32_t scale_bits, level;
+  };
+  using RuntimeValue = std::variant<std::monostate, std::shared_ptr<CtHandle>, std::shared_ptr<PtHandle>, std::vector<double>, LazyPlain>;
 
-  HipExecutor(Program &g, const HostContext &hc, evah_ctx *dev) : program(g), host(hc), ctx(dev), objects(g.size()) {
+  // queues: issue queues (HIP streams) of one device — queues[0] is the root context, the rest
+  // are its forks.  Independent DAG nodes are spread over them (the GPU counterpart of the
+  // reference's Galois worker threads, multicore_program_traversal.h:55-78); ordering between
+  // queues is enforced inside libeva_hip.so per buffer.
+  HipExecutor(Program &g, const HostContext &hc, std::vector<evah_ctx *> qs)
+      : program(g), host(hc), queues(std::move(qs)), ctx(queues.at(0)), objects(g.size()), queue_of(g.size(), 0) {
     if (program.vec_size() > host.N / 2) throw std::runtime_error("Vector size cannot be larger than slot count");
   }
 
@@ -166,13 +179,17 @@ public:
       return;
     }
     const auto &a = x.operands;
+    ctx = queues[choose_queue(t)];
     switch (x.op) {
     case Op::Constant: {
       std::vector<double> v;
       x.constant->expand_to(v, program.vec_size());
       objects[t] = std::move(v);
     } break;
-    case Op::Encode: objects[t] = encode_raw(a[0], x.encode_scale, x.encode_level); break;
+    case Op::Encode:
+      if (!is_raw(a[0])) throw std::runtime_error("Encode expects a raw operand");
+      objects[t] = LazyPlain{a[0], x.encode_scale, x.encode_level};
+      break;
     case Op::Add:
     case Op::Sub:
     case Op::Mul:
@@ -225,14 +242,44 @@ public:
       chk(evah_rescale(ctx, ct(a[0]), x.rescale_divisor, &h));
       objects[t] = std::make_shared<CtHandle>(ctx, h);
     } break;
-    case Op::Output: objects[t] = objects[a[0]]; break;
+    case Op::Output:
+      if (std::holds_alternative<LazyPlain>(objects[a[0]])) (void)pt(a[0]);
+      objects[t] = objects[a[0]];
+      break;
     default: throw std::runtime_error(std::string("Unhandled op ") + op_name(x.op));
     }
   }
 
-  // seal_executor.h:406-418 — release a value whose last consumer has run
+  // ---- hooks used when an execution is captured into a graph
+  const RuntimeValue &value(TermId t) const { return objects[t]; }
+  void set_value(TermId t, RuntimeValue v) { objects[t] = std::move(v); }
+  bool has_value(TermId t) const { return !std::holds_alternative<std::monostate>(objects[t]); }
+  // Evaluate, eagerly and on queue 0, every node that does not depend on a ciphertext or plaintext
+  // input (constants, raw arithmetic, Encode): these become persistent device plaintexts.
+  std::vector<char> prepare_constants() {
+    std::vector<char> done(program.size(), 0);
+    for (TermId t : program.topo_order()) {
+      const Term &x = program.at(t);
+      if (x.op == Op::Input || x.op == Op::Output) continue;
+      bool ok = true;
+      for (TermId o : x.operands)
+        if (!done[o]) ok = false;
+      if (x.operands.empty() && x.op != Op::Constant) ok = false;
+      if (!ok) continue;
+      (*this)(t);
+      if (std::holds_alternative<LazyPlain>(objects[t])) (void)pt(t);
+      done[t] = 1;
+    }
+    return done;
+  }
+
+  // seal_executor.h:406-418 — release a value whose last consumer has run.  Raw vectors that
+  // feed a not-yet-materialised Encode stay until that Encode is dropped.
   void free(TermId t) {
     if (program.at(t).op == Op::Output) return;
+    if (is_raw(t))
+      for (TermId u : program.at(t).uses)
+        if (std::holds_alternative<LazyPlain>(objects[u])) return;
     objects[t] = std::monostate{};
   }
 
@@ -263,12 +310,39 @@ public:
 private:
   Program &program;
   const HostContext &host;
-  evah_ctx *ctx;
+  std::vector<evah_ctx *> queues;
+  evah_ctx *ctx; // queue the current node is issued on
   std::vector<RuntimeValue> objects;
+  std::vector<uint32_t> queue_of;
+  uint32_t next_queue = 0;
   std::vector<double> scratch;
 
+  // Queue for node t: key-switching / rescaling consumers of a fanned-out value are spread
+  // round-robin (they are independent and heavy); everything else follows its first
+  // device-resident operand so chains stay on one stream and need no cross-queue ordering.
+  uint32_t choose_queue(TermId t) {
+    const Term &x = program.at(t);
+    uint32_t base = 0;
+    bool have = false;
+    for (TermId o : x.operands)
+      if (is_cipher(o)) { base = queue_of[o]; have = true; break; }
+    uint32_t q = base;
+    if (queues.size() > 1 && have) {
+      const bool heavy = x.op == Op::RotateLeftConst || x.op == Op::RotateRightConst || x.op == Op::Relinearize ||
+                         x.op == Op::Rescale || (x.op == Op::Mul && x.operands.size() == 2 && is_cipher(x.operands[0]) && is_cipher(x.operands[1]));
+      bool fanout = false;
+      for (TermId o : x.operands)
+        if (is_cipher(o) && program.at(o).uses.size() > 1) fanout = true;
+      if (heavy && fanout) q = next_queue++ % (uint32_t)queues.size();
+    }
+    queue_of[t] = q;
+    return q;
+  }
+
   bool is_cipher(TermId t) const { return std::holds_alternative<std::shared_ptr<CtHandle>>(objects[t]); }
-  bool is_plain(TermId t) const { return std::holds_alternative<std::shared_ptr<PtHandle>>(objects[t]); }
+  bool is_plain(TermId t) const {
+    return std::holds_alternative<std::shared_ptr<PtHandle>>(objects[t]) || std::holds_alternative<LazyPlain>(objects[t]);
+  }
   bool is_raw(TermId t) const { return std::holds_alternative<std::vector<double>>(objects[t]); }
   const std::vector<double> &raw(TermId t) const { return std::get<std::vector<double>>(objects[t]); }
   evah_ct *ct(TermId t) const {
@@ -276,7 +350,10 @@ private:
     if (!p) throw std::runtime_error("Unsupported operation encountered");
     return (*p)->h;
   }
-  evah_pt *pt(TermId t) const { return std::get<std::shared_ptr<PtHandle>>(objects[t])->h; }
+  evah_pt *pt(TermId t) {
+    if (auto *lz = std::get_if<LazyPlain>(&objects[t])) objects[t] = encode_raw(lz->src, lz->scale_bits, lz->level);
+    return std::get<std::shared_ptr<PtHandle>>(objects[t])->h;
+  }
 
   RuntimeValue wrap(evah_ct *h) { return std::make_shared<CtHandle>(ctx, h); }
 
@@ -347,12 +424,13 @@ template <class Exec> void run_serial(Program &p, Exec &ex) {
 // Dependency-counting walk that releases operands when their last consumer has run — the
 // single-queue form of MulticoreProgramTraversal::forwardPass (:55-78): device work is
 // stream-ordered, so "evaluated" means "enqueued".
-template <class Exec> void run_counted(Program &p, Exec &ex) {
+template <class Exec> void run_counted(Program &p, Exec &ex, const std::vector<char> *skip = nullptr) {
   auto order = p.topo_order();
   std::vector<uint32_t> succ(p.size(), 0);
   for (TermId t : order)
     for (TermId o : p.at(t).operands) succ[o]++;
   for (TermId t : order) {
+    if (skip && (*skip)[t]) continue;
     ex(t);
     for (TermId o : p.at(t).operands)
       if (--succ[o] == 0) ex.free(o);
@@ -378,6 +456,12 @@ public:
   std::map<uint32_t, SwitchKey> galois; // by Galois element
   int device = 0;
   bool free_eagerly = true;
+  std::array<double, 3> last_timing{0, 0, 0}; // ms: input upload, DAG enqueue (host), drain + output download
+  // HIP streams independent DAG nodes are spread over (EVA_NUM_STREAMS).  Default 1: at these
+  // kernel sizes a single in-order queue keeps the GPU as busy as the host can feed it; more
+  // queues are correct (ordering is enforced per buffer inside libeva_hip.so) and pay off when
+  // nodes are large enough to be GPU-bound.
+  int num_queues = 1;
 
   // SEALPublic::encrypt (seal.cpp:24-102)
   HipValuation encrypt(const Valuation &inputs, const CKKSSignature &sig) {
@@ -411,16 +495,38 @@ public:
     return out;
   }
 
-  // SEALPublic::execute (seal.cpp:104-122) — THE hot path: upload inputs, walk the DAG issuing
-  // HIP work, download outputs.
+  // SEALPublic::execute (seal.cpp:104-122) — THE hot path.  First call for a program: upload
+  // inputs, walk the DAG issuing HIP work over the queues, download outputs.  From the second call
+  // on (same program object, same input shapes, no Raw inputs) the whole walk is replayed from a
+  // captured hipGraph: per call the host refills the input slots, launches one graph, downloads.
+  bool use_graphs = true; // EVA_GRAPH=0 disables
   HipValuation execute(Program &program, const HipValuation &inputs) {
     ensure_device();
-    HipExecutor ex(program, *host, dev->h);
+    if (graphs_enabled() && graphable(program, inputs)) {
+      auto it = plans.find(&program);
+      if (it == plans.end()) {
+        seen[&program]++;
+        if (seen[&program] >= 2) it = plans.emplace(&program, build_plan(program, inputs)).first;
+      }
+      if (it != plans.end()) {
+        if (it->second->matches(program, inputs)) return run_plan(*it->second, inputs);
+        plans.erase(it); // same address, different program or shapes: forget the stale plan
+        seen[&program] = 1;
+      }
+    }
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+    HipExecutor ex(program, *host, queue_handles());
     ex.set_inputs(inputs);
+    auto t1 = clk::now();
     if (free_eagerly) run_counted(program, ex);
     else run_serial(program, ex);
+    auto t2 = clk::now();
     HipValuation out;
     ex.get_outputs(out);
+    auto t3 = clk::now();
+    last_timing = {std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                   std::chrono::duration<double, std::milli>(t3 - t2).count()};
     return out;
   }
 
@@ -429,8 +535,186 @@ public:
     return dev->h;
   }
 
+  ~HipPublic() {
+    plans.clear();
+    forks.clear(); // queues go before the root context
+    dev.reset();
+  }
+  void drop_graphs() { plans.clear(); seen.clear(); }
+
 private:
   std::shared_ptr<DeviceCtx> dev;
+  struct Fork {
+    evah_ctx *h = nullptr;
+    explicit Fork(evah_ctx *parent) { chk(evah_ctx_fork(parent, &h)); }
+    ~Fork() { evah_ctx_destroy(h); }
+    Fork(const Fork &) = delete;
+    Fork &operator=(const Fork &) = delete;
+  };
+  std::vector<std::unique_ptr<Fork>> forks;
+
+  // A captured execute(): its own queues (pools are exclusive to the graph), persistent input
+  // slots and constant plaintexts, the outputs' handles, the instantiated hipGraph.
+  static uint64_t program_hash(const Program &p) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    for (TermId t : p.topo_order()) {
+      const Term &x = p.at(t);
+      mix(t); mix((uint64_t)x.op); mix((uint64_t)(uint32_t)x.rotation); mix(x.rescale_divisor); mix(x.encode_scale); mix(x.encode_level);
+      for (TermId o : x.operands) mix(o);
+      if (x.constant) for (double v : x.constant->values) { uint64_t b; std::memcpy(&b, &v, 8); mix(b); }
+    }
+    return h;
+  }
+  struct GraphPlan {
+    size_t program_size = 0;
+    uint64_t hash = 0;
+    std::vector<std::unique_ptr<Fork>> queues;
+    std::unordered_map<std::string, std::shared_ptr<CtHandle>> in_ct;
+    std::unordered_map<std::string, std::shared_ptr<PtHandle>> in_pt;
+    std::vector<HipExecutor::RuntimeValue> persistent; // constants
+    std::unordered_map<std::string, HipExecutor::RuntimeValue> outputs;
+    evah_graph *graph = nullptr;
+    ~GraphPlan() {
+      outputs.clear();
+      persistent.clear();
+      in_ct.clear();
+      in_pt.clear();
+      evah_graph_free(graph);
+      queues.clear();
+    }
+    bool matches(const Program &p, const HipValuation &inputs) const {
+      if (p.size() != program_size || program_hash(p) != hash || inputs.values.size() != in_ct.size() + in_pt.size()) return false;
+      for (auto &kv : inputs.values) {
+        if (auto *c = std::get_if<HostCipher>(&kv.second)) {
+          auto it = in_ct.find(kv.first);
+          if (it == in_ct.end()) return false;
+          uint32_t s, l;
+          double sc;
+          if (evah_ct_info(it->second->h, &s, &l, &sc) || s != c->size || l != c->limbs || sc != c->scale) return false;
+        } else if (auto *pl = std::get_if<HostPlain>(&kv.second)) {
+          auto it = in_pt.find(kv.first);
+          if (it == in_pt.end()) return false;
+          uint32_t l;
+          double sc;
+          if (evah_pt_info(it->second->h, &l, &sc) || l != pl->limbs || sc != pl->scale) return false;
+        } else return false;
+      }
+      return true;
+    }
+  };
+  std::unordered_map<const Program *, std::unique_ptr<GraphPlan>> plans;
+  std::unordered_map<const Program *, int> seen;
+
+  bool graphs_enabled() const {
+    if (const char *e = std::getenv("EVA_GRAPH")) return std::atoi(e) != 0;
+    return use_graphs;
+  }
+  static bool graphable(const Program &p, const HipValuation &inputs) {
+    for (auto &kv : inputs.values)
+      if (std::holds_alternative<std::vector<double>>(kv.second)) return false; // Raw inputs feed host-side encodes
+    for (auto &kv : p.inputs())
+      if (p.at(kv.second).type_attr == Type::Raw) return false;
+    return true;
+  }
+
+  std::unique_ptr<GraphPlan> build_plan(Program &program, const HipValuation &inputs) {
+    auto plan = std::make_unique<GraphPlan>();
+    plan->program_size = program.size();
+    plan->hash = program_hash(program);
+    // One queue: multi-branch captures are both slow to launch and unstable to instantiate on
+    // the ROCm 7.2 runtime (recursion blow-up in hipStreamEndCapture on reconvergent DAGs); a
+    // linear graph replays with ~10 us of host time.
+    const int want = 1;
+    for (int i = 0; i < want; i++) plan->queues.push_back(std::make_unique<Fork>(dev->h));
+    std::vector<evah_ctx *> q;
+    for (auto &f : plan->queues) q.push_back(f->h);
+    evah_ctx *q0 = q[0];
+    HipExecutor ex(program, *host, q);
+    // persistent input slots
+    for (auto &kv : inputs.values) {
+      TermId t = program.input(kv.first);
+      if (auto *c = std::get_if<HostCipher>(&kv.second)) {
+        evah_ct *h = nullptr;
+        chk(evah_ct_upload(q0, c->size, c->limbs, c->scale, (const uint64_t *)c->data.data(), &h));
+        auto sp = std::make_shared<CtHandle>(q0, h);
+        plan->in_ct[kv.first] = sp;
+        ex.set_value(t, sp);
+      } else {
+        auto &pl = std::get<HostPlain>(kv.second);
+        evah_pt *h = nullptr;
+        chk(evah_pt_upload(q0, pl.limbs, pl.scale, (const uint64_t *)pl.data.data(), &h));
+        auto sp = std::make_shared<PtHandle>(q0, h);
+        plan->in_pt[kv.first] = sp;
+        ex.set_value(t, sp);
+      }
+    }
+    // constants: encoded once, resident for the life of the plan
+    std::vector<char> done = ex.prepare_constants();
+    for (TermId t = 0; t < program.size(); t++)
+      if (done[t]) plan->persistent.push_back(ex.value(t));
+    chk(evah_ctx_sync(q0));
+    // capture the walk
+    chk(evah_capture_begin(q0, q.data() + 1, (uint32_t)q.size() - 1));
+    try {
+      run_counted(program, ex, &done);
+      for (auto &kv : program.outputs()) plan->outputs[kv.first] = ex.value(kv.second);
+    } catch (...) {
+      evah_graph *g = nullptr;
+      (void)evah_capture_end(q0, q.data() + 1, (uint32_t)q.size() - 1, &g);
+      evah_graph_free(g);
+      throw;
+    }
+    chk(evah_capture_end(q0, q.data() + 1, (uint32_t)q.size() - 1, &plan->graph));
+    return plan;
+  }
+
+  HipValuation run_plan(GraphPlan &plan, const HipValuation &inputs) {
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+    evah_ctx *q0 = plan.queues[0]->h;
+    for (auto &kv : inputs.values) {
+      if (auto *c = std::get_if<HostCipher>(&kv.second)) chk(evah_ct_write(q0, plan.in_ct.at(kv.first)->h, (const uint64_t *)c->data.data()));
+      else chk(evah_pt_write(q0, plan.in_pt.at(kv.first)->h, (const uint64_t *)std::get<HostPlain>(kv.second).data.data()));
+    }
+    auto t1 = clk::now();
+    chk(evah_graph_launch(q0, plan.graph));
+    auto t2 = clk::now();
+    HipValuation out;
+    for (auto &kv : plan.outputs) {
+      if (auto *c = std::get_if<std::shared_ptr<CtHandle>>(&kv.second)) {
+        HostCipher hc;
+        chk(evah_ct_info((*c)->h, &hc.size, &hc.limbs, &hc.scale));
+        hc.data.resize((size_t)hc.size * hc.limbs * host->N);
+        chk(evah_ct_download(q0, (*c)->h, (uint64_t *)hc.data.data()));
+        out.values[kv.first] = std::move(hc);
+      } else if (auto *p = std::get_if<std::shared_ptr<PtHandle>>(&kv.second)) {
+        HostPlain hp;
+        chk(evah_pt_info((*p)->h, &hp.limbs, &hp.scale));
+        hp.data.resize((size_t)hp.limbs * host->N);
+        chk(evah_pt_download(q0, (*p)->h, (uint64_t *)hp.data.data()));
+        out.values[kv.first] = std::move(hp);
+      } else if (auto *r = std::get_if<std::vector<double>>(&kv.second)) {
+        out.values[kv.first] = *r;
+      } else {
+        throw std::runtime_error("Output " + kv.first + " was not computed");
+      }
+    }
+    auto t3 = clk::now();
+    last_timing = {std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                   std::chrono::duration<double, std::milli>(t3 - t2).count()};
+    return out;
+  }
+
+  std::vector<evah_ctx *> queue_handles() {
+    int want = num_queues;
+    if (const char *e = std::getenv("EVA_NUM_STREAMS")) want = std::atoi(e);
+    if (want < 1) want = 1;
+    while ((int)forks.size() + 1 < want) forks.push_back(std::make_unique<Fork>(dev->h));
+    std::vector<evah_ctx *> q{dev->h};
+    for (int i = 0; i + 1 < want; i++) q.push_back(forks[i]->h);
+    return q;
+  }
   void ensure_device() {
     if (dev) return;
     dev = std::make_shared<DeviceCtx>(host->N, host->primes, device);

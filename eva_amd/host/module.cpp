@@ -174,6 +174,10 @@ PYBIND11_MODULE(_eva, m) {
       .def("execute", &HipPublic::execute, py::arg("program"), py::arg("inputs"))
       .def_readwrite("device", &HipPublic::device)
       .def_readwrite("free_eagerly", &HipPublic::free_eagerly)
+      .def_readwrite("use_graphs", &HipPublic::use_graphs, "replay repeated executions of one program from a captured hipGraph")
+      .def("drop_graphs", &HipPublic::drop_graphs)
+      .def_readonly("last_timing", &HipPublic::last_timing, "ms of the last execute(): (input upload, DAG enqueue on the host, drain + output download)")
+      .def_readwrite("num_queues", &HipPublic::num_queues, "HIP streams independent DAG nodes are spread over")
       .def_property_readonly("poly_modulus_degree", [](const HipPublic &p) { return p.host->N; })
       .def_property_readonly("primes", [](const HipPublic &p) { return std::vector<uint64_t>(p.host->primes.begin(), p.host->primes.end()); })
       // host FP64 encoder + host NTT: the plaintext an Encode node produces (tests pin the

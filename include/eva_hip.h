@@ -26,6 +26,7 @@ extern "C" {
 typedef struct evah_ctx evah_ctx; /* replaces seal::SEALContext + seal::Evaluator (seal.h:58-66) */
 typedef struct evah_ct evah_ct;   /* replaces seal::Ciphertext in SEALExecutor::Objects (seal_executor.h:32-42) */
 typedef struct evah_pt evah_pt;   /* replaces seal::Plaintext  in SEALExecutor::Objects */
+typedef struct evah_graph evah_graph; /* a captured execute(): replaces re-walking the DAG per call */
 
 /* Last error message of the calling thread ("" if none). */
 const char *evah_last_error(void);
@@ -40,6 +41,12 @@ int evah_device_count(int *count);
  * The backend derives psi (minimal primitive 2N-th root) and all NTT tables itself. */
 int evah_ctx_create(uint32_t poly_degree, uint32_t n_primes, const uint64_t *primes, int device,
                     evah_ctx **out);
+/* A second issue queue on the same device state: shares the parent's tables and keys (uploaded
+ * through either), owns its own HIP stream and buffer pool.  Independent DAG nodes / independent
+ * programs issued through different forks overlap on the GPU — the stream-level counterpart of
+ * the reference's Galois worker threads (multicore_program_traversal.h:55-78).  A handle may be
+ * read by any fork once the producing fork has been synchronised. */
+int evah_ctx_fork(evah_ctx *parent, evah_ctx **out);
 void evah_ctx_destroy(evah_ctx *ctx);
 /* Launch on an external HIP stream (hipStream_t as void*); NULL restores the context's own. */
 int evah_ctx_set_stream(evah_ctx *ctx, void *hip_stream);
@@ -63,6 +70,9 @@ int evah_galois_elt_from_step(evah_ctx *ctx, int32_t steps, uint32_t *elt);
  * Replace SEALExecutor::setInputs / getOutputs / free (seal_executor.h:264-277,420-435,406-418). */
 int evah_ct_upload(evah_ctx *ctx, uint32_t size, uint32_t limbs, double scale,
                    const uint64_t *data /* [size][limbs][N] */, evah_ct **out);
+/* overwrite an existing handle's residues (same shape) — refills the input slots of a graph */
+int evah_ct_write(evah_ctx *ctx, evah_ct *ct, const uint64_t *data);
+int evah_pt_write(evah_ctx *ctx, evah_pt *pt, const uint64_t *data);
 int evah_ct_info(const evah_ct *ct, uint32_t *size, uint32_t *limbs, double *scale);
 int evah_ct_download(evah_ctx *ctx, const evah_ct *ct, uint64_t *out /* [size][limbs][N] */);
 void evah_ct_free(evah_ctx *ctx, evah_ct *ct);
@@ -108,6 +118,19 @@ int evah_rotate(evah_ctx *ctx, const evah_ct *a, int32_t steps, evah_ct **out);
 int evah_rescale(evah_ctx *ctx, const evah_ct *a, uint32_t divisor_bits, evah_ct **out);
 /* evaluator.mod_switch_to_next (seal_executor.h:206) */
 int evah_mod_switch(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
+
+/* ---- whole-DAG capture ------------------------------------------------------------------------
+ * Replaces the per-call DAG walk of SEALPublic::execute (seal.cpp:104-122) for repeated
+ * executions of one compiled program: every evaluator call issued on `q0` and `others` (forks of
+ * one context) between begin and end is recorded into a hipGraph, including the cross-queue
+ * ordering; evah_graph_launch replays it on q0's stream.  Handles created before the capture
+ * (inputs, pre-encoded plaintexts) and handles still alive at the end (outputs) keep their device
+ * addresses; calls that synchronise with the host (uploads, downloads) are rejected while
+ * capturing.  The queues' pools must not be used by anything else while the graph exists. */
+int evah_capture_begin(evah_ctx *q0, evah_ctx **others, uint32_t n_others);
+int evah_capture_end(evah_ctx *q0, evah_ctx **others, uint32_t n_others, evah_graph **out);
+int evah_graph_launch(evah_ctx *q0, evah_graph *g);
+void evah_graph_free(evah_graph *g);
 
 /* ---- test / measurement hooks -------------------------------------------------------------- */
 /* in-place negacyclic NTT (inverse=0) or INTT (inverse=1) of one host polynomial mod primes[i] */

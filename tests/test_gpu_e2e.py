@@ -212,3 +212,37 @@ def test_regression_programs():
     polyreg.set_output_ranges(30)
     compile_and_check(polyreg, {'x': [i * 0.01 for i in range(4096)],
                                 'e': [(4096 - i) * 0.001 for i in range(4096)]})
+
+
+def test_graph_replay_matches_eager_and_oracle():
+    """Repeated execute() of one compiled program replays a captured hipGraph (multi-queue);
+    results must be bit-identical to the eager walk and to the CPU oracle, for fresh inputs too."""
+    import numpy as np
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    from evatest import oracle_execute
+    sobel = _sobel(64, 64, 4096)
+    sobel.set_input_scales(25)
+    sobel.set_output_ranges(10)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(sobel)
+    params.poly_modulus_degree = 8192
+    pub, sec = generate_keys(params, 3)
+    for harris_too in (False, True):
+        if harris_too:
+            compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
+            params.poly_modulus_degree = 16384
+            pub, sec = generate_keys(params, 4)
+        enc_a = pub.encrypt(_image(4096), sig)
+        enc_b = pub.encrypt({'image': [((91 * i) % 256) / 255.0 for i in range(4096)]}, sig)
+        pub.use_graphs = False
+        eager_a = pub.execute(compiled, enc_a).get('image')
+        pub.use_graphs = True
+        outs = [pub.execute(compiled, e).get('image') for e in (enc_a, enc_a, enc_a, enc_b, enc_a)]
+        ref_a = oracle_execute(pub, compiled, enc_a).get('image')
+        ref_b = oracle_execute(pub, compiled, enc_b).get('image')
+        assert np.array_equal(eager_a[4], ref_a[4])
+        for i, o in enumerate(outs):
+            ref = ref_b if i == 3 else ref_a
+            assert o[:4] == ref[:4]
+            assert np.array_equal(o[4], ref[4]), f"execute() call {i} (graph replay from call 1 on) differs from the oracle"
+        assert pub.last_timing[1] < 5.0
