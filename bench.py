@@ -70,22 +70,17 @@ def main():
     args = ap.parse_args()
 
     import numpy as np
-    import torch  # first: the HIP runtime torch bundles must be the one every library shares
-    import torch.distributed as dist
+    # torch first (inside Dist): the HIP runtime torch bundles must be the one every library shares
+    from eva_amd.dist import Dist
+    import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
                          "the product path has no CPU fallback")
-    torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+    dist = Dist(backend="nccl")
+    rank, world, local = dist.rank, dist.world, dist.local_rank
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from eva_amd import backend
     from eva_amd.hostref import coeff_modulus_create
@@ -128,9 +123,7 @@ def main():
     def barrier():
         for q in queues:
             q.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        dist.barrier()  # torch.cuda.synchronize() + RCCL barrier
 
     for _ in range(args.warmup):
         step()
@@ -142,10 +135,7 @@ def main():
         step(profile=True)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = dist.max_over_ranks(dt)
     prof = {}
     for q in queues:
         for c, (n_, ms_) in q.profile_get().items():
@@ -208,8 +198,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    dist.close()
 
 
 if __name__ == "__main__":

@@ -9,6 +9,8 @@ import os
 
 import numpy as np
 
+from . import _hipruntime  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeva_hip.so")
 

@@ -1,0 +1,100 @@
+"""One-process-per-GPU sharding helpers (torch.distributed; backend "nccl" = RCCL on ROCm,
+"gloo" on CPU).
+
+The execute() path shards over independent units — ciphertext op batches or whole DAG instances
+(BASELINE config 4; SURVEY.md §8e "instance b -> GPU b mod G") — so there is no data-path
+collective: every rank owns its keys and inputs, the only communication is the barrier, the
+max-over-ranks wall time and, optionally, gathering per-unit results on rank 0.
+"""
+import os
+import time
+
+
+class Dist:
+    def __init__(self, backend=None, timeout_s=600):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+        self.on_gpu = torch.cuda.is_available()
+        if backend is None:
+            backend = "nccl" if self.on_gpu else "gloo"
+        self.backend = backend
+        self.owns_group = False
+        if self.on_gpu:
+            torch.cuda.set_device(self.local_rank)
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            import datetime
+            kw = {}
+            if backend == "nccl":
+                kw["device_id"] = torch.device("cuda", self.local_rank)
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world,
+                                    timeout=datetime.timedelta(seconds=timeout_s), **kw)
+            self.owns_group = True
+
+    # ---- partitioning
+    def my_units(self, n_units):
+        """Unit b runs on rank b mod world (keeps every rank's share within one unit of equal)."""
+        return list(range(self.rank, n_units, self.world))
+
+    # ---- collectives used around (never inside) the data path
+    def _device(self):
+        return "cuda" if (self.on_gpu and self.backend == "nccl") else "cpu"
+
+    def barrier(self):
+        if self.on_gpu:
+            self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return float(x)
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self._device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x):
+        if self.world == 1:
+            return float(x)
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self._device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def gather_units(self, local, n_units):
+        """local: {unit index: picklable result} of this rank -> on rank 0 the list of all
+        n_units results in unit order (None elsewhere)."""
+        if self.world == 1:
+            return [local[i] for i in range(n_units)]
+        parts = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object(local, parts, dst=0)
+        if self.rank != 0:
+            return None
+        merged = {}
+        for p in parts:
+            merged.update(p)
+        return [merged[i] for i in range(n_units)]
+
+    def timed(self, fn):
+        """barrier; fn(); barrier -> max over ranks of the wall time."""
+        self.barrier()
+        t0 = time.perf_counter()
+        out = fn()
+        self.barrier()
+        return out, self.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        if self.owns_group and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+def run_sharded(dist, n_units, work):
+    """Run work(unit) for this rank's units; returns (results on rank 0 | None, max wall seconds)."""
+    def body():
+        return {u: work(u) for u in dist.my_units(n_units)}
+    local, secs = dist.timed(body)
+    return dist.gather_units(local, n_units), secs
