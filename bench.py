@@ -3,7 +3,8 @@
 (multiply + relinearize + rescale) at N = 2^16, L = 10 data limbs (k = 11 key primes).
 
 One "step" = one batch of --batch independent op-triples through the C-ABI of libeva_hip.so
-(evah_multiply -> evah_relinearize -> evah_rescale), inputs and the relinearization key already
+(evah_multiply -> evah_relinearize_rescale, i.e. relinearize and rescale_to_next evaluated
+together with a bit-identical result), inputs and the relinearization key already
 resident in HBM.  One process per GPU; ranks run independent batches (the path shards over
 independent ciphertexts — no data-path collective), `value` = triples of all ranks / max time.
 
@@ -25,28 +26,20 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 def class_bytes(N, l, k):
     """Compulsory HBM bytes (distinct inputs read once + outputs written once) per launch of each
-    kernel class inside one op-triple (relinearize at l limbs, rescale l -> l-1); DESIGN.md §5."""
+    kernel class inside one op-triple as bench.py issues it — evah_multiply, then
+    evah_relinearize_rescale (relinearize at l limbs fused with the rescale l -> l-1); DESIGN.md §4.
+    W = one limb of one polynomial = 8N bytes."""
     W = 8 * N
-    relin = {
-        "intt_pass1": [2 * l * W, 2 * 2 * W],            # digits; special limbs of prod
-        "intt_pass2": [2 * l * W, 2 * 2 * W],
-        "ksdigit_pass1": [(l + l * l) * W],
-        "ksdigit_pass2": [2 * l * l * W],
-        "ks_mac": [(2 * l * (l + 1) + l * l + l + 2 * (l + 1)) * W],
-        "moddown_pass1": [(2 + 2 * l) * W],
-        "moddown_pass2": [(2 * l + 2 * l + 2 * l + 2 * l) * W],   # interm + prod + add + out
+    per_launch = {
+        "elementwise": [7 * l * W],                                   # multiply: 4 polys in, 3 out
+        "intt_pass1": [2 * l * W, 2 * 2 * W, (2 + 2 + 2 + 2) * W],   # digits; special limbs; t_K (a,prod,r in / t out)
+        "intt_pass2": [2 * l * W, 2 * 2 * W, (2 + 2 + 2 + 2) * W],
+        "ksdigit_pass1": [(l + l * l) * W],                           # l digits in, l^2 converted digits out
+        "ks_mac": [(l * l + l + 2 * l * (l + 1) + 2 * (l + 1)) * W],  # digits + target + key in, prod out
+        "moddown_pass1": [(2 + 2 + 2 * (l - 1)) * W],                 # r, t in; intermediates out
+        "moddown_pass2": [(4 * 2 * (l - 1)) * W],                     # interm + a + prod in; out
     }
-    resc = {
-        "intt_pass1": [2 * 2 * W],
-        "intt_pass2": [2 * 2 * W],
-        "moddown_pass1": [(2 + 2 * (l - 1)) * W],
-        "moddown_pass2": [(3 * 2 * (l - 1)) * W],
-    }
-    out = {"elementwise": [7 * l * W]}
-    for d in (relin, resc):
-        for kk, v in d.items():
-            out.setdefault(kk, []).extend(v)
-    return {kk: sum(v) / len(v) for kk, v in out.items()}
+    return {kk: sum(v) / len(v) for kk, v in per_launch.items()}
 
 
 def triple_bytes(N, l):
@@ -63,7 +56,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="independent op-triples per step")
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--limbs", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=32,
                     help="issue queues (forked contexts = HIP streams) the independent triples are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -114,11 +107,10 @@ def main():
             if sample:
                 q.profile(True)
             m = q.multiply(a, b)
-            r = q.relinearize(m)
-            o = q.rescale(r, 60)
+            o = q.relinearize_rescale(m, 60)   # == rescale(relinearize(m)), evaluated together
             if sample:
                 q.profile(False)
-            m.free(); r.free(); o.free()
+            m.free(); o.free()
 
     def barrier():
         for q in queues:

@@ -58,6 +58,7 @@ _SIGS = {
     "evah_square": [_vp, _vp, _vpp],
     "evah_multiply_plain": [_vp, _vp, _vp, _vpp],
     "evah_relinearize": [_vp, _vp, _vpp],
+    "evah_relinearize_rescale": [_vp, _vp, C.c_uint32, _vpp],
     "evah_rotate": [_vp, _vp, C.c_int32, _vpp],
     "evah_rescale": [_vp, _vp, C.c_uint32, _vpp],
     "evah_mod_switch": [_vp, _vp, _vpp],
@@ -343,6 +344,9 @@ class Context:
 
     def relinearize(self, a):
         return self._ct1(_lib.evah_relinearize, a)
+
+    def relinearize_rescale(self, a, divisor_bits):
+        return self._ct1(_lib.evah_relinearize_rescale, a, C.c_uint32(int(divisor_bits)))
 
     def rotate(self, a, steps):
         return self._ct1(_lib.evah_rotate, a, C.c_int32(int(steps)))

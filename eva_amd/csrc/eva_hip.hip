@@ -452,6 +452,8 @@ template <class Op> struct OpClass;
 template <> struct OpClass<OpPlain> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
 template <> struct OpClass<OpKsDigit> { static constexpr int fwd_a = KC_KSDIGIT_A, fwd_b = KC_KSDIGIT_B; };
 template <> struct OpClass<OpModDown> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
+template <> struct OpClass<OpRR> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
+template <> struct OpClass<OpRRLast> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 
 template <int P, int LR, bool STRIDED, bool INVERSE, class Op>
 static void launch_pass(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
@@ -521,18 +523,18 @@ template <class Op> static void ntt_inverse(evah_ctx *c, const typename Op::Para
 
 // SEAL Evaluator::switch_key_inplace, device version.
 //   out[K] = (add && K < add_polys ? add[K] : 0) + keyswitch(target)[K],  K in {0,1}
-static void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev &key, const u64 *add,
-                       size_t add_ps, uint32_t add_polys, u64 *out, size_t out_ps) {
+// steps 1-2 of switch_key: prod[K][I] (I <= l, slot l = special prime) = sum_J op(I,J) * key[J][K]
+static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev &key, u64 *prod_d) {
   const size_t N = c->N;
   if (key.n_digits < l) throw std::runtime_error("key switching key has too few digits");
   Scratch t(c, (size_t)l * N);                 // coefficient-form digits
   Scratch sc(c, (size_t)(l + 1) * l * N);      // converted digits, NTT form per output limb
-  Scratch prod(c, (size_t)2 * (l + 1) * N);    // [K][l+1][N]
+  struct { u64 *d; } prod{prod_d};
   // 1. digits to coefficient form
   OpPlain::Params ip{target, t.d, 0, 0, l, 0, 0};
   ntt_inverse<OpPlain>(c, ip, l);
   OpKsDigit::Params dp{t.d, sc.d, l};
-  if (c->fuse_mac) {
+  if (c->fuse_mac && l <= 20) { // 128-bit accumulation of l products of a lazy (<10q) operand
     // 2a. base-convert + first (strided) NTT pass of every digit under every output prime
     const int a = (c->logN + 1) / 2, b = c->logN / 2;
     launch_pass_p<true, false, OpKsDigit>(c, a, dp, (l + 1) * l);
@@ -546,6 +548,13 @@ static void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev 
                        key.d, prod.d, l);
     HIPCHK(hipGetLastError());
   }
+}
+
+static void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev &key, const u64 *add,
+                       size_t add_ps, uint32_t add_polys, u64 *out, size_t out_ps) {
+  const size_t N = c->N;
+  Scratch prod(c, (size_t)2 * (l + 1) * N);    // [K][l+1][N]
+  switch_key_products(c, l, target, key, prod.d);
   // 3. mod-down by the special prime: INTT(special limb) + P/2, then per-limb NTT + combine
   Scratch r(c, 2 * N);
   OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1};
@@ -641,8 +650,8 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
       if (t == 64 || t == 128 || t == 256) c->ks_threads = t;
     }
     for (u64 q : c->primes)
-      if (q >= ((u64)1 << 61) || (q - 1) % (2ull * N) || !is_prime(q))
-        throw std::invalid_argument("coeff modulus primes must be < 2^61, prime and 1 mod 2N");
+      if (q >= ((u64)1 << 60) || (q - 1) % (2ull * N) || !is_prime(q)) // SEAL_USER_MOD_BIT_COUNT_MAX = 60
+        throw std::invalid_argument("coeff modulus primes must be at most 60 bits, prime and 1 mod 2N");
     for (uint32_t l = 0; l <= k; l++) c->total_bits.push_back(l ? bitlen_of_product(c->primes, l) : 0);
     use(c);
     HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
@@ -1103,6 +1112,37 @@ int evah_relinearize(evah_ctx *c, const evah_ct *a, evah_ct **out) {
   evah_ct *o = ct_new(c, 2, a->limbs, a->scale);
   try {
     switch_key(c, a->limbs, a->d + 2 * a->ps, c->sh->relin, a->d, a->ps, 2, o->d, o->ps);
+  } catch (...) {
+    evah_ct_free(c, o);
+    throw;
+  }
+  *out = o;
+  API_END
+}
+
+int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bits, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  acquire(c, a->buf);
+  if (a->size != 3) throw std::invalid_argument("relinearize expects a size-3 ciphertext");
+  if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
+  if (a->limbs < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  const uint32_t l = a->limbs, last = l - 1, sp = c->k - 1;
+  const size_t N = c->N, pps = (size_t)(l + 1) * N;
+  evah_ct *o = ct_new(c, 2, l - 1, a->scale / std::pow(2.0, (double)divisor_bits));
+  try {
+    Scratch prod(c, 2 * pps);
+    switch_key_products(c, l, a->d + 2 * a->ps, c->sh->relin, prod.d);
+    Scratch r(c, 2 * N), t(c, 2 * N);
+    // r_K = INTT_P(prod[K][special]) + P/2
+    OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1};
+    ntt_inverse<OpPlain>(c, spp, 2);
+    // t_K = INTT_last(a[K][last] + prod[K][last] P^-1) - u_K,last P^-1 + q_last/2
+    OpRRLast::Params lp{a->d + (size_t)last * N, a->ps, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp};
+    ntt_inverse<OpRRLast>(c, lp, 2);
+    // out[K][i] = (a[K][i] + prod[K][i] P^-1 - NTT_i(u P^-1 + v)) q_last^-1
+    OpRR::Params rp{r.d, N, t.d, N, a->d, a->ps, prod.d, pps, o->d, o->ps, sp, last, l - 1};
+    ntt_forward<OpRR>(c, rp, 2 * (l - 1));
   } catch (...) {
     evah_ct_free(c, o);
     throw;

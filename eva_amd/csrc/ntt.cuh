@@ -16,8 +16,8 @@
 //
 // One workgroup owns a tile of up to 4096 coefficients in LDS (32 KiB + padding); each thread
 // keeps 16 coefficients in registers per round and runs up to 4 butterfly stages on them
-// (radix-16 worth of work per LDS round trip).  Harvey lazy butterflies: forward values live
-// in [0,4q), inverse in [0,2q); only the value finally stored is canonical.
+// (radix-16 worth of work per LDS round trip).  Lazy butterflies: forward values live in
+// [0,10q), inverse in [0,5q) (q < 2^60); only the value finally stored is canonical.
 //
 // The first pass reads through Op::load and the second writes through Op::store, which is how
 // the digit base-conversion, the rescale / mod-down combine and the +q/2 rounding offset are
@@ -44,19 +44,30 @@ template <int P, int LR> struct Rounds {
 __device__ __forceinline__ int lds_pad(int e) { return e + (e >> 4); }
 template <int P> constexpr int lds_sub_stride() { return (1 << P) + ((1 << P) >> 4) + 1; }
 
-// forward Cooley-Tukey butterfly, X,Y in [0,4q) -> [0,4q)
-__device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 q, u64 q2) {
-  u64 x = X - (X >= q2 ? q2 : 0);
-  u64 t = mul_shoup_lazy(Y, w.x, w.y, q);
-  X = x + t;
-  Y = x + q2 - t;
+// Twiddle product with a cheap quotient estimate.  Shoup's q^ = floor(x*ws / 2^64) needs the
+// full 64x64 high product (4 multiplies + carries); dropping the partial products that only
+// feed carries gives q~ with q^ - 3 <= q~ <= q^, i.e. x*w - q~*q in [0, 5q) for ANY 64-bit x,
+// with 3 multiplies.  x*w - q~*q is evaluated as x*w + q~*(2^64 - q) so the second product
+// accumulates onto the first (one mad chain, no 64-bit subtract).  Moduli are < 2^60, so every
+// lazy value below stays < 10q < 2^64.
+__device__ __forceinline__ u64 mul_tw_lazy5(u64 x, u64 w, u64 ws, u64 nq) {
+  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
+  const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
+  return x * w + qt * nq;
 }
-// inverse Gentleman-Sande butterfly, X,Y in [0,2q) -> [0,2q)
-__device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 q, u64 q2) {
+// forward Cooley-Tukey butterfly, X,Y in [0,10q) -> [0,10q)
+__device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q5) {
+  u64 x = X - (X >= q5 ? q5 : 0);
+  u64 t = mul_tw_lazy5(Y, w.x, w.y, nq);
+  X = x + t;
+  Y = x + q5 - t;
+}
+// inverse Gentleman-Sande butterfly, X,Y in [0,5q) -> [0,5q)
+__device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q5) {
   u64 s = X + Y;
-  u64 d = X + q2 - Y;
-  X = s - (s >= q2 ? q2 : 0);
-  Y = mul_shoup_lazy(d, w.x, w.y, q);
+  u64 d = X + q5 - Y;
+  X = s - (s >= q5 ? q5 : 0);
+  Y = mul_tw_lazy5(d, w.x, w.y, nq);
 }
 
 // One register round: RB stages over bit range [LO, LO+RB) of the P-bit local index.
@@ -66,7 +77,7 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
   constexpr int NTT_R = 1 << LR;
   constexpr int S = 1 << P, TPS = S / NTT_R, G = NTT_R >> RB, NU = 1 << RB;
   constexpr int S0 = P - LO - RB; // local stages above this round
-  const u64 q = pm.q, q2 = pm.q << 1;
+  const u64 q = pm.q, nq = 0ull - pm.q, q5 = 5 * pm.q;
   u64 x[NTT_R];
 #pragma unroll
   for (int g = 0; g < G; g++) {
@@ -86,7 +97,7 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
           if (u & half) continue;
           const int v = u >> (RB - s);
           const ulonglong2 w = tw[((size_t)node << s) + v];
-          bfly_fwd(x[g * NU + u], x[g * NU + u + half], w, q, q2);
+          bfly_fwd(x[g * NU + u], x[g * NU + u + half], w, nq, q5);
         }
       }
     } else {
@@ -100,13 +111,13 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
           if (u & half) continue;
           u64 &X = x[g * NU + u], &Y = x[g * NU + u + half];
           if (last) {
-            u64 sum = X + Y, d = X + q2 - Y;
+            u64 sum = X + Y, d = X + q5 - Y; // any 64-bit input is fine for the exact Shoup product
             X = mul_shoup(sum, pm.ninv, pm.ninv_s, q);
             Y = mul_shoup(d, pm.w0ninv, pm.w0ninv_s, q);
           } else {
             const int v = u >> (RB - s);
             const ulonglong2 w = tw[((size_t)node << s) + v];
-            bfly_inv(X, Y, w, q, q2);
+            bfly_inv(X, Y, w, nq, q5);
           }
         }
       }
@@ -176,7 +187,6 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
   __syncthreads();
 
   // ---- LDS -> global
-  const u64 q = pm.q, q2 = pm.q << 1;
 #pragma unroll
   for (int it = 0; it < NTT_R; it++) {
     const int idx = threadIdx.x + it * T;
@@ -195,10 +205,7 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
     if (FIRST) {
       jb.dst[n] = v; // lazy intermediate
     } else {
-      if (!INVERSE) { // forward final: [0,4q) -> canonical
-        v -= (v >= q2 ? q2 : 0);
-        v -= (v >= q ? q : 0);
-      }
+      if (!INVERSE) v = barrett64(v, pm.q, pm.brt); // forward final: [0,10q) -> canonical
       Op::store(cx, jb, pm, n, v);
     }
   }
@@ -259,7 +266,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target, const u64 *__restrict
       for (int it = 0; it < NPAIR; it++) {
         const int idx = 2 * (threadIdx.x + it * T);
         const int sb = idx >> P, e = idx & (S - 1);
-        val[2 * it] = lds[sb * SP + lds_pad(e)];       // lazy [0,4q): fine for the 128-bit MAC
+        val[2 * it] = lds[sb * SP + lds_pad(e)];       // lazy [0,10q): fine for the 128-bit MAC (l <= 20)
         val[2 * it + 1] = lds[sb * SP + lds_pad(e + 1)];
       }
     }
@@ -405,6 +412,102 @@ struct OpModDown {
     u64 v = mul_shoup(submod(j.c[n], U, pm.q), j.inv.x, j.inv.y, pm.q);
     if (j.add) v = addmod(j.add[n], v, pm.q);
     j.dst[n] = v;
+  }
+};
+
+// ---- relinearize followed by rescale, evaluated together (same canonical result as the two
+// SEAL calls in sequence, seal_executor.h:200 then :213).  With ct' = relinearize(a):
+//   ct'[K][i] = a[K][i] + (prod[K][i] - NTT_i(u_Ki)) * P^-1,  u_Ki = (r_K mod q_i) - floor(P/2) mod q_i
+//   out[K][i] = (ct'[K][i] - NTT_i(v_Ki)) * q_last^-1,        v_Ki = (t_K mod q_i) - floor(q_last/2) mod q_i
+// NTT is linear, so NTT_i(u)*P^-1 + NTT_i(v) = NTT_i(u*P^-1 + v): one forward transform per
+// (K,i) instead of two, and t_K = INTT(ct'[K][last]) + q_last/2 needs no NTT of u at all:
+//   t_K = INTT_last(a[K][last] + prod[K][last]*P^-1) - u_K,last*P^-1 + floor(q_last/2).
+
+// inverse transform producing t_K; job = K, prime = last data prime
+struct OpRRLast {
+  struct Params {
+    const u64 *a;     // a[0][last]
+    size_t a_ps;
+    const u64 *prod;  // prod[0][last]
+    size_t prod_ps;
+    const u64 *r;     // r_0 (INTT of the special limb + P/2)
+    size_t r_ps;
+    u64 *t;
+    size_t t_ps;
+    uint32_t last, sp;
+  };
+  struct Job {
+    uint32_t prime;
+    const u64 *a, *prod, *r;
+    u64 *dst;
+    u64 halfP;
+    ulonglong2 pinv;
+  };
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job, Job &j) {
+    j.prime = p.last;
+    j.a = p.a + job * p.a_ps;
+    j.prod = p.prod + job * p.prod_ps;
+    j.r = p.r + job * p.r_ps;
+    j.dst = p.t + job * p.t_ps;
+    j.halfP = cx.halfmod[p.sp * cx.k + p.last];
+    j.pinv = cx.invq[p.sp * cx.k + p.last];
+    return true;
+  }
+  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
+    return addmod(j.a[n], mul_shoup(j.prod[n], j.pinv.x, j.pinv.y, pm.q), pm.q);
+  }
+  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 x) {
+    const u64 u = submod(barrett64(j.r[n], pm.q, pm.brt), j.halfP, pm.q);
+    x = submod(x, mul_shoup(u, j.pinv.x, j.pinv.y, pm.q), pm.q);
+    j.dst[n] = addmod(x, pm.q >> 1, pm.q);
+  }
+};
+
+// forward transform of u*P^-1 + v with the combined epilogue; job -> (K = job / jl, i = job % jl)
+struct OpRR {
+  struct Params {
+    const u64 *r;
+    size_t r_ps;
+    const u64 *t;
+    size_t t_ps;
+    const u64 *a;
+    size_t a_ps;
+    const u64 *prod;
+    size_t prod_ps;
+    u64 *dst;
+    size_t dst_ps;
+    uint32_t sp, last, jl;
+  };
+  struct Job {
+    uint32_t prime;
+    const u64 *r, *t, *a, *prod;
+    u64 *dst;
+    u64 halfP, halfL;
+    ulonglong2 pinv, linv;
+  };
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job, Job &j) {
+    const uint32_t K = job / p.jl, i = job % p.jl;
+    j.prime = i;
+    j.r = p.r + K * p.r_ps;
+    j.t = p.t + K * p.t_ps;
+    j.a = p.a + K * p.a_ps + (size_t)i * cx.N;
+    j.prod = p.prod + K * p.prod_ps + (size_t)i * cx.N;
+    j.dst = p.dst + K * p.dst_ps + (size_t)i * cx.N;
+    j.halfP = cx.halfmod[p.sp * cx.k + i];
+    j.halfL = cx.halfmod[p.last * cx.k + i];
+    j.pinv = cx.invq[p.sp * cx.k + i];
+    j.linv = cx.invq[p.last * cx.k + i];
+    return true;
+  }
+  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
+    const u64 u = submod(barrett64(j.r[n], pm.q, pm.brt), j.halfP, pm.q);
+    const u64 v = submod(barrett64(j.t[n], pm.q, pm.brt), j.halfL, pm.q);
+    return addmod(mul_shoup(u, j.pinv.x, j.pinv.y, pm.q), v, pm.q);
+  }
+  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 W) {
+    u64 x = addmod(j.a[n], mul_shoup(j.prod[n], j.pinv.x, j.pinv.y, pm.q), pm.q);
+    x = submod(x, W, pm.q);
+    j.dst[n] = mul_shoup(x, j.linv.x, j.linv.y, pm.q);
   }
 };
 

@@ -69,6 +69,12 @@ public:
       for (u64 top = w.back(); top; top >>= 1) bits++;
       total_bits.push_back(bits);
     }
+    pow2_.resize(k);
+    for (uint32_t i = 0; i < k; i++) { // 2^e mod q_i for the encoder's multi-precision residues
+      pow2_[i].resize(1100);
+      u64 p = 1 % primes[i];
+      for (auto &v : pow2_[i]) { v = p; p = evah::addmod(p, p, primes[i]); }
+    }
     init_encoder();
   }
 
@@ -131,6 +137,27 @@ public:
     }
   }
 
+  // residues of an integer-valued double of any magnitude: v = m * 2^e exactly (53-bit m), so
+  // v mod q = (m mod q) * (2^e mod q) — what SEAL's multi-precision encode path computes
+  void residues_of(double v, uint32_t limbs, u64 *out, size_t stride) const {
+    const bool neg = std::signbit(v);
+    const double a = std::fabs(v);
+    int e = 0;
+    u64 mant;
+    if (a < 9007199254740992.0) { mant = (u64)a; }  // < 2^53: exact
+    else {
+      double fr = std::frexp(a, &e); // a = fr * 2^e, fr in [0.5,1)
+      mant = (u64)std::ldexp(fr, 53);
+      e -= 53;
+    }
+    for (uint32_t i = 0; i < limbs; i++) {
+      const u64 q = primes[i];
+      u64 r = mant % q;
+      if (e > 0) r = evah::mulmod(r, e < (int)pow2_[i].size() ? pow2_[i][e] : evah::powmod(2, (u64)e, q), q);
+      out[(size_t)i * stride] = (neg && r) ? q - r : r;
+    }
+  }
+
   // ---- CKKS encoder (A.9).  values: N/2 slots (already replicated by the caller).
   // Coefficient-form residues [limbs][N]; the forward NTT is done by the caller (device or host).
   void encode_coeff(const double *values, double scale, uint32_t limbs, u64 *out) const {
@@ -155,28 +182,15 @@ public:
     double max_coeff = 0;
     for (uint32_t j = 0; j < N; j++) max_coeff = std::max(max_coeff, std::fabs(c[j].real() * fix));
     int bitcount = (int)std::ceil(std::log2(std::max(max_coeff, 1.0))) + 1;
-    if (bitcount >= total_bits[limbs] || bitcount > 126) throw std::invalid_argument("encoded values are too large");
-    for (uint32_t j = 0; j < N; j++) {
-      double v = std::round(c[j].real() * fix);
-      bool neg = std::signbit(v);
-      u128 mag = (u128)std::fabs(v);
-      for (uint32_t i = 0; i < limbs; i++) {
-        u64 q = primes[i], r = (u64)(mag % q);
-        out[(size_t)i * N + j] = (neg && r) ? q - r : r;
-      }
-    }
+    if (bitcount >= total_bits[limbs]) throw std::invalid_argument("encoded values are too large");
+    for (uint32_t j = 0; j < N; j++) residues_of(std::round(c[j].real() * fix), limbs, out + j, N);
   }
   // residues of round(c*scale) per limb: the encoding of a uniform constant (every NTT slot)
   void encode_uniform(double value, double scale, uint32_t limbs, u64 *out) const {
     double v = std::round(value * scale);
     int bitcount = (int)std::ceil(std::log2(std::max(std::fabs(v), 1.0))) + 1;
-    if (bitcount >= total_bits[limbs] || bitcount > 126) throw std::invalid_argument("encoded values are too large");
-    bool neg = std::signbit(v);
-    u128 mag = (u128)std::fabs(v);
-    for (uint32_t i = 0; i < limbs; i++) {
-      u64 q = primes[i], r = (u64)(mag % q);
-      out[i] = (neg && r) ? q - r : r;
-    }
+    if (bitcount >= total_bits[limbs]) throw std::invalid_argument("encoded values are too large");
+    residues_of(v, limbs, out, 1);
   }
   // coefficient-form plaintext [limbs][N] (already INTT'd) -> N/2 slot values
   void decode_coeff(const u64 *coeff, uint32_t limbs, double scale, std::vector<double> &out) const {
@@ -262,6 +276,7 @@ public:
   }
 
 private:
+  std::vector<std::vector<u64>> pow2_;
   std::vector<uint32_t> slot_map_;
   std::vector<std::complex<double>> roots_; // roots_[m+g] = zeta^br(m+g), zeta = exp(2 pi i / 2N)
 

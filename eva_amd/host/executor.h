@@ -134,7 +134,12 @@ public:
     TermId src;
     uint32_t scale_bits, level;
   };
-  using RuntimeValue = std::variant<std::monostate, std::shared_ptr<CtHandle>, std::shared_ptr<PtHandle>, std::vector<double>, LazyPlain>;
+  // A Relinearize whose only consumer is a Rescale is evaluated together with it
+  // (evah_relinearize_rescale: identical result, fewer transforms).
+  struct LazyRelin {
+    TermId src;
+  };
+  using RuntimeValue = std::variant<std::monostate, std::shared_ptr<CtHandle>, std::shared_ptr<PtHandle>, std::vector<double>, LazyPlain, LazyRelin>;
 
   // queues: issue queues (HIP streams) of one device — queues[0] is the root context, the rest
   // are its forks.  Independent DAG nodes are spread over them (the GPU counterpart of the
@@ -228,6 +233,12 @@ public:
       }
       break;
     case Op::Relinearize: {
+      const auto &uses = x.uses;
+      if (fuse_relin_rescale && uses.size() == 1 && program.at(uses[0]).op == Op::Rescale) {
+        objects[t] = LazyRelin{a[0]};
+        queue_of[t] = queue_of[a[0]];
+        break;
+      }
       evah_ct *h = nullptr;
       chk(evah_relinearize(ctx, ct(a[0]), &h));
       objects[t] = std::make_shared<CtHandle>(ctx, h);
@@ -239,7 +250,8 @@ public:
     } break;
     case Op::Rescale: {
       evah_ct *h = nullptr;
-      chk(evah_rescale(ctx, ct(a[0]), x.rescale_divisor, &h));
+      if (auto *lz = std::get_if<LazyRelin>(&objects[a[0]])) chk(evah_relinearize_rescale(ctx, ct(lz->src), x.rescale_divisor, &h));
+      else chk(evah_rescale(ctx, ct(a[0]), x.rescale_divisor, &h));
       objects[t] = std::make_shared<CtHandle>(ctx, h);
     } break;
     case Op::Output:
@@ -280,7 +292,17 @@ public:
     if (is_raw(t))
       for (TermId u : program.at(t).uses)
         if (std::holds_alternative<LazyPlain>(objects[u])) return;
+    if (is_cipher(t))
+      for (TermId u : program.at(t).uses)
+        if (std::holds_alternative<LazyRelin>(objects[u])) { deferred_free.emplace_back(u, t); return; }
     objects[t] = std::monostate{};
+    // a consumed LazyRelin releases the size-3 value it was holding on to
+    for (size_t i = 0; i < deferred_free.size(); i++)
+      if (deferred_free[i].first == t) {
+        objects[deferred_free[i].second] = std::monostate{};
+        deferred_free.erase(deferred_free.begin() + i);
+        break;
+      }
   }
 
   // seal_executor.h:420-435 — outputs are downloaded into host values
@@ -316,6 +338,8 @@ private:
   std::vector<uint32_t> queue_of;
   uint32_t next_queue = 0;
   std::vector<double> scratch;
+  std::vector<std::pair<TermId, TermId>> deferred_free; // (lazy relin term, its source)
+  bool fuse_relin_rescale = std::getenv("EVA_FUSE_RELIN_RESCALE") ? std::atoi(std::getenv("EVA_FUSE_RELIN_RESCALE")) != 0 : true;
 
   // Queue for node t: key-switching / rescaling consumers of a fanned-out value are spread
   // round-robin (they are independent and heavy); everything else follows its first

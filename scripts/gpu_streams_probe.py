@@ -16,7 +16,7 @@ def rand(prefix, nl):
 g.upload_relin_key(rand((l, 2), k))
 a = g.upload_ct(rand((2,), l), 2.0**40)
 b = g.upload_ct(rand((2,), l), 2.0**40)
-for S in (1, 2, 4, 8, 16):
+for S in (int(x) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else "1,2,4,8,16".split(","))):
     ctxs = [g] + [g.fork() for _ in range(S - 1)]
     def run(n):
         for i in range(n):
@@ -25,7 +25,7 @@ for S in (1, 2, 4, 8, 16):
             m.free(); r.free(); o.free()
     run(2 * S)
     for c in ctxs: c.sync()
-    n = 128
+    n = max(128, 8 * S)
     t0 = time.perf_counter()
     run(n)
     t_host = time.perf_counter() - t0

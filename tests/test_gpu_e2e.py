@@ -77,6 +77,22 @@ def test_unencrypted_computation():
             compile_and_check(prog)
 
 
+def test_eager_relinearize_uses_fused_relin_rescale_bit_exact():
+    """lazy_relinearize=false puts Relinearize directly under Rescale: the executor evaluates the
+    pair with one fused call; the oracle walk evaluates them separately — outputs must be identical."""
+    from eva import Op
+    prog = EvaProgram('poly', vec_size=1024)
+    with prog:
+        x = Input('x')
+        y = Input('y')
+        Output('z', (x * y + x) * (x * x) + 0.5)
+    prog.set_output_ranges(20)
+    prog.set_input_scales(60)
+    compiled, _, _ = compile_and_check(prog, config={'lazy_relinearize': 'false'}, check_bit_exact=True)
+    terms = {d["id"]: d for d in compiled._dump()}
+    assert any(d["op"] == Op.Rescale and terms[d["operands"][0]]["op"] == Op.Relinearize for d in terms.values())
+
+
 def test_transparent_ciphertext():
     prog = EvaProgram('Transparent', vec_size=4096)
     with prog:

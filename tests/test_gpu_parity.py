@@ -119,6 +119,22 @@ def test_relinearize_bit_exact(cfg):
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"N{c[0]}")
+def test_relinearize_rescale_fused_bit_exact(cfg):
+    """The fused call must equal rescale_to_next(relinearize(x)) exactly."""
+    e = env(cfg)
+    key = e.rand_key()
+    e.g.upload_relin_key(key)
+    for l in sorted({e.k - 1, max(2, e.k - 2)}):
+        a3 = e.rand(3, l)
+        A3 = e.g.upload_ct(a3, 2.0 ** 50)
+        out = e.g.relinearize_rescale(A3, 30)
+        assert out.info() == (2, l - 1, 2.0 ** 20)
+        ref = e.o.rescale(e.o.relinearize(a3, key))
+        assert np.array_equal(out.download(), ref), f"fused relin+rescale mismatch at l={l}"
+        assert np.array_equal(e.g.rescale(e.g.relinearize(A3), 30).download(), ref)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"N{c[0]}")
 def test_rotate_bit_exact(cfg):
     e = env(cfg)
     l = e.k - 1
@@ -150,7 +166,10 @@ def test_op_triple_metric_config_bit_exact():
     A, B = e.g.upload_ct(a, 2.0 ** 40), e.g.upload_ct(b, 2.0 ** 40)
     out = e.g.rescale(e.g.relinearize(e.g.multiply(A, B)), 60)
     assert out.info() == (2, l - 1, 2.0 ** 20)
-    assert np.array_equal(out.download(), e.o.op_triple(a, b, key))
+    ref = e.o.op_triple(a, b, key)
+    assert np.array_equal(out.download(), ref)
+    fused = e.g.relinearize_rescale(e.g.multiply(A, B), 60)   # what bench.py issues
+    assert fused.info() == (2, l - 1, 2.0 ** 20) and np.array_equal(fused.download(), ref)
 
 
 def test_error_behaviour_matches_reference_preconditions():

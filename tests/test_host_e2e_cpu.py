@@ -62,3 +62,16 @@ def test_transparent_ciphertext():
     prog.set_output_ranges(20)
     prog.set_input_scales(30)
     compile_and_check(prog, executor="oracle")
+
+
+def test_constant_at_large_scale_encodes():
+    """A constant matched up to a 160-bit scale exceeds 128-bit coefficients: the encoder's
+    multi-precision path (mantissa * 2^e per residue) must handle it."""
+    prog = EvaProgram('poly', vec_size=256)
+    with prog:
+        x = Input('x')
+        y = Input('y')
+        Output('z', (x * y + x) * (x * x) + 0.5)
+    prog.set_output_ranges(20)
+    prog.set_input_scales(40)
+    compile_and_check(prog, config={'lazy_relinearize': 'false'}, executor="oracle")
