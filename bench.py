@@ -144,9 +144,16 @@ def main():
         avg_us = ms * 1e3 / max(n_l, 1)
         ach = cb[dom] / (avg_us * 1e-6) / 1e9 if dom in cb and n_l else 0.0
         kern_total_ms = sum(v[1] for v in prof.values())
+        traffic = None  # PMC bytes per launch of the dominant kernel, from the committed rocprofv3 passes
+        tpath = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath))["by_class"].get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "avg_launch_us": round(avg_us, 2), "launches_sampled": n_l,
             "sampling": f"HIP events around every launch of 1 in {PROF_EVERY} triples inside the timed region",
             "bytes_per_launch": int(cb.get(dom, 0)),

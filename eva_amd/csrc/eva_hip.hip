@@ -686,6 +686,8 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
       d.ninv_s = shoup(d.ninv, q);
       d.w0ninv = mulmod(irp[1], d.ninv, q);
       d.w0ninv_s = shoup(d.w0ninv, q);
+      d.nq = 0ull - q;
+      d.q5 = 5 * q;
       for (uint32_t a = 0; a < k; a++) {
         const u64 qa = c->primes[a];
         if (a == i) {

@@ -77,7 +77,7 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
   constexpr int NTT_R = 1 << LR;
   constexpr int S = 1 << P, TPS = S / NTT_R, G = NTT_R >> RB, NU = 1 << RB;
   constexpr int S0 = P - LO - RB; // local stages above this round
-  const u64 q = pm.q, nq = 0ull - pm.q, q5 = 5 * pm.q;
+  const u64 q = pm.q, nq = pm.nq, q5 = pm.q5;
   u64 x[NTT_R];
 #pragma unroll
   for (int g = 0; g < G; g++) {

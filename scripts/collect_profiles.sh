@@ -1,0 +1,16 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): bench line + rocprofv3 kernel trace + PMC traffic passes of the
+# same bench.py command.  Outputs under gpurun_out/prof_bench/ ; summaries are made by
+# scripts/rocprof_summary.py and scripts/pmc_traffic.py and committed under profiles/.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_bench
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 5 --warmup 1"
+python $R/bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
+tail -c 600 $OUT/bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py $ARGS --no-cpu-baseline > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+ls $OUT/trace/*/ | head
