@@ -309,6 +309,7 @@ struct evah_ctx {
   std::vector<hipEvent_t> sync_events; // recycled events for cross-queue ordering
   int ntt_lr = 3; // log2(coefficients per thread) in the NTT kernels (EVAH_NTT_LR=3|4)
   bool fuse_mac = true; // key-switch: fuse the inner product into the digit NTTs' second pass
+  int ks_lr = 2;        // log2(coefficients per thread) in the fused key-switch kernel (EVAH_KS_LR=2|3)
   int ks_threads = 256; // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS)
   // per-launch profile
   bool prof_on = false;
@@ -485,6 +486,7 @@ static void launch_pass_lr(evah_ctx *c, int P, const typename Op::Params &prm, u
 template <bool STRIDED, bool INVERSE, class Op>
 static void launch_pass_p(evah_ctx *c, int P, const typename Op::Params &prm, uint32_t jobs) {
   if (c->ntt_lr == 4) launch_pass_lr<4, STRIDED, INVERSE, Op>(c, P, prm, jobs);
+  else if (c->ntt_lr == 2) launch_pass_lr<2, STRIDED, INVERSE, Op>(c, P, prm, jobs);
   else launch_pass_lr<3, STRIDED, INVERSE, Op>(c, P, prm, jobs);
 }
 
@@ -500,14 +502,19 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
                      target, scratch, key, prod, l, logC);
   HIPCHK(hipGetLastError());
 }
-static void launch_ks_inner(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const u64 *key, u64 *prod, uint32_t l) {
+template <int LR>
+static void launch_ks_inner_lr(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const u64 *key, u64 *prod, uint32_t l) {
   switch (P) {
-  case 5: launch_ks_inner_plr<5, 3>(c, target, scratch, key, prod, l); break;
-  case 6: launch_ks_inner_plr<6, 3>(c, target, scratch, key, prod, l); break;
-  case 7: launch_ks_inner_plr<7, 3>(c, target, scratch, key, prod, l); break;
-  case 8: launch_ks_inner_plr<8, 3>(c, target, scratch, key, prod, l); break;
+  case 5: launch_ks_inner_plr<5, LR>(c, target, scratch, key, prod, l); break;
+  case 6: launch_ks_inner_plr<6, LR>(c, target, scratch, key, prod, l); break;
+  case 7: launch_ks_inner_plr<7, LR>(c, target, scratch, key, prod, l); break;
+  case 8: launch_ks_inner_plr<8, LR>(c, target, scratch, key, prod, l); break;
   default: throw std::runtime_error("unsupported poly_modulus_degree for the key-switch kernel");
   }
+}
+static void launch_ks_inner(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const u64 *key, u64 *prod, uint32_t l) {
+  if (c->ks_lr == 2) launch_ks_inner_lr<2>(c, P, target, scratch, key, prod, l);
+  else launch_ks_inner_lr<3>(c, P, target, scratch, key, prod, l);
 }
 
 template <class Op> static void ntt_forward(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
@@ -643,8 +650,9 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     c->logN = ilog2(N);
     c->k = k;
     c->primes.assign(primes, primes + k);
-    if (const char *e = std::getenv("EVAH_NTT_LR")) c->ntt_lr = std::atoi(e) == 4 ? 4 : 3;
+    if (const char *e = std::getenv("EVAH_NTT_LR")) c->ntt_lr = std::atoi(e) == 4 ? 4 : std::atoi(e) == 2 ? 2 : 3;
     if (const char *e = std::getenv("EVAH_FUSE_MAC")) c->fuse_mac = std::atoi(e) != 0;
+    if (const char *e = std::getenv("EVAH_KS_LR")) c->ks_lr = std::atoi(e) == 3 ? 3 : 2;
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {
       int t = std::atoi(e);
       if (t == 64 || t == 128 || t == 256) c->ks_threads = t;
@@ -737,6 +745,7 @@ int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
     c->ntt_lr = parent->ntt_lr;
     c->fuse_mac = parent->fuse_mac;
     c->ks_threads = parent->ks_threads;
+    c->ks_lr = parent->ks_lr;
     HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     HIPCHK(hipEventCreate(&c->ev0));
