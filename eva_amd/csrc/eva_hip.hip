@@ -463,7 +463,8 @@ static void launch_pass(evah_ctx *c, const typename Op::Params &prm, uint32_t jo
   const uint32_t max_tile = (uint32_t)NTT_THREADS << LR;
   const uint32_t tile = c->N < max_tile ? c->N : max_tile;
   const int logC = (int)ilog2(tile) - P;
-  const size_t lds = ((size_t)1 << logC) * lds_sub_stride<P>() * sizeof(u64);
+  size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64);
+  if (STRIDED) lds += ((size_t)1 << P) * sizeof(ulonglong2); // staged twiddles
   dim3 grid(c->N / tile, jobs), block(tile >> LR);
   hipLaunchKernelGGL((ntt_pass_kernel<P, LR, STRIDED, INVERSE, Op>), grid, block, lds, c->stream, c->dev,
                      prm, logC);
@@ -497,7 +498,9 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   const uint32_t tile = c->N < max_tile ? c->N : max_tile;
   const int logC = (int)ilog2(tile) - P;
   if (logC < 0) throw std::runtime_error("ks_inner tile smaller than one sub-transform");
-  const size_t lds = ((size_t)1 << logC) * lds_sub_stride<P>() * sizeof(u64);
+  // coefficients tile + per-sub twiddle heaps (16 B per node)
+  const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) +
+                     ((size_t)1 << (logC + P)) * sizeof(ulonglong2);
   hipLaunchKernelGGL((ks_inner_kernel<P, LR>), dim3(c->N / tile, l + 1), dim3(tile >> LR), lds, c->stream, c->dev,
                      target, scratch, key, prod, l, logC);
   HIPCHK(hipGetLastError());

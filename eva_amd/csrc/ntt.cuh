@@ -177,12 +177,17 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
     }
     lds[l] = FIRST ? Op::load(cx, jb, pm, n) : jb.dst[n];
   }
+  // strided pass: every column transform of the tile uses the same 2^P twiddles (heap nodes
+  // 1..2^P-1) — stage them in LDS once per workgroup instead of per-thread global loads
+  ulonglong2 *twl = reinterpret_cast<ulonglong2 *>(lds + ((C * SP + 1) & ~1));
+  if (STRIDED)
+    for (int idx = threadIdx.x; idx < S; idx += T) twl[idx] = tw[idx];
   __syncthreads();
 
   // ---- register rounds
   {
     const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
-    RoundSeq<P, LR, 0, INVERSE, STRIDED>::run(lds + sub * SP, tid, sub0 + sub, pre, tw, pm);
+    RoundSeq<P, LR, 0, INVERSE, STRIDED>::run(lds + sub * SP, tid, sub0 + sub, pre, STRIDED ? twl : tw, pm);
   }
   __syncthreads();
 
@@ -234,6 +239,19 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target, const u64 *__restrict
   const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
   const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
 
+  // The twiddles of this tile's sub-transforms are the same for every digit J: stage them in LDS
+  // once as per-sub local heaps (node n of sub s = global node ((2^pre + h_s) << depth(n)) + pos(n)),
+  // so the J loop touches global memory only for coefficients and key.
+  const int C = 1 << logC;
+  ulonglong2 *twl = reinterpret_cast<ulonglong2 *>(lds + ((C * SP + 1) & ~1));
+  for (int idx = threadIdx.x; idx < (C << P); idx += T) {
+    const int sb = idx >> P, n = idx & (S - 1);
+    if (n) {
+      const int d = 31 - __clz(n);
+      twl[idx] = tw[((size_t)((1u << pre) + sub0 + sb) << d) + (n - (1 << d))];
+    }
+  }
+
   u128_t acc0[NTT_R], acc1[NTT_R];
 #pragma unroll
   for (int i = 0; i < NTT_R; i++) { acc0[i] = {0, 0}; acc1[i] = {0, 0}; }
@@ -260,7 +278,8 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target, const u64 *__restrict
         lds[sb * SP + lds_pad(e + 1)] = v.y;
       }
       __syncthreads();
-      RoundSeq<P, LR, 0, false, false>::run(lds + sub * SP, tid, sub0 + sub, pre, tw, pm);
+      // STRIDED=true selects local-heap node indexing, which is what the LDS copy uses
+      RoundSeq<P, LR, 0, false, true>::run(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
       __syncthreads();
 #pragma unroll
       for (int it = 0; it < NPAIR; it++) {
