@@ -4,7 +4,7 @@ import sys as _sys
 
 import eva_amd as _impl
 from eva_amd import *  # noqa: F401,F403
-from eva_amd import Expr, EvaProgram, Input, Output, py_to_eva, evaluate, set_num_threads  # noqa: F401
+from eva_amd import Expr, EvaProgram, Input, Output, py_to_eva, evaluate, save, load, set_num_threads  # noqa: F401
 from eva_amd import ckks, seal, metric, std  # noqa: F401
 import eva_amd.std.numeric as _numeric
 

@@ -9,7 +9,7 @@ Importing this package does not import torch.
 import numbers
 
 from . import _hipruntime  # noqa: F401  (one HIP runtime per process; must precede the native modules)
-from ._eva import *  # noqa: F401,F403  (Program, Term, Op, Type, evaluate, set_num_threads)
+from ._eva import *  # noqa: F401,F403  (Program, Term, Op, Type, evaluate, save, load, set_num_threads)
 from . import _eva
 
 __version__ = "0.1.0"

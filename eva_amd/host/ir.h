@@ -144,6 +144,10 @@ public:
     return id;
   }
 
+  // used when rebuilding a program from a file
+  void bind_input(const std::string &name, TermId t) { inputs_[name] = t; }
+  void bind_output(const std::string &name, TermId t) { outputs_[name] = t; }
+
   // ---- access
   Term &at(TermId t) { return terms_.at(t); }
   const Term &at(TermId t) const { return terms_.at(t); }

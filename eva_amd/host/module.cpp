@@ -7,6 +7,7 @@
 #include <pybind11/stl.h>
 
 #include "executor.h"
+#include "serialization.h"
 
 namespace py = pybind11;
 using namespace evahost;
@@ -103,6 +104,23 @@ PYBIND11_MODULE(_eva, m) {
       });
 
   m.def("evaluate", &evaluate, py::arg("program"), py::arg("inputs"), "Evaluate the program without homomorphic encryption (reference semantics)");
+  // serialization (wrapper.cpp:110-116)
+  m.def("save", [](const Program &o, const std::string &path) { save_to_file(Kind::Program, o, path); }, py::arg("obj"), py::arg("path"));
+  m.def("save", [](const CKKSParameters &o, const std::string &path) { save_to_file(Kind::Parameters, o, path); }, py::arg("obj"), py::arg("path"));
+  m.def("save", [](const CKKSSignature &o, const std::string &path) { save_to_file(Kind::Signature, o, path); }, py::arg("obj"), py::arg("path"));
+  m.def("save", [](const HipValuation &o, const std::string &path) { save_to_file(Kind::Valuation, o, path); }, py::arg("obj"), py::arg("path"));
+  m.def("save", [](const HipPublic &o, const std::string &path) { save_to_file(Kind::Public, o, path); }, py::arg("obj"), py::arg("path"));
+  m.def("save", [](const HipSecret &o, const std::string &path) { save_to_file(Kind::Secret, o, path); }, py::arg("obj"), py::arg("path"));
+  m.def("load", [](const std::string &path) -> py::object {
+    KnownType k = load_from_file(path);
+    if (auto *p = std::get_if<std::unique_ptr<Program>>(&k)) return py::cast(std::move(*p));
+    if (auto *p = std::get_if<CKKSParameters>(&k)) return py::cast(*p);
+    if (auto *p = std::get_if<CKKSSignature>(&k)) return py::cast(*p);
+    if (auto *p = std::get_if<HipValuation>(&k)) return py::cast(std::move(*p));
+    if (auto *p = std::get_if<std::shared_ptr<HipPublic>>(&k)) return py::cast(*p);
+    return py::cast(std::get<std::shared_ptr<HipSecret>>(k));
+  }, py::arg("path"), "Load a previously saved object (same class as was saved)");
+
   m.def("set_num_threads", [](int n) { if (n < 1) throw std::invalid_argument("num_threads must be positive"); g_num_threads = n; }, py::arg("num_threads"),
         "Kept for API compatibility: node-level parallelism is HIP streams on the GPU, not host threads");
   struct GaloisGuard {};

@@ -1,0 +1,99 @@
+"""save / load of all six object kinds (reference: tests/features.py:154-217,
+examples/serialization.py).  CPU part: round trips + the execute step walked over the oracle;
+GPU part: the reference's full client / server flow through execute() on the MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from eva import EvaProgram, Input, Output, evaluate, save, load, Op
+from eva.ckks import CKKSCompiler
+from eva.metric import valuation_mse
+from eva.seal import generate_keys
+from evatest import oracle_execute
+
+
+def _flow(tmp_path, execute):
+    poly = EvaProgram('Polynomial', vec_size=1024)
+    with poly:
+        x = Input('x')
+        Output('y', 3 * x ** 2 + 5 * x - 2)
+    poly.set_output_ranges(20)
+    poly.set_input_scales(30)
+    inputs = {'x': [i / 100.0 for i in range(poly.vec_size)]}
+    reference = evaluate(poly, inputs)
+    poly, params, signature = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(poly)
+    p = lambda n: os.path.join(tmp_path, n)
+    save(poly, p('poly.eva'))
+    save(params, p('poly.evaparams'))
+    save(signature, p('poly.evasignature'))
+    params = load(p('poly.evaparams'))
+    public_ctx, secret_ctx = generate_keys(params)
+    save(public_ctx, p('poly.sealpublic'))
+    save(secret_ctx, p('poly.sealsecret'))
+    signature = load(p('poly.evasignature'))
+    public_ctx = load(p('poly.sealpublic'))
+    enc_inputs = public_ctx.encrypt(inputs, signature)
+    save(enc_inputs, p('poly_inputs.sealvals'))
+    poly = load(p('poly.eva'))
+    public_ctx = load(p('poly.sealpublic'))
+    enc_inputs = load(p('poly_inputs.sealvals'))
+    enc_outputs = execute(public_ctx, poly, enc_inputs)
+    save(enc_outputs, p('poly_outputs.sealvals'))
+    secret_ctx = load(p('poly.sealsecret'))
+    enc_outputs = load(p('poly_outputs.sealvals'))
+    outputs = secret_ctx.decrypt(enc_outputs, signature)
+    assert valuation_mse(reference, evaluate(poly, inputs)) < 1e-10
+    assert valuation_mse(outputs, reference) < 0.01
+
+
+def test_serialization_flow_cpu(tmp_path):
+    _flow(str(tmp_path), lambda pub, prog, enc: oracle_execute(pub, prog, enc))
+
+
+@pytest.mark.gpu
+def test_serialization_flow_gpu(tmp_path):
+    _flow(str(tmp_path), lambda pub, prog, enc: pub.execute(prog, enc))
+
+
+def test_round_trips_are_exact(tmp_path):
+    prog = EvaProgram('p', vec_size=64)
+    with prog:
+        x = Input('x')
+        y = Input('y', is_encrypted=False)
+        Output('z', (x << 3) * [float(i) for i in range(64)] + y * 0.25 - (x >> 1))
+    prog.set_output_ranges(20)
+    prog.set_input_scales(30)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    f = lambda n: os.path.join(str(tmp_path), n)
+    save(compiled, f('a'))
+    back = load(f('a'))
+    # term ids are re-densified on save, so the topological listing may come back in another
+    # (equally valid) order: compare as multisets of (op, arity, attributes)
+    strip = lambda dump: sorted(repr(sorted(({k: v for k, v in d.items() if k != 'id'} | {'operands': len(d['operands'])}).items(), key=str)) for d in dump)
+    assert back.name == compiled.name and back.vec_size == 64
+    assert strip(back._dump()) == strip(compiled._dump())
+    inputs = {'x': [i * 0.1 for i in range(64)], 'y': [1.0] * 64}
+    assert evaluate(back, inputs) == evaluate(compiled, inputs)
+    save(params, f('b'))
+    p2 = load(f('b'))
+    assert list(p2.prime_bits) == list(params.prime_bits) and set(p2.rotations) == set(params.rotations)
+    assert p2.poly_modulus_degree == params.poly_modulus_degree
+    save(sig, f('c'))
+    s2 = load(f('c'))
+    assert s2.vec_size == sig.vec_size and {k: (v.input_type, v.scale, v.level) for k, v in s2.inputs.items()} == \
+        {k: (v.input_type, v.scale, v.level) for k, v in sig.inputs.items()}
+    pub, sec = generate_keys(params, 5)
+    enc = pub.encrypt(inputs, sig)
+    save(enc, f('d'))
+    e2 = load(f('d'))
+    for name in enc.names():
+        a, b = enc.get(name), e2.get(name)
+        assert a[:4] == b[:4] and np.array_equal(np.asarray(a[4]), np.asarray(b[4]))
+    save(pub, f('e'))
+    pub2 = load(f('e'))
+    assert np.array_equal(pub.relin_key(), pub2.relin_key()) and pub.primes == pub2.primes
+    assert all(np.array_equal(v, pub2.galois_keys()[k]) for k, v in pub.galois_keys().items())
+    with pytest.raises(RuntimeError):
+        open(f('bad'), 'wb').write(b'nonsense')
+        load(f('bad'))
