@@ -60,6 +60,7 @@ _SIGS = {
     "evah_relinearize": [_vp, _vp, _vpp],
     "evah_relinearize_rescale": [_vp, _vp, C.c_uint32, _vpp],
     "evah_rotate": [_vp, _vp, C.c_int32, _vpp],
+    "evah_rotate_many": [_vp, _vp, C.POINTER(C.c_int32), C.c_uint32, _vpp],
     "evah_rescale": [_vp, _vp, C.c_uint32, _vpp],
     "evah_mod_switch": [_vp, _vp, _vpp],
     "evah_test_ntt": [_vp, C.c_uint32, C.c_int, _u64p],
@@ -350,6 +351,13 @@ class Context:
 
     def rotate(self, a, steps):
         return self._ct1(_lib.evah_rotate, a, C.c_int32(int(steps)))
+
+    def rotate_many(self, a, steps):
+        n = len(steps)
+        arr = (C.c_int32 * n)(*[int(x) for x in steps])
+        outs = (C.c_void_p * n)()
+        _chk(_lib.evah_rotate_many(self.h, a.h, arr, n, outs))
+        return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n)]
 
     def rescale(self, a, divisor_bits):
         return self._ct1(_lib.evah_rescale, a, C.c_uint32(int(divisor_bits)))

@@ -137,6 +137,23 @@ k_galois_perm(DevCtx cx, const u64 *a, size_t a_ps, const uint32_t *perm, u64 *o
   st2(out + p * o_ps + off, r);
 }
 
+// K8 for a batch of sibling rotations of one ciphertext: out[r][p][i][n] = in[p][i][perm_r[n]];
+// grid.z = r * 2 + p
+struct PermTables {
+  const uint32_t *perm[KS_BATCH_MAX];
+};
+__global__ void __launch_bounds__(256)
+k_galois_perm_many(DevCtx cx, const u64 *a, size_t a_ps, PermTables pt, u64 *out, size_t o_ps) {
+  const uint32_t z = blockIdx.z, r = z >> 1, p = z & 1, i = blockIdx.y;
+  const uint32_t n = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+  const uint2 pi = *reinterpret_cast<const uint2 *>(pt.perm[r] + n);
+  const u64 *src = a + p * a_ps + (size_t)i * cx.N;
+  ulonglong2 v;
+  v.x = src[pi.x];
+  v.y = src[pi.y];
+  st2(out + z * o_ps + (size_t)i * cx.N + n, v);
+}
+
 // per-limb constant fill (uniform-constant plaintexts); the per-limb values travel as a
 // kernel argument so the call needs no host->device copy and no synchronisation
 struct LimbVals {
@@ -491,8 +508,13 @@ static void launch_pass_p(evah_ctx *c, int P, const typename Op::Params &prm, ui
   else launch_pass_lr<3, STRIDED, INVERSE, Op>(c, P, prm, jobs);
 }
 
+struct KsBatch { // one launch worth of key-switches: regular strides, irregular keys
+  uint32_t n = 1;
+  size_t target_bs = 0, scratch_bs = 0, prod_bs = 0;
+  KsKeys keys{};
+};
 template <int P, int LR>
-static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scratch, const u64 *key, u64 *prod, uint32_t l) {
+static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scratch, const KsBatch &kb, u64 *prod, uint32_t l) {
   ProfScope ps(c, KC_KSMAC);
   const uint32_t max_tile = (uint32_t)c->ks_threads << LR;
   const uint32_t tile = c->N < max_tile ? c->N : max_tile;
@@ -501,12 +523,12 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   // coefficients tile + per-sub twiddle heaps (16 B per node)
   const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) +
                      ((size_t)1 << (logC + P)) * sizeof(ulonglong2);
-  hipLaunchKernelGGL((ks_inner_kernel<P, LR>), dim3(c->N / tile, l + 1), dim3(tile >> LR), lds, c->stream, c->dev,
-                     target, scratch, key, prod, l, logC);
+  hipLaunchKernelGGL((ks_inner_kernel<P, LR>), dim3(c->N / tile, l + 1, kb.n), dim3(tile >> LR), lds, c->stream, c->dev,
+                     target, kb.target_bs, scratch, kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, logC);
   HIPCHK(hipGetLastError());
 }
 template <int LR>
-static void launch_ks_inner_lr(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const u64 *key, u64 *prod, uint32_t l) {
+static void launch_ks_inner_lr(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const KsBatch &key, u64 *prod, uint32_t l) {
   switch (P) {
   case 5: launch_ks_inner_plr<5, LR>(c, target, scratch, key, prod, l); break;
   case 6: launch_ks_inner_plr<6, LR>(c, target, scratch, key, prod, l); break;
@@ -515,7 +537,7 @@ static void launch_ks_inner_lr(evah_ctx *c, int P, const u64 *target, const u64 
   default: throw std::runtime_error("unsupported poly_modulus_degree for the key-switch kernel");
   }
 }
-static void launch_ks_inner(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const u64 *key, u64 *prod, uint32_t l) {
+static void launch_ks_inner(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const KsBatch &key, u64 *prod, uint32_t l) {
   if (c->ks_lr == 2) launch_ks_inner_lr<2>(c, P, target, scratch, key, prod, l);
   else launch_ks_inner_lr<3>(c, P, target, scratch, key, prod, l);
 }
@@ -533,30 +555,43 @@ template <class Op> static void ntt_inverse(evah_ctx *c, const typename Op::Para
 
 // SEAL Evaluator::switch_key_inplace, device version.
 //   out[K] = (add && K < add_polys ? add[K] : 0) + keyswitch(target)[K],  K in {0,1}
-// steps 1-2 of switch_key: prod[K][I] (I <= l, slot l = special prime) = sum_J op(I,J) * key[J][K]
-static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev &key, u64 *prod_d) {
+// steps 1-2 of switch_key for a batch of n (target, key) pairs in one set of launches:
+// prod[b][K][I] (I <= l, slot l = special prime) = sum_J op_b(I,J) * key_b[J][K].
+// target_b = target + b * target_bs; prod_b = prod_d + b * 2 (l+1) N.
+static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t target_bs, const KeyDev *const *keys,
+                                uint32_t n, u64 *prod_d) {
   const size_t N = c->N;
-  if (key.n_digits < l) throw std::runtime_error("key switching key has too few digits");
-  Scratch t(c, (size_t)l * N);                 // coefficient-form digits
-  Scratch sc(c, (size_t)(l + 1) * l * N);      // converted digits, NTT form per output limb
-  struct { u64 *d; } prod{prod_d};
-  // 1. digits to coefficient form
-  OpPlain::Params ip{target, t.d, 0, 0, l, 0, 0};
-  ntt_inverse<OpPlain>(c, ip, l);
-  OpKsDigit::Params dp{t.d, sc.d, l};
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::runtime_error("key-switch batch out of range");
+  KsBatch kb;
+  kb.n = n;
+  kb.target_bs = target_bs;
+  kb.scratch_bs = (size_t)(l + 1) * l * N;
+  kb.prod_bs = (size_t)2 * (l + 1) * N;
+  for (uint32_t b = 0; b < n; b++) {
+    if (keys[b]->n_digits < l) throw std::runtime_error("key switching key has too few digits");
+    kb.keys.key[b] = keys[b]->d;
+  }
+  Scratch t(c, (size_t)n * l * N);        // coefficient-form digits
+  Scratch sc(c, n * kb.scratch_bs);       // converted digits, NTT form per output limb
+  // 1. digits to coefficient form (job -> (b, J))
+  OpPlain::Params ip{target, t.d, target_bs, (size_t)l * N, l, 0, 0};
+  ntt_inverse<OpPlain>(c, ip, n * l);
+  OpKsDigit::Params dp{t.d, sc.d, l, (size_t)l * N, kb.scratch_bs};
   if (c->fuse_mac && l <= 20) { // 128-bit accumulation of l products of a lazy (<10q) operand
     // 2a. base-convert + first (strided) NTT pass of every digit under every output prime
     const int a = (c->logN + 1) / 2, b = c->logN / 2;
-    launch_pass_p<true, false, OpKsDigit>(c, a, dp, (l + 1) * l);
+    launch_pass_p<true, false, OpKsDigit>(c, a, dp, n * (l + 1) * l);
     // 2b. second (contiguous) pass fused with the inner product with the key
-    launch_ks_inner(c, b, target, sc.d, key.d, prod.d, l);
+    launch_ks_inner(c, b, target, sc.d, kb, prod_d, l);
   } else {
     // unfused reference path (EVAH_FUSE_MAC=0): full digit NTTs, then a separate MAC kernel
-    ntt_forward<OpKsDigit>(c, dp, (l + 1) * l);
-    ProfScope ps(c, KC_KSMAC);
-    hipLaunchKernelGGL(k_ks_mac, dim3(c->N / 512, l + 1), dim3(256), 0, c->stream, c->dev, target, sc.d,
-                       key.d, prod.d, l);
-    HIPCHK(hipGetLastError());
+    ntt_forward<OpKsDigit>(c, dp, n * (l + 1) * l);
+    for (uint32_t b = 0; b < n; b++) {
+      ProfScope ps(c, KC_KSMAC);
+      hipLaunchKernelGGL(k_ks_mac, dim3(c->N / 512, l + 1), dim3(256), 0, c->stream, c->dev, target + b * target_bs,
+                         sc.d + b * kb.scratch_bs, keys[b]->d, prod_d + b * kb.prod_bs, l);
+      HIPCHK(hipGetLastError());
+    }
   }
 }
 
@@ -564,7 +599,8 @@ static void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev 
                        size_t add_ps, uint32_t add_polys, u64 *out, size_t out_ps) {
   const size_t N = c->N;
   Scratch prod(c, (size_t)2 * (l + 1) * N);    // [K][l+1][N]
-  switch_key_products(c, l, target, key, prod.d);
+  const KeyDev *kp = &key;
+  switch_key_products(c, l, target, 0, &kp, 1, prod.d);
   // 3. mod-down by the special prime: INTT(special limb) + P/2, then per-limb NTT + combine
   Scratch r(c, 2 * N);
   OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1};
@@ -1146,7 +1182,8 @@ int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bit
   evah_ct *o = ct_new(c, 2, l - 1, a->scale / std::pow(2.0, (double)divisor_bits));
   try {
     Scratch prod(c, 2 * pps);
-    switch_key_products(c, l, a->d + 2 * a->ps, c->sh->relin, prod.d);
+    const KeyDev *kp = &c->sh->relin;
+    switch_key_products(c, l, a->d + 2 * a->ps, 0, &kp, 1, prod.d);
     Scratch r(c, 2 * N), t(c, 2 * N);
     // r_K = INTT_P(prod[K][special]) + P/2
     OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1};
@@ -1162,6 +1199,84 @@ int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bit
     throw;
   }
   *out = o;
+  API_END
+}
+
+// NTT-domain permutation table of a Galois element (SEAL GaloisTool::generate_table_ntt), cached
+static const uint32_t *perm_table(evah_ctx *c, uint32_t elt) {
+  auto pit = c->sh->perms.find(elt);
+  if (pit != c->sh->perms.end()) return pit->second;
+  if (c->capturing) throw std::logic_error("first use of a Galois element cannot be captured into a graph");
+  const size_t N = c->N;
+  std::vector<uint32_t> tab(N);
+  for (uint32_t i = 0; i < N; i++) {
+    uint32_t reversed = bitrev((uint32_t)N + i, c->logN + 1);
+    u64 raw = (((u64)elt * reversed) >> 1) & (u64)(N - 1);
+    tab[i] = bitrev((uint32_t)raw, c->logN);
+  }
+  uint32_t *d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(uint32_t) * N));
+  HIPCHK(hipMemcpy(d, tab.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+  c->sh->perms.emplace(elt, d);
+  return d;
+}
+
+// Several rotations of ONE ciphertext (the convolution pattern: image << i*w+j for a 3x3
+// window) issued as one set of wide launches: same results as n evah_rotate calls, 1/n of the
+// kernel launches, each launch n times wider.
+int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32_t n, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  acquire(c, a->buf);
+  if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("rotate_many handles 1..16 rotations per call");
+  const uint32_t l = a->limbs;
+  const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
+  PermTables pt{};
+  std::vector<const KeyDev *> keys(n);
+  for (uint32_t r = 0; r < n; r++) {
+    if (steps[r] == 0) throw std::invalid_argument("rotate_many: zero steps are copies, not key switches");
+    uint32_t elt = 0;
+    if (evah_galois_elt_from_step(c, steps[r], &elt)) throw std::invalid_argument(g_err);
+    auto kit = c->sh->galois.find(elt);
+    if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
+    keys[r] = &kit->second;
+    pt.perm[r] = perm_table(c, elt);
+  }
+  // one buffer for all outputs; the n handles are views into it
+  Buffer *ob = buf_new(c, (size_t)n * 2 * pps);
+  try {
+    Scratch perm(c, (size_t)n * 2 * pps); // [r][c0 permuted | c1 permuted = key-switch target]
+    {
+      ProfScope ps(c, KC_EW);
+      hipLaunchKernelGGL(k_galois_perm_many, dim3(c->N / 512, l, 2 * n), dim3(256), 0, c->stream, c->dev, a->d, a->ps, pt,
+                         perm.d, pps);
+    }
+    HIPCHK(hipGetLastError());
+    Scratch prod(c, n * prod_bs);
+    switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), n, prod.d);
+    Scratch r(c, (size_t)n * 2 * N);
+    // INTT of the special limbs, job = r*2 + K
+    OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1};
+    ntt_inverse<OpPlain>(c, sp, 2 * n);
+    // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
+    OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, perm.d, pps, ~0u, ob->d, pps, c->k - 1, l};
+    ntt_forward<OpModDown>(c, mp, 2 * n * l);
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)n;
+  for (uint32_t r = 0; r < n; r++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)r * 2 * pps;
+    t->size = 2;
+    t->limbs = l;
+    t->ps = pps;
+    t->scale = a->scale;
+    outs[r] = t;
+  }
   API_END
 }
 
@@ -1181,23 +1296,11 @@ int evah_rotate(evah_ctx *c, const evah_ct *a, int32_t steps, evah_ct **out) {
     if (evah_galois_elt_from_step(c, steps, &elt)) throw std::invalid_argument(g_err);
     auto kit = c->sh->galois.find(elt);
     if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
-    auto pit = c->sh->perms.find(elt);
-    if (pit == c->sh->perms.end()) {
-      std::vector<uint32_t> tab(N);
-      for (uint32_t i = 0; i < N; i++) {
-        uint32_t reversed = bitrev((uint32_t)N + i, c->logN + 1);
-        u64 raw = (((u64)elt * reversed) >> 1) & (u64)(N - 1);
-        tab[i] = bitrev((uint32_t)raw, c->logN);
-      }
-      uint32_t *d = nullptr;
-      HIPCHK(hipMalloc(&d, sizeof(uint32_t) * N));
-      HIPCHK(hipMemcpy(d, tab.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
-      pit = c->sh->perms.emplace(elt, d).first;
-    }
+    const uint32_t *ptab = perm_table(c, elt);
     Scratch perm(c, (size_t)2 * a->limbs * N); // [c0 permuted][c1 permuted = key-switch target]
     const size_t pps = (size_t)a->limbs * N;
     EW_LAUNCH(k_galois_perm, ew_grid(c, a->limbs, 2), dim3(256), 0, c->stream, c->dev, a->d, a->ps,
-                       pit->second, perm.d, pps);
+                       ptab, perm.d, pps);
     HIPCHK(hipGetLastError());
     evah_ct *o = ct_new(c, 2, a->limbs, a->scale);
     try {

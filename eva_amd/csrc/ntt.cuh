@@ -222,11 +222,21 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
 // (or taking target[J] as is when I == J) and multiply-accumulating with key[J][0/1][kappa] into
 // 128-bit register accumulators.  The l^2 N converted digits are therefore never written back:
 // HBM sees the pass-1 intermediates once, the key once and prod[2][l+1][N] once.
+// Keys of a batch of key-switches issued as one launch (sibling rotations of one ciphertext).
+constexpr int KS_BATCH_MAX = 16;
+struct KsKeys {
+  const u64 *key[KS_BATCH_MAX];
+};
+
 template <int P, int LR>
 __global__ void __launch_bounds__(NTT_THREADS)
-ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target, const u64 *__restrict__ scratch,
-                const u64 *__restrict__ key, u64 *__restrict__ prod, uint32_t l, int logC) {
+ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
+                size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, int logC) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  const u64 *__restrict__ target = target_b + blockIdx.z * target_bs;
+  const u64 *__restrict__ scratch = scratch_b + blockIdx.z * scratch_bs;
+  const u64 *__restrict__ key = keys.key[blockIdx.z];
+  u64 *__restrict__ prod = prod_b + blockIdx.z * prod_bs;
   constexpr int NTT_R = 1 << LR, NPAIR = NTT_R / 2;
   constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
   const uint32_t I = blockIdx.y;
@@ -358,9 +368,10 @@ struct OpPlain {
 // scratch[I][J] = NTT_{kappa(I)}( t[J] mod q_kappa(I) ), I == J skipped (NTT form reused).
 struct OpKsDigit {
   struct Params {
-    const u64 *t;   // [l][N] coefficient-form digits
-    u64 *scratch;   // [l+1][l][N]
+    const u64 *t;   // [batch][l][N] coefficient-form digits
+    u64 *scratch;   // [batch][l+1][l][N]
     uint32_t l;
+    size_t t_bs, scratch_bs; // batch strides
   };
   struct Job {
     uint32_t prime;
@@ -369,11 +380,12 @@ struct OpKsDigit {
   };
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job,
                                                Job &j) {
-    const uint32_t I = job / p.l, J = job % p.l;
+    const uint32_t per = (p.l + 1) * p.l, b = job / per, rem = job % per;
+    const uint32_t I = rem / p.l, J = rem % p.l;
     if (I == J) return false;
     j.prime = (I == p.l) ? cx.k - 1 : I;
-    j.src = p.t + (size_t)J * cx.N;
-    j.dst = p.scratch + ((size_t)I * p.l + J) * cx.N;
+    j.src = p.t + b * p.t_bs + (size_t)J * cx.N;
+    j.dst = p.scratch + b * p.scratch_bs + ((size_t)I * p.l + J) * cx.N;
     return true;
   }
   static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm,
@@ -396,7 +408,7 @@ struct OpModDown {
     size_t r_ps;
     const u64 *c;
     size_t c_ps;
-    const u64 *add; // nullable; applies to polys p < add_polys
+    const u64 *add; // nullable; applies to polys p < add_polys (add_polys == ~0u: even p only)
     size_t add_ps;
     uint32_t add_polys;
     u64 *dst;
@@ -416,7 +428,8 @@ struct OpModDown {
     j.prime = i;
     j.src = p.r + pp * p.r_ps;
     j.c = p.c + pp * p.c_ps + (size_t)i * cx.N;
-    j.add = (p.add && pp < p.add_polys) ? p.add + pp * p.add_ps + (size_t)i * cx.N : nullptr;
+    const bool use_add = p.add && (p.add_polys == ~0u ? (pp & 1u) == 0 : pp < p.add_polys);
+    j.add = use_add ? p.add + pp * p.add_ps + (size_t)i * cx.N : nullptr;
     j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
     j.halfm = cx.halfmod[p.a * cx.k + i];
     j.inv = cx.invq[p.a * cx.k + i];

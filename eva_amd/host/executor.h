@@ -215,10 +215,35 @@ public:
         else rotate_right(raw(a[0]), x.rotation, o);
         objects[t] = std::move(o);
       } else {
+        if (has_value(t)) break; // already produced together with its sibling rotations
         // rightRotate passes the negated step (seal_executor.h:188)
-        evah_ct *h = nullptr;
-        chk(evah_rotate(ctx, ct(a[0]), x.op == Op::RotateLeftConst ? x.rotation : -x.rotation, &h));
-        objects[t] = std::make_shared<CtHandle>(ctx, h);
+        auto step_of = [&](TermId r) { const Term &y = program.at(r); return y.op == Op::RotateLeftConst ? y.rotation : -y.rotation; };
+        // sibling rotations of the same ciphertext (convolution windows) go out as one wide call
+        std::vector<TermId> group;
+        if (batch_rotations)
+          for (TermId u : program.at(a[0]).uses) {
+            const Term &y = program.at(u);
+            if ((y.op == Op::RotateLeftConst || y.op == Op::RotateRightConst) && step_of(u) != 0 && !has_value(u) &&
+                std::find(group.begin(), group.end(), u) == group.end())
+              group.push_back(u);
+          }
+        if (group.size() >= 2 && step_of(t) != 0) {
+          for (size_t i = 0; i < group.size(); i += 16) {
+            const uint32_t n = (uint32_t)std::min<size_t>(16, group.size() - i);
+            std::vector<int32_t> steps(n);
+            std::vector<evah_ct *> outs(n, nullptr);
+            for (uint32_t r = 0; r < n; r++) steps[r] = step_of(group[i + r]);
+            chk(evah_rotate_many(ctx, ct(a[0]), steps.data(), n, outs.data()));
+            for (uint32_t r = 0; r < n; r++) {
+              objects[group[i + r]] = std::make_shared<CtHandle>(ctx, outs[r]);
+              queue_of[group[i + r]] = queue_of[t];
+            }
+          }
+        } else {
+          evah_ct *h = nullptr;
+          chk(evah_rotate(ctx, ct(a[0]), step_of(t), &h));
+          objects[t] = std::make_shared<CtHandle>(ctx, h);
+        }
       }
       break;
     case Op::Negate:
@@ -339,6 +364,7 @@ private:
   uint32_t next_queue = 0;
   std::vector<double> scratch;
   std::vector<std::pair<TermId, TermId>> deferred_free; // (lazy relin term, its source)
+  bool batch_rotations = std::getenv("EVA_BATCH_ROTATIONS") ? std::atoi(std::getenv("EVA_BATCH_ROTATIONS")) != 0 : true;
   bool fuse_relin_rescale = std::getenv("EVA_FUSE_RELIN_RESCALE") ? std::atoi(std::getenv("EVA_FUSE_RELIN_RESCALE")) != 0 : true;
 
   // Queue for node t: key-switching / rescaling consumers of a fanned-out value are spread

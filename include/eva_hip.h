@@ -117,6 +117,10 @@ int evah_relinearize_rescale(evah_ctx *ctx, const evah_ct *a, uint32_t divisor_b
 /* evaluator.rotate_vector(a, steps) (seal_executor.h:181; rightRotate passes -steps, :188);
  * steps == 0 copies; needs the Galois key for exactly this step's element */
 int evah_rotate(evah_ctx *ctx, const evah_ct *a, int32_t steps, evah_ct **out);
+/* n (<= 16) non-zero rotations of the SAME ciphertext — n evaluator.rotate_vector calls
+ * (seal_executor.h:181) issued as one set of n-times-wider launches; outs[r] == evah_rotate(a, steps[r]).
+ * The host executor groups the sibling rotations of a term (convolution windows) into one call. */
+int evah_rotate_many(evah_ctx *ctx, const evah_ct *a, const int32_t *steps, uint32_t n, evah_ct **outs);
 /* evaluator.rescale_to_next + scale fix-up out.scale = a.scale / 2^divisor_bits
  * (seal_executor.h:213-214) */
 int evah_rescale(evah_ctx *ctx, const evah_ct *a, uint32_t divisor_bits, evah_ct **out);

@@ -155,6 +155,33 @@ def test_rotate_bit_exact(cfg):
         assert np.array_equal(out, e.o.rotate(e.o.mod_switch(a2), -(e.N // 4), key))
 
 
+@pytest.mark.parametrize("cfg", CONFIGS[:6], ids=lambda c: f"N{c[0]}")
+def test_rotate_many_equals_single_rotations(cfg):
+    """Sibling rotations issued as one wide launch set == the individual rotate_vector calls."""
+    e = env(cfg)
+    l = e.k - 1
+    a2 = e.rand(2, l)
+    A2 = e.g.upload_ct(a2, 2.0 ** 20)
+    steps = [1, 2, 64, 65, 66, 128, 129, 130, -3]
+    keys = {}
+    for st in steps:
+        elt = e.g.galois_elt_from_step(st)
+        keys[st] = e.rand_key()
+        e.g.upload_galois_key(elt, keys[st])
+    outs = e.g.rotate_many(A2, steps)
+    for st, o in zip(steps, outs):
+        assert o.info() == (2, l, 2.0 ** 20)
+        assert np.array_equal(o.download(), e.o.rotate(a2, st, keys[st])), f"rotate_many step {st}"
+    del outs
+    # from a mod-switched view, and a batch of one
+    if l > 1:
+        ms = e.g.mod_switch(A2)
+        o1 = e.g.rotate_many(ms, [65])[0]
+        assert np.array_equal(o1.download(), e.o.rotate(e.o.mod_switch(a2), 65, keys[65]))
+    with pytest.raises(backend.EvaHipError, match="zero steps"):
+        e.g.rotate_many(A2, [1, 0])
+
+
 def test_op_triple_metric_config_bit_exact():
     """BASELINE metric unit: multiply + relinearize + rescale at N=2^16, L=10."""
     N, bits = 65536, [60] * 11
