@@ -196,7 +196,13 @@ def main():
                        "parallelism": f"independent ciphertexts sharded over {world} GPU(s), no collective"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    # orderly teardown: values, then forked queues, then the root context
+    for a, b in pairs:
+        a.free(); b.free()
+    for q in queues[1:]:
+        q.close()
+    g.close()
     dist.close()
 
 
