@@ -165,7 +165,7 @@ def main():
             "by_class_share": {c: round(v[1] / kern_total_ms, 3) for c, v in prof.items() if v[0]},
         }
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
             from oracle import pyoracle as po  # checker / reported baseline only
             o = po.Oracle(N, primes)
             a, b = host_pairs[0]
