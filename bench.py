@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="independent op-triples per step")
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--limbs", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=32,
+    ap.add_argument("--streams", type=int, default=8,
                     help="issue queues (forked contexts = HIP streams) the independent triples are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)

@@ -25,7 +25,8 @@ struct DevPrime {
   u64 w0ninv;   // irp[1] * N^-1 mod q  (last inverse stage twiddle with the scaling folded in)
   u64 w0ninv_s;
   u64 nq;       // 2^64 - q   (kept as data: the compiler must not turn x + t*nq back into x - t*q)
-  u64 q5;       // 5q, the lazy-butterfly threshold
+  u64 q5;       // 5q, the inverse lazy-butterfly threshold
+  u64 q4, q8;   // 4q (forward difference offset), 8q (forward reduction threshold)
 };
 
 // Device-side view of a context (passed by value to kernels).

@@ -326,6 +326,7 @@ struct evah_ctx {
   std::vector<hipEvent_t> sync_events; // recycled events for cross-queue ordering
   int ntt_lr = 3; // log2(coefficients per thread) in the NTT kernels (EVAH_NTT_LR=3|4)
   bool fuse_mac = true; // key-switch: fuse the inner product into the digit NTTs' second pass
+  int ks_groups = 1;    // output-limb slices per key-switch (EVAH_KS_GROUPS)
   int ks_lr = 2;        // log2(coefficients per thread) in the fused key-switch kernel (EVAH_KS_LR=2|3)
   int ks_threads = 256; // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS)
   // per-launch profile
@@ -510,6 +511,7 @@ static void launch_pass_p(evah_ctx *c, int P, const typename Op::Params &prm, ui
 
 struct KsBatch { // one launch worth of key-switches: regular strides, irregular keys
   uint32_t n = 1;
+  uint32_t i0 = 0, ni = 0; // output-limb slice
   size_t target_bs = 0, scratch_bs = 0, prod_bs = 0;
   KsKeys keys{};
 };
@@ -523,8 +525,8 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   // coefficients tile + per-sub twiddle heaps (16 B per node)
   const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) +
                      ((size_t)1 << (logC + P)) * sizeof(ulonglong2);
-  hipLaunchKernelGGL((ks_inner_kernel<P, LR>), dim3(c->N / tile, l + 1, kb.n), dim3(tile >> LR), lds, c->stream, c->dev,
-                     target, kb.target_bs, scratch, kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, logC);
+  hipLaunchKernelGGL((ks_inner_kernel<P, LR>), dim3(c->N / tile, kb.ni, kb.n), dim3(tile >> LR), lds, c->stream, c->dev,
+                     target, kb.target_bs, scratch, kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC);
   HIPCHK(hipGetLastError());
 }
 template <int LR>
@@ -576,13 +578,22 @@ static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size
   // 1. digits to coefficient form (job -> (b, J))
   OpPlain::Params ip{target, t.d, target_bs, (size_t)l * N, l, 0, 0};
   ntt_inverse<OpPlain>(c, ip, n * l);
-  OpKsDigit::Params dp{t.d, sc.d, l, (size_t)l * N, kb.scratch_bs};
-  if (c->fuse_mac && l <= 20) { // 128-bit accumulation of l products of a lazy (<10q) operand
-    // 2a. base-convert + first (strided) NTT pass of every digit under every output prime
+  OpKsDigit::Params dp{t.d, sc.d, l, (size_t)l * N, kb.scratch_bs, 0, l + 1};
+  if (c->fuse_mac && l <= 16) { // 128-bit accumulation of l products of a lazy (<16q) operand
+    // Output limbs are processed in slices so that a slice's converted digits (ni * l * N words)
+    // are still in L2 / Infinity Cache when the fused second pass consumes them.
     const int a = (c->logN + 1) / 2, b = c->logN / 2;
-    launch_pass_p<true, false, OpKsDigit>(c, a, dp, n * (l + 1) * l);
-    // 2b. second (contiguous) pass fused with the inner product with the key
-    launch_ks_inner(c, b, target, sc.d, kb, prod_d, l);
+    const uint32_t groups = std::min<uint32_t>(std::max(1, c->ks_groups), l + 1);
+    for (uint32_t g = 0; g < groups; g++) {
+      const uint32_t i0 = (uint32_t)((uint64_t)(l + 1) * g / groups), i1 = (uint32_t)((uint64_t)(l + 1) * (g + 1) / groups);
+      if (i1 == i0) continue;
+      dp.i0 = kb.i0 = i0;
+      dp.ni = kb.ni = i1 - i0;
+      // 2a. base-convert + first (strided) NTT pass of every digit under the slice's output primes
+      launch_pass_p<true, false, OpKsDigit>(c, a, dp, n * (i1 - i0) * l);
+      // 2b. second (contiguous) pass fused with the inner product with the key
+      launch_ks_inner(c, b, target, sc.d, kb, prod_d, l);
+    }
   } else {
     // unfused reference path (EVAH_FUSE_MAC=0): full digit NTTs, then a separate MAC kernel
     ntt_forward<OpKsDigit>(c, dp, n * (l + 1) * l);
@@ -692,6 +703,7 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     if (const char *e = std::getenv("EVAH_NTT_LR")) c->ntt_lr = std::atoi(e) == 4 ? 4 : std::atoi(e) == 2 ? 2 : 3;
     if (const char *e = std::getenv("EVAH_FUSE_MAC")) c->fuse_mac = std::atoi(e) != 0;
     if (const char *e = std::getenv("EVAH_KS_LR")) c->ks_lr = std::atoi(e) == 3 ? 3 : 2;
+    if (const char *e = std::getenv("EVAH_KS_GROUPS")) c->ks_groups = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {
       int t = std::atoi(e);
       if (t == 64 || t == 128 || t == 256) c->ks_threads = t;
@@ -735,6 +747,8 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
       d.w0ninv_s = shoup(d.w0ninv, q);
       d.nq = 0ull - q;
       d.q5 = 5 * q;
+      d.q4 = 4 * q;
+      d.q8 = 8 * q;
       for (uint32_t a = 0; a < k; a++) {
         const u64 qa = c->primes[a];
         if (a == i) {
@@ -785,6 +799,7 @@ int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
     c->fuse_mac = parent->fuse_mac;
     c->ks_threads = parent->ks_threads;
     c->ks_lr = parent->ks_lr;
+    c->ks_groups = parent->ks_groups;
     HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     HIPCHK(hipEventCreate(&c->ev0));

@@ -17,7 +17,8 @@
 // One workgroup owns a tile of up to 4096 coefficients in LDS (32 KiB + padding); each thread
 // keeps 16 coefficients in registers per round and runs up to 4 butterfly stages on them
 // (radix-16 worth of work per LDS round trip).  Lazy butterflies: forward values live in
-// [0,10q), inverse in [0,5q) (q < 2^60); only the value finally stored is canonical.
+// [0,16q) with a conditional subtraction every other stage, inverse in [0,5q) (q < 2^60); only
+// the value finally stored is canonical.
 //
 // The first pass reads through Op::load and the second writes through Op::store, which is how
 // the digit base-conversion, the rescale / mod-down combine and the +q/2 rounding offset are
@@ -55,12 +56,17 @@ __device__ __forceinline__ u64 mul_tw_lazy5(u64 x, u64 w, u64 ws, u64 nq) {
   const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
   return x * w + qt * nq;
 }
-// forward Cooley-Tukey butterfly, X,Y in [0,10q) -> [0,10q)
-__device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q5) {
-  u64 x = X - (X >= q5 ? q5 : 0);
+// forward Cooley-Tukey butterfly.  The twiddle product is in [0,4q), so each stage grows the
+// bound by 4q; moduli are < 2^60 (16q < 2^64), which leaves room to reduce only every other stage:
+//   REDUCE stage : X < 16q -> x < 8q  -> outputs < 12q
+//   plain stage  : X < 12q            -> outputs < 16q
+// (Y only feeds the multiply, which accepts any 64-bit value.)
+template <bool REDUCE>
+__device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q4, u64 q8) {
+  u64 x = REDUCE ? X - (X >= q8 ? q8 : 0) : X;
   u64 t = mul_tw_lazy5(Y, w.x, w.y, nq);
   X = x + t;
-  Y = x + q5 - t;
+  Y = x + q4 - t;
 }
 // inverse Gentleman-Sande butterfly, X,Y in [0,5q) -> [0,5q)
 __device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q5) {
@@ -71,13 +77,17 @@ __device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u
 }
 
 // One register round: RB stages over bit range [LO, LO+RB) of the P-bit local index.
-template <int P, int LR, int RB, int LO, bool INVERSE, bool STRIDED>
+// RED_EVEN: forward passes reduce on even (true) or odd (false) local stage indices — the first
+// (strided) pass starts from canonical input and reduces on odd stages, so it always exits < 16q;
+// the second pass therefore reduces on even stages.
+template <int P, int LR, int RB, int LO, bool INVERSE, bool STRIDED, bool RED_EVEN>
 __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
                                           const ulonglong2 *__restrict__ tw, const DevPrime &pm) {
   constexpr int NTT_R = 1 << LR;
   constexpr int S = 1 << P, TPS = S / NTT_R, G = NTT_R >> RB, NU = 1 << RB;
   constexpr int S0 = P - LO - RB; // local stages above this round
-  const u64 q = pm.q, nq = pm.nq, q5 = pm.q5;
+  const u64 q = pm.q, nq = pm.nq, q5 = pm.q5, q4 = pm.q4, q8 = pm.q8;
+  (void)q4; (void)q8; (void)q5;
   u64 x[NTT_R];
 #pragma unroll
   for (int g = 0; g < G; g++) {
@@ -97,7 +107,8 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
           if (u & half) continue;
           const int v = u >> (RB - s);
           const ulonglong2 w = tw[((size_t)node << s) + v];
-          bfly_fwd(x[g * NU + u], x[g * NU + u + half], w, nq, q5);
+          if ((((S0 + s) & 1) == 0) == RED_EVEN) bfly_fwd<true>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8);
+          else bfly_fwd<false>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8);
         }
       }
     } else {
@@ -127,16 +138,16 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
   }
 }
 
-template <int P, int LR, int I, bool INVERSE, bool STRIDED> struct RoundSeq {
+template <int P, int LR, int I, bool INVERSE, bool STRIDED, bool RED_EVEN> struct RoundSeq {
   // forward: rounds 0..NR-1 (top bits first); inverse: NR-1..0 (low bits first)
   static __device__ __forceinline__ void run(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
                                              const ulonglong2 *tw, const DevPrime &pm) {
     using RS = Rounds<P, LR>;
     constexpr int idx = INVERSE ? (RS::NR - 1 - I) : I;
-    ntt_round<P, LR, RS::bits(idx), RS::lo(idx), INVERSE, STRIDED>(sub_lds, tid, h, pre, tw, pm);
+    ntt_round<P, LR, RS::bits(idx), RS::lo(idx), INVERSE, STRIDED, RED_EVEN>(sub_lds, tid, h, pre, tw, pm);
     if constexpr (I + 1 < RS::NR) {
       __syncthreads();
-      RoundSeq<P, LR, I + 1, INVERSE, STRIDED>::run(sub_lds, tid, h, pre, tw, pm);
+      RoundSeq<P, LR, I + 1, INVERSE, STRIDED, RED_EVEN>::run(sub_lds, tid, h, pre, tw, pm);
     }
   }
 };
@@ -187,7 +198,7 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
   // ---- register rounds
   {
     const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
-    RoundSeq<P, LR, 0, INVERSE, STRIDED>::run(lds + sub * SP, tid, sub0 + sub, pre, STRIDED ? twl : tw, pm);
+    RoundSeq<P, LR, 0, INVERSE, STRIDED, !STRIDED>::run(lds + sub * SP, tid, sub0 + sub, pre, STRIDED ? twl : tw, pm);
   }
   __syncthreads();
 
@@ -210,7 +221,7 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
     if (FIRST) {
       jb.dst[n] = v; // lazy intermediate
     } else {
-      if (!INVERSE) v = barrett64(v, pm.q, pm.brt); // forward final: [0,10q) -> canonical
+      if (!INVERSE) v = barrett64(v, pm.q, pm.brt); // forward final: [0,16q) -> canonical
       Op::store(cx, jb, pm, n, v);
     }
   }
@@ -231,7 +242,8 @@ struct KsKeys {
 template <int P, int LR>
 __global__ void __launch_bounds__(NTT_THREADS)
 ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
-                size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, int logC) {
+                size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, uint32_t i0,
+                int logC) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   const u64 *__restrict__ target = target_b + blockIdx.z * target_bs;
   const u64 *__restrict__ scratch = scratch_b + blockIdx.z * scratch_bs;
@@ -239,7 +251,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   u64 *__restrict__ prod = prod_b + blockIdx.z * prod_bs;
   constexpr int NTT_R = 1 << LR, NPAIR = NTT_R / 2;
   constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
-  const uint32_t I = blockIdx.y;
+  const uint32_t I = i0 + blockIdx.y;
   const uint32_t kap = (I == l) ? cx.k - 1 : I;
   const DevPrime pm = cx.primes[kap];
   const ulonglong2 *tw = cx.tw_fwd + (size_t)kap * cx.N;
@@ -289,13 +301,13 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
       }
       __syncthreads();
       // STRIDED=true selects local-heap node indexing, which is what the LDS copy uses
-      RoundSeq<P, LR, 0, false, true>::run(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
+      RoundSeq<P, LR, 0, false, true, true>::run(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
       __syncthreads();
 #pragma unroll
       for (int it = 0; it < NPAIR; it++) {
         const int idx = 2 * (threadIdx.x + it * T);
         const int sb = idx >> P, e = idx & (S - 1);
-        val[2 * it] = lds[sb * SP + lds_pad(e)];       // lazy [0,10q): fine for the 128-bit MAC (l <= 20)
+        val[2 * it] = lds[sb * SP + lds_pad(e)];       // lazy [0,16q): fine for the 128-bit MAC (l <= 16)
         val[2 * it + 1] = lds[sb * SP + lds_pad(e + 1)];
       }
     }
@@ -372,6 +384,7 @@ struct OpKsDigit {
     u64 *scratch;   // [batch][l+1][l][N]
     uint32_t l;
     size_t t_bs, scratch_bs; // batch strides
+    uint32_t i0, ni;         // output-limb slice [i0, i0+ni) handled by this launch
   };
   struct Job {
     uint32_t prime;
@@ -380,8 +393,8 @@ struct OpKsDigit {
   };
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job,
                                                Job &j) {
-    const uint32_t per = (p.l + 1) * p.l, b = job / per, rem = job % per;
-    const uint32_t I = rem / p.l, J = rem % p.l;
+    const uint32_t per = p.ni * p.l, b = job / per, rem = job % per;
+    const uint32_t I = p.i0 + rem / p.l, J = rem % p.l;
     if (I == J) return false;
     j.prime = (I == p.l) ? cx.k - 1 : I;
     j.src = p.t + b * p.t_bs + (size_t)J * cx.N;

@@ -262,3 +262,28 @@ def test_graph_replay_matches_eager_and_oracle():
             assert o[:4] == ref[:4]
             assert np.array_equal(o[4], ref[4]), f"execute() call {i} (graph replay from call 1 on) differs from the oracle"
         assert pub.last_timing[1] < 5.0
+
+
+def test_executor_options_give_identical_ciphertexts():
+    """Issue-queue count, rotation batching and relinearize+rescale fusion are scheduling choices:
+    every combination must produce the same output ciphertext as the plain serial walk."""
+    import numpy as np
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false', 'lazy_relinearize': 'false'}).compile(_harris())
+    params.poly_modulus_degree = 16384
+    pub, sec = generate_keys(params, 9)
+    enc = pub.encrypt(_image(4096), sig)
+    pub.use_graphs = False
+    base = None
+    import os
+    for queues in (1, 3, 8):
+        for batch in ("1", "0"):
+            for fuse in ("1", "0"):
+                os.environ["EVA_BATCH_ROTATIONS"], os.environ["EVA_FUSE_RELIN_RESCALE"] = batch, fuse
+                pub.num_queues = queues
+                out = pub.execute(compiled, enc).get('image')
+                if base is None:
+                    base = out
+                assert out[:4] == base[:4] and np.array_equal(out[4], base[4]), (queues, batch, fuse)
+    os.environ.pop("EVA_BATCH_ROTATIONS"); os.environ.pop("EVA_FUSE_RELIN_RESCALE")

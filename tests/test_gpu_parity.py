@@ -182,6 +182,28 @@ def test_rotate_many_equals_single_rotations(cfg):
         e.g.rotate_many(A2, [1, 0])
 
 
+@pytest.mark.parametrize("cfg", [(4096, [40] * 19 + [41]), (131072, [60, 50, 60, 60])], ids=["l19_unfused", "N131072"])
+def test_key_switch_extremes_bit_exact(cfg):
+    """l > 16 takes the unfused digit-NTT + MAC path (128-bit accumulator headroom); N = 2^17 is
+    the largest degree the kernels support."""
+    e = Env(*cfg)
+    l = e.k - 1
+    key = e.rand_key()
+    e.g.upload_relin_key(key)
+    a3 = e.rand(3, l)
+    A3 = e.g.upload_ct(a3, 2.0 ** 35)
+    ref = e.o.relinearize(a3, key)
+    assert np.array_equal(e.g.relinearize(A3).download(), ref)
+    assert np.array_equal(e.g.relinearize_rescale(A3, 20).download(), e.o.rescale(ref))
+    gk = e.rand_key()
+    e.g.upload_galois_key(e.g.galois_elt_from_step(7), gk)
+    a2 = e.rand(2, l)
+    A2 = e.g.upload_ct(a2, 2.0 ** 20)
+    want = e.o.rotate(a2, 7, gk)
+    assert np.array_equal(e.g.rotate(A2, 7).download(), want)
+    assert np.array_equal(e.g.rotate_many(A2, [7])[0].download(), want)
+
+
 def test_op_triple_metric_config_bit_exact():
     """BASELINE metric unit: multiply + relinearize + rescale at N=2^16, L=10."""
     N, bits = 65536, [60] * 11
