@@ -324,10 +324,8 @@ struct evah_ctx {
   bool capturing = false;              // inside evah_capture_begin/end: no syncs, no profiling events
   std::vector<hipEvent_t> capture_events; // events consumed by the capture in progress
   std::vector<hipEvent_t> sync_events; // recycled events for cross-queue ordering
-  int ntt_lr = 3; // log2(coefficients per thread) in the NTT kernels (EVAH_NTT_LR=3|4)
   bool fuse_mac = true; // key-switch: fuse the inner product into the digit NTTs' second pass
   int ks_groups = 1;    // output-limb slices per key-switch (EVAH_KS_GROUPS)
-  int ks_lr = 2;        // log2(coefficients per thread) in the fused key-switch kernel (EVAH_KS_LR=2|3)
   int ks_threads = 256; // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS)
   // per-launch profile
   bool prof_on = false;
@@ -502,11 +500,11 @@ static void launch_pass_lr(evah_ctx *c, int P, const typename Op::Params &prm, u
   default: throw std::runtime_error("unsupported poly_modulus_degree for the NTT kernels");
   }
 }
+// 8 coefficients per thread measured best for the stand-alone passes on MI355X (vs 4: +12 %,
+// vs 16: +10 %, profiles/r01_tuning_notes.md); the fused key-switch kernel uses 4.
 template <bool STRIDED, bool INVERSE, class Op>
 static void launch_pass_p(evah_ctx *c, int P, const typename Op::Params &prm, uint32_t jobs) {
-  if (c->ntt_lr == 4) launch_pass_lr<4, STRIDED, INVERSE, Op>(c, P, prm, jobs);
-  else if (c->ntt_lr == 2) launch_pass_lr<2, STRIDED, INVERSE, Op>(c, P, prm, jobs);
-  else launch_pass_lr<3, STRIDED, INVERSE, Op>(c, P, prm, jobs);
+  launch_pass_lr<3, STRIDED, INVERSE, Op>(c, P, prm, jobs);
 }
 
 struct KsBatch { // one launch worth of key-switches: regular strides, irregular keys
@@ -540,8 +538,7 @@ static void launch_ks_inner_lr(evah_ctx *c, int P, const u64 *target, const u64 
   }
 }
 static void launch_ks_inner(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const KsBatch &key, u64 *prod, uint32_t l) {
-  if (c->ks_lr == 2) launch_ks_inner_lr<2>(c, P, target, scratch, key, prod, l);
-  else launch_ks_inner_lr<3>(c, P, target, scratch, key, prod, l);
+  launch_ks_inner_lr<2>(c, P, target, scratch, key, prod, l); // 4 coefficients per thread: 32 accumulator VGPRs
 }
 
 template <class Op> static void ntt_forward(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
@@ -700,9 +697,7 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     c->logN = ilog2(N);
     c->k = k;
     c->primes.assign(primes, primes + k);
-    if (const char *e = std::getenv("EVAH_NTT_LR")) c->ntt_lr = std::atoi(e) == 4 ? 4 : std::atoi(e) == 2 ? 2 : 3;
     if (const char *e = std::getenv("EVAH_FUSE_MAC")) c->fuse_mac = std::atoi(e) != 0;
-    if (const char *e = std::getenv("EVAH_KS_LR")) c->ks_lr = std::atoi(e) == 3 ? 3 : 2;
     if (const char *e = std::getenv("EVAH_KS_GROUPS")) c->ks_groups = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {
       int t = std::atoi(e);
@@ -795,10 +790,8 @@ int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
     c->primes = parent->primes;
     c->total_bits = parent->total_bits;
     c->dev = parent->dev;
-    c->ntt_lr = parent->ntt_lr;
     c->fuse_mac = parent->fuse_mac;
     c->ks_threads = parent->ks_threads;
-    c->ks_lr = parent->ks_lr;
     c->ks_groups = parent->ks_groups;
     HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
