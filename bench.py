@@ -3,8 +3,8 @@
 (multiply + relinearize + rescale) at N = 2^16, L = 10 data limbs (k = 11 key primes).
 
 One "step" = one batch of --batch independent op-triples through the C-ABI of libeva_hip.so
-(evah_multiply -> evah_relinearize_rescale, i.e. relinearize and rescale_to_next evaluated
-together with a bit-identical result), inputs and the relinearization key already
+(evah_multiply per triple, then evah_relinearize_rescale_many per group of --group triples:
+relinearize and rescale_to_next evaluated together, bit-identical to the separate calls), inputs and the relinearization key already
 resident in HBM.  One process per GPU; ranks run independent batches (the path shards over
 independent ciphertexts — no data-path collective), `value` = triples of all ranks / max time.
 
@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def class_bytes(N, l, k):
+def class_bytes(N, l, k, G=1):
     """Compulsory HBM bytes (distinct inputs read once + outputs written once) per launch of each
     kernel class inside one op-triple as bench.py issues it — evah_multiply, then
     evah_relinearize_rescale (relinearize at l limbs fused with the rescale l -> l-1); DESIGN.md §4.
@@ -39,7 +39,8 @@ def class_bytes(N, l, k):
         "moddown_pass1": [(2 + 2 + 2 * (l - 1)) * W],                 # r, t in; intermediates out
         "moddown_pass2": [(4 * 2 * (l - 1)) * W],                     # interm + a + prod in; out
     }
-    return {kk: sum(v) / len(v) for kk, v in per_launch.items()}
+    # launches of the batched call cover G triples each; the multiply is issued per triple
+    return {kk: (sum(v) / len(v)) * (1 if kk == "elementwise" else G) for kk, v in per_launch.items()}
 
 
 def triple_bytes(N, l):
@@ -56,8 +57,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="independent op-triples per step")
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--limbs", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=4,
                     help="issue queues (forked contexts = HIP streams) the independent triples are spread over")
+    ap.add_argument("--group", type=int, default=4,
+                    help="triples handed to one evah_relinearize_rescale_many call (wide launches, shared key)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -99,18 +102,22 @@ def main():
 
     PROF_EVERY = 8  # HIP-event brackets on every 8th triple only: keeps the timed region honest
 
+    G = max(1, min(args.group, 16, args.batch))
+
     def step(profile=False):
-        for i in range(args.batch):
-            a, b = pairs[i % npairs]
-            q = queues[i % len(queues)]
-            sample = profile and (i % PROF_EVERY == 0)
+        # the batch is issued in groups of G independent triples per queue: G multiplies, then one
+        # relinearize_rescale_many (== rescale(relinearize(m)) for each m) as one wide launch set
+        for gi, i0 in enumerate(range(0, args.batch, G)):
+            q = queues[gi % len(queues)]
+            sample = profile and (gi % max(1, PROF_EVERY // G) == 0)
             if sample:
                 q.profile(True)
-            m = q.multiply(a, b)
-            o = q.relinearize_rescale(m, 60)   # == rescale(relinearize(m)), evaluated together
+            ms = [q.multiply(*pairs[i % npairs]) for i in range(i0, min(i0 + G, args.batch))]
+            outs = q.relinearize_rescale_many(ms, 60) if len(ms) > 1 else [q.relinearize_rescale(ms[0], 60)]
             if sample:
                 q.profile(False)
-            m.free(); o.free()
+            for h in ms + outs:
+                h.free()
 
     def barrier():
         for q in queues:
@@ -138,7 +145,7 @@ def main():
     value = triples / dt
 
     if rank == 0:
-        cb = class_bytes(N, l, k)
+        cb = class_bytes(N, l, k, G)
         dom = max(prof, key=lambda c: prof[c][1])
         n_l, ms = prof[dom]
         avg_us = ms * 1e3 / max(n_l, 1)
@@ -211,7 +218,7 @@ def main():
                                    f"L={l} data limbs + 1 special prime (60-bit), "
                                    f"{args.batch} independent triples per step per GPU",
                        "poly_modulus_degree": N, "limbs": l, "batch_per_gpu": args.batch,
-                       "streams_per_gpu": len(queues),
+                       "streams_per_gpu": len(queues), "triples_per_call": G,
                        "parallelism": f"independent ciphertexts sharded over {world} GPU(s), no collective"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

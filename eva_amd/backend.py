@@ -59,6 +59,7 @@ _SIGS = {
     "evah_multiply_plain": [_vp, _vp, _vp, _vpp],
     "evah_relinearize": [_vp, _vp, _vpp],
     "evah_relinearize_rescale": [_vp, _vp, C.c_uint32, _vpp],
+    "evah_relinearize_rescale_many": [_vp, _vpp, C.c_uint32, C.c_uint32, _vpp],
     "evah_rotate": [_vp, _vp, C.c_int32, _vpp],
     "evah_rotate_many": [_vp, _vp, C.POINTER(C.c_int32), C.c_uint32, _vpp],
     "evah_rescale": [_vp, _vp, C.c_uint32, _vpp],
@@ -348,6 +349,13 @@ class Context:
 
     def relinearize_rescale(self, a, divisor_bits):
         return self._ct1(_lib.evah_relinearize_rescale, a, C.c_uint32(int(divisor_bits)))
+
+    def relinearize_rescale_many(self, cts, divisor_bits):
+        n = len(cts)
+        ins = (C.c_void_p * n)(*[ct.h for ct in cts])
+        outs = (C.c_void_p * n)()
+        _chk(_lib.evah_relinearize_rescale_many(self.h, ins, n, C.c_uint32(int(divisor_bits)), outs))
+        return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n)]
 
     def rotate(self, a, steps):
         return self._ct1(_lib.evah_rotate, a, C.c_int32(int(steps)))

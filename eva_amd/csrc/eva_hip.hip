@@ -512,6 +512,7 @@ struct KsBatch { // one launch worth of key-switches: regular strides, irregular
   uint32_t i0 = 0, ni = 0; // output-limb slice
   size_t target_bs = 0, scratch_bs = 0, prod_bs = 0;
   KsKeys keys{};
+  PtrTab targets{}; // used when the targets are separate allocations (target == nullptr)
 };
 template <int P, int LR>
 static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scratch, const KsBatch &kb, u64 *prod, uint32_t l) {
@@ -523,8 +524,10 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   // coefficients tile + per-sub twiddle heaps (16 B per node)
   const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) +
                      ((size_t)1 << (logC + P)) * sizeof(ulonglong2);
-  hipLaunchKernelGGL((ks_inner_kernel<P, LR>), dim3(c->N / tile, kb.ni, kb.n), dim3(tile >> LR), lds, c->stream, c->dev,
-                     target, kb.target_bs, scratch, kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC);
+  const uint32_t n_tiles = c->N / tile;
+  hipLaunchKernelGGL((ks_inner_kernel<P, LR>), dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev,
+                     target, kb.target_bs, scratch, kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n,
+                     kb.targets);
   HIPCHK(hipGetLastError());
 }
 template <int LR>
@@ -558,7 +561,7 @@ template <class Op> static void ntt_inverse(evah_ctx *c, const typename Op::Para
 // prod[b][K][I] (I <= l, slot l = special prime) = sum_J op_b(I,J) * key_b[J][K].
 // target_b = target + b * target_bs; prod_b = prod_d + b * 2 (l+1) N.
 static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t target_bs, const KeyDev *const *keys,
-                                uint32_t n, u64 *prod_d) {
+                                uint32_t n, u64 *prod_d, const PtrTab *target_tab = nullptr) {
   const size_t N = c->N;
   if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::runtime_error("key-switch batch out of range");
   KsBatch kb;
@@ -570,10 +573,12 @@ static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size
     if (keys[b]->n_digits < l) throw std::runtime_error("key switching key has too few digits");
     kb.keys.key[b] = keys[b]->d;
   }
+  if (target_tab) kb.targets = *target_tab; // target == nullptr: separately allocated targets
   Scratch t(c, (size_t)n * l * N);        // coefficient-form digits
   Scratch sc(c, n * kb.scratch_bs);       // converted digits, NTT form per output limb
   // 1. digits to coefficient form (job -> (b, J))
-  OpPlain::Params ip{target, t.d, target_bs, (size_t)l * N, l, 0, 0};
+  OpPlain::Params ip{target, t.d, target_bs, (size_t)l * N, l, 0, 0, {}};
+  if (target_tab) ip.src_tab = *target_tab;
   ntt_inverse<OpPlain>(c, ip, n * l);
   OpKsDigit::Params dp{t.d, sc.d, l, (size_t)l * N, kb.scratch_bs, 0, l + 1};
   if (c->fuse_mac && l <= 16) { // 128-bit accumulation of l products of a lazy (<16q) operand
@@ -596,8 +601,9 @@ static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size
     ntt_forward<OpKsDigit>(c, dp, n * (l + 1) * l);
     for (uint32_t b = 0; b < n; b++) {
       ProfScope ps(c, KC_KSMAC);
-      hipLaunchKernelGGL(k_ks_mac, dim3(c->N / 512, l + 1), dim3(256), 0, c->stream, c->dev, target + b * target_bs,
-                         sc.d + b * kb.scratch_bs, keys[b]->d, prod_d + b * kb.prod_bs, l);
+      hipLaunchKernelGGL(k_ks_mac, dim3(c->N / 512, l + 1), dim3(256), 0, c->stream, c->dev,
+                         target ? target + b * target_bs : target_tab->p[b], sc.d + b * kb.scratch_bs, keys[b]->d,
+                         prod_d + b * kb.prod_bs, l);
       HIPCHK(hipGetLastError());
     }
   }
@@ -611,7 +617,7 @@ static void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev 
   switch_key_products(c, l, target, 0, &kp, 1, prod.d);
   // 3. mod-down by the special prime: INTT(special limb) + P/2, then per-limb NTT + combine
   Scratch r(c, 2 * N);
-  OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1};
+  OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
   ntt_inverse<OpPlain>(c, sp, 2);
   OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, add, add_ps, add_polys, out, out_ps,
                        c->k - 1, l};
@@ -1023,7 +1029,7 @@ int evah_pt_upload_coeff(evah_ctx *c, uint32_t limbs, double scale, const uint64
   if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
   evah_pt *t = pt_new(c, limbs, scale);
   HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)limbs * c->N, hipMemcpyHostToDevice, c->stream));
-  OpPlain::Params p{t->d, t->d, 0, 0, limbs, 0, 0};
+  OpPlain::Params p{t->d, t->d, 0, 0, limbs, 0, 0, {}};
   ntt_forward<OpPlain>(c, p, limbs);
   HIPCHK(hipStreamSynchronize(c->stream)); // the pageable host buffer may go away after return
   t->buf->ready_everywhere = true;
@@ -1194,19 +1200,73 @@ int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bit
     switch_key_products(c, l, a->d + 2 * a->ps, 0, &kp, 1, prod.d);
     Scratch r(c, 2 * N), t(c, 2 * N);
     // r_K = INTT_P(prod[K][special]) + P/2
-    OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1};
+    OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
     ntt_inverse<OpPlain>(c, spp, 2);
     // t_K = INTT_last(a[K][last] + prod[K][last] P^-1) - u_K,last P^-1 + q_last/2
-    OpRRLast::Params lp{a->d + (size_t)last * N, a->ps, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp};
+    OpRRLast::Params lp{a->d + (size_t)last * N, a->ps, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, {}};
     ntt_inverse<OpRRLast>(c, lp, 2);
     // out[K][i] = (a[K][i] + prod[K][i] P^-1 - NTT_i(u P^-1 + v)) q_last^-1
-    OpRR::Params rp{r.d, N, t.d, N, a->d, a->ps, prod.d, pps, o->d, o->ps, sp, last, l - 1};
+    OpRR::Params rp{r.d, N, t.d, N, a->d, a->ps, prod.d, pps, o->d, o->ps, sp, last, l - 1, {}};
     ntt_forward<OpRR>(c, rp, 2 * (l - 1));
   } catch (...) {
     evah_ct_free(c, o);
     throw;
   }
   *out = o;
+  API_END
+}
+
+// n (<= 16) independent size-3 ciphertexts at the same level, all relinearized with the (shared)
+// relinearization key and rescaled: one set of n-times-wider launches; instances are co-scheduled
+// per XCD so the key tiles are read from HBM once per XCD, not once per instance.
+int evah_relinearize_rescale_many(evah_ctx *c, const evah_ct *const *as, uint32_t n, uint32_t divisor_bits, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("relinearize_rescale_many handles 1..16 ciphertexts per call");
+  if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
+  const uint32_t l = as[0]->limbs;
+  if (l < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  const uint32_t last = l - 1, sp = c->k - 1;
+  const size_t N = c->N, pps = (size_t)(l + 1) * N, ops = (size_t)(l - 1) * N;
+  PtrTab c2{}, a_last{}, a_polys{};
+  for (uint32_t b = 0; b < n; b++) {
+    const evah_ct *a = as[b];
+    if (a->size != 3) throw std::invalid_argument("relinearize expects a size-3 ciphertext");
+    if (a->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    acquire(c, a->buf);
+    c2.p[b] = a->d + 2 * a->ps;
+    for (uint32_t K = 0; K < 2; K++) {
+      a_last.p[2 * b + K] = a->d + K * a->ps + (size_t)last * N;
+      a_polys.p[2 * b + K] = a->d + K * a->ps;
+    }
+  }
+  Buffer *ob = buf_new(c, (size_t)n * 2 * ops);
+  try {
+    Scratch prod(c, (size_t)n * 2 * pps);
+    std::vector<const KeyDev *> keys(n, &c->sh->relin);
+    switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2);
+    Scratch r(c, (size_t)n * 2 * N), t(c, (size_t)n * 2 * N);
+    OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
+    ntt_inverse<OpPlain>(c, spp, 2 * n);
+    OpRRLast::Params lp{nullptr, 0, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, a_last};
+    ntt_inverse<OpRRLast>(c, lp, 2 * n);
+    OpRR::Params rp{r.d, N, t.d, N, nullptr, 0, prod.d, pps, ob->d, ops, sp, last, l - 1, a_polys};
+    ntt_forward<OpRR>(c, rp, 2 * n * (l - 1));
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)n;
+  for (uint32_t b = 0; b < n; b++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)b * 2 * ops;
+    t->size = 2;
+    t->limbs = l - 1;
+    t->ps = ops;
+    t->scale = as[b]->scale / std::pow(2.0, (double)divisor_bits);
+    outs[b] = t;
+  }
   API_END
 }
 
@@ -1265,7 +1325,7 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
     switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), n, prod.d);
     Scratch r(c, (size_t)n * 2 * N);
     // INTT of the special limbs, job = r*2 + K
-    OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1};
+    OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
     ntt_inverse<OpPlain>(c, sp, 2 * n);
     // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
     OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, perm.d, pps, ~0u, ob->d, pps, c->k - 1, l};
@@ -1331,7 +1391,7 @@ int evah_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bits, evah_ct *
   const size_t N = c->N;
   evah_ct *o = ct_new(c, a->size, l - 1, a->scale / std::pow(2.0, (double)divisor_bits));
   Scratch r(c, (size_t)a->size * N);
-  OpPlain::Params ip{a->d + (size_t)(l - 1) * N, r.d, a->ps, N, 1, l - 1, 1};
+  OpPlain::Params ip{a->d + (size_t)(l - 1) * N, r.d, a->ps, N, 1, l - 1, 1, {}};
   ntt_inverse<OpPlain>(c, ip, a->size);
   OpModDown::Params mp{r.d, N, a->d, a->ps, nullptr, 0, 0, o->d, o->ps, l - 1, l - 1};
   ntt_forward<OpModDown>(c, mp, a->size * (l - 1));
@@ -1359,7 +1419,7 @@ int evah_test_ntt(evah_ctx *c, uint32_t prime_idx, int inverse, uint64_t *host) 
   if (prime_idx >= c->k) throw std::invalid_argument("prime index out of range");
   Scratch s(c, c->N);
   HIPCHK(hipMemcpyAsync(s.d, host, sizeof(u64) * c->N, hipMemcpyHostToDevice, c->stream));
-  OpPlain::Params p{s.d, s.d, 0, 0, 1, prime_idx, 0};
+  OpPlain::Params p{s.d, s.d, 0, 0, 1, prime_idx, 0, {}};
   if (inverse) ntt_inverse<OpPlain>(c, p, 1);
   else ntt_forward<OpPlain>(c, p, 1);
   HIPCHK(hipMemcpyAsync(host, s.d, sizeof(u64) * c->N, hipMemcpyDeviceToHost, c->stream));

@@ -238,17 +238,33 @@ constexpr int KS_BATCH_MAX = 16;
 struct KsKeys {
   const u64 *key[KS_BATCH_MAX];
 };
+// Base pointers of a batch of separately allocated polynomials (2 per instance), passed by value.
+struct PtrTab {
+  const u64 *p[2 * KS_BATCH_MAX];
+};
 
 template <int P, int LR>
 __global__ void __launch_bounds__(NTT_THREADS)
 ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
                 size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, uint32_t i0,
-                int logC) {
+                int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
-  const u64 *__restrict__ target = target_b + blockIdx.z * target_bs;
-  const u64 *__restrict__ scratch = scratch_b + blockIdx.z * scratch_bs;
-  const u64 *__restrict__ key = keys.key[blockIdx.z];
-  u64 *__restrict__ prod = prod_b + blockIdx.z * prod_bs;
+  // grid.x carries (tile, instance): instances of one tile are placed 8 block ids apart, i.e. on
+  // the same XCD (blocks are dealt round-robin over the 8 XCDs) and close in dispatch order, so
+  // instances that share a key find its tile in that XCD's L2.  Speed only, never correctness.
+  uint32_t tile_idx, inst;
+  if ((n_tiles & 7u) == 0) {
+    const uint32_t x = blockIdx.x, lo = x & 7u, rest = x >> 3;
+    inst = rest % n_inst;
+    tile_idx = (rest / n_inst) * 8u + lo;
+  } else {
+    inst = blockIdx.x / n_tiles;
+    tile_idx = blockIdx.x % n_tiles;
+  }
+  const u64 *__restrict__ target = target_b ? target_b + inst * target_bs : targets.p[inst];
+  const u64 *__restrict__ scratch = scratch_b + inst * scratch_bs;
+  const u64 *__restrict__ key = keys.key[inst];
+  u64 *__restrict__ prod = prod_b + inst * prod_bs;
   constexpr int NTT_R = 1 << LR, NPAIR = NTT_R / 2;
   constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
   const uint32_t I = i0 + blockIdx.y;
@@ -257,7 +273,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   const ulonglong2 *tw = cx.tw_fwd + (size_t)kap * cx.N;
   const int T = blockDim.x;
   const uint32_t pre = cx.logN - P;
-  const uint32_t sub0 = blockIdx.x << logC, gbase = sub0 << P;
+  const uint32_t sub0 = tile_idx << logC, gbase = sub0 << P;
   const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
   const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
 
@@ -349,6 +365,7 @@ struct OpPlain {
     size_t src_ps, dst_ps; // poly strides (elements)
     uint32_t jl, prime0;
     int addhalf;
+    PtrTab src_tab; // used when src == nullptr: polynomial pp starts at src_tab.p[pp]
   };
   struct Job {
     uint32_t prime;
@@ -360,7 +377,7 @@ struct OpPlain {
                                                Job &j) {
     const uint32_t pp = job / p.jl, i = job % p.jl;
     j.prime = p.prime0 + i;
-    j.src = p.src + pp * p.src_ps + (size_t)i * cx.N;
+    j.src = (p.src ? p.src + pp * p.src_ps : p.src_tab.p[pp]) + (size_t)i * cx.N;
     j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
     j.addhalf = p.addhalf;
     return true;
@@ -480,6 +497,7 @@ struct OpRRLast {
     u64 *t;
     size_t t_ps;
     uint32_t last, sp;
+    PtrTab a_tab; // used when a == nullptr: a_tab.p[job] = poly K of instance b at limb `last` (job = 2b+K)
   };
   struct Job {
     uint32_t prime;
@@ -490,7 +508,7 @@ struct OpRRLast {
   };
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job, Job &j) {
     j.prime = p.last;
-    j.a = p.a + job * p.a_ps;
+    j.a = p.a ? p.a + job * p.a_ps : p.a_tab.p[job];
     j.prod = p.prod + job * p.prod_ps;
     j.r = p.r + job * p.r_ps;
     j.dst = p.t + job * p.t_ps;
@@ -522,6 +540,7 @@ struct OpRR {
     u64 *dst;
     size_t dst_ps;
     uint32_t sp, last, jl;
+    PtrTab a_tab; // used when a == nullptr: a_tab.p[K] = poly K (limb 0), K = 2b + {0,1}
   };
   struct Job {
     uint32_t prime;
@@ -535,7 +554,7 @@ struct OpRR {
     j.prime = i;
     j.r = p.r + K * p.r_ps;
     j.t = p.t + K * p.t_ps;
-    j.a = p.a + K * p.a_ps + (size_t)i * cx.N;
+    j.a = (p.a ? p.a + K * p.a_ps : p.a_tab.p[K]) + (size_t)i * cx.N;
     j.prod = p.prod + K * p.prod_ps + (size_t)i * cx.N;
     j.dst = p.dst + K * p.dst_ps + (size_t)i * cx.N;
     j.halfP = cx.halfmod[p.sp * cx.k + i];

@@ -155,6 +155,29 @@ def test_rotate_bit_exact(cfg):
         assert np.array_equal(out, e.o.rotate(e.o.mod_switch(a2), -(e.N // 4), key))
 
 
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"N{c[0]}")
+def test_relinearize_rescale_many_equals_single_calls(cfg):
+    """A batch of independent size-3 ciphertexts through one wide launch set == the oracle's
+    rescale(relinearize(x)) on each; inputs are separate allocations, one a mod-switched view."""
+    e = env(cfg)
+    key = e.rand_key()
+    e.g.upload_relin_key(key)
+    l = e.k - 1
+    if l < 3:
+        pytest.skip("needs three data limbs for the view case")
+    lv = l - 1
+    hosts = [e.rand(3, lv) for _ in range(4)]
+    wide = e.rand(3, l)
+    cts = [e.g.upload_ct(h, 2.0 ** 50) for h in hosts] + [e.g.mod_switch(e.g.upload_ct(wide, 2.0 ** 50))]
+    hosts.append(e.o.mod_switch(wide))
+    outs = e.g.relinearize_rescale_many(cts, 30)
+    for h, o in zip(hosts, outs):
+        assert o.info() == (2, lv - 1, 2.0 ** 20)
+        assert np.array_equal(o.download(), e.o.rescale(e.o.relinearize(h, key)))
+    one = e.g.relinearize_rescale_many(cts[:1], 30)[0]
+    assert np.array_equal(one.download(), e.o.rescale(e.o.relinearize(hosts[0], key)))
+
+
 @pytest.mark.parametrize("cfg", CONFIGS[:6], ids=lambda c: f"N{c[0]}")
 def test_rotate_many_equals_single_rotations(cfg):
     """Sibling rotations issued as one wide launch set == the individual rotate_vector calls."""
