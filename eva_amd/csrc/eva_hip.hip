@@ -1216,13 +1216,13 @@ int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bit
   API_END
 }
 
-// n (<= 16) independent size-3 ciphertexts at the same level, all relinearized with the (shared)
+// n (<= 64) independent size-3 ciphertexts at the same level, all relinearized with the (shared)
 // relinearization key and rescaled: one set of n-times-wider launches; instances are co-scheduled
 // per XCD so the key tiles are read from HBM once per XCD, not once per instance.
 int evah_relinearize_rescale_many(evah_ctx *c, const evah_ct *const *as, uint32_t n, uint32_t divisor_bits, evah_ct **outs) {
   API_BEGIN
   use(c);
-  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("relinearize_rescale_many handles 1..16 ciphertexts per call");
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("relinearize_rescale_many handles 1..64 ciphertexts per call");
   if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
   const uint32_t l = as[0]->limbs;
   if (l < 2) throw std::invalid_argument("end of modulus switching chain reached");
@@ -1297,7 +1297,7 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
   use(c);
   acquire(c, a->buf);
   if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
-  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("rotate_many handles 1..16 rotations per call");
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("rotate_many handles 1..64 rotations per call");
   const uint32_t l = a->limbs;
   const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
   PermTables pt{};
@@ -1430,8 +1430,7 @@ int evah_test_ntt(evah_ctx *c, uint32_t prime_idx, int inverse, uint64_t *host) 
 int evah_profile_enable(evah_ctx *c, int on) {
   API_BEGIN
   use(c);
-  prof_drain(c);
-  c->prof_on = on != 0;
+  c->prof_on = on != 0; // no host wait here: the records are resolved by evah_profile_get/_reset
   API_END
 }
 int evah_profile_reset(evah_ctx *c) {

@@ -234,7 +234,7 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
 // 128-bit register accumulators.  The l^2 N converted digits are therefore never written back:
 // HBM sees the pass-1 intermediates once, the key once and prod[2][l+1][N] once.
 // Keys of a batch of key-switches issued as one launch (sibling rotations of one ciphertext).
-constexpr int KS_BATCH_MAX = 16;
+constexpr int KS_BATCH_MAX = 64;
 struct KsKeys {
   const u64 *key[KS_BATCH_MAX];
 };

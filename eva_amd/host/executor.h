@@ -228,8 +228,8 @@ public:
               group.push_back(u);
           }
         if (group.size() >= 2 && step_of(t) != 0) {
-          for (size_t i = 0; i < group.size(); i += 16) {
-            const uint32_t n = (uint32_t)std::min<size_t>(16, group.size() - i);
+          for (size_t i = 0; i < group.size(); i += 64) {
+            const uint32_t n = (uint32_t)std::min<size_t>(64, group.size() - i);
             std::vector<int32_t> steps(n);
             std::vector<evah_ct *> outs(n, nullptr);
             for (uint32_t r = 0; r < n; r++) steps[r] = step_of(group[i + r]);

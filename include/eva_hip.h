@@ -114,7 +114,7 @@ int evah_relinearize(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
  * result (seal_executor.h:200 then :213-214), evaluated together: identical ciphertext, ~13% fewer
  * transforms.  The host executor uses it when a Relinearize term's only use is a Rescale. */
 int evah_relinearize_rescale(evah_ctx *ctx, const evah_ct *a, uint32_t divisor_bits, evah_ct **out);
-/* the same for n (<= 16) independent ciphertexts at one level (a batch of multiplications to be
+/* the same for n (<= 64) independent ciphertexts at one level (a batch of multiplications to be
  * relinearized and rescaled): outs[b] == evah_relinearize_rescale(as[b]); one wide launch set,
  * the shared relinearization key is streamed once per XCD for the whole batch. */
 int evah_relinearize_rescale_many(evah_ctx *ctx, const evah_ct *const *as, uint32_t n, uint32_t divisor_bits,
@@ -122,7 +122,7 @@ int evah_relinearize_rescale_many(evah_ctx *ctx, const evah_ct *const *as, uint3
 /* evaluator.rotate_vector(a, steps) (seal_executor.h:181; rightRotate passes -steps, :188);
  * steps == 0 copies; needs the Galois key for exactly this step's element */
 int evah_rotate(evah_ctx *ctx, const evah_ct *a, int32_t steps, evah_ct **out);
-/* n (<= 16) non-zero rotations of the SAME ciphertext — n evaluator.rotate_vector calls
+/* n (<= 64) non-zero rotations of the SAME ciphertext — n evaluator.rotate_vector calls
  * (seal_executor.h:181) issued as one set of n-times-wider launches; outs[r] == evah_rotate(a, steps[r]).
  * The host executor groups the sibling rotations of a term (convolution windows) into one call. */
 int evah_rotate_many(evah_ctx *ctx, const evah_ct *a, const int32_t *steps, uint32_t n, evah_ct **outs);

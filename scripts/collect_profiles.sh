@@ -5,7 +5,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_bench
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 1"
 python $R/bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
