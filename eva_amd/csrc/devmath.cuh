@@ -15,7 +15,7 @@ struct u128_t {
   u64 lo, hi;
 };
 
-// Per-prime constants, device resident (one 64-byte record per RNS prime).
+// Per-prime constants, device resident (one record per RNS prime).
 struct DevPrime {
   u64 q;        // modulus
   u64 brt;      // floor(2^64 / q)            (64-bit Barrett)
@@ -27,6 +27,7 @@ struct DevPrime {
   u64 nq;       // 2^64 - q   (kept as data: the compiler must not turn x + t*nq back into x - t*q)
   u64 q5;       // 5q, the inverse lazy-butterfly threshold
   u64 q4, q8;   // 4q (forward difference offset), 8q (forward reduction threshold)
+  u64 nq5, nq8; // 2^64 - 5q, 2^64 - 8q: conditional subtraction as select + one 64-bit add (data, as nq)
 };
 
 // Device-side view of a context (passed by value to kernels).

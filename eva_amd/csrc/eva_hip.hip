@@ -481,9 +481,19 @@ static void launch_pass(evah_ctx *c, const typename Op::Params &prm, uint32_t jo
   const int logC = (int)ilog2(tile) - P;
   size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64);
   if (STRIDED) lds += ((size_t)1 << P) * sizeof(ulonglong2); // staged twiddles
-  dim3 grid(c->N / tile, jobs), block(tile >> LR);
-  hipLaunchKernelGGL((ntt_pass_kernel<P, LR, STRIDED, INVERSE, Op>), grid, block, lds, c->stream, c->dev,
-                     prm, logC);
+  const uint32_t n_tiles = c->N / tile;
+  const int log_tiles = (int)ilog2(n_tiles);
+  dim3 grid = Op::grid(prm, jobs), block(tile >> LR);
+  grid.x *= n_tiles;
+  if (tile == max_tile) {
+    hipLaunchKernelGGL((ntt_pass_kernel<P, LR, STRIDED, INVERSE, Op, true>), grid, block, lds, c->stream, c->dev,
+                       prm, logC, log_tiles);
+  } else if constexpr (P == 5) { // N = 1024: one partial tile per polynomial
+    hipLaunchKernelGGL((ntt_pass_kernel<P, LR, STRIDED, INVERSE, Op, false>), grid, block, lds, c->stream, c->dev,
+                       prm, logC, log_tiles);
+  } else {
+    throw std::logic_error("partial NTT tile with P != 5");
+  }
   HIPCHK(hipGetLastError());
 }
 
@@ -750,6 +760,8 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
       d.q5 = 5 * q;
       d.q4 = 4 * q;
       d.q8 = 8 * q;
+      d.nq5 = 0ull - 5 * q;
+      d.nq8 = 0ull - 8 * q;
       for (uint32_t a = 0; a < k; a++) {
         const u64 qa = c->primes[a];
         if (a == i) {

@@ -25,6 +25,7 @@
 // fused into the transforms instead of being separate HBM round trips.
 #pragma once
 #include "devmath.cuh"
+#include <type_traits>
 
 namespace evah {
 
@@ -62,17 +63,17 @@ __device__ __forceinline__ u64 mul_tw_lazy5(u64 x, u64 w, u64 ws, u64 nq) {
 //   plain stage  : X < 12q            -> outputs < 16q
 // (Y only feeds the multiply, which accepts any 64-bit value.)
 template <bool REDUCE>
-__device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q4, u64 q8) {
-  u64 x = REDUCE ? X - (X >= q8 ? q8 : 0) : X;
+__device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q4, u64 q8, u64 nq8) {
+  u64 x = REDUCE ? X + (X >= q8 ? nq8 : 0) : X;
   u64 t = mul_tw_lazy5(Y, w.x, w.y, nq);
   X = x + t;
   Y = x + q4 - t;
 }
 // inverse Gentleman-Sande butterfly, X,Y in [0,5q) -> [0,5q)
-__device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q5) {
+__device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q5, u64 nq5) {
   u64 s = X + Y;
   u64 d = X + q5 - Y;
-  X = s - (s >= q5 ? q5 : 0);
+  X = s + (s >= q5 ? nq5 : 0);
   Y = mul_tw_lazy5(d, w.x, w.y, nq);
 }
 
@@ -86,16 +87,19 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
   constexpr int NTT_R = 1 << LR;
   constexpr int S = 1 << P, TPS = S / NTT_R, G = NTT_R >> RB, NU = 1 << RB;
   constexpr int S0 = P - LO - RB; // local stages above this round
-  const u64 q = pm.q, nq = pm.nq, q5 = pm.q5, q4 = pm.q4, q8 = pm.q8;
-  (void)q4; (void)q8; (void)q5;
+  const u64 q = pm.q, nq = pm.nq, q5 = pm.q5, q4 = pm.q4, q8 = pm.q8, nq5 = pm.nq5, nq8 = pm.nq8;
+  (void)q4; (void)q8; (void)q5; (void)nq5; (void)nq8;
   u64 x[NTT_R];
 #pragma unroll
   for (int g = 0; g < G; g++) {
     const int o = g * TPS + tid;
     const int o_lo = o & ((1 << LO) - 1), o_hi = o >> LO;
     const int ebase = (o_hi << (LO + RB)) | o_lo;
+    // ebase and (u << LO) occupy disjoint bit fields, so pad(ebase | u << LO) = pad(ebase) + pad(u << LO):
+    // one padded base per group, the per-element part is an immediate offset of the LDS access
+    u64 *grp = sub_lds + lds_pad(ebase);
 #pragma unroll
-    for (int u = 0; u < NU; u++) x[g * NU + u] = sub_lds[lds_pad(ebase | (u << LO))];
+    for (int u = 0; u < NU; u++) x[g * NU + u] = grp[lds_pad(u << LO)];
     const uint32_t node = STRIDED ? ((1u << S0) | (uint32_t)o_hi)
                                   : ((1u << (pre + S0)) | (h << S0) | (uint32_t)o_hi);
     if (!INVERSE) {
@@ -107,8 +111,8 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
           if (u & half) continue;
           const int v = u >> (RB - s);
           const ulonglong2 w = tw[((size_t)node << s) + v];
-          if ((((S0 + s) & 1) == 0) == RED_EVEN) bfly_fwd<true>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8);
-          else bfly_fwd<false>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8);
+          if ((((S0 + s) & 1) == 0) == RED_EVEN) bfly_fwd<true>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8);
+          else bfly_fwd<false>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8);
         }
       }
     } else {
@@ -128,13 +132,13 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
           } else {
             const int v = u >> (RB - s);
             const ulonglong2 w = tw[((size_t)node << s) + v];
-            bfly_inv(X, Y, w, nq, q5);
+            bfly_inv(X, Y, w, nq, q5, nq5);
           }
         }
       }
     }
 #pragma unroll
-    for (int u = 0; u < NU; u++) sub_lds[lds_pad(ebase | (u << LO))] = x[g * NU + u];
+    for (int u = 0; u < NU; u++) grp[lds_pad(u << LO)] = x[g * NU + u];
   }
 }
 
@@ -152,42 +156,71 @@ template <int P, int LR, int I, bool INVERSE, bool STRIDED, bool RED_EVEN> struc
   }
 };
 
-// One pass.  grid.x = N / tile, grid.y = jobs, block = tile >> LR threads.
-template <int P, int LR, bool STRIDED, bool INVERSE, class Op>
+// One pass.  grid.x = (N / tile) * jx-count (tile index in the low log_tiles bits), grid.y / grid.z
+// = the op's job coordinates (no integer division in the kernel), block = tile >> LR threads.
+// FULL: the tile is the full NTT_THREADS << LR coefficients (every N >= 2048), so the thread
+// count and the tile shape are compile-time constants and the per-element global / LDS addresses
+// of the load and store loops are one base plus immediate steps.
+template <int P, int LR, bool STRIDED, bool INVERSE, class Op, bool FULL>
 __global__ void __launch_bounds__(NTT_THREADS)
-ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
+ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC_rt, int log_tiles) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   constexpr int NTT_R = 1 << LR;
   constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
   constexpr bool FIRST = (STRIDED != INVERSE);
+  const uint32_t tile_idx = blockIdx.x & ((1u << log_tiles) - 1u);
   typename Op::Job jb;
-  if (!Op::setup(cx, prm, blockIdx.y, jb)) return; // block-uniform
+  if (!Op::setup(cx, prm, blockIdx.x >> log_tiles, blockIdx.y, blockIdx.z, jb)) return; // block-uniform
   const DevPrime pm = cx.primes[jb.prime];
   const ulonglong2 *tw = (INVERSE ? cx.tw_inv : cx.tw_fwd) + (size_t)jb.prime * cx.N;
-  const int C = 1 << logC, T = blockDim.x;
+  const int logC = FULL ? (8 + LR - P) : logC_rt;
+  const int C = 1 << logC, T = FULL ? NTT_THREADS : (int)blockDim.x;
   const uint32_t pre = STRIDED ? 0u : (cx.logN - P);
   const uint32_t stride_log = cx.logN - P; // strided pass: distance between local elements
 
-  // ---- tile -> LDS
+  // ---- element it of this thread: global index n0 + it * nstep, LDS slot lds_at(it)
   uint32_t gbase, sub0 = 0;
-  if (STRIDED) gbase = blockIdx.x << logC; // column c0 (pre = 0 => single prefix)
-  else { sub0 = blockIdx.x << logC; gbase = sub0 << P; }
-#pragma unroll
-  for (int it = 0; it < NTT_R; it++) {
-    const int idx = threadIdx.x + it * T;
-    uint32_t n;
-    int l;
-    if (STRIDED) {
-      const int c = idx & (C - 1), e = idx >> logC;
-      n = gbase + ((uint32_t)e << stride_log) + c;
-      l = c * SP + lds_pad(e);
-    } else {
-      const int sub = idx >> P, e = idx & (S - 1);
-      n = gbase + idx;
-      l = sub * SP + lds_pad(e);
-    }
-    lds[l] = FIRST ? Op::load(cx, jb, pm, n) : jb.dst[n];
+  if (STRIDED) gbase = tile_idx << logC; // column c0 (pre = 0 => single prefix)
+  else { sub0 = tile_idx << logC; gbase = sub0 << P; }
+  // strided: idx = tid + it*T -> column c = idx mod C (fixed, T is a multiple of C), row e = e0 + it*(T/C)
+  // contig : idx = tid + it*T -> sub-transform (tid >> P) + it*(T >> P), element tid mod S (fixed, P <= 8)
+  constexpr int ES = 1 << (P - LR); // FULL: rows per step of the strided pass = NTT_THREADS >> logC
+  constexpr bool LINEAR = FULL && (STRIDED ? (ES % 16 == 0) : (P <= 8));
+  uint32_t n0, nstep;
+  int l0;
+  if (STRIDED) {
+    const int c = threadIdx.x & (C - 1), e0 = threadIdx.x >> logC;
+    n0 = gbase + ((uint32_t)e0 << stride_log) + c;
+    nstep = (uint32_t)(T >> logC) << stride_log;
+    l0 = c * SP + lds_pad(e0);
+  } else {
+    n0 = gbase + threadIdx.x;
+    nstep = T;
+    l0 = (threadIdx.x >> P) * SP + lds_pad(threadIdx.x & (S - 1));
   }
+  auto lds_at = [&](int it) -> int {
+    if constexpr (LINEAR) {
+      return l0 + it * (STRIDED ? lds_pad(ES) : (NTT_THREADS >> P) * SP);
+    } else {
+      const int idx = threadIdx.x + it * T;
+      if (STRIDED) return (idx & (C - 1)) * SP + lds_pad(idx >> logC);
+      return (idx >> P) * SP + lds_pad(idx & (S - 1));
+    }
+  };
+
+  // ---- tile -> LDS.  First passes fuse the op's input transform; when the moduli involved are
+  // of similar size (block-uniform test in Op::setup) the cheap form is used: the butterflies
+  // accept lazy values (< 12q forward), so no Barrett reduction is needed on the way in
+  auto fill = [&](auto lazy_tag) {
+    constexpr bool LZ = decltype(lazy_tag)::value;
+#pragma unroll
+    for (int it = 0; it < NTT_R; it++) {
+      const uint32_t n = n0 + it * nstep;
+      lds[lds_at(it)] = FIRST ? Op::template load<LZ>(cx, jb, pm, n) : jb.dst[n];
+    }
+  };
+  if (FIRST && !INVERSE && jb.lazy) fill(std::true_type{});
+  else fill(std::false_type{});
   // strided pass: every column transform of the tile uses the same 2^P twiddles (heap nodes
   // 1..2^P-1) — stage them in LDS once per workgroup instead of per-thread global loads
   ulonglong2 *twl = reinterpret_cast<ulonglong2 *>(lds + ((C * SP + 1) & ~1));
@@ -205,24 +238,13 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC) {
   // ---- LDS -> global
 #pragma unroll
   for (int it = 0; it < NTT_R; it++) {
-    const int idx = threadIdx.x + it * T;
-    uint32_t n;
-    int l;
-    if (STRIDED) {
-      const int c = idx & (C - 1), e = idx >> logC;
-      n = gbase + ((uint32_t)e << stride_log) + c;
-      l = c * SP + lds_pad(e);
-    } else {
-      const int sub = idx >> P, e = idx & (S - 1);
-      n = gbase + idx;
-      l = sub * SP + lds_pad(e);
-    }
-    u64 v = lds[l];
+    const uint32_t n = n0 + it * nstep;
+    u64 v = lds[lds_at(it)];
     if (FIRST) {
       jb.dst[n] = v; // lazy intermediate
     } else {
-      if (!INVERSE) v = barrett64(v, pm.q, pm.brt); // forward final: [0,16q) -> canonical
-      Op::store(cx, jb, pm, n, v);
+      if constexpr (INVERSE) Op::store(cx, jb, pm, n, v);   // canonical
+      else Op::store_fwd(cx, jb, pm, n, v);                 // lazy [0,16q): the op reduces as it needs
     }
   }
 }
@@ -372,24 +394,31 @@ struct OpPlain {
     const u64 *src;
     u64 *dst;
     int addhalf;
+    bool lazy;
   };
-  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job,
-                                               Job &j) {
-    const uint32_t pp = job / p.jl, i = job % p.jl;
+  // jobs = polys * jl: grid.y = limb i, grid.z = poly
+  static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i,
+                                               uint32_t pp, Job &j) {
     j.prime = p.prime0 + i;
     j.src = (p.src ? p.src + pp * p.src_ps : p.src_tab.p[pp]) + (size_t)i * cx.N;
     j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
     j.addhalf = p.addhalf;
+    j.lazy = false;
     return true;
   }
-  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &,
-                                             uint32_t n) {
+  template <bool LZ>
+  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &, uint32_t n) {
     return j.src[n];
   }
   static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm,
                                                uint32_t n, u64 v) {
     if (j.addhalf) v = addmod(v, pm.q >> 1, pm.q);
     j.dst[n] = v;
+  }
+  static __device__ __forceinline__ void store_fwd(const DevCtx &cx, const Job &j, const DevPrime &pm,
+                                                   uint32_t n, u64 v) {
+    store(cx, j, pm, n, barrett64(v, pm.q, pm.brt));
   }
 };
 
@@ -407,24 +436,28 @@ struct OpKsDigit {
     uint32_t prime;
     const u64 *src;
     u64 *dst;
+    bool lazy;
   };
-  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job,
-                                               Job &j) {
-    const uint32_t per = p.ni * p.l, b = job / per, rem = job % per;
-    const uint32_t I = p.i0 + rem / p.l, J = rem % p.l;
+  // jobs = batch * ni * l: grid.x carries the digit J, grid.y the output limb, grid.z the batch
+  static dim3 grid(const Params &p, uint32_t jobs) { return dim3(p.l, p.ni, jobs / (p.ni * p.l)); }
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t J, uint32_t iy,
+                                               uint32_t b, Job &j) {
+    const uint32_t I = p.i0 + iy;
     if (I == J) return false;
     j.prime = (I == p.l) ? cx.k - 1 : I;
+    // t_J < q_J: when q_J <= 8 q_kappa the digit is already a valid lazy input (< 12 q_kappa)
+    j.lazy = cx.primes[J].q <= cx.primes[j.prime].q8;
     j.src = p.t + b * p.t_bs + (size_t)J * cx.N;
     j.dst = p.scratch + b * p.scratch_bs + ((size_t)I * p.l + J) * cx.N;
     return true;
   }
-  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm,
-                                             uint32_t n) {
-    return barrett64(j.src[n], pm.q, pm.brt);
+  template <bool LZ>
+  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
+    return LZ ? j.src[n] : barrett64(j.src[n], pm.q, pm.brt);
   }
-  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &,
-                                               uint32_t n, u64 v) {
-    j.dst[n] = v;
+  static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &j, const DevPrime &pm,
+                                                   uint32_t n, u64 v) {
+    j.dst[n] = barrett64(v, pm.q, pm.brt);
   }
 };
 
@@ -451,10 +484,11 @@ struct OpModDown {
     u64 *dst;
     u64 halfm;
     ulonglong2 inv;
+    bool lazy;
   };
-  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job,
-                                               Job &j) {
-    const uint32_t pp = job / p.jl, i = job % p.jl;
+  static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i,
+                                               uint32_t pp, Job &j) {
     j.prime = i;
     j.src = p.r + pp * p.r_ps;
     j.c = p.c + pp * p.c_ps + (size_t)i * cx.N;
@@ -463,15 +497,18 @@ struct OpModDown {
     j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
     j.halfm = cx.halfmod[p.a * cx.k + i];
     j.inv = cx.invq[p.a * cx.k + i];
+    j.lazy = cx.primes[p.a].q <= cx.primes[i].q8; // r < q_a: r + (q_i - halfm) < 9 q_i
     return true;
   }
-  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm,
-                                             uint32_t n) {
+  template <bool LZ>
+  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
+    if (LZ) return j.src[n] + (pm.q - j.halfm);
     return submod(barrett64(j.src[n], pm.q, pm.brt), j.halfm, pm.q);
   }
-  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm,
-                                               uint32_t n, u64 U) {
-    u64 v = mul_shoup(submod(j.c[n], U, pm.q), j.inv.x, j.inv.y, pm.q);
+  static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &j, const DevPrime &pm,
+                                                   uint32_t n, u64 U) {
+    U += (U >= pm.q8 ? pm.nq8 : 0);                       // [0,16q) -> [0,8q)
+    u64 v = mul_shoup(j.c[n] + pm.q8 - U, j.inv.x, j.inv.y, pm.q); // exact for any 64-bit operand
     if (j.add) v = addmod(j.add[n], v, pm.q);
     j.dst[n] = v;
   }
@@ -505,8 +542,11 @@ struct OpRRLast {
     u64 *dst;
     u64 halfP;
     ulonglong2 pinv;
+    bool lazy;
   };
-  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job, Job &j) {
+  static dim3 grid(const Params &, uint32_t jobs) { return dim3(1, jobs, 1); }
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t job, uint32_t,
+                                               Job &j) {
     j.prime = p.last;
     j.a = p.a ? p.a + job * p.a_ps : p.a_tab.p[job];
     j.prod = p.prod + job * p.prod_ps;
@@ -514,8 +554,10 @@ struct OpRRLast {
     j.dst = p.t + job * p.t_ps;
     j.halfP = cx.halfmod[p.sp * cx.k + p.last];
     j.pinv = cx.invq[p.sp * cx.k + p.last];
+    j.lazy = false;
     return true;
   }
+  template <bool LZ>
   static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
     return addmod(j.a[n], mul_shoup(j.prod[n], j.pinv.x, j.pinv.y, pm.q), pm.q);
   }
@@ -548,9 +590,11 @@ struct OpRR {
     u64 *dst;
     u64 halfP, halfL;
     ulonglong2 pinv, linv;
+    bool lazy;
   };
-  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t job, Job &j) {
-    const uint32_t K = job / p.jl, i = job % p.jl;
+  static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i, uint32_t K,
+                                               Job &j) {
     j.prime = i;
     j.r = p.r + K * p.r_ps;
     j.t = p.t + K * p.t_ps;
@@ -561,17 +605,22 @@ struct OpRR {
     j.halfL = cx.halfmod[p.last * cx.k + i];
     j.pinv = cx.invq[p.sp * cx.k + i];
     j.linv = cx.invq[p.last * cx.k + i];
+    // lazy input: lazy5(r + q_i - halfP) + t + q_i - halfL < 5q_i + q_last + q_i <= 10 q_i
+    j.lazy = cx.primes[p.last].q <= cx.primes[i].q4 && cx.primes[p.sp].q <= cx.primes[i].q8;
     return true;
   }
+  template <bool LZ>
   static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
+    if (LZ)
+      return mul_tw_lazy5(j.r[n] + (pm.q - j.halfP), j.pinv.x, j.pinv.y, pm.nq) + (j.t[n] + (pm.q - j.halfL));
     const u64 u = submod(barrett64(j.r[n], pm.q, pm.brt), j.halfP, pm.q);
     const u64 v = submod(barrett64(j.t[n], pm.q, pm.brt), j.halfL, pm.q);
     return addmod(mul_shoup(u, j.pinv.x, j.pinv.y, pm.q), v, pm.q);
   }
-  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 W) {
-    u64 x = addmod(j.a[n], mul_shoup(j.prod[n], j.pinv.x, j.pinv.y, pm.q), pm.q);
-    x = submod(x, W, pm.q);
-    j.dst[n] = mul_shoup(x, j.linv.x, j.linv.y, pm.q);
+  static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 W) {
+    W += (W >= pm.q8 ? pm.nq8 : 0);                                                  // [0,16q) -> [0,8q)
+    const u64 x = j.a[n] + mul_tw_lazy5(j.prod[n], j.pinv.x, j.pinv.y, pm.nq) + pm.q8 - W; // < 14q < 2^64
+    j.dst[n] = mul_shoup(x, j.linv.x, j.linv.y, pm.q);                               // exact for any 64-bit operand
   }
 };
 
