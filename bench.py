@@ -3,7 +3,7 @@
 (multiply + relinearize + rescale) at N = 2^16, L = 10 data limbs (k = 11 key primes).
 
 One "step" = one batch of --batch independent op-triples through the C-ABI of libeva_hip.so
-(evah_multiply per triple, then evah_relinearize_rescale_many per group of --group triples:
+(per group of --group triples: evah_multiply_many, then evah_relinearize_rescale_many =
 relinearize and rescale_to_next evaluated together, bit-identical to the separate calls), inputs and the relinearization key already
 resident in HBM.  One process per GPU; ranks run independent batches (the path shards over
 independent ciphertexts — no data-path collective), `value` = triples of all ranks / max time.
@@ -39,8 +39,8 @@ def class_bytes(N, l, k, G=1):
         "moddown_pass1": [(2 + 2 + 2 * (l - 1)) * W],                 # r, t in; intermediates out
         "moddown_pass2": [(4 * 2 * (l - 1)) * W],                     # interm + a + prod in; out
     }
-    # launches of the batched call cover G triples each; the multiply is issued per triple
-    return {kk: (sum(v) / len(v)) * (1 if kk == "elementwise" else G) for kk, v in per_launch.items()}
+    # every launch of the batched calls covers G triples
+    return {kk: (sum(v) / len(v)) * G for kk, v in per_launch.items()}
 
 
 def triple_bytes(N, l):
@@ -112,8 +112,13 @@ def main():
             sample = profile and (gi % max(1, PROF_EVERY // G) == 0)
             if sample:
                 q.profile(True)
-            ms = [q.multiply(*pairs[i % npairs]) for i in range(i0, min(i0 + G, args.batch))]
-            outs = q.relinearize_rescale_many(ms, 60) if len(ms) > 1 else [q.relinearize_rescale(ms[0], 60)]
+            idx = range(i0, min(i0 + G, args.batch))
+            if len(idx) > 1:
+                ms = q.multiply_many([pairs[i % npairs][0] for i in idx], [pairs[i % npairs][1] for i in idx])
+                outs = q.relinearize_rescale_many(ms, 60)
+            else:
+                ms = [q.multiply(*pairs[i0 % npairs])]
+                outs = [q.relinearize_rescale(ms[0], 60)]
             if sample:
                 q.profile(False)
             for h in ms + outs:
@@ -152,8 +157,12 @@ def main():
     q0.profile_reset()
     q0.profile(True)
     for _ in range(3):
-        ms = [q0.multiply(*pairs[i % npairs]) for i in range(G)]
-        outs = q0.relinearize_rescale_many(ms, 60) if G > 1 else [q0.relinearize_rescale(ms[0], 60)]
+        if G > 1:
+            ms = q0.multiply_many([pairs[i % npairs][0] for i in range(G)], [pairs[i % npairs][1] for i in range(G)])
+            outs = q0.relinearize_rescale_many(ms, 60)
+        else:
+            ms = [q0.multiply(*pairs[0])]
+            outs = [q0.relinearize_rescale(ms[0], 60)]
         for h in ms + outs:
             h.free()
     q0.profile(False)

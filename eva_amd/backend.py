@@ -60,6 +60,7 @@ _SIGS = {
     "evah_relinearize": [_vp, _vp, _vpp],
     "evah_relinearize_rescale": [_vp, _vp, C.c_uint32, _vpp],
     "evah_relinearize_rescale_many": [_vp, _vpp, C.c_uint32, C.c_uint32, _vpp],
+    "evah_multiply_many": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_rotate": [_vp, _vp, C.c_int32, _vpp],
     "evah_rotate_many": [_vp, _vp, C.POINTER(C.c_int32), C.c_uint32, _vpp],
     "evah_rescale": [_vp, _vp, C.c_uint32, _vpp],
@@ -334,6 +335,14 @@ class Context:
 
     def multiply(self, a, b):
         return self._ct2(_lib.evah_multiply, a, b)
+
+    def multiply_many(self, cts_a, cts_b):
+        n = len(cts_a)
+        ia = (C.c_void_p * n)(*[ct.h for ct in cts_a])
+        ib = (C.c_void_p * n)(*[ct.h for ct in cts_b])
+        outs = (C.c_void_p * n)()
+        _chk(_lib.evah_multiply_many(self.h, ia, ib, n, outs))
+        return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n)]
 
     def multiply_plain(self, a, pt):
         return self._ct2(_lib.evah_multiply_plain, a, pt)

@@ -96,6 +96,35 @@ k_mul22(DevCtx cx, const u64 *a, size_t a_ps, const u64 *b, size_t b_ps, u64 *ou
   st2(out + 2 * o_ps + off, d2);
 }
 
+// K4 batched: n independent 2x2 products in one launch; grid.z = instance
+struct MulTab {
+  const u64 *a[KS_BATCH_MAX], *b[KS_BATCH_MAX];
+  uint32_t a_ps[KS_BATCH_MAX], b_ps[KS_BATCH_MAX]; // poly strides in units of N coefficients
+};
+__global__ void __launch_bounds__(256)
+k_mul22_many(DevCtx cx, MulTab tab, u64 *out_b, size_t o_ps) {
+  EW_SETUP
+  const u64 *a = tab.a[p], *b = tab.b[p];
+  const size_t a_ps = (size_t)tab.a_ps[p] * cx.N, b_ps = (size_t)tab.b_ps[p] * cx.N;
+  u64 *out = out_b + (size_t)p * 3 * o_ps;
+  ulonglong2 a0 = ld2(a + off), a1 = ld2(a + a_ps + off);
+  ulonglong2 b0 = ld2(b + off), b1 = ld2(b + b_ps + off);
+  ulonglong2 d0, d1, d2;
+  d0.x = mulmod(a0.x, b0.x, pm);
+  d0.y = mulmod(a0.y, b0.y, pm);
+  d2.x = mulmod(a1.x, b1.x, pm);
+  d2.y = mulmod(a1.y, b1.y, pm);
+  u128_t t = mul128(a0.x, b1.x);
+  acc128(t, a1.x, b0.x);
+  d1.x = barrett128(t, pm);
+  t = mul128(a0.y, b1.y);
+  acc128(t, a1.y, b0.y);
+  d1.y = barrett128(t, pm);
+  st2(out + off, d0);
+  st2(out + o_ps + off, d1);
+  st2(out + 2 * o_ps + off, d2);
+}
+
 // K5: square 2 -> 3: (a0^2, 2 a0 a1, a1^2)
 __global__ void __launch_bounds__(256)
 k_square(DevCtx cx, const u64 *a, size_t a_ps, u64 *out, size_t o_ps) {
@@ -1147,6 +1176,46 @@ int evah_multiply(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct **out
   EW_LAUNCH(k_mul22, ew_grid(c, a->limbs, 1), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, b->ps, o->d, o->ps);
   HIPCHK(hipGetLastError());
   *out = o;
+  API_END
+}
+
+// n (<= 64) independent products at one level as ONE launch (same ciphertexts as n evah_multiply
+// calls); the outputs are views into one allocation.
+int evah_multiply_many(evah_ctx *c, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("multiply_many handles 1..64 products per call");
+  const uint32_t l = as[0]->limbs;
+  const size_t N = c->N, ops = (size_t)l * N;
+  MulTab tab{};
+  std::vector<double> scales(n);
+  for (uint32_t i = 0; i < n; i++) {
+    const evah_ct *a = as[i], *b = bs[i];
+    if (a->size != 2 || b->size != 2) throw std::invalid_argument("multiply supports size-2 operands only (relinearize first)");
+    if (a->limbs != l || b->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    scales[i] = a->scale * b->scale;
+    check_scale(c, scales[i], l);
+    acquire(c, a->buf);
+    acquire(c, b->buf);
+    tab.a[i] = a->d;
+    tab.b[i] = b->d;
+    tab.a_ps[i] = (uint32_t)(a->ps / N);
+    tab.b_ps[i] = (uint32_t)(b->ps / N);
+  }
+  Buffer *ob = buf_new(c, (size_t)n * 3 * ops);
+  EW_LAUNCH(k_mul22_many, ew_grid(c, l, n), dim3(256), 0, c->stream, c->dev, tab, ob->d, ops);
+  HIPCHK(hipGetLastError());
+  ob->refs = (int)n;
+  for (uint32_t i = 0; i < n; i++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)i * 3 * ops;
+    t->size = 3;
+    t->limbs = l;
+    t->ps = ops;
+    t->scale = scales[i];
+    outs[i] = t;
+  }
   API_END
 }
 

@@ -104,6 +104,10 @@ int evah_sub_plain(evah_ctx *ctx, const evah_ct *a, const evah_pt *b, evah_ct **
 int evah_negate(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
 /* evaluator.multiply, both operands size 2 (seal_executor.h:164) */
 int evah_multiply(evah_ctx *ctx, const evah_ct *a, const evah_ct *b, evah_ct **out);
+/* n (<= 64) independent evaluator.multiply calls at one level (seal_executor.h:164, once per
+ * independent Multiply node / per ciphertext of a batch) issued as ONE launch; outs[i] ==
+ * evah_multiply(as[i], bs[i]) bit for bit, the outputs share one allocation */
+int evah_multiply_many(evah_ctx *ctx, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n, evah_ct **outs);
 /* evaluator.square, operand size 2 (seal_executor.h:162) */
 int evah_square(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
 /* evaluator.multiply_plain (seal_executor.h:168) */

@@ -179,6 +179,30 @@ def test_relinearize_rescale_many_equals_single_calls(cfg):
 
 
 @pytest.mark.parametrize("cfg", CONFIGS[:6], ids=lambda c: f"N{c[0]}")
+def test_multiply_many_equals_single_calls(cfg):
+    """A batch of independent 2x2 products as one launch == the oracle's multiply on each pair;
+    operands are separate allocations, one of them a mod-switched view (larger poly stride)."""
+    e = env(cfg)
+    l = e.k - 1
+    if l < 2:
+        pytest.skip("needs two data limbs for the view case")
+    lv = l - 1
+    ha = [e.rand(2, lv) for _ in range(3)]
+    hb = [e.rand(2, lv) for _ in range(3)]
+    wide = e.rand(2, l)
+    ca = [e.g.upload_ct(h, 2.0 ** 10) for h in ha] + [e.g.mod_switch(e.g.upload_ct(wide, 2.0 ** 10))]
+    cb = [e.g.upload_ct(h, 2.0 ** 10) for h in hb] + [ca[0]]
+    ha.append(e.o.mod_switch(wide))
+    hb.append(ha[0])
+    outs = e.g.multiply_many(ca, cb)
+    for x, y, o in zip(ha, hb, outs):
+        assert o.info() == (3, lv, 2.0 ** 20)
+        assert np.array_equal(o.download(), e.o.multiply(x, y))
+    with pytest.raises(RuntimeError):
+        e.g.multiply_many([outs[0]], [ca[0]])  # size-3 operand
+
+
+@pytest.mark.parametrize("cfg", CONFIGS[:6], ids=lambda c: f"N{c[0]}")
 def test_rotate_many_equals_single_rotations(cfg):
     """Sibling rotations issued as one wide launch set == the individual rotate_vector calls."""
     e = env(cfg)
