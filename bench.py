@@ -26,21 +26,25 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 def class_bytes(N, l, k, G=1):
     """Compulsory HBM bytes (distinct inputs read once + outputs written once) per launch of each
-    kernel class inside one op-triple as bench.py issues it — evah_multiply, then
-    evah_relinearize_rescale (relinearize at l limbs fused with the rescale l -> l-1); DESIGN.md §4.
+    kernel class for a group of G op-triples as bench.py issues it — evah_multiply_many, then
+    evah_relinearize_rescale_many (relinearize at l limbs fused with the rescale l -> l-1);
+    DESIGN.md §4.  Every launch covers the G triples of the group; the relinearization key is one
+    input of the fused key-switch launch however many triples share it, so it is counted once
+    per launch (the op-level figure below keeps SURVEY §8(d)'s per-op key bytes).
     W = one limb of one polynomial = 8N bytes."""
     W = 8 * N
-    per_launch = {
+    per_triple = {
         "elementwise": [7 * l * W],                                   # multiply: 4 polys in, 3 out
         "intt_pass1": [2 * l * W, 2 * 2 * W, (2 + 2 + 2 + 2) * W],   # digits; special limbs; t_K (a,prod,r in / t out)
         "intt_pass2": [2 * l * W, 2 * 2 * W, (2 + 2 + 2 + 2) * W],
         "ksdigit_pass1": [(l + l * l) * W],                           # l digits in, l^2 converted digits out
-        "ks_mac": [(l * l + l + 2 * l * (l + 1) + 2 * (l + 1)) * W],  # digits + target + key in, prod out
+        "ks_mac": [(l * l + l + 2 * (l + 1)) * W],                    # digits + target in, prod out (key: below)
         "moddown_pass1": [(2 + 2 + 2 * (l - 1)) * W],                 # r, t in; intermediates out
         "moddown_pass2": [(4 * 2 * (l - 1)) * W],                     # interm + a + prod in; out
     }
-    # every launch of the batched calls covers G triples
-    return {kk: (sum(v) / len(v)) * G for kk, v in per_launch.items()}
+    out = {kk: (sum(v) / len(v)) * G for kk, v in per_triple.items()}
+    out["ks_mac"] += 2 * l * (l + 1) * W                              # the shared key, read once per launch
+    return out
 
 
 def triple_bytes(N, l):
@@ -57,9 +61,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="independent op-triples per step")
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--limbs", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=1,
                     help="issue queues (forked contexts = HIP streams) the independent triples are spread over")
-    ap.add_argument("--group", type=int, default=16,
+    ap.add_argument("--group", type=int, default=32,
                     help="triples handed to one evah_relinearize_rescale_many call (wide launches, shared key)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)

@@ -61,6 +61,7 @@ _SIGS = {
     "evah_relinearize_rescale": [_vp, _vp, C.c_uint32, _vpp],
     "evah_relinearize_rescale_many": [_vp, _vpp, C.c_uint32, C.c_uint32, _vpp],
     "evah_multiply_many": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
+    "evah_execute": [_vp, _vp, C.c_uint32, _vp, C.c_uint32],
     "evah_rotate": [_vp, _vp, C.c_int32, _vpp],
     "evah_rotate_many": [_vp, _vp, C.POINTER(C.c_int32), C.c_uint32, _vpp],
     "evah_rescale": [_vp, _vp, C.c_uint32, _vpp],
@@ -80,6 +81,22 @@ _VOID = {
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + list(_VOID) + [
     "evah_last_error", "evah_abi_version", "evah_profile_classes", "evah_profile_class_name"])
+
+
+
+class EvahVal(C.Structure):
+    """include/eva_hip.h evah_val"""
+    _fields_ = [("kind", C.c_uint32), ("h", C.c_void_p)]
+
+
+class EvahOp(C.Structure):
+    """include/eva_hip.h evah_op"""
+    _fields_ = [("op", C.c_uint32), ("dst", C.c_uint32), ("src0", C.c_uint32), ("src1", C.c_uint32),
+                ("imm", C.c_int32), ("flags", C.c_uint32)]
+
+
+VAL_NONE, VAL_CT, VAL_PT = 0, 1, 2
+OPF_FREE_SRC0, OPF_FREE_SRC1 = 1, 2
 
 _lib = None
 
@@ -343,6 +360,33 @@ class Context:
         outs = (C.c_void_p * n)()
         _chk(_lib.evah_multiply_many(self.h, ia, ib, n, outs))
         return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n)]
+
+    def execute(self, ops, values, n_vals=None):
+        """evah_execute: `ops` = [(op, dst, src0, src1, imm, flags)], `values` = {slot: Ciphertext |
+        Plaintext} placed by the caller.  Returns {slot: handle} for every non-empty slot afterwards;
+        wrappers whose handle the library released (EVAH_OPF_FREE_*) or moved (Output) are detached."""
+        n_vals = n_vals if n_vals is not None else 1 + max([max(o[1], o[2], o[3]) for o in ops] + list(values))
+        tab = (EvahVal * n_vals)()
+        for i, v in values.items():
+            tab[i].kind = VAL_CT if isinstance(v, Ciphertext) else VAL_PT
+            tab[i].h = v.h.value if isinstance(v.h, C.c_void_p) else v.h
+        arr = (EvahOp * len(ops))(*[EvahOp(*o) for o in ops])
+        before = {i: tab[i].h for i in values}
+        rc = _lib.evah_execute(self.h, arr, len(ops), tab, n_vals)
+        out = {}
+        for i in range(n_vals):
+            if tab[i].kind == VAL_NONE:
+                continue
+            if i in values and tab[i].h == before[i]:
+                out[i] = values[i]
+            else:
+                cls = Ciphertext if tab[i].kind == VAL_CT else Plaintext
+                out[i] = cls(self, C.c_void_p(tab[i].h))
+        for i, v in values.items():  # released or moved inside the library: this wrapper no longer owns it
+            if out.get(i) is not v:
+                v.h = None
+        _chk(rc)
+        return out
 
     def multiply_plain(self, a, pt):
         return self._ct2(_lib.evah_multiply_plain, a, pt)

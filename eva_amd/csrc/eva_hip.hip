@@ -1508,6 +1508,137 @@ int evah_test_ntt(evah_ctx *c, uint32_t prime_idx, int inverse, uint64_t *host) 
   API_END
 }
 
+// Whole-DAG submit over a value table (include/eva_hip.h).  Dispatch rules follow
+// seal_executor.h:114-215; the calls below are the same entry points a per-node host loop uses.
+int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab, uint32_t n_vals) {
+  auto slot = [&](uint32_t i) -> evah_val & {
+    if (i >= n_vals) throw std::invalid_argument("value index out of range");
+    return tab[i];
+  };
+  auto ct_of = [&](uint32_t i) -> evah_ct * {
+    evah_val &v = slot(i);
+    if (v.kind != EVAH_VAL_CT || !v.h) throw std::invalid_argument("operand is not a ciphertext");
+    return static_cast<evah_ct *>(v.h);
+  };
+  auto release = [&](uint32_t i) {
+    evah_val &v = slot(i);
+    if (v.kind == EVAH_VAL_CT) evah_ct_free(c, static_cast<evah_ct *>(v.h));
+    else if (v.kind == EVAH_VAL_PT) evah_pt_free(c, static_cast<evah_pt *>(v.h));
+    v.kind = EVAH_VAL_NONE;
+    v.h = nullptr;
+  };
+  auto chk = [&](int rc) {
+    if (rc) throw std::runtime_error(g_err);
+  };
+  auto put = [&](uint32_t dst, evah_ct *o) {
+    evah_val &v = slot(dst);
+    if (v.kind != EVAH_VAL_NONE) release(dst);
+    v.kind = EVAH_VAL_CT;
+    v.h = o;
+  };
+  API_BEGIN
+  use(c);
+  for (uint32_t i = 0; i < n_ops; i++) {
+    const evah_op &o = ops[i];
+    evah_ct *out = nullptr;
+    uint32_t consumed = 1; // ops handled by this iteration
+    switch (o.op) {
+    case 1: case 3: case 23: // Input / Constant / Encode: the caller placed the value
+      if (slot(o.dst).kind == EVAH_VAL_NONE) throw std::invalid_argument("input / plaintext slot is empty");
+      continue;
+    case 2: { // Output
+      if (o.dst != o.src0) {
+        evah_val &d = slot(o.dst), &s0 = slot(o.src0);
+        if (d.kind != EVAH_VAL_NONE) release(o.dst);
+        d = s0;
+        s0.kind = EVAH_VAL_NONE;
+        s0.h = nullptr;
+      }
+      continue;
+    }
+    case 10: chk(evah_negate(c, ct_of(o.src0), &out)); break;
+    case 11: case 13: { // Add / Mul: a plaintext first operand goes behind the ciphertext
+      uint32_t a = o.src0, b = o.src1;
+      if (slot(a).kind != EVAH_VAL_CT) std::swap(a, b);
+      evah_ct *x = ct_of(a);
+      const evah_val &y = slot(b);
+      if (y.kind == EVAH_VAL_CT) {
+        if (o.op == 11) chk(evah_add(c, x, static_cast<evah_ct *>(y.h), &out));
+        else if (a == b) chk(evah_square(c, x, &out));
+        else chk(evah_multiply(c, x, static_cast<evah_ct *>(y.h), &out));
+      } else if (y.kind == EVAH_VAL_PT) {
+        if (o.op == 11) chk(evah_add_plain(c, x, static_cast<evah_pt *>(y.h), &out));
+        else chk(evah_multiply_plain(c, x, static_cast<evah_pt *>(y.h), &out));
+      } else {
+        throw std::runtime_error("Unsupported operation encountered");
+      }
+      break;
+    }
+    case 12: {
+      evah_ct *x = ct_of(o.src0);
+      const evah_val &y = slot(o.src1);
+      if (y.kind == EVAH_VAL_CT) chk(evah_sub(c, x, static_cast<evah_ct *>(y.h), &out));
+      else if (y.kind == EVAH_VAL_PT) chk(evah_sub_plain(c, x, static_cast<evah_pt *>(y.h), &out));
+      else throw std::runtime_error("Unsupported operation encountered");
+      break;
+    }
+    case 14: case 15: {
+      // a run of rotations of the same operand -> one wide launch set (steps 0 stay single calls)
+      auto steps_of = [](const evah_op &r) { return r.op == 14 ? r.imm : -r.imm; };
+      uint32_t n = 1;
+      while (i + n < n_ops && n < (uint32_t)KS_BATCH_MAX && (ops[i + n].op == 14 || ops[i + n].op == 15) &&
+             ops[i + n].src0 == o.src0 && !(ops[i + n - 1].flags & EVAH_OPF_FREE_SRC0))
+        n++;
+      bool all_nonzero = true;
+      for (uint32_t j = 0; j < n; j++) all_nonzero = all_nonzero && steps_of(ops[i + j]) != 0;
+      if (n > 1 && all_nonzero) {
+        std::vector<int32_t> st(n);
+        std::vector<evah_ct *> outs(n, nullptr);
+        for (uint32_t j = 0; j < n; j++) st[j] = steps_of(ops[i + j]);
+        chk(evah_rotate_many(c, ct_of(o.src0), st.data(), n, outs.data()));
+        for (uint32_t j = 0; j < n; j++) put(ops[i + j].dst, outs[j]);
+        if (ops[i + n - 1].flags & EVAH_OPF_FREE_SRC0) release(o.src0);
+        i += n - 1;
+        continue;
+      }
+      chk(evah_rotate(c, ct_of(o.src0), steps_of(o), &out));
+      break;
+    }
+    case 20: {
+      // Relinearize whose result is consumed and released by the next op, a Rescale: fused form
+      if (i + 1 < n_ops && ops[i + 1].op == 22 && ops[i + 1].src0 == o.dst && o.dst != o.src0 &&
+          (ops[i + 1].flags & EVAH_OPF_FREE_SRC0)) {
+        chk(evah_relinearize_rescale(c, ct_of(o.src0), (uint32_t)ops[i + 1].imm, &out));
+        if (o.flags & EVAH_OPF_FREE_SRC0) release(o.src0);
+        put(ops[i + 1].dst, out);
+        i += 1;
+        continue;
+      }
+      chk(evah_relinearize(c, ct_of(o.src0), &out));
+      break;
+    }
+    case 21: chk(evah_mod_switch(c, ct_of(o.src0), &out)); break;
+    case 22: chk(evah_rescale(c, ct_of(o.src0), (uint32_t)o.imm, &out)); break;
+    default: throw std::runtime_error("Unhandled op " + std::to_string(o.op));
+    }
+    (void)consumed;
+    const bool binary = o.op == 11 || o.op == 12 || o.op == 13;
+    // the result is stored before operands are released (dst may reuse an operand's slot)
+    evah_val keep0 = slot(o.src0), keep1 = binary ? slot(o.src1) : evah_val{EVAH_VAL_NONE, nullptr};
+    const bool f0 = o.flags & EVAH_OPF_FREE_SRC0, f1 = binary && (o.flags & EVAH_OPF_FREE_SRC1) && o.src1 != o.src0;
+    if (f0) { slot(o.src0).kind = EVAH_VAL_NONE; slot(o.src0).h = nullptr; }
+    if (f1) { slot(o.src1).kind = EVAH_VAL_NONE; slot(o.src1).h = nullptr; }
+    put(o.dst, out);
+    auto drop = [&](const evah_val &v) {
+      if (v.kind == EVAH_VAL_CT) evah_ct_free(c, static_cast<evah_ct *>(v.h));
+      else if (v.kind == EVAH_VAL_PT) evah_pt_free(c, static_cast<evah_pt *>(v.h));
+    };
+    if (f0) drop(keep0);
+    if (f1) drop(keep1);
+  }
+  API_END
+}
+
 int evah_profile_enable(evah_ctx *c, int on) {
   API_BEGIN
   use(c);

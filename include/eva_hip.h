@@ -136,6 +136,27 @@ int evah_rescale(evah_ctx *ctx, const evah_ct *a, uint32_t divisor_bits, evah_ct
 /* evaluator.mod_switch_to_next (seal_executor.h:206) */
 int evah_mod_switch(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
 
+/* ---- whole-DAG submit: a topologically sorted flat op list over a value table.
+ * One call replaces the per-node loop ProgramTraversal::forwardPass + SEALExecutor::operator()
+ * (program_traversal.h:36-93, seal_executor.h:279-404) for the encrypted part of a program.
+ *   op    : the reference's Op codes (eva/ir/ops.h:11-25): Negate 10, Add 11, Sub 12, Mul 13,
+ *           RotateLeftConst 14, RotateRightConst 15, Relinearize 20, ModSwitch 21, Rescale 22,
+ *           Output 2 (dst becomes an alias of src0; src0's slot is emptied)
+ *   imm   : rotation steps (14/15), rescale divisor bits (22)
+ *   flags : EVAH_OPF_FREE_SRC0/1 = release that operand after this op (its last use; the reference
+ *           frees at last use under Galois, multicore_program_traversal.h:62-67)
+ * Operand kinds select the evaluator call exactly as seal_executor.h:114-175 does: Add/Mul swap a
+ * plaintext first operand behind the ciphertext, Mul with src0 == src1 is square, Sub needs a
+ * ciphertext first.  Inputs, encoded plaintexts (Encode/Constant nodes) are placed in the table
+ * by the caller; on return the slots named by executed ops hold new handles owned by the caller.
+ * Inside, Relinearize followed by the Rescale that consumes (and frees) it, and runs of rotations
+ * of one operand, are issued through the fused / batched forms (same ciphertexts). */
+enum { EVAH_VAL_NONE = 0, EVAH_VAL_CT = 1, EVAH_VAL_PT = 2 };
+enum { EVAH_OPF_FREE_SRC0 = 1, EVAH_OPF_FREE_SRC1 = 2 };
+typedef struct evah_val { uint32_t kind; void *h; } evah_val;
+typedef struct evah_op { uint32_t op, dst, src0, src1; int32_t imm; uint32_t flags; } evah_op;
+int evah_execute(evah_ctx *ctx, const evah_op *ops, uint32_t n_ops, evah_val *table, uint32_t n_vals);
+
 /* ---- whole-DAG capture ------------------------------------------------------------------------
  * Replaces the per-call DAG walk of SEALPublic::execute (seal.cpp:104-122) for repeated
  * executions of one compiled program: every evaluator call issued on `q0` and `others` (forks of

@@ -1,0 +1,139 @@
+"""evah_execute (the whole-DAG submit of SURVEY.md §8(b)): a compiled program lowered to the
+flat evah_op list over a value table and run through the C-ABI in ONE call must give, bit for
+bit, the ciphertexts the CPU oracle gets walking the same DAG (tests/oracle_executor.py), with
+last-use frees, the fused Relinearize->Rescale form and batched sibling rotations exercised."""
+import numpy as np
+import pytest
+
+from eva import EvaProgram, Input, Output, Op
+from eva.ckks import CKKSCompiler
+from eva.seal import generate_keys
+from eva_amd import backend as be
+from test_compiler import _sobel
+
+pytestmark = pytest.mark.gpu
+
+
+def _lower(compiled, enc_inputs, pub, g):
+    """term list -> (ops, values): encrypted part only; raw (vector<double>) nodes are host work
+    (seal_executor.h:63-112) and are folded here, Encode nodes are encoded by the product's host
+    encoder and uploaded as plaintexts."""
+    dump = compiled._dump()
+    uses = {}
+    for d in dump:
+        for a in d["operands"]:
+            uses[a] = uses.get(a, 0) + 1
+    raw, values, ops = {}, {}, []
+    inputs = {name: t.index for name, t in compiled.inputs.items()}
+    for name in enc_inputs.names():
+        kind, size, limbs, scale, data = enc_inputs.get(name)
+        t = inputs[name]
+        if kind == "cipher":
+            values[t] = g.upload_ct(data, scale)
+        elif kind == "plain":
+            values[t] = g.upload_pt(data, scale)
+        else:
+            raw[t] = list(data) * (compiled.vec_size // len(data))
+    seen = {}
+    for d in dump:
+        t, op, a = d["id"], d["op"], d["operands"]
+        if op == Op.Input:
+            continue
+        if op == Op.Constant:
+            raw[t] = list(d["constant"]) * (compiled.vec_size // len(d["constant"]))
+            continue
+        if op == Op.Encode:
+            data = pub._encode(raw[a[0]], d["encode_scale"], d["encode_level"])
+            values[t] = g.upload_pt(data, 2.0 ** d["encode_scale"])
+            continue
+        if all(x in raw for x in a):
+            x = [raw[i] for i in a]
+            if op == Op.Add: raw[t] = [u + v for u, v in zip(*x)]
+            elif op == Op.Sub: raw[t] = [u - v for u, v in zip(*x)]
+            elif op == Op.Mul: raw[t] = [u * v for u, v in zip(*x)]
+            elif op == Op.Negate: raw[t] = [-u for u in x[0]]
+            else: raise RuntimeError("raw op not needed by these programs")
+            continue
+        imm = d.get("rotation", d.get("rescale_divisor", 0)) or 0
+        flags = 0
+        for pos, s in enumerate(a):
+            seen[s] = seen.get(s, 0) + 1
+        for pos, s in enumerate(a[:2]):
+            # last use of an intermediate (never an input or a plaintext the caller still holds)
+            if seen[s] == uses[s] and s not in values and not (pos == 1 and a[0] == a[1]):
+                flags |= be.OPF_FREE_SRC0 if pos == 0 else be.OPF_FREE_SRC1
+        ops.append((int(op), t, a[0], a[1] if len(a) > 1 else 0, int(imm), flags))
+    outs = {name: t.index for name, t in compiled.outputs.items()}
+    return ops, values, outs
+
+
+def _check(prog, inputs, N=None):
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    if N:
+        params.poly_modulus_degree = N
+    pub, sec = generate_keys(params, 3)
+    enc = pub.encrypt(inputs, sig)
+    g = be.Context(pub.poly_modulus_degree, list(pub.primes))
+    g.upload_relin_key(pub.relin_key())
+    for elt, key in pub.galois_keys().items():
+        g.upload_galois_key(elt, key)
+    ops, values, outs = _lower(compiled, enc, pub, g)
+    res = g.execute(ops, values)
+    from oracle_executor import OracleExecutor
+    ref = OracleExecutor(pub).execute(compiled, enc)
+    for name, t in outs.items():
+        assert np.array_equal(res[t].download(), ref[name].data), f"output {name} differs from the oracle walk"
+        assert res[t].scale == ref[name].scale
+    # every intermediate was released at its last use: only caller-placed values and outputs remain
+    assert set(res) <= set(values) | set(outs.values())
+    return ops
+
+
+def test_execute_polynomial_and_fused_relin_rescale():
+    poly = EvaProgram('p', vec_size=64)
+    with poly:
+        x = Input('x')
+        Output('y', 3 * x ** 2 + 5 * x - 2)
+    poly.set_output_ranges(20)
+    poly.set_input_scales(30)
+    ops = _check(poly, {'x': [i / 64.0 for i in range(64)]})
+    assert any(o[0] == int(Op.Relinearize) for o in ops)
+
+
+def test_execute_rotations_and_mixed_ops():
+    p = EvaProgram('r', vec_size=32)
+    with p:
+        x, y = Input('x'), Input('y')
+        s = (x << 1) + (x << 2) + (x >> 3) + (x << 0)
+        Output('a', s * y - x)
+        Output('b', -(x * x) + 0.5)
+    p.set_output_ranges(20)
+    p.set_input_scales(25)
+    rng = np.random.default_rng(5)
+    _check(p, {'x': list(rng.uniform(-1, 1, 32)), 'y': list(rng.uniform(-1, 1, 32))})
+
+
+def test_execute_sobel_n8192():
+    """BASELINE config 2 through the one-call submit"""
+    sob = _sobel(64, 64, 4096)
+    sob.set_input_scales(25)
+    sob.set_output_ranges(10)
+    img = [((37 * i) % 256) / 255.0 for i in range(4096)]
+    ops = _check(sob, {'image': img}, N=8192)
+    assert sum(1 for o in ops if o[0] in (int(Op.RotateLeftConst), int(Op.RotateRightConst))) >= 8
+
+
+def test_execute_reports_errors():
+    g = be.Context(1024, be.default_test_primes(1024)) if hasattr(be, "default_test_primes") else None
+    if g is None:
+        from eva_amd.hostref import coeff_modulus_create
+        g = be.Context(1024, coeff_modulus_create(1024, [30, 30, 30]))
+    rng = np.random.default_rng(1)
+    a = g.upload_ct(rng.integers(0, 1 << 20, size=(2, 2, 1024), dtype=np.uint64), 2.0 ** 10)
+    with pytest.raises(RuntimeError, match="not a ciphertext|out of range"):
+        g.execute([(int(Op.Negate), 1, 5, 0, 0, 0)], {0: a}, n_vals=3)
+    with pytest.raises(RuntimeError, match="Unhandled op"):
+        g.execute([(99, 1, 0, 0, 0, 0)], {0: a}, n_vals=3)
+    with pytest.raises(RuntimeError, match="relinearization key not present|size-3"):
+        g.execute([(int(Op.Relinearize), 1, 0, 0, 0, 0)], {0: a}, n_vals=3)
+    assert a.h is not None and a.info()[0] == 2  # a failed submit leaves caller values alone
