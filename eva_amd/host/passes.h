@@ -119,9 +119,10 @@ struct ReductionCombiner {
     const Term &x = p.at(t);
     if (x.operands.empty() || x.uses.empty()) return;
     if (x.op != Op::Add && x.op != Op::Mul) return;
-    auto uses = p.uses_of(t);
-    if (uses.size() != 1 || p.at(uses[0]).op != x.op) return;
-    TermId use = uses[0];
+    // one use EDGE (reduction_balancer.h:44-45: Term::getUses lists a user once per operand slot,
+    // so t*t with t = a*a is left alone instead of being flattened into a 4-ary product)
+    if (p.num_uses(t) != 1 || p.at(x.uses[0]).op != x.op) return;
+    TermId use = x.uses[0];
     while (p.erase_operand(use, t))
       for (TermId o : std::vector<TermId>(p.at(t).operands)) p.add_operand(use, o);
   }

@@ -1,5 +1,7 @@
-"""execute() wall time for the BASELINE DAG configs (Sobel N=2^13, Harris N=2^15) on the GPU vs
-the CPU oracle walking the same compiled DAG (1 core).  usage: dag_bench.py [reps] [--no-cpu]"""
+"""execute() wall time for the BASELINE DAG configs on one GPU vs the CPU oracle walking the same
+compiled DAG (1 core): C1 README polynomial, C2 Sobel N=2^13, C3 Harris N=2^15, one instance of
+C4 (Sobel N=2^14) and C5 (3x3 convolution + depth-8 squaring chain, N=2^16, 13 primes).
+usage: dag_bench.py [reps] [--no-cpu]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,11 +15,16 @@ from test_gpu_e2e import _harris, _image
 reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
 no_cpu = "--no-cpu" in sys.argv
 
-def run(name, prog, N):
+def run(name, prog, N, inputs=None, pad_primes=0):
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
-    params.poly_modulus_degree = N
+    if N:
+        params.poly_modulus_degree = N
+    if pad_primes and len(params.prime_bits) < pad_primes:  # pad with 60-bit primes to the stated L
+        pb = list(params.prime_bits)
+        params.prime_bits = pb[:1] + [60] * (pad_primes - len(pb)) + pb[1:]
+    N = params.poly_modulus_degree
     pub, sec = generate_keys(params, 1)
-    inputs = _image(4096)
+    inputs = inputs if inputs is not None else _image(4096)
     enc = pub.encrypt(inputs, sig)
     ops = {}
     for d in compiled._dump():
@@ -35,6 +42,29 @@ def run(name, prog, N):
         line += f"\n  CPU oracle walk (1 core): {tc*1e3:.1f} ms   -> GPU speed-up {tc/min(ts):.1f}x"
     print(line, flush=True)
 
+from eva import EvaProgram, Input, Output
+poly = EvaProgram('Polynomial', vec_size=1024)
+with poly:
+    x = Input('x')
+    Output('y', 3 * x ** 2 + 5 * x - 2)
+poly.set_output_ranges(30); poly.set_input_scales(30)
+run("C1 readme-poly", poly, None, {'x': [i / 1024.0 for i in range(1024)]})
+
 sob = _sobel(64, 64, 4096); sob.set_input_scales(25); sob.set_output_ranges(10)
-run("sobel", sob, 8192)
-run("harris", _harris(), 32768)
+run("C2 sobel", sob, 8192)
+run("C3 harris", _harris(), 32768)
+run("C4 sobel (one of the batch)", sob, 16384)
+
+deep = EvaProgram('conv+depth8', vec_size=4096)
+with deep:
+    image = Input('image')
+    acc = None
+    for i in range(3):
+        for j in range(3):
+            t = (image << (i * 64 + j)) * (1.0 / 9.0)
+            acc = t if acc is None else acc + t
+    for _ in range(8):
+        acc = acc * acc
+    Output('y', acc)
+deep.set_input_scales(30); deep.set_output_ranges(20)
+run("C5 conv+depth-8", deep, 65536, pad_primes=13)

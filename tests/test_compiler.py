@@ -178,3 +178,23 @@ def test_program_api_errors():
         Output('y', x)
     with pytest.raises(RuntimeError, match="length of all inputs"):
         evaluate(p, {'x': [1, 2, 3]})
+
+
+def test_repeated_squaring_is_not_flattened():
+    """reduction_balancer.h:44-45: a term used twice by the same product (acc*acc) has two use
+    edges and is not merged into its user — a depth-8 squaring chain stays 8 multiplications."""
+    from eva import EvaProgram, Input, Output, Op
+    from eva.ckks import CKKSCompiler
+    prog = EvaProgram('chain', vec_size=64)
+    with prog:
+        acc = Input('x')
+        for _ in range(8):
+            acc = acc * acc
+        Output('y', acc)
+    prog.set_input_scales(30)
+    prog.set_output_ranges(20)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    ops = [d["op"] for d in compiled._dump()]
+    assert ops.count(Op.Relinearize) == 8
+    assert sum(1 for d in compiled._dump() if d["op"] == Op.Mul and d["operands"][0] == d["operands"][1]) == 8
+    assert len(params.prime_bits) == 10  # 8 rescale primes + one output prime + special
