@@ -62,6 +62,10 @@ _SIGS = {
     "evah_relinearize_rescale_many": [_vp, _vpp, C.c_uint32, C.c_uint32, _vpp],
     "evah_multiply_many": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_execute": [_vp, _vp, C.c_uint32, _vp, C.c_uint32],
+    "evah_ct_upload_batch": [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, _u64p, _vpp],
+    "evah_ct_batch": [_vp, C.POINTER(C.c_uint32)],
+    "evah_ct_stack": [_vp, _vpp, C.c_uint32, _vpp],
+    "evah_ct_unstack": [_vp, _vp, C.c_uint32, _vpp],
     "evah_rotate": [_vp, _vp, C.c_int32, _vpp],
     "evah_rotate_many": [_vp, _vp, C.POINTER(C.c_int32), C.c_uint32, _vpp],
     "evah_rescale": [_vp, _vp, C.c_uint32, _vpp],
@@ -165,11 +169,24 @@ class Ciphertext:
     limbs = property(lambda self: self.info()[1])
     scale = property(lambda self: self.info()[2])
 
+    @property
+    def batch(self):
+        b = C.c_uint32()
+        _chk(_lib.evah_ct_batch(self.h, C.byref(b)))
+        return b.value
+
     def download(self):
+        """[size][limbs][N]; a batched handle downloads as [batch][size][limbs][N]"""
         s, l, _ = self.info()
-        out = np.empty((s, l, self.ctx.N), dtype=np.uint64)
+        b = self.batch
+        out = np.empty((b, s, l, self.ctx.N), dtype=np.uint64)
         _chk(_lib.evah_ct_download(self.ctx.h, self.h, _p(out)))
-        return out
+        return out if b > 1 else out[0]
+
+    def unstack(self, b):
+        h = C.c_void_p()
+        _chk(_lib.evah_ct_unstack(self.ctx.h, self.h, int(b), C.byref(h)))
+        return Ciphertext(self.ctx, h)
 
     def free(self):
         if self.h:
@@ -310,6 +327,22 @@ class Context:
         assert n == self.N
         h = C.c_void_p()
         _chk(_lib.evah_ct_upload(self.h, size, limbs, float(scale), _p(data), C.byref(h)))
+        return Ciphertext(self, h)
+
+    def upload_ct_batch(self, data, scale):
+        """data [batch][size][limbs][N] -> one batched handle"""
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        batch, size, limbs, n = data.shape
+        assert n == self.N
+        h = C.c_void_p()
+        _chk(_lib.evah_ct_upload_batch(self.h, batch, size, limbs, float(scale), _p(data), C.byref(h)))
+        return Ciphertext(self, h)
+
+    def stack(self, cts):
+        n = len(cts)
+        ins = (C.c_void_p * n)(*[ct.h for ct in cts])
+        h = C.c_void_p()
+        _chk(_lib.evah_ct_stack(self.h, ins, n, C.byref(h)))
         return Ciphertext(self, h)
 
     def upload_pt(self, data, scale, coeff_form=False):

@@ -48,17 +48,20 @@ __device__ __forceinline__ void st2(u64 *p, ulonglong2 v) { *reinterpret_cast<ul
 // polys of the longer operand copied (or negated when it is the subtrahend).
 __global__ void __launch_bounds__(256)
 k_addsub(DevCtx cx, const u64 *a, size_t a_ps, uint32_t sa, const u64 *b, size_t b_ps, uint32_t sb,
-         u64 *out, size_t o_ps, int sub) {
+         u64 *out, size_t o_ps, int sub, uint32_t smax) {
   EW_SETUP
+  // grid.z = instance * smax + poly (smax = max(sa, sb)); a plaintext operand has b_ps == 0
+  const uint32_t inst = p / smax, pp = p % smax;
+  const size_t ao = (size_t)(inst * sa + pp) * a_ps + off, bo = (size_t)(inst * sb + pp) * b_ps + off;
   ulonglong2 r;
-  if (p < sa && p < sb) {
-    ulonglong2 x = ld2(a + p * a_ps + off), y = ld2(b + p * b_ps + off);
+  if (pp < sa && pp < sb) {
+    ulonglong2 x = ld2(a + ao), y = ld2(b + bo);
     r.x = sub ? submod(x.x, y.x, pm.q) : addmod(x.x, y.x, pm.q);
     r.y = sub ? submod(x.y, y.y, pm.q) : addmod(x.y, y.y, pm.q);
-  } else if (p < sa) {
-    r = ld2(a + p * a_ps + off);
+  } else if (pp < sa) {
+    r = ld2(a + ao);
   } else {
-    r = ld2(b + p * b_ps + off);
+    r = ld2(b + bo);
     if (sub) { r.x = negmod(r.x, pm.q); r.y = negmod(r.y, pm.q); }
   }
   st2(out + p * o_ps + off, r);
@@ -74,10 +77,13 @@ k_negate(DevCtx cx, const u64 *a, size_t a_ps, u64 *out, size_t o_ps) {
   st2(out + p * o_ps + off, r);
 }
 
-// K4: multiply 2x2 -> 3: (a0b0, a0b1 + a1b0, a1b1); grid.z = 1
+// K4: multiply 2x2 -> 3: (a0b0, a0b1 + a1b0, a1b1); grid.z = instance of a batched handle
 __global__ void __launch_bounds__(256)
 k_mul22(DevCtx cx, const u64 *a, size_t a_ps, const u64 *b, size_t b_ps, u64 *out, size_t o_ps) {
   EW_SETUP
+  a += (size_t)p * 2 * a_ps;
+  b += (size_t)p * 2 * b_ps;
+  out += (size_t)p * 3 * o_ps;
   ulonglong2 a0 = ld2(a + off), a1 = ld2(a + a_ps + off);
   ulonglong2 b0 = ld2(b + off), b1 = ld2(b + b_ps + off);
   ulonglong2 d0, d1, d2;
@@ -129,6 +135,8 @@ k_mul22_many(DevCtx cx, MulTab tab, u64 *out_b, size_t o_ps) {
 __global__ void __launch_bounds__(256)
 k_square(DevCtx cx, const u64 *a, size_t a_ps, u64 *out, size_t o_ps) {
   EW_SETUP
+  a += (size_t)p * 2 * a_ps;
+  out += (size_t)p * 3 * o_ps;
   ulonglong2 a0 = ld2(a + off), a1 = ld2(a + a_ps + off);
   ulonglong2 d0, d1, d2;
   d0.x = mulmod(a0.x, a0.x, pm);
@@ -172,11 +180,12 @@ struct PermTables {
   const uint32_t *perm[KS_BATCH_MAX];
 };
 __global__ void __launch_bounds__(256)
-k_galois_perm_many(DevCtx cx, const u64 *a, size_t a_ps, PermTables pt, u64 *out, size_t o_ps) {
+k_galois_perm_many(DevCtx cx, const u64 *a, size_t a_ps, PermTables pt, u64 *out, size_t o_ps, uint32_t B) {
+  // z = 2 * (j * B + b) + K: rotation j of instance b, polynomial K
   const uint32_t z = blockIdx.z, r = z >> 1, p = z & 1, i = blockIdx.y;
   const uint32_t n = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
-  const uint2 pi = *reinterpret_cast<const uint2 *>(pt.perm[r] + n);
-  const u64 *src = a + p * a_ps + (size_t)i * cx.N;
+  const uint2 pi = *reinterpret_cast<const uint2 *>(pt.perm[r / B] + n);
+  const u64 *src = a + ((size_t)(r % B) * 2 + p) * a_ps + (size_t)i * cx.N;
   ulonglong2 v;
   v.x = src[pi.x];
   v.y = src[pi.y];
@@ -312,6 +321,11 @@ struct evah_ct {
   uint32_t size, limbs;
   size_t ps; // poly stride in elements
   double scale;
+  // `batch` independent ciphertexts of identical shape in one handle: instance b starts at
+  // d + b * size * ps, i.e. the handle is batch * size polynomials at a uniform stride.  Every
+  // evaluator entry point applies to all instances in one launch set (plaintext operands and keys
+  // are shared); this is how a batch of independent DAG instances is run (BASELINE config 4).
+  uint32_t batch = 1;
 };
 struct evah_pt {
   Buffer *buf;
@@ -460,9 +474,10 @@ static void buf_unref(evah_ctx *c, Buffer *b) {
     delete b;
   }
 }
-static evah_ct *ct_new(evah_ctx *c, uint32_t size, uint32_t limbs, double scale) {
+static evah_ct *ct_new(evah_ctx *c, uint32_t size, uint32_t limbs, double scale, uint32_t batch = 1) {
   evah_ct *t = new evah_ct;
-  t->buf = buf_new(c, (size_t)size * limbs * c->N);
+  t->batch = batch;
+  t->buf = buf_new(c, (size_t)batch * size * limbs * c->N);
   t->d = t->buf->d;
   t->size = size;
   t->limbs = limbs;
@@ -947,13 +962,71 @@ int evah_ct_upload(evah_ctx *c, uint32_t size, uint32_t limbs, double scale, con
   API_END
 }
 
+// `batch` ciphertexts of one shape as ONE handle; data = [batch][size][limbs][N]
+int evah_ct_upload_batch(evah_ctx *c, uint32_t batch, uint32_t size, uint32_t limbs, double scale, const uint64_t *data,
+                         evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  if (batch < 1 || batch > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("batch must be 1..64");
+  if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
+  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
+  evah_ct *t = ct_new(c, size, limbs, scale, batch);
+  HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)batch * size * limbs * c->N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  t->buf->ready_everywhere = true;
+  *out = t;
+  API_END
+}
+
+int evah_ct_batch(const evah_ct *ct, uint32_t *batch) {
+  API_BEGIN
+  *batch = ct->batch;
+  API_END
+}
+
+// n single ciphertexts of one shape and scale -> one batched handle (device copies)
+int evah_ct_stack(evah_ctx *c, const evah_ct *const *cts, uint32_t n, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("batch must be 1..64");
+  const evah_ct *f = cts[0];
+  for (uint32_t i = 0; i < n; i++) {
+    if (cts[i]->batch != 1) throw std::invalid_argument("stack takes single ciphertexts");
+    if (cts[i]->size != f->size || cts[i]->limbs != f->limbs) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    if (!same_scale(cts[i]->scale, f->scale)) throw std::invalid_argument("scale mismatch");
+    acquire(c, cts[i]->buf);
+  }
+  evah_ct *o = ct_new(c, f->size, f->limbs, f->scale, n);
+  const size_t row = sizeof(u64) * (size_t)f->limbs * c->N;
+  for (uint32_t i = 0; i < n; i++)
+    HIPCHK(hipMemcpy2DAsync(o->d + (size_t)i * o->size * o->ps, sizeof(u64) * o->ps, cts[i]->d, sizeof(u64) * cts[i]->ps, row,
+                            f->size, hipMemcpyDeviceToDevice, c->stream));
+  *out = o;
+  API_END
+}
+
+// instance b of a batched handle as a single-ciphertext view (shares the buffer)
+int evah_ct_unstack(evah_ctx *c, const evah_ct *ct, uint32_t b, evah_ct **out) {
+  API_BEGIN
+  (void)c;
+  if (b >= ct->batch) throw std::invalid_argument("instance index out of range");
+  evah_ct *o = new evah_ct(*ct);
+  o->d = ct->d + (size_t)b * ct->size * ct->ps;
+  o->batch = 1;
+  o->buf->refs++;
+  *out = o;
+  API_END
+}
+
 int evah_ct_write(evah_ctx *c, evah_ct *ct, const uint64_t *data) {
   API_BEGIN
   use(c);
   if (c->capturing) throw std::logic_error("evah_ct_write cannot be captured into a graph");
   if (ct->ps != (size_t)ct->limbs * c->N) throw std::invalid_argument("cannot write into a mod-switched view");
   acquire(c, ct->buf);
-  HIPCHK(hipMemcpyAsync(ct->d, data, sizeof(u64) * (size_t)ct->size * ct->limbs * c->N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(ct->d, data, sizeof(u64) * (size_t)ct->batch * ct->size * ct->limbs * c->N, hipMemcpyHostToDevice,
+                        c->stream));
   HIPCHK(hipStreamSynchronize(c->stream)); // pageable source: the caller may reuse it after return
   API_END
 }
@@ -1039,7 +1112,8 @@ int evah_ct_download(evah_ctx *c, const evah_ct *ct, uint64_t *out) {
   if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
   acquire(c, ct->buf);
   const size_t row = sizeof(u64) * (size_t)ct->limbs * c->N;
-  HIPCHK(hipMemcpy2DAsync(out, row, ct->d, sizeof(u64) * ct->ps, row, ct->size, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpy2DAsync(out, row, ct->d, sizeof(u64) * ct->ps, row, (size_t)ct->size * ct->batch, hipMemcpyDeviceToHost,
+                          c->stream)); // a batched handle downloads as [batch][size][limbs][N]
   HIPCHK(hipStreamSynchronize(c->stream));
   API_END
 }
@@ -1124,10 +1198,11 @@ static int addsub_impl(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct 
   acquire(c, b->buf);
   if (a->limbs != b->limbs) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
   if (!same_scale(a->scale, b->scale)) throw std::invalid_argument("scale mismatch");
+  if (a->batch != b->batch) throw std::invalid_argument("batch size mismatch");
   const uint32_t s = std::max(a->size, b->size);
-  evah_ct *o = ct_new(c, s, a->limbs, a->scale);
-  EW_LAUNCH(k_addsub, ew_grid(c, a->limbs, s), dim3(256), 0, c->stream, c->dev, a->d, a->ps, a->size,
-                     b->d, b->ps, b->size, o->d, o->ps, sub);
+  evah_ct *o = ct_new(c, s, a->limbs, a->scale, a->batch);
+  EW_LAUNCH(k_addsub, ew_grid(c, a->limbs, s * a->batch), dim3(256), 0, c->stream, c->dev, a->d, a->ps, a->size,
+                     b->d, b->ps, b->size, o->d, o->ps, sub, s);
   HIPCHK(hipGetLastError());
   *out = o;
   API_END
@@ -1142,9 +1217,9 @@ static int addsub_plain_impl(evah_ctx *c, const evah_ct *a, const evah_pt *b, ev
   acquire(c, b->buf);
   if (a->limbs != b->limbs) throw std::invalid_argument("encrypted and plain parameter mismatch");
   if (!same_scale(a->scale, b->scale)) throw std::invalid_argument("scale mismatch");
-  evah_ct *o = ct_new(c, a->size, a->limbs, a->scale);
-  EW_LAUNCH(k_addsub, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps,
-                     a->size, b->d, (size_t)0, 1u, o->d, o->ps, sub);
+  evah_ct *o = ct_new(c, a->size, a->limbs, a->scale, a->batch);
+  EW_LAUNCH(k_addsub, ew_grid(c, a->limbs, a->size * a->batch), dim3(256), 0, c->stream, c->dev, a->d, a->ps,
+                     a->size, b->d, (size_t)0, 1u, o->d, o->ps, sub, a->size);
   HIPCHK(hipGetLastError());
   *out = o;
   API_END
@@ -1156,8 +1231,8 @@ int evah_negate(evah_ctx *c, const evah_ct *a, evah_ct **out) {
   API_BEGIN
   use(c);
   acquire(c, a->buf);
-  evah_ct *o = ct_new(c, a->size, a->limbs, a->scale);
-  EW_LAUNCH(k_negate, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps, o->d, o->ps);
+  evah_ct *o = ct_new(c, a->size, a->limbs, a->scale, a->batch);
+  EW_LAUNCH(k_negate, ew_grid(c, a->limbs, a->size * a->batch), dim3(256), 0, c->stream, c->dev, a->d, a->ps, o->d, o->ps);
   HIPCHK(hipGetLastError());
   *out = o;
   API_END
@@ -1172,8 +1247,9 @@ int evah_multiply(evah_ctx *c, const evah_ct *a, const evah_ct *b, evah_ct **out
   if (a->size != 2 || b->size != 2) throw std::invalid_argument("multiply supports size-2 operands only (relinearize first)");
   const double ns = a->scale * b->scale;
   check_scale(c, ns, a->limbs);
-  evah_ct *o = ct_new(c, 3, a->limbs, ns);
-  EW_LAUNCH(k_mul22, ew_grid(c, a->limbs, 1), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, b->ps, o->d, o->ps);
+  if (a->batch != b->batch) throw std::invalid_argument("batch size mismatch");
+  evah_ct *o = ct_new(c, 3, a->limbs, ns, a->batch);
+  EW_LAUNCH(k_mul22, ew_grid(c, a->limbs, a->batch), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, b->ps, o->d, o->ps);
   HIPCHK(hipGetLastError());
   *out = o;
   API_END
@@ -1192,6 +1268,7 @@ int evah_multiply_many(evah_ctx *c, const evah_ct *const *as, const evah_ct *con
   for (uint32_t i = 0; i < n; i++) {
     const evah_ct *a = as[i], *b = bs[i];
     if (a->size != 2 || b->size != 2) throw std::invalid_argument("multiply supports size-2 operands only (relinearize first)");
+    if (a->batch != 1 || b->batch != 1) throw std::invalid_argument("multiply_many takes single ciphertexts (a batched handle already multiplies in one launch)");
     if (a->limbs != l || b->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
     scales[i] = a->scale * b->scale;
     check_scale(c, scales[i], l);
@@ -1226,8 +1303,8 @@ int evah_square(evah_ctx *c, const evah_ct *a, evah_ct **out) {
   if (a->size != 2) throw std::invalid_argument("square supports size-2 operands only (relinearize first)");
   const double ns = a->scale * a->scale;
   check_scale(c, ns, a->limbs);
-  evah_ct *o = ct_new(c, 3, a->limbs, ns);
-  EW_LAUNCH(k_square, ew_grid(c, a->limbs, 1), dim3(256), 0, c->stream, c->dev, a->d, a->ps, o->d, o->ps);
+  evah_ct *o = ct_new(c, 3, a->limbs, ns, a->batch);
+  EW_LAUNCH(k_square, ew_grid(c, a->limbs, a->batch), dim3(256), 0, c->stream, c->dev, a->d, a->ps, o->d, o->ps);
   HIPCHK(hipGetLastError());
   *out = o;
   API_END
@@ -1241,8 +1318,8 @@ int evah_multiply_plain(evah_ctx *c, const evah_ct *a, const evah_pt *b, evah_ct
   if (a->limbs != b->limbs) throw std::invalid_argument("encrypted and plain parameter mismatch");
   const double ns = a->scale * b->scale;
   check_scale(c, ns, a->limbs);
-  evah_ct *o = ct_new(c, a->size, a->limbs, ns);
-  EW_LAUNCH(k_mul_plain, ew_grid(c, a->limbs, a->size), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, o->d, o->ps);
+  evah_ct *o = ct_new(c, a->size, a->limbs, ns, a->batch);
+  EW_LAUNCH(k_mul_plain, ew_grid(c, a->limbs, a->size * a->batch), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, o->d, o->ps);
   HIPCHK(hipGetLastError());
   *out = o;
   API_END
@@ -1254,9 +1331,27 @@ int evah_relinearize(evah_ctx *c, const evah_ct *a, evah_ct **out) {
   acquire(c, a->buf);
   if (a->size != 3) throw std::invalid_argument("relinearize expects a size-3 ciphertext");
   if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
-  evah_ct *o = ct_new(c, 2, a->limbs, a->scale);
+  evah_ct *o = ct_new(c, 2, a->limbs, a->scale, a->batch);
   try {
-    switch_key(c, a->limbs, a->d + 2 * a->ps, c->sh->relin, a->d, a->ps, 2, o->d, o->ps);
+    if (a->batch == 1) {
+      switch_key(c, a->limbs, a->d + 2 * a->ps, c->sh->relin, a->d, a->ps, 2, o->d, o->ps);
+    } else { // all instances in one launch set (chunks of KS_BATCH_MAX)
+      const uint32_t l = a->limbs;
+      const size_t N = c->N, pps = (size_t)(l + 1) * N;
+      for (uint32_t b0 = 0; b0 < a->batch; b0 += KS_BATCH_MAX) {
+        const uint32_t n = std::min<uint32_t>(KS_BATCH_MAX, a->batch - b0);
+        const u64 *a0 = a->d + (size_t)b0 * 3 * a->ps;
+        Scratch prod(c, (size_t)n * 2 * pps);
+        std::vector<const KeyDev *> keys(n, &c->sh->relin);
+        switch_key_products(c, l, a0 + 2 * a->ps, 3 * a->ps, keys.data(), n, prod.d);
+        Scratch r(c, (size_t)n * 2 * N);
+        OpPlain::Params sp{prod.d + (size_t)l * N, r.d, pps, N, 1, c->k - 1, 1, {}};
+        ntt_inverse<OpPlain>(c, sp, 2 * n);
+        OpModDown::Params mp{r.d, N, prod.d, pps, a0, a->ps, 2, o->d + (size_t)b0 * 2 * o->ps, o->ps, c->k - 1, l};
+        mp.add_bs = 3 * a->ps;
+        ntt_forward<OpModDown>(c, mp, 2 * n * l);
+      }
+    }
   } catch (...) {
     evah_ct_free(c, o);
     throw;
@@ -1264,6 +1359,8 @@ int evah_relinearize(evah_ctx *c, const evah_ct *a, evah_ct **out) {
   *out = o;
   API_END
 }
+
+static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n, u64 *out_d);
 
 int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bits, evah_ct **out) {
   API_BEGIN
@@ -1274,7 +1371,27 @@ int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bit
   if (a->limbs < 2) throw std::invalid_argument("end of modulus switching chain reached");
   const uint32_t l = a->limbs, last = l - 1, sp = c->k - 1;
   const size_t N = c->N, pps = (size_t)(l + 1) * N;
-  evah_ct *o = ct_new(c, 2, l - 1, a->scale / std::pow(2.0, (double)divisor_bits));
+  evah_ct *o = ct_new(c, 2, l - 1, a->scale / std::pow(2.0, (double)divisor_bits), a->batch);
+  if (a->batch > 1) { // every instance through the batched form, KS_BATCH_MAX at a time
+    try {
+      std::vector<evah_ct> views(a->batch, *a);
+      std::vector<const evah_ct *> ptrs(a->batch);
+      for (uint32_t b = 0; b < a->batch; b++) {
+        views[b].d = a->d + (size_t)b * 3 * a->ps;
+        views[b].batch = 1;
+        ptrs[b] = &views[b];
+      }
+      for (uint32_t b0 = 0; b0 < a->batch; b0 += KS_BATCH_MAX)
+        relin_rescale_core(c, ptrs.data() + b0, std::min<uint32_t>(KS_BATCH_MAX, a->batch - b0),
+                           o->d + (size_t)b0 * 2 * o->ps);
+    } catch (...) {
+      evah_ct_free(c, o);
+      throw;
+    }
+    *out = o;
+    g_err.clear();
+    return 0;
+  }
   try {
     Scratch prod(c, 2 * pps);
     const KeyDev *kp = &c->sh->relin;
@@ -1300,6 +1417,32 @@ int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bit
 // n (<= 64) independent size-3 ciphertexts at the same level, all relinearized with the (shared)
 // relinearization key and rescaled: one set of n-times-wider launches; instances are co-scheduled
 // per XCD so the key tiles are read from HBM once per XCD, not once per instance.
+// core of the batched form: n (<= KS_BATCH_MAX) size-3 ciphertexts at one level -> out_d[n][2][(l-1) N]
+static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n, u64 *out_d) {
+  const uint32_t l = as[0]->limbs;
+  const uint32_t last = l - 1, sp = c->k - 1;
+  const size_t N = c->N, pps = (size_t)(l + 1) * N, ops = (size_t)(l - 1) * N;
+  PtrTab c2{}, a_last{}, a_polys{};
+  for (uint32_t b = 0; b < n; b++) {
+    const evah_ct *a = as[b];
+    c2.p[b] = a->d + 2 * a->ps;
+    for (uint32_t K = 0; K < 2; K++) {
+      a_last.p[2 * b + K] = a->d + K * a->ps + (size_t)last * N;
+      a_polys.p[2 * b + K] = a->d + K * a->ps;
+    }
+  }
+  Scratch prod(c, (size_t)n * 2 * pps);
+  std::vector<const KeyDev *> keys(n, &c->sh->relin);
+  switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2);
+  Scratch r(c, (size_t)n * 2 * N), t(c, (size_t)n * 2 * N);
+  OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
+  ntt_inverse<OpPlain>(c, spp, 2 * n);
+  OpRRLast::Params lp{nullptr, 0, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, a_last};
+  ntt_inverse<OpRRLast>(c, lp, 2 * n);
+  OpRR::Params rp{r.d, N, t.d, N, nullptr, 0, prod.d, pps, out_d, ops, sp, last, l - 1, a_polys};
+  ntt_forward<OpRR>(c, rp, 2 * n * (l - 1));
+}
+
 int evah_relinearize_rescale_many(evah_ctx *c, const evah_ct *const *as, uint32_t n, uint32_t divisor_bits, evah_ct **outs) {
   API_BEGIN
   use(c);
@@ -1307,32 +1450,17 @@ int evah_relinearize_rescale_many(evah_ctx *c, const evah_ct *const *as, uint32_
   if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
   const uint32_t l = as[0]->limbs;
   if (l < 2) throw std::invalid_argument("end of modulus switching chain reached");
-  const uint32_t last = l - 1, sp = c->k - 1;
-  const size_t N = c->N, pps = (size_t)(l + 1) * N, ops = (size_t)(l - 1) * N;
-  PtrTab c2{}, a_last{}, a_polys{};
+  const size_t N = c->N, ops = (size_t)(l - 1) * N;
   for (uint32_t b = 0; b < n; b++) {
     const evah_ct *a = as[b];
     if (a->size != 3) throw std::invalid_argument("relinearize expects a size-3 ciphertext");
+    if (a->batch != 1) throw std::invalid_argument("relinearize_rescale_many takes single ciphertexts (a batched handle goes through evah_relinearize_rescale)");
     if (a->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
     acquire(c, a->buf);
-    c2.p[b] = a->d + 2 * a->ps;
-    for (uint32_t K = 0; K < 2; K++) {
-      a_last.p[2 * b + K] = a->d + K * a->ps + (size_t)last * N;
-      a_polys.p[2 * b + K] = a->d + K * a->ps;
-    }
   }
   Buffer *ob = buf_new(c, (size_t)n * 2 * ops);
   try {
-    Scratch prod(c, (size_t)n * 2 * pps);
-    std::vector<const KeyDev *> keys(n, &c->sh->relin);
-    switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2);
-    Scratch r(c, (size_t)n * 2 * N), t(c, (size_t)n * 2 * N);
-    OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
-    ntt_inverse<OpPlain>(c, spp, 2 * n);
-    OpRRLast::Params lp{nullptr, 0, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, a_last};
-    ntt_inverse<OpRRLast>(c, lp, 2 * n);
-    OpRR::Params rp{r.d, N, t.d, N, nullptr, 0, prod.d, pps, ob->d, ops, sp, last, l - 1, a_polys};
-    ntt_forward<OpRR>(c, rp, 2 * n * (l - 1));
+    relin_rescale_core(c, as, n, ob->d);
   } catch (...) {
     buf_unref(c, ob);
     throw;
@@ -1379,53 +1507,74 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
   acquire(c, a->buf);
   if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
   if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("rotate_many handles 1..64 rotations per call");
-  const uint32_t l = a->limbs;
+  const uint32_t l = a->limbs, B = a->batch;
   const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
-  PermTables pt{};
-  std::vector<const KeyDev *> keys(n);
+  std::vector<const KeyDev *> step_key(n);
+  std::vector<const uint32_t *> step_perm(n);
   for (uint32_t r = 0; r < n; r++) {
     if (steps[r] == 0) throw std::invalid_argument("rotate_many: zero steps are copies, not key switches");
     uint32_t elt = 0;
     if (evah_galois_elt_from_step(c, steps[r], &elt)) throw std::invalid_argument(g_err);
     auto kit = c->sh->galois.find(elt);
     if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
-    keys[r] = &kit->second;
-    pt.perm[r] = perm_table(c, elt);
+    step_key[r] = &kit->second;
+    step_perm[r] = perm_table(c, elt);
   }
-  // one buffer for all outputs; the n handles are views into it
-  Buffer *ob = buf_new(c, (size_t)n * 2 * pps);
+  // (rotation j, instance b) pairs go out KS_BATCH_MAX at a time: m rotations x B instances per
+  // launch set; pair index r = j * B + b, so rotation j's B outputs are one batched handle.
+  const uint32_t m_max = std::max<uint32_t>(1, KS_BATCH_MAX / B);
+  std::vector<evah_ct *> made;
   try {
-    Scratch perm(c, (size_t)n * 2 * pps); // [r][c0 permuted | c1 permuted = key-switch target]
-    {
-      ProfScope ps(c, KC_EW);
-      hipLaunchKernelGGL(k_galois_perm_many, dim3(c->N / 512, l, 2 * n), dim3(256), 0, c->stream, c->dev, a->d, a->ps, pt,
-                         perm.d, pps);
+    for (uint32_t j0 = 0; j0 < n; j0 += m_max) {
+      const uint32_t m = std::min(m_max, n - j0), np = m * B;
+      PermTables pt{};
+      std::vector<const KeyDev *> keys(np);
+      for (uint32_t j = 0; j < m; j++) {
+        pt.perm[j] = step_perm[j0 + j];
+        for (uint32_t b = 0; b < B; b++) keys[j * B + b] = step_key[j0 + j];
+      }
+      Buffer *ob = buf_new(c, (size_t)np * 2 * pps); // one buffer for the chunk; the m handles are views into it
+      ob->refs = 0;
+      try {
+        Scratch perm(c, (size_t)np * 2 * pps); // [r][c0 permuted | c1 permuted = key-switch target]
+        {
+          ProfScope ps(c, KC_EW);
+          hipLaunchKernelGGL(k_galois_perm_many, dim3(c->N / 512, l, 2 * np), dim3(256), 0, c->stream, c->dev, a->d, a->ps, pt,
+                             perm.d, pps, B);
+        }
+        HIPCHK(hipGetLastError());
+        Scratch prod(c, np * prod_bs);
+        switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), np, prod.d);
+        Scratch r(c, (size_t)np * 2 * N);
+        // INTT of the special limbs, job = r*2 + K
+        OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
+        ntt_inverse<OpPlain>(c, sp, 2 * np);
+        // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
+        OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, perm.d, pps, ~0u, ob->d, pps, c->k - 1, l};
+        ntt_forward<OpModDown>(c, mp, 2 * np * l);
+      } catch (...) {
+        ob->refs = 1;
+        buf_unref(c, ob);
+        throw;
+      }
+      for (uint32_t j = 0; j < m; j++) {
+        evah_ct *t = new evah_ct;
+        t->buf = ob;
+        ob->refs++;
+        t->d = ob->d + (size_t)j * B * 2 * pps;
+        t->size = 2;
+        t->limbs = l;
+        t->ps = pps;
+        t->scale = a->scale;
+        t->batch = B;
+        made.push_back(t);
+      }
     }
-    HIPCHK(hipGetLastError());
-    Scratch prod(c, n * prod_bs);
-    switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), n, prod.d);
-    Scratch r(c, (size_t)n * 2 * N);
-    // INTT of the special limbs, job = r*2 + K
-    OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
-    ntt_inverse<OpPlain>(c, sp, 2 * n);
-    // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
-    OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, perm.d, pps, ~0u, ob->d, pps, c->k - 1, l};
-    ntt_forward<OpModDown>(c, mp, 2 * n * l);
   } catch (...) {
-    buf_unref(c, ob);
+    for (evah_ct *t : made) evah_ct_free(c, t);
     throw;
   }
-  ob->refs = (int)n;
-  for (uint32_t r = 0; r < n; r++) {
-    evah_ct *t = new evah_ct;
-    t->buf = ob;
-    t->d = ob->d + (size_t)r * 2 * pps;
-    t->size = 2;
-    t->limbs = l;
-    t->ps = pps;
-    t->scale = a->scale;
-    outs[r] = t;
-  }
+  for (uint32_t r = 0; r < n; r++) outs[r] = made[r];
   API_END
 }
 
@@ -1436,10 +1585,13 @@ int evah_rotate(evah_ctx *c, const evah_ct *a, int32_t steps, evah_ct **out) {
   if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
   const size_t N = c->N;
   if (steps == 0) { // SEAL rotate_internal: no-op
-    evah_ct *o = ct_new(c, 2, a->limbs, a->scale);
+    evah_ct *o = ct_new(c, 2, a->limbs, a->scale, a->batch);
     const size_t row = sizeof(u64) * (size_t)a->limbs * N;
-    HIPCHK(hipMemcpy2DAsync(o->d, sizeof(u64) * o->ps, a->d, sizeof(u64) * a->ps, row, 2, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpy2DAsync(o->d, sizeof(u64) * o->ps, a->d, sizeof(u64) * a->ps, row, (size_t)2 * a->batch,
+                            hipMemcpyDeviceToDevice, c->stream));
     *out = o;
+  } else if (a->batch > 1) {
+    if (evah_rotate_many(c, a, &steps, 1, out)) throw std::runtime_error(g_err);
   } else {
     uint32_t elt = 0;
     if (evah_galois_elt_from_step(c, steps, &elt)) throw std::invalid_argument(g_err);
@@ -1470,12 +1622,13 @@ int evah_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bits, evah_ct *
   if (a->limbs < 2) throw std::invalid_argument("end of modulus switching chain reached");
   const uint32_t l = a->limbs;
   const size_t N = c->N;
-  evah_ct *o = ct_new(c, a->size, l - 1, a->scale / std::pow(2.0, (double)divisor_bits));
-  Scratch r(c, (size_t)a->size * N);
+  const uint32_t polys = a->size * a->batch; // a batched handle is batch * size polynomials at stride ps
+  evah_ct *o = ct_new(c, a->size, l - 1, a->scale / std::pow(2.0, (double)divisor_bits), a->batch);
+  Scratch r(c, (size_t)polys * N);
   OpPlain::Params ip{a->d + (size_t)(l - 1) * N, r.d, a->ps, N, 1, l - 1, 1, {}};
-  ntt_inverse<OpPlain>(c, ip, a->size);
+  ntt_inverse<OpPlain>(c, ip, polys);
   OpModDown::Params mp{r.d, N, a->d, a->ps, nullptr, 0, 0, o->d, o->ps, l - 1, l - 1};
-  ntt_forward<OpModDown>(c, mp, a->size * (l - 1));
+  ntt_forward<OpModDown>(c, mp, polys * (l - 1));
   *out = o;
   API_END
 }

@@ -484,6 +484,7 @@ struct OpModDown {
     u64 *dst;
     size_t dst_ps;
     uint32_t a, jl;
+    size_t add_bs = 0; // != 0: poly pp = 2b + K adds add[b * add_bs + K * add_ps] (batched relinearize)
   };
   struct Job {
     uint32_t prime;
@@ -499,8 +500,9 @@ struct OpModDown {
     j.prime = i;
     j.src = p.r + pp * p.r_ps;
     j.c = p.c + pp * p.c_ps + (size_t)i * cx.N;
-    const bool use_add = p.add && (p.add_polys == ~0u ? (pp & 1u) == 0 : pp < p.add_polys);
-    j.add = use_add ? p.add + pp * p.add_ps + (size_t)i * cx.N : nullptr;
+    const bool use_add = p.add && (p.add_bs ? true : p.add_polys == ~0u ? (pp & 1u) == 0 : pp < p.add_polys);
+    const size_t add_off = p.add_bs ? (pp >> 1) * p.add_bs + (pp & 1u) * p.add_ps : pp * p.add_ps;
+    j.add = use_add ? p.add + add_off + (size_t)i * cx.N : nullptr;
     j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
     j.halfm = cx.halfmod[p.a * cx.k + i];
     j.inv = cx.invq[p.a * cx.k + i];

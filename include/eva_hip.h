@@ -70,6 +70,20 @@ int evah_galois_elt_from_step(evah_ctx *ctx, int32_t steps, uint32_t *elt);
  * Replace SEALExecutor::setInputs / getOutputs / free (seal_executor.h:264-277,420-435,406-418). */
 int evah_ct_upload(evah_ctx *ctx, uint32_t size, uint32_t limbs, double scale,
                    const uint64_t *data /* [size][limbs][N] */, evah_ct **out);
+/* ---- batched handles: `batch` (<= 64) independent ciphertexts of one shape in ONE handle
+ * ([batch][size][limbs][N]).  Every evaluator entry point above/below accepts them and applies the
+ * SEAL call to each instance in one launch set (plaintext operands and keys are shared by the
+ * instances; two ciphertext operands must have the same batch).  This is the unit a batch of
+ * independent program instances runs on (BASELINE config 4: 256 Sobel DAGs) — the reference runs
+ * such a batch as `batch` separate SEALPublic::execute calls (seal.cpp:104-122). */
+int evah_ct_upload_batch(evah_ctx *ctx, uint32_t batch, uint32_t size, uint32_t limbs, double scale,
+                         const uint64_t *data /* [batch][size][limbs][N] */, evah_ct **out);
+int evah_ct_batch(const evah_ct *ct, uint32_t *batch);
+/* n single ciphertexts (same shape, scale) -> one batched handle; device-side copies */
+int evah_ct_stack(evah_ctx *ctx, const evah_ct *const *cts, uint32_t n, evah_ct **out);
+/* instance b of a batched handle as a single-ciphertext view (shares the buffer; free separately) */
+int evah_ct_unstack(evah_ctx *ctx, const evah_ct *ct, uint32_t b, evah_ct **out);
+
 /* overwrite an existing handle's residues (same shape) — refills the input slots of a graph */
 int evah_ct_write(evah_ctx *ctx, evah_ct *ct, const uint64_t *data);
 int evah_pt_write(evah_ctx *ctx, evah_pt *pt, const uint64_t *data);
