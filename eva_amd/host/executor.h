@@ -171,6 +171,86 @@ public:
     }
   }
 
+  // A batch of independent input valuations for ONE program (BASELINE config 4): every encrypted
+  // input becomes one batched device handle ([B][size][limbs][N]); from there each node is a
+  // single backend call that covers all B instances.  Plaintext / raw inputs are shared by the
+  // batch, so they have to be identical across the instances.
+  void set_inputs_batch(const std::vector<const HipValuation *> &batch) {
+    const uint32_t B = (uint32_t)batch.size();
+    for (auto &kv : batch[0]->values) {
+      TermId t = program.input(kv.first);
+      for (const HipValuation *v : batch)
+        if (!v->values.count(kv.first) || v->values.at(kv.first).index() != kv.second.index())
+          throw std::runtime_error("execute_batch: input " + kv.first + " is not present with one type in every valuation");
+      if (auto *c0 = std::get_if<HostCipher>(&kv.second)) {
+        std::vector<const uint64_t *> ptrs(B);
+        for (uint32_t b = 0; b < B; b++) {
+          const auto &c = std::get<HostCipher>(batch[b]->values.at(kv.first));
+          if (c.size != c0->size || c.limbs != c0->limbs || c.scale != c0->scale)
+            throw std::runtime_error("execute_batch: input " + kv.first + " differs in shape or scale across the batch");
+          ptrs[b] = (const uint64_t *)c.data.data();
+        }
+        evah_ct *h = nullptr;
+        chk(evah_ct_upload_instances(ctx, B, c0->size, c0->limbs, c0->scale, ptrs.data(), &h));
+        objects[t] = std::make_shared<CtHandle>(ctx, h);
+      } else if (auto *p = std::get_if<HostPlain>(&kv.second)) {
+        for (const HipValuation *v : batch) {
+          const auto &q = std::get<HostPlain>(v->values.at(kv.first));
+          if (q.limbs != p->limbs || q.scale != p->scale || q.data != p->data)
+            throw std::runtime_error("execute_batch: plaintext input " + kv.first + " must be the same for every instance");
+        }
+        evah_pt *h = nullptr;
+        chk(evah_pt_upload(ctx, p->limbs, p->scale, (const uint64_t *)p->data.data(), &h));
+        objects[t] = std::make_shared<PtHandle>(ctx, h);
+      } else {
+        const auto &raw = std::get<std::vector<double>>(kv.second);
+        for (const HipValuation *v : batch)
+          if (std::get<std::vector<double>>(v->values.at(kv.first)) != raw)
+            throw std::runtime_error("execute_batch: unencrypted input " + kv.first + " must be the same for every instance");
+        std::vector<double> v;
+        ConstantValue{raw}.expand_to(v, program.vec_size());
+        objects[t] = std::move(v);
+      }
+    }
+  }
+  // outputs of a batched run, split back into one valuation per instance
+  void get_outputs_batch(std::vector<HipValuation> &outs) {
+    for (auto &kv : program.outputs()) {
+      auto &o = objects[kv.second];
+      if (auto *c = std::get_if<std::shared_ptr<CtHandle>>(&o)) {
+        HostCipher hc;
+        uint32_t B = 1;
+        chk(evah_ct_info((*c)->h, &hc.size, &hc.limbs, &hc.scale));
+        chk(evah_ct_batch((*c)->h, &B));
+        if (B != outs.size()) throw std::runtime_error("Output " + kv.first + " does not depend on an encrypted input of the batch");
+        const size_t each = (size_t)hc.size * hc.limbs * host.N;
+        std::vector<uint64_t *> ptrs(B);
+        for (uint32_t b = 0; b < B; b++) {
+          HostCipher one = hc;
+          one.data.resize(each);
+          outs[b].values[kv.first] = std::move(one);
+          ptrs[b] = (uint64_t *)std::get<HostCipher>(outs[b].values[kv.first]).data.data();
+        }
+        chk(evah_ct_download_instances(ctx, (*c)->h, ptrs.data()));
+      } else {
+        HipValuation one;
+        Program &pr = program;
+        (void)pr;
+        if (auto *p = std::get_if<std::shared_ptr<PtHandle>>(&o)) {
+          HostPlain hp;
+          chk(evah_pt_info((*p)->h, &hp.limbs, &hp.scale));
+          hp.data.resize((size_t)hp.limbs * host.N);
+          chk(evah_pt_download(ctx, (*p)->h, (uint64_t *)hp.data.data()));
+          for (auto &ov : outs) ov.values[kv.first] = hp;
+        } else if (auto *r = std::get_if<std::vector<double>>(&o)) {
+          for (auto &ov : outs) ov.values[kv.first] = *r;
+        } else {
+          throw std::runtime_error("Output " + kv.first + " was not computed");
+        }
+      }
+    }
+  }
+
   void operator()(TermId t) {
     const Term &x = program.at(t);
     if (verbosity() >= 2) {
@@ -580,6 +660,45 @@ public:
     return out;
   }
 
+  // A batch of independent executions of one program (BASELINE config 4): instances are grouped
+  // `batch_chunk` at a time into batched device handles, so each DAG node is one backend call —
+  // one launch set — per group instead of per instance.  Results are those of execute() on each
+  // valuation, bit for bit.  The reference has no counterpart: it loops SEALPublic::execute.
+  uint32_t batch_chunk = 32;
+  std::vector<HipValuation> execute_batch(Program &program, const std::vector<const HipValuation *> &inputs) {
+    ensure_device();
+    if (batch_chunk < 1 || batch_chunk > 64) throw std::runtime_error("batch_chunk must be 1..64");
+    std::vector<HipValuation> all;
+    all.reserve(inputs.size());
+    // groups alternate between two issue queues and are pipelined by one: while the device works
+    // on group g the host uploads and enqueues group g+1, and only then drains g's outputs
+    if (!batch_fork) batch_fork = std::make_unique<Fork>(dev->h);
+    evah_ctx *qs[2] = {dev->h, batch_fork->h};
+    std::unique_ptr<HipExecutor> prev;
+    size_t prev_n = 0;
+    auto drain = [&]() {
+      if (!prev) return;
+      std::vector<HipValuation> outs(prev_n);
+      prev->get_outputs_batch(outs);
+      for (auto &o : outs) all.push_back(std::move(o));
+      prev.reset();
+    };
+    size_t g = 0;
+    for (size_t i0 = 0; i0 < inputs.size(); i0 += batch_chunk, g++) {
+      const size_t n = std::min<size_t>(batch_chunk, inputs.size() - i0);
+      std::vector<const HipValuation *> chunk(inputs.begin() + i0, inputs.begin() + i0 + n);
+      auto ex = std::make_unique<HipExecutor>(program, *host, std::vector<evah_ctx *>{qs[g & 1]});
+      ex->set_inputs_batch(chunk);
+      if (free_eagerly) run_counted(program, *ex);
+      else run_serial(program, *ex);
+      drain();
+      prev = std::move(ex);
+      prev_n = n;
+    }
+    drain();
+    return all;
+  }
+
   evah_ctx *device_ctx() {
     ensure_device();
     return dev->h;
@@ -587,6 +706,7 @@ public:
 
   ~HipPublic() {
     plans.clear();
+    batch_fork.reset();
     forks.clear(); // queues go before the root context
     dev.reset();
   }
@@ -602,6 +722,7 @@ private:
     Fork &operator=(const Fork &) = delete;
   };
   std::vector<std::unique_ptr<Fork>> forks;
+  std::unique_ptr<Fork> batch_fork; // second issue queue of execute_batch
 
   // A captured execute(): its own queues (pools are exclusive to the graph), persistent input
   // slots and constant plaintexts, the outputs' handles, the instantiated hipGraph.

@@ -190,6 +190,11 @@ PYBIND11_MODULE(_eva, m) {
   py::class_<HipPublic, std::shared_ptr<HipPublic>>(mseal, "SEALPublic", "Public context: encryption and execution on the MI355X")
       .def("encrypt", &HipPublic::encrypt, py::arg("inputs"), py::arg("signature"))
       .def("execute", &HipPublic::execute, py::arg("program"), py::arg("inputs"))
+      .def("execute_batch", [](HipPublic &p, Program &program, const std::vector<const HipValuation *> &inputs) {
+        return p.execute_batch(program, inputs);
+      }, py::arg("program"), py::arg("inputs"),
+           "execute() for a list of independent input valuations of one program; instances run batch_chunk at a time as batched device handles")
+      .def_readwrite("batch_chunk", &HipPublic::batch_chunk, "instances per batched device handle in execute_batch (1..64)")
       .def_readwrite("device", &HipPublic::device)
       .def_readwrite("free_eagerly", &HipPublic::free_eagerly)
       .def_readwrite("use_graphs", &HipPublic::use_graphs, "replay repeated executions of one program from a captured hipGraph")

@@ -78,6 +78,11 @@ int evah_ct_upload(evah_ctx *ctx, uint32_t size, uint32_t limbs, double scale,
  * such a batch as `batch` separate SEALPublic::execute calls (seal.cpp:104-122). */
 int evah_ct_upload_batch(evah_ctx *ctx, uint32_t batch, uint32_t size, uint32_t limbs, double scale,
                          const uint64_t *data /* [batch][size][limbs][N] */, evah_ct **out);
+/* the same from `batch` separate host arrays, each [size][limbs][N] */
+int evah_ct_upload_instances(evah_ctx *ctx, uint32_t batch, uint32_t size, uint32_t limbs, double scale,
+                             const uint64_t *const *data, evah_ct **out);
+/* every instance of a batched handle into its own host array out[b] ([size][limbs][N] each) */
+int evah_ct_download_instances(evah_ctx *ctx, const evah_ct *ct, uint64_t *const *out);
 int evah_ct_batch(const evah_ct *ct, uint32_t *batch);
 /* n single ciphertexts (same shape, scale) -> one batched handle; device-side copies */
 int evah_ct_stack(evah_ctx *ctx, const evah_ct *const *cts, uint32_t n, evah_ct **out);

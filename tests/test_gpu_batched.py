@@ -4,7 +4,7 @@ for that instance alone — the unit BASELINE config 4 (a batch of independent S
 import numpy as np
 import pytest
 
-from test_gpu_parity import CONFIGS, env
+from test_gpu_parity import CONFIGS, Env, env
 
 pytestmark = pytest.mark.gpu
 B = 3
@@ -66,7 +66,7 @@ def test_batched_elementwise_and_rescale(cfg):
 
 @pytest.mark.parametrize("cfg", CONFIGS[:6], ids=lambda c: f"N{c[0]}")
 def test_batched_key_switching(cfg):
-    e = env(cfg)
+    e = Env(*cfg)  # own context: this test installs Galois keys
     l = e.k - 1
     key = e.rand_key()
     e.g.upload_relin_key(key)
@@ -103,7 +103,7 @@ def test_batched_key_switching(cfg):
 
 def test_batched_rotations_are_chunked():
     """24 instances x 9 steps = 216 (step, instance) pairs > 64 per launch set"""
-    e = env(CONFIGS[0])
+    e = Env(*CONFIGS[0])
     l = e.k - 1
     nb = 24
     a2 = np.stack([e.rand(2, l) for _ in range(nb)])

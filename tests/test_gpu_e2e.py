@@ -287,3 +287,35 @@ def test_executor_options_give_identical_ciphertexts():
                     base = out
                 assert out[:4] == base[:4] and np.array_equal(out[4], base[4]), (queues, batch, fuse)
     os.environ.pop("EVA_BATCH_ROTATIONS"); os.environ.pop("EVA_FUSE_RELIN_RESCALE")
+
+
+def test_execute_batch_equals_execute_per_instance():
+    """BASELINE config 4's unit: a batch of independent input valuations of one program through
+    execute_batch (batched device handles, one launch set per node per group) gives, instance by
+    instance, the ciphertexts of execute() — which the other tests pin to the oracle."""
+    import numpy as np
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    from eva.metric import valuation_mse
+    from eva import evaluate
+    sob = _sobel(32, 32, 1024)
+    sob.set_input_scales(25)
+    sob.set_output_ranges(10)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(sob)
+    pub, sec = generate_keys(params, 7)
+    imgs = [{'image': [((37 * i + 11 * u) % 256) / 255.0 for i in range(1024)]} for u in range(5)]
+    encs = [pub.encrypt(x, sig) for x in imgs]
+    pub.batch_chunk = 3   # 5 instances -> groups of 3 and 2
+    outs = pub.execute_batch(compiled, encs)
+    assert len(outs) == 5
+    pub.use_graphs = False
+    for x, e, o in zip(imgs, encs, outs):
+        one = pub.execute(compiled, e)
+        for name in one.names():
+            g, r = o.get(name), one.get(name)
+            assert g[:4] == r[:4]
+            assert np.array_equal(g[4], r[4]), f"{name}: batched instance differs from the single execute()"
+        assert valuation_mse(sec.decrypt(o, sig), evaluate(compiled, x)) < 0.01
+    with pytest.raises(RuntimeError, match="batch_chunk"):
+        pub.batch_chunk = 65
+        pub.execute_batch(compiled, encs)
