@@ -62,6 +62,7 @@ _SIGS = {
     "evah_relinearize_rescale_many": [_vp, _vpp, C.c_uint32, C.c_uint32, _vpp],
     "evah_multiply_many": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_execute": [_vp, _vp, C.c_uint32, _vp, C.c_uint32],
+    "evah_weighted_sum": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_ct_upload_batch": [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, _u64p, _vpp],
     "evah_ct_upload_instances": [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(_u64p), _vpp],
     "evah_ct_download_instances": [_vp, _vp, C.POINTER(_u64p)],
@@ -422,6 +423,15 @@ class Context:
                 v.h = None
         _chk(rc)
         return out
+
+    def weighted_sum(self, cts, pts):
+        """sum_j cts[j] (*) pts[j]; pts[j] may be None (the ciphertext itself)"""
+        n = len(cts)
+        ic = (C.c_void_p * n)(*[ct.h for ct in cts])
+        ip = (C.c_void_p * n)(*[(pt.h if pt is not None else None) for pt in pts])
+        h = C.c_void_p()
+        _chk(_lib.evah_weighted_sum(self.h, ic, ip, n, C.byref(h)))
+        return Ciphertext(self, h)
 
     def multiply_plain(self, a, pt):
         return self._ct2(_lib.evah_multiply_plain, a, pt)

@@ -132,6 +132,35 @@ k_mul22_many(DevCtx cx, MulTab tab, u64 *out_b, size_t o_ps) {
   st2(out + 2 * o_ps + off, d2);
 }
 
+// K6b: out = sum_j ct_j (*) pt_j  (pt_j == nullptr: ct_j itself) — a convolution / linear-layer
+// row as ONE pass: every input word is read once, products accumulate unreduced in 128 bits
+// (n <= 64 terms of < 2^122) and are reduced once.  Same canonical result as the
+// multiply_plain / add sequence it stands for.
+struct WsTab {
+  const u64 *ct[KS_BATCH_MAX], *pt[KS_BATCH_MAX];
+  uint32_t ct_ps[KS_BATCH_MAX]; // poly strides in units of N coefficients
+};
+__global__ void __launch_bounds__(256)
+k_weighted_sum(DevCtx cx, WsTab tab, uint32_t n, u64 *out, size_t o_ps) {
+  EW_SETUP
+  u128_t a0 = {0, 0}, a1 = {0, 0};
+  for (uint32_t j = 0; j < n; j++) {
+    const ulonglong2 x = ld2(tab.ct[j] + (size_t)p * tab.ct_ps[j] * cx.N + off);
+    if (tab.pt[j]) {
+      const ulonglong2 w = ld2(tab.pt[j] + off);
+      acc128(a0, x.x, w.x);
+      acc128(a1, x.y, w.y);
+    } else {
+      acc128(a0, x.x, 1);
+      acc128(a1, x.y, 1);
+    }
+  }
+  ulonglong2 r;
+  r.x = barrett128(a0, pm);
+  r.y = barrett128(a1, pm);
+  st2(out + p * o_ps + off, r);
+}
+
 // K5: square 2 -> 3: (a0^2, 2 a0 a1, a1^2)
 __global__ void __launch_bounds__(256)
 k_square(DevCtx cx, const u64 *a, size_t a_ps, u64 *out, size_t o_ps) {
@@ -1373,6 +1402,37 @@ int evah_multiply_plain(evah_ctx *c, const evah_ct *a, const evah_pt *b, evah_ct
   check_scale(c, ns, a->limbs);
   evah_ct *o = ct_new(c, a->size, a->limbs, ns, a->batch);
   EW_LAUNCH(k_mul_plain, ew_grid(c, a->limbs, a->size * a->batch), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, o->d, o->ps);
+  HIPCHK(hipGetLastError());
+  *out = o;
+  API_END
+}
+
+// sum_j cts[j] (*) pts[j], pts[j] == NULL standing for the ciphertext itself: the value of
+// add(... add(multiply_plain(cts[0], pts[0]), multiply_plain(cts[1], pts[1])) ...) in one pass
+int evah_weighted_sum(evah_ctx *c, const evah_ct *const *cts, const evah_pt *const *pts, uint32_t n, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("weighted_sum handles 1..64 terms per call");
+  const evah_ct *f = cts[0];
+  const double scale = f->scale * (pts[0] ? pts[0]->scale : 1.0);
+  WsTab tab{};
+  for (uint32_t j = 0; j < n; j++) {
+    const evah_ct *a = cts[j];
+    if (a->limbs != f->limbs) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+    if (a->size != f->size) throw std::invalid_argument("weighted_sum terms must have one size");
+    if (a->batch != f->batch) throw std::invalid_argument("batch size mismatch");
+    if (pts[j] && pts[j]->limbs != a->limbs) throw std::invalid_argument("encrypted and plain parameter mismatch");
+    const double sj = a->scale * (pts[j] ? pts[j]->scale : 1.0);
+    if (pts[j]) check_scale(c, sj, a->limbs);
+    if (!same_scale(sj, scale)) throw std::invalid_argument("scale mismatch");
+    acquire(c, a->buf);
+    if (pts[j]) acquire(c, pts[j]->buf);
+    tab.ct[j] = a->d;
+    tab.pt[j] = pts[j] ? pts[j]->d : nullptr;
+    tab.ct_ps[j] = (uint32_t)(a->ps / c->N);
+  }
+  evah_ct *o = ct_new(c, f->size, f->limbs, scale, f->batch);
+  EW_LAUNCH(k_weighted_sum, ew_grid(c, f->limbs, f->size * f->batch), dim3(256), 0, c->stream, c->dev, tab, n, o->d, o->ps);
   HIPCHK(hipGetLastError());
   *out = o;
   API_END

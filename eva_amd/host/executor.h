@@ -139,7 +139,15 @@ public:
   struct LazyRelin {
     TermId src;
   };
-  using RuntimeValue = std::variant<std::monostate, std::shared_ptr<CtHandle>, std::shared_ptr<PtHandle>, std::vector<double>, LazyPlain, LazyRelin>;
+  // A sum of ciphertext x plaintext products (and plain ciphertext terms) whose partial sums have
+  // no other consumer: the multiply_plain / add chain of a convolution window is evaluated as one
+  // evah_weighted_sum pass when its root is reached (same ciphertext, one launch instead of 2n-1).
+  struct LazySum {
+    std::vector<std::pair<std::shared_ptr<CtHandle>, std::shared_ptr<PtHandle>>> terms;
+    uint32_t size = 0, limbs = 0; // shape and scale every term (product) has
+    double scale = 0;
+  };
+  using RuntimeValue = std::variant<std::monostate, std::shared_ptr<CtHandle>, std::shared_ptr<PtHandle>, std::vector<double>, LazyPlain, LazyRelin, LazySum>;
 
   // queues: issue queues (HIP streams) of one device — queues[0] is the root context, the rest
   // are its forks.  Independent DAG nodes are spread over them (the GPU counterpart of the
@@ -283,9 +291,10 @@ public:
         std::vector<double> o(u.size());
         for (size_t i = 0; i < u.size(); i++) o[i] = x.op == Op::Add ? u[i] + v[i] : x.op == Op::Sub ? u[i] - v[i] : u[i] * v[i];
         objects[t] = std::move(o);
-      } else if (x.op == Op::Add) objects[t] = add(a[0], a[1]);
-      else if (x.op == Op::Sub) objects[t] = sub(a[0], a[1]);
-      else objects[t] = mul(a[0], a[1]);
+      } else if (x.op == Op::Add) {
+        if (!try_lazy_add(t, a[0], a[1])) objects[t] = add(a[0], a[1]);
+      } else if (x.op == Op::Sub) objects[t] = sub(a[0], a[1]);
+      else if (!try_lazy_mul(t, a[0], a[1])) objects[t] = mul(a[0], a[1]);
       break;
     case Op::RotateLeftConst:
     case Op::RotateRightConst:
@@ -446,6 +455,7 @@ private:
   std::vector<std::pair<TermId, TermId>> deferred_free; // (lazy relin term, its source)
   bool batch_rotations = std::getenv("EVA_BATCH_ROTATIONS") ? std::atoi(std::getenv("EVA_BATCH_ROTATIONS")) != 0 : true;
   bool fuse_relin_rescale = std::getenv("EVA_FUSE_RELIN_RESCALE") ? std::atoi(std::getenv("EVA_FUSE_RELIN_RESCALE")) != 0 : true;
+  bool fuse_sums = std::getenv("EVA_FUSE_SUMS") ? std::atoi(std::getenv("EVA_FUSE_SUMS")) != 0 : true;
 
   // Queue for node t: key-switching / rescaling consumers of a fanned-out value are spread
   // round-robin (they are independent and heavy); everything else follows its first
@@ -469,13 +479,78 @@ private:
     return q;
   }
 
-  bool is_cipher(TermId t) const { return std::holds_alternative<std::shared_ptr<CtHandle>>(objects[t]); }
+  bool is_cipher(TermId t) const {
+    return std::holds_alternative<std::shared_ptr<CtHandle>>(objects[t]) || std::holds_alternative<LazySum>(objects[t]);
+  }
+  bool is_device_ct(TermId t) const { return std::holds_alternative<std::shared_ptr<CtHandle>>(objects[t]); }
+  // the only consumer of t is one operand slot of an Add: its value can stay an unevaluated sum
+  bool feeds_one_add(TermId t) const {
+    const auto &u = program.at(t).uses;
+    return u.size() == 1 && program.at(u[0]).op == Op::Add;
+  }
+  RuntimeValue weighted_sum(const LazySum &ls) {
+    const uint32_t n = (uint32_t)ls.terms.size();
+    std::vector<const evah_ct *> cts(n);
+    std::vector<const evah_pt *> pts(n);
+    for (uint32_t i = 0; i < n; i++) {
+      cts[i] = ls.terms[i].first->h;
+      pts[i] = ls.terms[i].second ? ls.terms[i].second->h : nullptr;
+    }
+    evah_ct *h = nullptr;
+    chk(evah_weighted_sum(ctx, cts.data(), pts.data(), n, &h));
+    return wrap(h);
+  }
+  // Mul(cipher, plain) feeding one Add: keep it as a one-term sum
+  bool try_lazy_mul(TermId t, TermId a, TermId b) {
+    if (!fuse_sums || !feeds_one_add(t)) return false;
+    if (!is_device_ct(a)) std::swap(a, b);
+    if (!is_device_ct(a) || !is_plain(b)) return false;
+    evah_pt *ph = pt(b); // materialises a lazily encoded plaintext
+    LazySum ls;
+    uint32_t pl = 0;
+    double ps = 0;
+    chk(evah_ct_info(ct(a), &ls.size, &ls.limbs, &ls.scale));
+    chk(evah_pt_info(ph, &pl, &ps));
+    if (pl != ls.limbs) return false; // let multiply_plain report the mismatch
+    ls.scale *= ps;
+    ls.terms.emplace_back(std::get<std::shared_ptr<CtHandle>>(objects[a]), std::get<std::shared_ptr<PtHandle>>(objects[b]));
+    objects[t] = std::move(ls);
+    return true;
+  }
+  // Add over sums / ciphertexts of one shape and scale: concatenate; evaluate when the chain ends
+  bool try_lazy_add(TermId t, TermId a, TermId b) {
+    if (!fuse_sums) return false;
+    const bool la = std::holds_alternative<LazySum>(objects[a]), lb = std::holds_alternative<LazySum>(objects[b]);
+    const bool ca = is_device_ct(a), cb = is_device_ct(b);
+    if (!((la || ca) && (lb || cb))) return false;              // a plaintext / raw operand: the ordinary add
+    if (!la && !lb && !feeds_one_add(t)) return false;          // an isolated ct + ct
+    LazySum ls;
+    bool first = true;
+    for (TermId o : {a, b}) {
+      uint32_t sz = 0, lm = 0;
+      double sc = 0;
+      if (auto *l = std::get_if<LazySum>(&objects[o])) {
+        sz = l->size; lm = l->limbs; sc = l->scale;
+        ls.terms.insert(ls.terms.end(), l->terms.begin(), l->terms.end());
+      } else {
+        chk(evah_ct_info(std::get<std::shared_ptr<CtHandle>>(objects[o])->h, &sz, &lm, &sc));
+        ls.terms.emplace_back(std::get<std::shared_ptr<CtHandle>>(objects[o]), nullptr);
+      }
+      if (first) { ls.size = sz; ls.limbs = lm; ls.scale = sc; first = false; }
+      else if (sz != ls.size || lm != ls.limbs || sc != ls.scale) return false; // mixed shapes: the ordinary add decides
+    }
+    if (ls.terms.size() > 64) return false;                     // (ct() evaluates the operands, then the ordinary add)
+    if (feeds_one_add(t) && ls.terms.size() < 64) objects[t] = std::move(ls);
+    else objects[t] = weighted_sum(ls);
+    return true;
+  }
   bool is_plain(TermId t) const {
     return std::holds_alternative<std::shared_ptr<PtHandle>>(objects[t]) || std::holds_alternative<LazyPlain>(objects[t]);
   }
   bool is_raw(TermId t) const { return std::holds_alternative<std::vector<double>>(objects[t]); }
   const std::vector<double> &raw(TermId t) const { return std::get<std::vector<double>>(objects[t]); }
-  evah_ct *ct(TermId t) const {
+  evah_ct *ct(TermId t) {
+    if (auto *ls = std::get_if<LazySum>(&objects[t])) objects[t] = weighted_sum(*ls);
     auto *p = std::get_if<std::shared_ptr<CtHandle>>(&objects[t]);
     if (!p) throw std::runtime_error("Unsupported operation encountered");
     return (*p)->h;

@@ -127,6 +127,10 @@ int evah_multiply(evah_ctx *ctx, const evah_ct *a, const evah_ct *b, evah_ct **o
  * independent Multiply node / per ciphertext of a batch) issued as ONE launch; outs[i] ==
  * evah_multiply(as[i], bs[i]) bit for bit, the outputs share one allocation */
 int evah_multiply_many(evah_ctx *ctx, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n, evah_ct **outs);
+/* sum_j cts[j] (*) pts[j] in one pass (pts[j] == NULL: cts[j] itself): the value of the
+ * evaluator.multiply_plain (seal_executor.h:168) + evaluator.add (:124) chain a convolution or
+ * linear-layer row lowers to; n <= 64 terms of one size, level and product scale */
+int evah_weighted_sum(evah_ctx *ctx, const evah_ct *const *cts, const evah_pt *const *pts, uint32_t n, evah_ct **out);
 /* evaluator.square, operand size 2 (seal_executor.h:162) */
 int evah_square(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
 /* evaluator.multiply_plain (seal_executor.h:168) */

@@ -179,6 +179,36 @@ def test_relinearize_rescale_many_equals_single_calls(cfg):
 
 
 @pytest.mark.parametrize("cfg", CONFIGS[:6], ids=lambda c: f"N{c[0]}")
+def test_weighted_sum_equals_multiply_plain_add_chain(cfg):
+    """sum_j ct_j (*) pt_j (+ bare ciphertext terms) in one pass == the oracle's multiply_plain /
+    add chain; terms are separate allocations, one a mod-switched view; sizes 2 and 3."""
+    e = env(cfg)
+    l = e.k - 1
+    lv = l - 1 if l >= 2 else l
+    for size in (2, 3):
+        hs = [e.rand(size, lv) for _ in range(4)]
+        ws = [e.rand(1, lv)[0] for _ in range(4)]
+        cts = [e.g.upload_ct(h, 2.0 ** 8) for h in hs]
+        if l >= 2:
+            wide = e.rand(size, l)
+            cts.append(e.g.mod_switch(e.g.upload_ct(wide, 2.0 ** 8)))
+            hs.append(e.o.mod_switch(wide))
+            ws.append(e.rand(1, lv)[0])
+        pts = [e.g.upload_pt(w, 2.0 ** 4) for w in ws]
+        bare_h = e.rand(size, lv)
+        bare = e.g.upload_ct(bare_h, 2.0 ** 12)
+        out = e.g.weighted_sum(cts + [bare], pts + [None])
+        ref = e.o.multiply_plain(hs[0], ws[0])
+        for h, w in zip(hs[1:], ws[1:]):
+            ref = e.o.add(ref, e.o.multiply_plain(h, w))
+        ref = e.o.add(ref, bare_h)
+        assert out.info() == (size, lv, 2.0 ** 12)
+        assert np.array_equal(out.download(), ref)
+    with pytest.raises(backend.EvaHipError, match="scale mismatch"):
+        e.g.weighted_sum(cts[:2], [pts[0], None])
+
+
+@pytest.mark.parametrize("cfg", CONFIGS[:6], ids=lambda c: f"N{c[0]}")
 def test_multiply_many_equals_single_calls(cfg):
     """A batch of independent 2x2 products as one launch == the oracle's multiply on each pair;
     operands are separate allocations, one of them a mod-switched view (larger poly stride)."""
