@@ -323,27 +323,48 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
 #pragma unroll
   for (int i = 0; i < NTT_R; i++) { acc0[i] = {0, 0}; acc1[i] = {0, 0}; }
 
+  // Software pipeline over the digits: the key words of digit J are requested before its
+  // transform starts and the coefficients of digit J+1 as soon as those of J sit in LDS, so both
+  // streams are in flight during the register rounds instead of being waited for at their use.
+  auto digit_src = [&](uint32_t J) -> const u64 * {
+    return (I == J ? target + (size_t)J * N : scratch + ((size_t)I * l + J) * N) + gbase;
+  };
+  ulonglong2 dreg[NPAIR];
+  {
+    const u64 *src = digit_src(0);
+#pragma unroll
+    for (int it = 0; it < NPAIR; it++) dreg[it] = *reinterpret_cast<const ulonglong2 *>(src + 2 * (threadIdx.x + it * T));
+  }
   for (uint32_t J = 0; J < l; J++) {
+    ulonglong2 k0r[NPAIR], k1r[NPAIR];
+    const u64 *kp = key + J * key_digit + (size_t)kap * N + gbase;
+#pragma unroll
+    for (int it = 0; it < NPAIR; it++) {
+      const int idx = 2 * (threadIdx.x + it * T);
+      k0r[it] = *reinterpret_cast<const ulonglong2 *>(kp + idx);
+      k1r[it] = *reinterpret_cast<const ulonglong2 *>(kp + (size_t)cx.k * N + idx);
+    }
     u64 val[NTT_R];
+    const u64 *nsrc = digit_src(J + 1 < l ? J + 1 : J);
     if (I == J) { // already in NTT form mod q_J: use the key-switch target directly
-      const u64 *src = target + (size_t)J * N + gbase;
 #pragma unroll
       for (int it = 0; it < NPAIR; it++) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + 2 * (threadIdx.x + it * T));
-        val[2 * it] = v.x;
-        val[2 * it + 1] = v.y;
+        val[2 * it] = dreg[it].x;
+        val[2 * it + 1] = dreg[it].y;
       }
+#pragma unroll
+      for (int it = 0; it < NPAIR; it++) dreg[it] = *reinterpret_cast<const ulonglong2 *>(nsrc + 2 * (threadIdx.x + it * T));
     } else {
-      const u64 *src = scratch + ((size_t)I * l + J) * N + gbase;
       __syncthreads(); // previous iteration's LDS reads are done
 #pragma unroll
       for (int it = 0; it < NPAIR; it++) {
         const int idx = 2 * (threadIdx.x + it * T);
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + idx);
         const int sb = idx >> P, e = idx & (S - 1);
-        lds[sb * SP + lds_pad(e)] = v.x;
-        lds[sb * SP + lds_pad(e + 1)] = v.y;
+        lds[sb * SP + lds_pad(e)] = dreg[it].x;
+        lds[sb * SP + lds_pad(e + 1)] = dreg[it].y;
       }
+#pragma unroll
+      for (int it = 0; it < NPAIR; it++) dreg[it] = *reinterpret_cast<const ulonglong2 *>(nsrc + 2 * (threadIdx.x + it * T));
       __syncthreads();
       // STRIDED=true selects local-heap node indexing, which is what the LDS copy uses
       RoundSeq<P, LR, 0, false, true, true>::run(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
@@ -356,16 +377,12 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
         val[2 * it + 1] = lds[sb * SP + lds_pad(e + 1)];
       }
     }
-    const u64 *kp = key + J * key_digit + (size_t)kap * N + gbase;
 #pragma unroll
     for (int it = 0; it < NPAIR; it++) {
-      const int idx = 2 * (threadIdx.x + it * T);
-      const ulonglong2 k0 = *reinterpret_cast<const ulonglong2 *>(kp + idx);
-      const ulonglong2 k1 = *reinterpret_cast<const ulonglong2 *>(kp + (size_t)cx.k * N + idx);
-      acc128(acc0[2 * it], val[2 * it], k0.x);
-      acc128(acc0[2 * it + 1], val[2 * it + 1], k0.y);
-      acc128(acc1[2 * it], val[2 * it], k1.x);
-      acc128(acc1[2 * it + 1], val[2 * it + 1], k1.y);
+      acc128(acc0[2 * it], val[2 * it], k0r[it].x);
+      acc128(acc0[2 * it + 1], val[2 * it + 1], k0r[it].y);
+      acc128(acc1[2 * it], val[2 * it], k1r[it].x);
+      acc128(acc1[2 * it + 1], val[2 * it + 1], k1r[it].y);
     }
   }
   u64 *p0 = prod + (size_t)I * N + gbase, *p1 = prod + ((size_t)(l + 1) + I) * N + gbase;
