@@ -91,7 +91,8 @@ def main():
     g = backend.Context(N, primes, device=local)
     queues = [g] + [g.fork() for _ in range(max(1, args.streams) - 1)]
 
-    # synthetic inputs: uniform residues; 4 distinct operand pairs per rank
+    # synthetic inputs: uniform residues; every triple of a step has its own
+    # operand pair (distinct HBM data: no triple finds its inputs in cache because another used them)
     rng = np.random.default_rng(0xE7A + rank)
 
     def rand(prefix, nl):
@@ -100,9 +101,13 @@ def main():
 
     key_host = rand((l, 2), k)
     g.upload_relin_key(key_host)
-    npairs = 4
-    host_pairs = [(rand((2,), l), rand((2,), l)) for _ in range(npairs)]
-    pairs = [(g.upload_ct(a, 2.0 ** 40), g.upload_ct(b, 2.0 ** 40)) for a, b in host_pairs]
+    npairs = args.batch
+    host_pairs, pairs = [], []
+    for i in range(npairs):
+        a, b = rand((2,), l), rand((2,), l)
+        pairs.append((g.upload_ct(a, 2.0 ** 40), g.upload_ct(b, 2.0 ** 40)))
+        if i < 4:
+            host_pairs.append((a, b))  # the CPU baseline leg runs the first four
 
     PROF_EVERY = 8  # HIP-event brackets on every 8th triple only: keeps the timed region honest
 
@@ -218,7 +223,7 @@ def main():
             n = max(1, min(50, int(args.cpu_seconds / max(one, 1e-3))))
             t1 = time.perf_counter()
             for i in range(n):
-                a, b = host_pairs[i % npairs]
+                a, b = host_pairs[i % len(host_pairs)]
                 o.op_triple(a, b, key_host)
             cdt = time.perf_counter() - t1
             # the same port on many host cores at once (independent triples, one per thread; ctypes
@@ -228,7 +233,7 @@ def main():
             done = []
 
             def worker(i):
-                a_, b_ = host_pairs[i % npairs]
+                a_, b_ = host_pairs[i % len(host_pairs)]
                 o.op_triple(a_, b_, key_host)
                 done.append(i)
             ths = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]

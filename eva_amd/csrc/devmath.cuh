@@ -41,9 +41,10 @@ struct DevCtx {
 };
 
 __device__ __forceinline__ u128_t mul128(u64 a, u64 b) {
+  const unsigned __int128 p = (unsigned __int128)a * b; // 4 v_mad_u64_u32 (a*b and __umul64hi separately: 7 multiplies)
   u128_t r;
-  r.lo = a * b;
-  r.hi = __umul64hi(a, b);
+  r.lo = (u64)p;
+  r.hi = (u64)(p >> 64);
   return r;
 }
 // acc += a*b (128-bit).  Written on unsigned __int128 so the backend keeps the sum in a
