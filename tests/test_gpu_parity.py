@@ -155,6 +155,25 @@ def test_rotate_bit_exact(cfg):
         assert np.array_equal(out, e.o.rotate(e.o.mod_switch(a2), -(e.N // 4), key))
 
 
+def test_key_switch_at_max_degree_n131072():
+    """SEAL's largest poly_modulus_degree (2^17: 9-stage strided pass, 8-stage fused pass) through
+    relinearize, the fused relinearize+rescale, rescale and a rotation."""
+    e = Env(131072, [60, 60, 60])
+    l = e.k - 1
+    key = e.rand_key()
+    e.g.upload_relin_key(key)
+    a3 = e.rand(3, l)
+    A3 = e.g.upload_ct(a3, 2.0 ** 50)
+    relin = e.o.relinearize(a3, key)
+    assert np.array_equal(e.g.relinearize(A3).download(), relin)
+    assert np.array_equal(e.g.relinearize_rescale(A3, 30).download(), e.o.rescale(relin))
+    assert np.array_equal(e.g.rescale(A3, 30).download(), e.o.rescale(a3))
+    gk = e.rand_key()
+    e.g.upload_galois_key(e.g.galois_elt_from_step(3), gk)
+    a2 = e.rand(2, l)
+    assert np.array_equal(e.g.rotate(e.g.upload_ct(a2, 2.0 ** 20), 3).download(), e.o.rotate(a2, 3, gk))
+
+
 @pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"N{c[0]}")
 def test_relinearize_rescale_many_equals_single_calls(cfg):
     """A batch of independent size-3 ciphertexts through one wide launch set == the oracle's
