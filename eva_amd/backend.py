@@ -86,7 +86,7 @@ _VOID = {
     "evah_pt_free": [_vp, _vp],
     "evah_graph_free": [_vp],
 }
-EXPORTED_SYMBOLS = sorted(list(_SIGS) + list(_VOID) + [
+EXPORTED_SYMBOLS = sorted(list(_SIGS) + list(_VOID) + ["evah_host_alloc", "evah_host_free"] + [
     "evah_last_error", "evah_abi_version", "evah_profile_classes", "evah_profile_class_name"])
 
 

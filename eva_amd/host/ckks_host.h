@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "hostmath.h"
+#include "../../include/eva_hip.h"
 
 namespace evahost {
 
@@ -441,10 +442,35 @@ private:
 };
 
 // Host ciphertext / plaintext values (what encrypt() hands to execute() and execute() to decrypt())
+// Ciphertext words live in pinned host memory when the device library can provide it
+// (evah_host_alloc): they are what execute() uploads and downloads, and DMA from pinned pages runs
+// at PCIe rate.  Without a device the allocator is plain operator new.
+template <class T> struct HostAlloc {
+  using value_type = T;
+  HostAlloc() = default;
+  template <class U> HostAlloc(const HostAlloc<U> &) {}
+  T *allocate(size_t n) {
+    // 64-byte header in front of the data remembers where the block came from
+    const size_t bytes = n * sizeof(T) + 64;
+    char *base = static_cast<char *>(evah_host_alloc(bytes));
+    const bool pinned = base != nullptr;
+    if (!base) base = static_cast<char *>(::operator new(bytes));
+    *reinterpret_cast<uint64_t *>(base) = pinned ? 0x50494e4eull : 0x48454150ull;
+    return reinterpret_cast<T *>(base + 64);
+  }
+  void deallocate(T *p, size_t) {
+    char *base = reinterpret_cast<char *>(p) - 64;
+    if (*reinterpret_cast<uint64_t *>(base) == 0x50494e4eull) evah_host_free(base);
+    else ::operator delete(base);
+  }
+  template <class U> bool operator==(const HostAlloc<U> &) const { return true; }
+  template <class U> bool operator!=(const HostAlloc<U> &) const { return false; }
+};
+using CipherWords = std::vector<u64, HostAlloc<u64>>;
 struct HostCipher {
   uint32_t size = 0, limbs = 0;
   double scale = 1.0;
-  std::vector<u64> data; // [size][limbs][N]
+  CipherWords data; // [size][limbs][N]
 };
 struct HostPlain {
   uint32_t limbs = 0;

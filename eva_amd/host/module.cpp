@@ -26,7 +26,7 @@ std::vector<TermId> ids_of(const std::vector<PyTerm> &v) {
   return out;
 }
 
-py::array_t<uint64_t> to_numpy(const std::vector<u64> &v, std::vector<py::ssize_t> shape) {
+template <class Vec> py::array_t<uint64_t> to_numpy(const Vec &v, std::vector<py::ssize_t> shape) {
   py::array_t<uint64_t> a(shape);
   std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(u64));
   return a;

@@ -25,7 +25,7 @@ public:
     buf.insert(buf.end(), p, p + sizeof(T));
   }
   void str(const std::string &s) { pod<uint64_t>(s.size()); buf.insert(buf.end(), s.begin(), s.end()); }
-  template <class T> void vec(const std::vector<T> &v) {
+  template <class T, class A> void vec(const std::vector<T, A> &v) {
     pod<uint64_t>(v.size());
     const char *p = reinterpret_cast<const char *>(v.data());
     buf.insert(buf.end(), p, p + v.size() * sizeof(T));
@@ -162,7 +162,7 @@ inline HipValuation read_valuation(Reader &r) {
   for (uint64_t i = 0; i < n; i++) {
     std::string name = r.str();
     uint32_t kind = r.pod<uint32_t>();
-    if (kind == 1) { HostCipher c; c.size = r.pod<uint32_t>(); c.limbs = r.pod<uint32_t>(); c.scale = r.pod<double>(); c.data = r.vec<u64>(); v.values[name] = std::move(c); }
+    if (kind == 1) { HostCipher c; c.size = r.pod<uint32_t>(); c.limbs = r.pod<uint32_t>(); c.scale = r.pod<double>(); { auto w = r.vec<u64>(); c.data.assign(w.begin(), w.end()); } v.values[name] = std::move(c); }
     else if (kind == 2) { HostPlain p; p.limbs = r.pod<uint32_t>(); p.scale = r.pod<double>(); p.data = r.vec<u64>(); v.values[name] = std::move(p); }
     else if (kind == 3) v.values[name] = r.vec<double>();
     else throw std::runtime_error("Could not parse message: unknown value kind");

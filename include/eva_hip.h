@@ -70,6 +70,11 @@ int evah_galois_elt_from_step(evah_ctx *ctx, int32_t steps, uint32_t *elt);
  * Replace SEALExecutor::setInputs / getOutputs / free (seal_executor.h:264-277,420-435,406-418). */
 int evah_ct_upload(evah_ctx *ctx, uint32_t size, uint32_t limbs, double scale,
                    const uint64_t *data /* [size][limbs][N] */, evah_ct **out);
+/* ---- pinned host memory for values that will be uploaded / downloaded (recycled by size);
+ * NULL when no device memory can be pinned — use ordinary memory then.  Thread-safe. */
+void *evah_host_alloc(size_t bytes);
+void evah_host_free(void *p);
+
 /* ---- batched handles: `batch` (<= 64) independent ciphertexts of one shape in ONE handle
  * ([batch][size][limbs][N]).  Every evaluator entry point above/below accepts them and applies the
  * SEAL call to each instance in one launch set (plaintext operands and keys are shared by the
