@@ -280,13 +280,15 @@ def test_executor_options_give_identical_ciphertexts():
     for queues in (1, 3, 8):
         for batch in ("1", "0"):
             for fuse in ("1", "0"):
-                os.environ["EVA_BATCH_ROTATIONS"], os.environ["EVA_FUSE_RELIN_RESCALE"] = batch, fuse
-                pub.num_queues = queues
-                out = pub.execute(compiled, enc).get('image')
-                if base is None:
-                    base = out
-                assert out[:4] == base[:4] and np.array_equal(out[4], base[4]), (queues, batch, fuse)
-    os.environ.pop("EVA_BATCH_ROTATIONS"); os.environ.pop("EVA_FUSE_RELIN_RESCALE")
+                for sums in ("1", "0"):
+                    os.environ["EVA_BATCH_ROTATIONS"], os.environ["EVA_FUSE_RELIN_RESCALE"] = batch, fuse
+                    os.environ["EVA_FUSE_SUMS"] = sums
+                    pub.num_queues = queues
+                    out = pub.execute(compiled, enc).get('image')
+                    if base is None:
+                        base = out
+                    assert out[:4] == base[:4] and np.array_equal(out[4], base[4]), (queues, batch, fuse, sums)
+    os.environ.pop("EVA_BATCH_ROTATIONS"); os.environ.pop("EVA_FUSE_RELIN_RESCALE"); os.environ.pop("EVA_FUSE_SUMS")
 
 
 def test_execute_batch_equals_execute_per_instance():

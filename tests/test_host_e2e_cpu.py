@@ -75,3 +75,12 @@ def test_constant_at_large_scale_encodes():
     prog.set_output_ranges(20)
     prog.set_input_scales(40)
     compile_and_check(prog, config={'lazy_relinearize': 'false'}, executor="oracle")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_programs_compile_and_decrypt_on_the_oracle(seed):
+    """The generator of tests/test_gpu_fuzz.py on the CPU: compiled semantics == source semantics,
+    and the compiled DAG walked over the oracle decrypts to the reference (tests/common.py:34)."""
+    from test_gpu_fuzz import _random_program
+    prog, inputs = _random_program(100 + seed, 32)
+    compile_and_check(prog, inputs, executor="oracle", seed=seed + 1)
