@@ -1849,7 +1849,6 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
   for (uint32_t i = 0; i < n_ops; i++) {
     const evah_op &o = ops[i];
     evah_ct *out = nullptr;
-    uint32_t consumed = 1; // ops handled by this iteration
     switch (o.op) {
     case 1: case 3: case 23: // Input / Constant / Encode: the caller placed the value
       if (slot(o.dst).kind == EVAH_VAL_NONE) throw std::invalid_argument("input / plaintext slot is empty");
@@ -1929,7 +1928,6 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     case 22: chk(evah_rescale(c, ct_of(o.src0), (uint32_t)o.imm, &out)); break;
     default: throw std::runtime_error("Unhandled op " + std::to_string(o.op));
     }
-    (void)consumed;
     const bool binary = o.op == 11 || o.op == 12 || o.op == 13;
     // the result is stored before operands are released (dst may reuse an operand's slot)
     evah_val keep0 = slot(o.src0), keep1 = binary ? slot(o.src1) : evah_val{EVAH_VAL_NONE, nullptr};

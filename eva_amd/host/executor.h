@@ -241,9 +241,6 @@ public:
         }
         chk(evah_ct_download_instances(ctx, (*c)->h, ptrs.data()));
       } else {
-        HipValuation one;
-        Program &pr = program;
-        (void)pr;
         if (auto *p = std::get_if<std::shared_ptr<PtHandle>>(&o)) {
           HostPlain hp;
           chk(evah_pt_info((*p)->h, &hp.limbs, &hp.scale));
