@@ -401,7 +401,8 @@ struct evah_ctx {
   std::vector<hipEvent_t> sync_events; // recycled events for cross-queue ordering
   bool fuse_mac = true; // key-switch: fuse the inner product into the digit NTTs' second pass
   int ks_groups = 1;    // output-limb slices per key-switch (EVAH_KS_GROUPS)
-  int ks_threads = 256; // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS)
+  int ks_threads = 64;  // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS): one wave = one
+                        // 2^P-point sub-transform per workgroup measured best (barriers are intra-wave)
   // per-launch profile
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
