@@ -612,9 +612,16 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) +
                      ((size_t)1 << (logC + P)) * sizeof(ulonglong2);
   const uint32_t n_tiles = c->N / tile;
-  hipLaunchKernelGGL((ks_inner_kernel<P, LR>), dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev,
-                     target, kb.target_bs, scratch, kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n,
-                     kb.targets);
+  // the one-wave workgroup (the default) is compiled with its own launch bound: the register
+  // allocator is not held to the 256-thread budget
+  if ((tile >> LR) <= 64)
+    hipLaunchKernelGGL((ks_inner_kernel<P, LR, 64>), dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev,
+                       target, kb.target_bs, scratch, kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n,
+                       kb.targets);
+  else
+    hipLaunchKernelGGL((ks_inner_kernel<P, LR, NTT_THREADS>), dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev,
+                       target, kb.target_bs, scratch, kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n,
+                       kb.targets);
   HIPCHK(hipGetLastError());
 }
 template <int LR>

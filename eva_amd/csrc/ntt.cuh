@@ -272,8 +272,8 @@ struct PtrTab {
   const u64 *p[2 * KS_BATCH_MAX];
 };
 
-template <int P, int LR>
-__global__ void __launch_bounds__(NTT_THREADS)
+template <int P, int LR, int MAXT>
+__global__ void __launch_bounds__(MAXT)
 ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
                 size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, uint32_t i0,
                 int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets) {
