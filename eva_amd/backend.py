@@ -63,6 +63,7 @@ _SIGS = {
     "evah_multiply_many": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_execute": [_vp, _vp, C.c_uint32, _vp, C.c_uint32],
     "evah_weighted_sum": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
+    "evah_pt_encode": [_vp, C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_double, _vpp],
     "evah_ct_upload_batch": [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, _u64p, _vpp],
     "evah_ct_upload_instances": [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(_u64p), _vpp],
     "evah_ct_download_instances": [_vp, _vp, C.POINTER(_u64p)],
@@ -355,6 +356,13 @@ class Context:
         h = C.c_void_p()
         fn = _lib.evah_pt_upload_coeff if coeff_form else _lib.evah_pt_upload
         _chk(fn(self.h, limbs, float(scale), _p(data), C.byref(h)))
+        return Plaintext(self, h)
+
+    def encode_pt(self, values, limbs, scale):
+        """device CKKS encoder: reals (replicated over the slots) -> NTT-form plaintext"""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        h = C.c_void_p()
+        _chk(_lib.evah_pt_encode(self.h, v.ctypes.data_as(C.POINTER(C.c_double)), v.shape[0], int(limbs), float(scale), C.byref(h)))
         return Plaintext(self, h)
 
     def uniform_pt(self, values, scale):

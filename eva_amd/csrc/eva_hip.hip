@@ -224,6 +224,49 @@ k_galois_perm_many(DevCtx cx, const u64 *a, size_t a_ps, PermTables pt, u64 *out
   st2(out + z * o_ps + (size_t)i * cx.N + n, v);
 }
 
+// ---- CKKS encoder on the device (SEAL CKKSEncoder::encode): values -> conjugate-
+// symmetric slot vector -> inverse special FFT (FP64, Gentleman-Sande, one launch per stage) ->
+// round(x * scale / N) -> residues.  Operation order and rounding are exactly those of the host
+// encoder (eva_amd/host/ckks_host.h encode_coeff) and FMA contraction is off, so the plaintext is
+// the same bit for bit.
+__global__ void __launch_bounds__(256)
+k_enc_scatter(const double *vals, uint32_t n_vals, const uint32_t *slot_map, double2 *c, uint32_t slots) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= slots) return;
+  const double v = vals[i % n_vals]; // the vector is replicated over the N/2 slots (seal_executor.h:226-240)
+  c[slot_map[i]] = make_double2(v, 0.0);
+  c[slot_map[slots + i]] = make_double2(v, 0.0); // conjugate of a real value
+}
+__global__ void __launch_bounds__(256)
+k_enc_fft_stage(double2 *c, const double2 *roots, uint32_t mm, uint32_t log_gap, uint32_t half_n) {
+#pragma clang fp contract(off)
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= half_n) return;
+  const uint32_t gap = 1u << log_gap, g = idx >> log_gap, j = idx & (gap - 1);
+  const uint32_t a = 2 * g * gap + j, b = a + gap;
+  const double2 r = roots[mm + g];
+  const double wx = r.x, wy = -r.y; // conj(root)
+  const double2 u = c[a], v = c[b];
+  c[a] = make_double2(u.x + v.x, u.y + v.y);
+  const double dx = u.x - v.x, dy = u.y - v.y;
+  c[b] = make_double2(dx * wx - dy * wy, dx * wy + dy * wx);
+}
+__global__ void __launch_bounds__(256)
+k_enc_round(DevCtx cx, const double2 *c, double fix, uint32_t limbs, u64 *out) {
+#pragma clang fp contract(off)
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cx.N) return;
+  const double t = c[j].x * fix;
+  const double x = fabs(t) < 4503599627370496.0 ? round(t) : t; // >= 2^52: already an integer
+  const bool neg = signbit(x);
+  const u64 mant = (u64)fabs(x); // |x| < 2^63 is guaranteed by the caller's bound
+  for (uint32_t i = 0; i < limbs; i++) {
+    const DevPrime pm = cx.primes[i];
+    const u64 r = barrett64(mant, pm.q, pm.brt);
+    out[(size_t)i * cx.N + j] = (neg && r) ? pm.q - r : r;
+  }
+}
+
 // per-limb constant fill (uniform-constant plaintexts); the per-limb values travel as a
 // kernel argument so the call needs no host->device copy and no synchronisation
 struct LimbVals {
@@ -377,8 +420,12 @@ struct SharedDev {
   KeyDev relin;
   std::map<uint32_t, KeyDev> galois;
   std::map<uint32_t, uint32_t *> perms;
+  double2 *enc_roots = nullptr;     // CKKS encoder: zeta^br(j), zeta = exp(2 pi i / 2N)
+  uint32_t *enc_slot_map = nullptr; // slot i (and its conjugate, at slots + i) -> FFT input index
   ~SharedDev() {
     (void)hipSetDevice(device);
+    if (enc_roots) (void)hipFree(enc_roots);
+    if (enc_slot_map) (void)hipFree(enc_slot_map);
     if (relin.d) (void)hipFree(relin.d);
     for (auto &kv : galois) (void)hipFree(kv.second.d);
     for (auto &kv : perms) (void)hipFree(kv.second);
@@ -1279,6 +1326,69 @@ int evah_pt_upload_coeff(evah_ctx *c, uint32_t limbs, double scale, const uint64
   OpPlain::Params p{t->d, t->d, 0, 0, limbs, 0, 0, {}};
   ntt_forward<OpPlain>(c, p, limbs);
   HIPCHK(hipStreamSynchronize(c->stream)); // the pageable host buffer may go away after return
+  t->buf->ready_everywhere = true;
+  *out = t;
+  API_END
+}
+
+// encoder tables of a context family (built on first use, never inside a capture)
+static void enc_tables(evah_ctx *c) {
+  if (c->sh->enc_roots) return;
+  if (c->capturing) throw std::logic_error("first use of the device encoder cannot be captured into a graph");
+  const uint32_t N = c->N, slots = N >> 1, m = 2 * N;
+  std::vector<uint32_t> map(N);
+  u64 pos = 1;
+  for (uint32_t i = 0; i < slots; i++) {
+    map[i] = bitrev((uint32_t)((pos - 1) >> 1), c->logN);
+    map[slots + i] = bitrev((uint32_t)((m - pos - 1) >> 1), c->logN);
+    pos = (pos * 3) & (m - 1);
+  }
+  std::vector<double> roots(2 * (size_t)N);
+  const double PI2 = 6.283185307179586476925286766559;
+  roots[0] = 1.0;
+  roots[1] = 0.0;
+  for (uint32_t j = 1; j < N; j++) {
+    const double ang = PI2 * (double)bitrev(j, c->logN) / (double)m;
+    roots[2 * j] = std::cos(ang);
+    roots[2 * j + 1] = std::sin(ang);
+  }
+  HIPCHK(hipMalloc(&c->sh->enc_slot_map, sizeof(uint32_t) * N));
+  HIPCHK(hipMalloc(&c->sh->enc_roots, sizeof(double2) * N));
+  HIPCHK(hipMemcpy(c->sh->enc_slot_map, map.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->sh->enc_roots, roots.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+}
+
+// CKKSEncoder::encode of `n_values` reals replicated over the N/2 slots, at 2^scale_bits... (scale is
+// passed as the double SEAL takes), to `limbs` primes, NTT form.  The caller guarantees that every
+// coefficient round(x * scale / N) is below 2^62 in magnitude (the host checks a bound on
+// sum |values|); larger encodings take the host's multi-precision path + evah_pt_upload_coeff.
+int evah_pt_encode(evah_ctx *c, const double *values, uint32_t n_values, uint32_t limbs, double scale, evah_pt **out) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
+  const uint32_t N = c->N, slots = N >> 1;
+  if (n_values < 1 || n_values > slots || slots % n_values) throw std::invalid_argument("value count must divide the slot count");
+  enc_tables(c);
+  evah_pt *t = pt_new(c, limbs, scale);
+  try {
+    Scratch vals(c, n_values), cbuf(c, 2 * (size_t)N); // doubles / double2 in u64-sized words
+    HIPCHK(hipMemcpyAsync(vals.d, values, sizeof(double) * n_values, hipMemcpyHostToDevice, c->stream));
+    double2 *cd = reinterpret_cast<double2 *>(cbuf.d);
+    ProfScope ps(c, KC_EW);
+    hipLaunchKernelGGL(k_enc_scatter, dim3((slots + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const double *>(vals.d),
+                       n_values, c->sh->enc_slot_map, cd, slots);
+    for (uint32_t mm = N >> 1, lg = 0; mm >= 1; mm >>= 1, lg++)
+      hipLaunchKernelGGL(k_enc_fft_stage, dim3((slots + 255) / 256), dim3(256), 0, c->stream, cd, c->sh->enc_roots, mm, lg, slots);
+    hipLaunchKernelGGL(k_enc_round, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->dev, cd, scale / (double)N, limbs, t->d);
+    HIPCHK(hipGetLastError());
+    OpPlain::Params p{t->d, t->d, 0, 0, limbs, 0, 0, {}};
+    ntt_forward<OpPlain>(c, p, limbs);
+    HIPCHK(hipStreamSynchronize(c->stream)); // `values` is pageable host memory
+  } catch (...) {
+    evah_pt_free(c, t);
+    throw;
+  }
   t->buf->ready_everywhere = true;
   *out = t;
   API_END

@@ -452,6 +452,22 @@ private:
   std::vector<std::pair<TermId, TermId>> deferred_free; // (lazy relin term, its source)
   bool batch_rotations = std::getenv("EVA_BATCH_ROTATIONS") ? std::atoi(std::getenv("EVA_BATCH_ROTATIONS")) != 0 : true;
   bool fuse_relin_rescale = std::getenv("EVA_FUSE_RELIN_RESCALE") ? std::atoi(std::getenv("EVA_FUSE_RELIN_RESCALE")) != 0 : true;
+  bool device_encode = std::getenv("EVA_DEVICE_ENCODE") ? std::atoi(std::getenv("EVA_DEVICE_ENCODE")) != 0 : true;
+  // every coefficient of the encoding is bounded by 2 * sum|slot values| * scale / N; the device
+  // path needs that below 2^62 (and within the modulus, so that the host's exact range check —
+  // which throws "encoded values are too large" — is not needed)
+  bool device_encodable(const std::vector<double> &in, double scale, uint32_t limbs) const {
+    const size_t slots = host.N / 2;
+    if (in.empty() || in.size() > slots || slots % in.size()) return false;
+    double sum = 0;
+    for (double v : in) {
+      if (!std::isfinite(v)) return false;
+      sum += std::fabs(v);
+    }
+    const double bound = 2.0 * sum * (double)(slots / in.size()) * scale / (double)host.N;
+    const int bits = (int)std::ceil(std::log2(std::max(bound, 1.0))) + 1;
+    return bits < 62 && bits < host.total_bits[limbs];
+  }
   bool fuse_sums = std::getenv("EVA_FUSE_SUMS") ? std::atoi(std::getenv("EVA_FUSE_SUMS")) != 0 : true;
 
   // Queue for node t: key-switching / rescaling consumers of a fanned-out value are spread
@@ -606,6 +622,9 @@ private:
       std::vector<u64> vals(limbs);
       host.encode_uniform(in[0], scale, limbs, vals.data());
       chk(evah_pt_uniform(ctx, limbs, scale, (const uint64_t *)vals.data(), &h));
+    } else if (device_encode && device_encodable(in, scale, limbs)) {
+      // FP64 special FFT, rounding, residues and NTT all on the device (same plaintext, bit for bit)
+      chk(evah_pt_encode(ctx, in.data(), (uint32_t)in.size(), limbs, scale, &h));
     } else {
       const size_t slots = host.N / 2;
       scratch.clear();

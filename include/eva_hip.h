@@ -107,6 +107,12 @@ int evah_pt_upload(evah_ctx *ctx, uint32_t limbs, double scale, const uint64_t *
  * forward NTT — the device half of CKKSEncoder::encode (seal_executor.h:242). */
 int evah_pt_upload_coeff(evah_ctx *ctx, uint32_t limbs, double scale, const uint64_t *data,
                          evah_pt **out);
+/* encoder.encode (seal_executor.h:242) entirely on the device: `n_values` reals (replicated over
+ * the N/2 slots as seal_executor.h:226-240 does) -> inverse special FFT in FP64 -> round(x*scale/N)
+ * -> residues -> NTT.  Bit-identical to the host encoder followed by evah_pt_upload_coeff; valid when
+ * every rounded coefficient is below 2^62 in magnitude (the caller checks a bound), otherwise use
+ * the host's multi-precision path */
+int evah_pt_encode(evah_ctx *ctx, const double *values, uint32_t n_values, uint32_t limbs, double scale, evah_pt **out);
 /* plaintext whose every slot is the same residue per limb: encode of a uniform constant
  * (Program::makeUniformConstant, program.h:58-60) — value[i] = round(c*scale) mod primes[i]. */
 int evah_pt_uniform(evah_ctx *ctx, uint32_t limbs, double scale, const uint64_t *value /* [limbs] */,

@@ -339,3 +339,33 @@ def test_error_behaviour_matches_reference_preconditions():
         one = e.g.mod_switch(one)
     with pytest.raises(backend.EvaHipError, match="end of modulus switching chain"):
         e.g.rescale(one, 10)
+
+
+@pytest.mark.parametrize("logn", [10, 12, 13, 15, 16])
+def test_device_encoder_equals_host_encoder(logn):
+    """evah_pt_encode (FP64 special FFT, rounding, residues, NTT on the device) gives the plaintext
+    of the product's host encoder (the one the DAG-level parity tests feed the oracle with), bit
+    for bit; the oracle's own encoder is pinned separately through the canonical embedding
+    (tests/test_oracle_kat.py)."""
+    from eva import EvaProgram, Input, Output
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    N = 1 << logn
+    prog = EvaProgram('enc', vec_size=8)
+    with prog:
+        Output('y', Input('x') * 0.5)
+    prog.set_input_scales(30)
+    prog.set_output_ranges(20)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    params.poly_modulus_degree = N
+    params.prime_bits = [60, 40, 60]
+    pub, sec = generate_keys(params, 2)
+    g = backend.Context(N, list(pub.primes))
+    rng = np.random.default_rng(logn)
+    for n_vals, scale_bits, level in ((N // 2, 30, 0), (8, 40, 0), (1, 20, 1), (64, 55, 0)):
+        vals = rng.uniform(-3, 3, n_vals)
+        limbs = len(pub.primes) - 1 - level
+        host = pub._encode(list(vals) * ((N // 2) // n_vals), scale_bits, level)
+        dev = g.encode_pt(vals, limbs, 2.0 ** scale_bits).download()
+        assert dev.shape == host.shape
+        assert np.array_equal(dev, host), f"device encoding differs (N=2^{logn}, {n_vals} values, scale 2^{scale_bits})"
