@@ -56,8 +56,8 @@ def triple_bytes(N, l):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="independent op-triples per step")
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--limbs", type=int, default=10)
