@@ -14,15 +14,17 @@
 // rooted at heap node `node` uses tw[(node << s) + v] at its local stage s: both passes share
 // one table and no re-indexing is needed.
 //
-// One workgroup owns a tile of up to 4096 coefficients in LDS (32 KiB + padding); each thread
-// keeps 16 coefficients in registers per round and runs up to 4 butterfly stages on them
-// (radix-16 worth of work per LDS round trip).  Lazy butterflies: forward values live in
+// One workgroup (256 threads) owns a tile of 2048 coefficients in LDS (16 KiB + padding); each
+// thread keeps 8 coefficients in registers per round and runs 3 butterfly stages on them per LDS
+// round trip (measured best on MI355X: vs 4 per thread +12 %, vs 16 +10 %; the fused key-switch
+// kernel below uses one wave and 4 per thread).  Lazy butterflies: forward values live in
 // [0,16q) with a conditional subtraction every other stage, inverse in [0,5q) (q < 2^60); only
 // the value finally stored is canonical.
 //
-// The first pass reads through Op::load and the second writes through Op::store, which is how
-// the digit base-conversion, the rescale / mod-down combine and the +q/2 rounding offset are
-// fused into the transforms instead of being separate HBM round trips.
+// The first pass reads through Op::load and the second writes through Op::store / store_fwd,
+// which is how the digit base-conversion, the rescale / mod-down combine and the +q/2 rounding
+// offset are fused into the transforms instead of being separate HBM round trips; the ops work
+// on lazy values where the moduli allow it (no Barrett reduction on the way in or out).
 #pragma once
 #include "devmath.cuh"
 #include <type_traits>
