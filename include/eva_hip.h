@@ -70,8 +70,10 @@ int evah_galois_elt_from_step(evah_ctx *ctx, int32_t steps, uint32_t *elt);
  * Replace SEALExecutor::setInputs / getOutputs / free (seal_executor.h:264-277,420-435,406-418). */
 int evah_ct_upload(evah_ctx *ctx, uint32_t size, uint32_t limbs, double scale,
                    const uint64_t *data /* [size][limbs][N] */, evah_ct **out);
-/* ---- pinned host memory for values that will be uploaded / downloaded (recycled by size);
- * NULL when no device memory can be pinned — use ordinary memory then.  Thread-safe. */
+/* ---- pinned host memory for the values setInputs copies in and getOutputs copies out
+ * (seal_executor.h:269-270, 420-435; in the reference they live in SEAL's MemoryPool): blocks are
+ * page-locked once and recycled by size, so the copies are DMA transfers at PCIe rate.  NULL when
+ * no memory can be pinned (no device) — use ordinary memory then.  Thread-safe. */
 void *evah_host_alloc(size_t bytes);
 void evah_host_free(void *p);
 
