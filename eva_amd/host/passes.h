@@ -777,7 +777,7 @@ private:
     LevelsChecker lc{p, types};
     forward_pass(p, lc);
     try {
-      ParameterChecker pc{p, types, {}};
+      ParameterChecker pc{p, types, TermTable<std::vector<uint32_t>>{}};
       forward_pass(p, pc);
     } catch (const InconsistentParameters &) {
       switch (config.rescaler) {
@@ -810,7 +810,7 @@ private:
   CKKSParameters determine_parameters(Program &p, Types &types, Scales &scales) {
     if (config.security_level > 256)
       throw std::runtime_error("EVA has support for up to 256 bit security, but " + std::to_string(config.security_level) + " bit security was requested.");
-    EncryptionParametersSelector eps{p, scales, types, {}};
+    EncryptionParametersSelector eps{p, scales, types, TermTable<std::vector<uint32_t>>{}};
     forward_pass(p, eps);
     RotationKeysSelector rks{p, types, {}};
     forward_pass(p, rks);
