@@ -110,3 +110,29 @@ def test_rotation_round_trip_and_encode_decode_n32768():
         assert np.max(np.abs(np.array(o['plain']) - np.array(inputs['x']))) < 1e-4
     assert outs[1] == outs[2]  # graph replay is deterministic
     assert valuation_mse(outs[0], evaluate(compiled, inputs)) < 1e-8
+
+
+def test_op_triple_decrypts_at_metric_size_n65536_l10():
+    """BASELINE's metric configuration end to end: at N = 2^16 with 10 data limbs + the special
+    prime, multiply -> relinearize -> rescale on the GPU (the op-triple bench.py times) decrypts to
+    the slot-wise product — a semantic check at full size that needs no oracle."""
+    from eva import EvaProgram, Input, Output
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    prog = EvaProgram('triple', vec_size=32768)
+    with prog:
+        Output('z', Input('x') * Input('y'))
+    prog.set_output_ranges(30)
+    prog.set_input_scales(60)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    ops = [str(d["op"]).split(".")[-1] for d in compiled._dump()]
+    assert ops.count("Mul") == 1 and ops.count("Relinearize") == 1 and ops.count("Rescale") == 1
+    params.poly_modulus_degree = 65536
+    pb = list(params.prime_bits)
+    params.prime_bits = pb[:1] + [60] * (11 - len(pb)) + pb[1:]   # pad to L = 10 data limbs + special
+    pub, sec = generate_keys(params, 21)
+    assert len(pub.primes) == 11
+    rng = np.random.default_rng(8)
+    x, y = rng.uniform(-2, 2, 32768), rng.uniform(-2, 2, 32768)
+    out = sec.decrypt(pub.execute(compiled, pub.encrypt({'x': list(x), 'y': list(y)}, sig)), sig)
+    assert np.max(np.abs(np.array(out['z']) - x * y)) < 1e-6
