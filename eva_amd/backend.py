@@ -63,6 +63,9 @@ _SIGS = {
     "evah_multiply_many": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_execute": [_vp, _vp, C.c_uint32, _vp, C.c_uint32],
     "evah_weighted_sum": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
+    "evah_rotate_pairs": [_vp, _vpp, C.POINTER(C.c_int32), C.c_uint32, _vpp],
+    "evah_rescale_many": [_vp, _vpp, C.c_uint32, C.c_uint32, _vpp],
+    "evah_relinearize_many": [_vp, _vpp, C.c_uint32, _vpp],
     "evah_pt_encode": [_vp, C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_double, _vpp],
     "evah_ct_upload_batch": [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, _u64p, _vpp],
     "evah_ct_upload_instances": [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(_u64p), _vpp],
@@ -472,6 +475,24 @@ class Context:
         outs = (C.c_void_p * n)()
         _chk(_lib.evah_rotate_many(self.h, a.h, arr, n, outs))
         return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n)]
+
+    def _many(self, fn, cts, *extra):
+        n = len(cts)
+        ins = (C.c_void_p * n)(*[ct.h for ct in cts])
+        outs = (C.c_void_p * n)()
+        _chk(fn(self.h, ins, *extra, outs))
+        return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n)]
+
+    def rotate_pairs(self, cts, steps):
+        n = len(cts)
+        arr = (C.c_int32 * n)(*[int(x) for x in steps])
+        return self._many(_lib.evah_rotate_pairs, cts, arr, C.c_uint32(n))
+
+    def rescale_many(self, cts, divisor_bits):
+        return self._many(_lib.evah_rescale_many, cts, C.c_uint32(len(cts)), C.c_uint32(int(divisor_bits)))
+
+    def relinearize_many(self, cts):
+        return self._many(_lib.evah_relinearize_many, cts, C.c_uint32(len(cts)))
 
     def rescale(self, a, divisor_bits):
         return self._ct1(_lib.evah_rescale, a, C.c_uint32(int(divisor_bits)))

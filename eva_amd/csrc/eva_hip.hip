@@ -267,6 +267,24 @@ k_enc_round(DevCtx cx, const double2 *c, double fix, uint32_t limbs, u64 *out) {
   }
 }
 
+// K8 for (ciphertext, rotation) pairs: pair r reads its own source; grid.z = r * 2 + p
+struct PermPairs {
+  const uint32_t *perm[KS_BATCH_MAX];
+  const u64 *src[KS_BATCH_MAX];
+  uint32_t src_ps[KS_BATCH_MAX]; // poly strides in units of N coefficients
+};
+__global__ void __launch_bounds__(256)
+k_galois_perm_pairs(DevCtx cx, PermPairs pt, u64 *out, size_t o_ps) {
+  const uint32_t z = blockIdx.z, r = z >> 1, p = z & 1, i = blockIdx.y;
+  const uint32_t n = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+  const uint2 pi = *reinterpret_cast<const uint2 *>(pt.perm[r] + n);
+  const u64 *src = pt.src[r] + ((size_t)p * pt.src_ps[r] + i) * cx.N;
+  ulonglong2 v;
+  v.x = src[pi.x];
+  v.y = src[pi.y];
+  st2(out + z * o_ps + (size_t)i * cx.N + n, v);
+}
+
 // per-limb constant fill (uniform-constant plaintexts); the per-limb values travel as a
 // kernel argument so the call needs no host->device copy and no synchronisation
 struct LimbVals {
@@ -1848,6 +1866,160 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
     throw;
   }
   for (uint32_t r = 0; r < n; r++) outs[r] = made[r];
+  API_END
+}
+
+// n (<= 64) independent (ciphertext, step) rotations at one level as one launch set: the sibling
+// rotations of SEVERAL ciphertexts (independent convolutions of one program level)
+int evah_rotate_pairs(evah_ctx *c, const evah_ct *const *cts, const int32_t *steps, uint32_t n, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("rotate_pairs handles 1..64 rotations per call");
+  const uint32_t l = cts[0]->limbs;
+  const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
+  PermPairs pt{};
+  std::vector<const KeyDev *> keys(n);
+  for (uint32_t r = 0; r < n; r++) {
+    const evah_ct *a = cts[r];
+    if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
+    if (a->batch != 1) throw std::invalid_argument("rotate_pairs takes single ciphertexts");
+    if (a->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    if (steps[r] == 0) throw std::invalid_argument("rotate_pairs: zero steps are copies, not key switches");
+    acquire(c, a->buf);
+    uint32_t elt = 0;
+    if (evah_galois_elt_from_step(c, steps[r], &elt)) throw std::invalid_argument(g_err);
+    auto kit = c->sh->galois.find(elt);
+    if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
+    keys[r] = &kit->second;
+    pt.perm[r] = perm_table(c, elt);
+    pt.src[r] = a->d;
+    pt.src_ps[r] = (uint32_t)(a->ps / N);
+  }
+  Buffer *ob = buf_new(c, (size_t)n * 2 * pps);
+  try {
+    Scratch perm(c, (size_t)n * 2 * pps);
+    {
+      ProfScope ps(c, KC_EW);
+      hipLaunchKernelGGL(k_galois_perm_pairs, dim3(c->N / 512, l, 2 * n), dim3(256), 0, c->stream, c->dev, pt, perm.d, pps);
+    }
+    HIPCHK(hipGetLastError());
+    Scratch prod(c, n * prod_bs);
+    switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), n, prod.d);
+    Scratch r(c, (size_t)n * 2 * N);
+    OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
+    ntt_inverse<OpPlain>(c, sp, 2 * n);
+    OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, perm.d, pps, ~0u, ob->d, pps, c->k - 1, l};
+    ntt_forward<OpModDown>(c, mp, 2 * n * l);
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)n;
+  for (uint32_t r = 0; r < n; r++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)r * 2 * pps;
+    t->size = 2;
+    t->limbs = l;
+    t->ps = pps;
+    t->scale = cts[r]->scale;
+    outs[r] = t;
+  }
+  API_END
+}
+
+// n independent ciphertexts of one size and level rescaled in one launch set (n * size <= 128)
+int evah_rescale_many(evah_ctx *c, const evah_ct *const *cts, uint32_t n, uint32_t divisor_bits, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  const uint32_t size = cts[0]->size, l = cts[0]->limbs;
+  if (n < 1 || (size_t)n * size > 2 * KS_BATCH_MAX) throw std::invalid_argument("rescale_many: too many polynomials for one call");
+  if (l < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  const size_t N = c->N, ops = (size_t)(l - 1) * N;
+  const uint32_t polys = n * size;
+  PtrTab last{}, all{};
+  for (uint32_t b = 0; b < n; b++) {
+    const evah_ct *a = cts[b];
+    if (a->size != size || a->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    if (a->batch != 1) throw std::invalid_argument("rescale_many takes single ciphertexts");
+    acquire(c, a->buf);
+    for (uint32_t p = 0; p < size; p++) {
+      all.p[b * size + p] = a->d + (size_t)p * a->ps;
+      last.p[b * size + p] = a->d + (size_t)p * a->ps + (size_t)(l - 1) * N;
+    }
+  }
+  Buffer *ob = buf_new(c, (size_t)polys * ops);
+  try {
+    Scratch r(c, (size_t)polys * N);
+    OpPlain::Params ip{nullptr, r.d, 0, N, 1, l - 1, 1, last};
+    ntt_inverse<OpPlain>(c, ip, polys);
+    OpModDown::Params mp{r.d, N, nullptr, 0, nullptr, 0, 0, ob->d, ops, l - 1, l - 1};
+    mp.c_tab = all;
+    ntt_forward<OpModDown>(c, mp, polys * (l - 1));
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)n;
+  for (uint32_t b = 0; b < n; b++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)b * size * ops;
+    t->size = size;
+    t->limbs = l - 1;
+    t->ps = ops;
+    t->scale = cts[b]->scale / std::pow(2.0, (double)divisor_bits);
+    outs[b] = t;
+  }
+  API_END
+}
+
+// n (<= 64) independent size-3 ciphertexts of one level relinearized in one launch set
+int evah_relinearize_many(evah_ctx *c, const evah_ct *const *cts, uint32_t n, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("relinearize_many handles 1..64 ciphertexts per call");
+  if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
+  const uint32_t l = cts[0]->limbs;
+  const size_t N = c->N, pps = (size_t)(l + 1) * N, ops = (size_t)l * N;
+  PtrTab c2{}, c01{};
+  for (uint32_t b = 0; b < n; b++) {
+    const evah_ct *a = cts[b];
+    if (a->size != 3) throw std::invalid_argument("relinearize expects a size-3 ciphertext");
+    if (a->batch != 1) throw std::invalid_argument("relinearize_many takes single ciphertexts");
+    if (a->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    acquire(c, a->buf);
+    c2.p[b] = a->d + 2 * a->ps;
+    c01.p[2 * b] = a->d;
+    c01.p[2 * b + 1] = a->d + a->ps;
+  }
+  Buffer *ob = buf_new(c, (size_t)n * 2 * ops);
+  try {
+    Scratch prod(c, (size_t)n * 2 * pps);
+    std::vector<const KeyDev *> keys(n, &c->sh->relin);
+    switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2);
+    Scratch r(c, (size_t)n * 2 * N);
+    OpPlain::Params sp{prod.d + (size_t)l * N, r.d, pps, N, 1, c->k - 1, 1, {}};
+    ntt_inverse<OpPlain>(c, sp, 2 * n);
+    OpModDown::Params mp{r.d, N, prod.d, pps, nullptr, 0, 0, ob->d, ops, c->k - 1, l};
+    mp.use_add_tab = true;
+    mp.add_tab = c01;
+    ntt_forward<OpModDown>(c, mp, 2 * n * l);
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)n;
+  for (uint32_t b = 0; b < n; b++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)b * 2 * ops;
+    t->size = 2;
+    t->limbs = l;
+    t->ps = ops;
+    t->scale = cts[b]->scale;
+    outs[b] = t;
+  }
   API_END
 }
 

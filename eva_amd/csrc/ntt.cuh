@@ -504,6 +504,10 @@ struct OpModDown {
     size_t dst_ps;
     uint32_t a, jl;
     size_t add_bs = 0; // != 0: poly pp = 2b + K adds add[b * add_bs + K * add_ps] (batched relinearize)
+    // separately allocated operands (the *_many entry points): used when c == nullptr /
+    // use_add_tab; entry pp is limb 0 of polynomial pp, a null add entry means "nothing to add"
+    bool use_add_tab = false;
+    PtrTab c_tab{}, add_tab{};
   };
   struct Job {
     uint32_t prime;
@@ -518,10 +522,14 @@ struct OpModDown {
                                                uint32_t pp, Job &j) {
     j.prime = i;
     j.src = p.r + pp * p.r_ps;
-    j.c = p.c + pp * p.c_ps + (size_t)i * cx.N;
-    const bool use_add = p.add && (p.add_bs ? true : p.add_polys == ~0u ? (pp & 1u) == 0 : pp < p.add_polys);
-    const size_t add_off = p.add_bs ? (pp >> 1) * p.add_bs + (pp & 1u) * p.add_ps : pp * p.add_ps;
-    j.add = use_add ? p.add + add_off + (size_t)i * cx.N : nullptr;
+    j.c = (p.c ? p.c + pp * p.c_ps : p.c_tab.p[pp]) + (size_t)i * cx.N;
+    if (p.use_add_tab) {
+      j.add = p.add_tab.p[pp] ? p.add_tab.p[pp] + (size_t)i * cx.N : nullptr;
+    } else {
+      const bool use_add = p.add && (p.add_bs ? true : p.add_polys == ~0u ? (pp & 1u) == 0 : pp < p.add_polys);
+      const size_t add_off = p.add_bs ? (pp >> 1) * p.add_bs + (pp & 1u) * p.add_ps : pp * p.add_ps;
+      j.add = use_add ? p.add + add_off + (size_t)i * cx.N : nullptr;
+    }
     j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
     j.halfm = cx.halfmod[p.a * cx.k + i];
     j.inv = cx.invq[p.a * cx.k + i];

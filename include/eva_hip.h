@@ -166,6 +166,15 @@ int evah_rotate(evah_ctx *ctx, const evah_ct *a, int32_t steps, evah_ct **out);
  * (seal_executor.h:181) issued as one set of n-times-wider launches; outs[r] == evah_rotate(a, steps[r]).
  * The host executor groups the sibling rotations of a term (convolution windows) into one call. */
 int evah_rotate_many(evah_ctx *ctx, const evah_ct *a, const int32_t *steps, uint32_t n, evah_ct **outs);
+/* n (<= 64) rotations of SEVERAL ciphertexts of one level, pair i = (cts[i], steps[i] != 0): the
+ * sibling rotations of independent sub-expressions (seal_executor.h:181/188 called once per node)
+ * as one launch set; outs[i] == evah_rotate(cts[i], steps[i]) bit for bit */
+int evah_rotate_pairs(evah_ctx *ctx, const evah_ct *const *cts, const int32_t *steps, uint32_t n, evah_ct **outs);
+/* n independent evaluator.rescale_to_next calls (seal_executor.h:213) of one size and level,
+ * n * size <= 128, as one launch set */
+int evah_rescale_many(evah_ctx *ctx, const evah_ct *const *cts, uint32_t n, uint32_t divisor_bits, evah_ct **outs);
+/* n (<= 64) independent evaluator.relinearize calls (seal_executor.h:200) of one level as one launch set */
+int evah_relinearize_many(evah_ctx *ctx, const evah_ct *const *cts, uint32_t n, evah_ct **outs);
 /* evaluator.rescale_to_next + scale fix-up out.scale = a.scale / 2^divisor_bits
  * (seal_executor.h:213-214) */
 int evah_rescale(evah_ctx *ctx, const evah_ct *a, uint32_t divisor_bits, evah_ct **out);

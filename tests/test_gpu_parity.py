@@ -369,3 +369,46 @@ def test_device_encoder_equals_host_encoder(logn):
         dev = g.encode_pt(vals, limbs, 2.0 ** scale_bits).download()
         assert dev.shape == host.shape
         assert np.array_equal(dev, host), f"device encoding differs (N=2^{logn}, {n_vals} values, scale 2^{scale_bits})"
+
+
+@pytest.mark.parametrize("cfg", CONFIGS[:6], ids=lambda c: f"N{c[0]}")
+def test_level_batched_forms_equal_single_calls(cfg):
+    """evah_rescale_many / evah_relinearize_many / evah_rotate_pairs: independent nodes of one DAG
+    level as one launch set == the oracle's result for each; operands are separate allocations,
+    one a mod-switched view."""
+    e = Env(*cfg)
+    l = e.k - 1
+    if l < 2:
+        pytest.skip("needs two data limbs")
+    lv = l - 1
+    key = e.rand_key()
+    e.g.upload_relin_key(key)
+    for size in (2, 3):
+        hs = [e.rand(size, lv) for _ in range(3)]
+        wide = e.rand(size, l)
+        cts = [e.g.upload_ct(h, 2.0 ** 12) for h in hs] + [e.g.mod_switch(e.g.upload_ct(wide, 2.0 ** 12))]
+        hs.append(e.o.mod_switch(wide))
+        if lv >= 2:
+            outs = e.g.rescale_many(cts, 5)
+            for h, o in zip(hs, outs):
+                assert o.info() == (size, lv - 1, 2.0 ** 7)
+                assert np.array_equal(o.download(), e.o.rescale(h))
+        if size == 3:
+            outs = e.g.relinearize_many(cts)
+            for h, o in zip(hs, outs):
+                assert o.info() == (2, lv, 2.0 ** 12)
+                assert np.array_equal(o.download(), e.o.relinearize(h, key))
+    steps = [1, -2, 1, 7]
+    keys = {}
+    for s in set(steps):
+        keys[s] = e.rand_key()
+        e.g.upload_galois_key(e.g.galois_elt_from_step(s), keys[s])
+    hs = [e.rand(2, lv) for _ in range(3)]
+    wide = e.rand(2, l)
+    cts = [e.g.upload_ct(h, 2.0 ** 12) for h in hs] + [e.g.mod_switch(e.g.upload_ct(wide, 2.0 ** 12))]
+    hs.append(e.o.mod_switch(wide))
+    outs = e.g.rotate_pairs(cts, steps)
+    for h, s, o in zip(hs, steps, outs):
+        assert np.array_equal(o.download(), e.o.rotate(h, s, keys[s]))
+    with pytest.raises(backend.EvaHipError, match="zero steps"):
+        e.g.rotate_pairs(cts[:1], [0])
