@@ -17,7 +17,9 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <memory>
+#include <tuple>
 #include <random>
 #include <string>
 #include <unordered_map>
@@ -370,6 +372,128 @@ public:
       objects[t] = objects[a[0]];
       break;
     default: throw std::runtime_error(std::string("Unhandled op ") + op_name(x.op));
+    }
+  }
+
+  // Level-synchronous walk: nodes are taken by depth (longest path from the sources), so the nodes
+  // of one level are mutually independent, and the key-switching / rescaling / ct x ct nodes of a
+  // level go out together through the batched entry points (evah_rotate_pairs, _rescale_many,
+  // _relinearize_many, _relinearize_rescale_many, _multiply_many): the three independent
+  // convolution chains of a Harris detector become one launch set per step instead of three.
+  // Same ciphertexts as the node-by-node walk; `skip` marks nodes already evaluated (constants of
+  // a captured plan); free_values releases operands after the level of their last consumer.
+  void run_levelled(const std::vector<char> *skip, bool free_values) {
+    auto order = program.topo_order();
+    std::vector<uint32_t> level(program.size(), 0), succ(program.size(), 0);
+    uint32_t depth = 0;
+    for (TermId t : order) {
+      uint32_t lv = 0;
+      for (TermId o : program.at(t).operands) {
+        lv = std::max(lv, level[o] + 1);
+        succ[o]++;
+      }
+      level[t] = lv;
+      depth = std::max(depth, lv);
+    }
+    std::vector<std::vector<TermId>> buckets(depth + 1);
+    for (TermId t : order) buckets[level[t]].push_back(t);
+    ctx = queues[0];
+    auto info = [&](evah_ct *h, uint32_t &size, uint32_t &limbs) {
+      double sc;
+      chk(evah_ct_info(h, &size, &limbs, &sc));
+    };
+    for (auto &nodes : buckets) {
+      // (group key, node) lists of the batchable kinds of this level
+      std::map<uint32_t, std::vector<TermId>> rots, relins, muls;
+      std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<TermId>> rescales; // (size, limbs, divisor)
+      std::map<std::pair<uint32_t, uint32_t>, std::vector<TermId>> fused;              // (limbs, divisor)
+      for (TermId t : nodes) {
+        if (skip && (*skip)[t]) continue;
+        const Term &x = program.at(t);
+        const auto &a = x.operands;
+        uint32_t size = 0, limbs = 0;
+        if ((x.op == Op::RotateLeftConst || x.op == Op::RotateRightConst) && is_cipher(a[0]) && x.rotation != 0) {
+          info(ct(a[0]), size, limbs);
+          rots[limbs].push_back(t);
+        } else if (x.op == Op::Rescale && std::holds_alternative<LazyRelin>(objects[a[0]])) {
+          info(ct(std::get<LazyRelin>(objects[a[0]]).src), size, limbs);
+          fused[{limbs, x.rescale_divisor}].push_back(t);
+        } else if (x.op == Op::Rescale && is_cipher(a[0])) {
+          info(ct(a[0]), size, limbs);
+          rescales[{size, limbs, x.rescale_divisor}].push_back(t);
+        } else if (x.op == Op::Relinearize && is_cipher(a[0]) &&
+                   !(fuse_relin_rescale && x.uses.size() == 1 && program.at(x.uses[0]).op == Op::Rescale)) {
+          info(ct(a[0]), size, limbs);
+          relins[limbs].push_back(t);
+        } else if (x.op == Op::Mul && a[0] != a[1] && is_cipher(a[0]) && is_cipher(a[1])) {
+          info(ct(a[0]), size, limbs);
+          muls[limbs].push_back(t);
+        } else {
+          (*this)(t);
+        }
+      }
+      // flush: groups of one take the ordinary path
+      auto each_chunk = [&](std::vector<TermId> &g, size_t cap, auto &&fn) {
+        if (g.size() == 1) { (*this)(g[0]); return; }
+        for (size_t i = 0; i < g.size(); i += cap) fn(g.data() + i, (uint32_t)std::min(cap, g.size() - i));
+      };
+      auto store = [&](const TermId *ts, uint32_t n, std::vector<evah_ct *> &outs) {
+        for (uint32_t i = 0; i < n; i++) objects[ts[i]] = std::make_shared<CtHandle>(ctx, outs[i]);
+      };
+      for (auto &kv : rots)
+        each_chunk(kv.second, 64, [&](const TermId *ts, uint32_t n) {
+          std::vector<const evah_ct *> in(n);
+          std::vector<int32_t> steps(n);
+          std::vector<evah_ct *> outs(n, nullptr);
+          for (uint32_t i = 0; i < n; i++) {
+            const Term &y = program.at(ts[i]);
+            in[i] = ct(y.operands[0]);
+            steps[i] = y.op == Op::RotateLeftConst ? y.rotation : -y.rotation; // seal_executor.h:188
+          }
+          chk(evah_rotate_pairs(ctx, in.data(), steps.data(), n, outs.data()));
+          store(ts, n, outs);
+        });
+      for (auto &kv : fused)
+        each_chunk(kv.second, 64, [&](const TermId *ts, uint32_t n) {
+          std::vector<const evah_ct *> in(n);
+          std::vector<evah_ct *> outs(n, nullptr);
+          for (uint32_t i = 0; i < n; i++) in[i] = ct(std::get<LazyRelin>(objects[program.at(ts[i]).operands[0]]).src);
+          chk(evah_relinearize_rescale_many(ctx, in.data(), n, kv.first.second, outs.data()));
+          store(ts, n, outs);
+        });
+      for (auto &kv : rescales)
+        each_chunk(kv.second, 128 / std::get<0>(kv.first), [&](const TermId *ts, uint32_t n) {
+          std::vector<const evah_ct *> in(n);
+          std::vector<evah_ct *> outs(n, nullptr);
+          for (uint32_t i = 0; i < n; i++) in[i] = ct(program.at(ts[i]).operands[0]);
+          chk(evah_rescale_many(ctx, in.data(), n, std::get<2>(kv.first), outs.data()));
+          store(ts, n, outs);
+        });
+      for (auto &kv : relins)
+        each_chunk(kv.second, 64, [&](const TermId *ts, uint32_t n) {
+          std::vector<const evah_ct *> in(n);
+          std::vector<evah_ct *> outs(n, nullptr);
+          for (uint32_t i = 0; i < n; i++) in[i] = ct(program.at(ts[i]).operands[0]);
+          chk(evah_relinearize_many(ctx, in.data(), n, outs.data()));
+          store(ts, n, outs);
+        });
+      for (auto &kv : muls)
+        each_chunk(kv.second, 64, [&](const TermId *ts, uint32_t n) {
+          std::vector<const evah_ct *> ia(n), ib(n);
+          std::vector<evah_ct *> outs(n, nullptr);
+          for (uint32_t i = 0; i < n; i++) {
+            ia[i] = ct(program.at(ts[i]).operands[0]);
+            ib[i] = ct(program.at(ts[i]).operands[1]);
+          }
+          chk(evah_multiply_many(ctx, ia.data(), ib.data(), n, outs.data()));
+          store(ts, n, outs);
+        });
+      if (free_values)
+        for (TermId t : nodes) {
+          if (skip && (*skip)[t]) continue;
+          for (TermId o : program.at(t).operands)
+            if (--succ[o] == 0) free(o);
+        }
     }
   }
 
@@ -740,7 +864,8 @@ public:
     HipExecutor ex(program, *host, queue_handles());
     ex.set_inputs(inputs);
     auto t1 = clk::now();
-    if (free_eagerly) run_counted(program, ex);
+    if (level_batching && num_queues <= 1) ex.run_levelled(nullptr, free_eagerly);
+    else if (free_eagerly) run_counted(program, ex);
     else run_serial(program, ex);
     auto t2 = clk::now();
     HipValuation out;
@@ -755,6 +880,8 @@ public:
   // `batch_chunk` at a time into batched device handles, so each DAG node is one backend call —
   // one launch set — per group instead of per instance.  Results are those of execute() on each
   // valuation, bit for bit.  The reference has no counterpart: it loops SEALPublic::execute.
+  // independent nodes of one DAG level through the batched entry points (EVA_LEVEL_BATCHING=0 disables)
+  bool level_batching = std::getenv("EVA_LEVEL_BATCHING") ? std::atoi(std::getenv("EVA_LEVEL_BATCHING")) != 0 : true;
   uint32_t batch_chunk = 32;
   std::vector<HipValuation> execute_batch(Program &program, const std::vector<const HipValuation *> &inputs) {
     ensure_device();
@@ -919,7 +1046,8 @@ private:
     // capture the walk
     chk(evah_capture_begin(q0, q.data() + 1, (uint32_t)q.size() - 1));
     try {
-      run_counted(program, ex, &done);
+      if (level_batching) ex.run_levelled(&done, true);
+      else run_counted(program, ex, &done);
       for (auto &kv : program.outputs()) plan->outputs[kv.first] = ex.value(kv.second);
     } catch (...) {
       evah_graph *g = nullptr;
