@@ -2029,11 +2029,9 @@ int evah_rotate(evah_ctx *c, const evah_ct *a, int32_t steps, evah_ct **out) {
   acquire(c, a->buf);
   if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
   const size_t N = c->N;
-  if (steps == 0) { // SEAL rotate_internal: no-op
-    evah_ct *o = ct_new(c, 2, a->limbs, a->scale, a->batch);
-    const size_t row = sizeof(u64) * (size_t)a->limbs * N;
-    HIPCHK(hipMemcpy2DAsync(o->d, sizeof(u64) * o->ps, a->d, sizeof(u64) * a->ps, row, (size_t)2 * a->batch,
-                            hipMemcpyDeviceToDevice, c->stream));
+  if (steps == 0) { // SEAL rotate_internal: no-op — the result is the operand; handles are immutable, so share the buffer
+    evah_ct *o = new evah_ct(*a);
+    o->buf->refs++;
     *out = o;
   } else if (a->batch > 1) {
     if (evah_rotate_many(c, a, &steps, 1, out)) throw std::runtime_error(g_err);
