@@ -901,14 +901,26 @@ public:
       for (auto &o : outs) all.push_back(std::move(o));
       prev.reset();
     };
+    // constants (Constant / Encode nodes and raw arithmetic on them) are evaluated once, by the
+    // first group, and shared by all groups: their plaintexts stay resident for the whole call
+    std::vector<char> done;
+    std::vector<HipExecutor::RuntimeValue> consts;
     size_t g = 0;
     for (size_t i0 = 0; i0 < inputs.size(); i0 += batch_chunk, g++) {
       const size_t n = std::min<size_t>(batch_chunk, inputs.size() - i0);
       std::vector<const HipValuation *> chunk(inputs.begin() + i0, inputs.begin() + i0 + n);
       auto ex = std::make_unique<HipExecutor>(program, *host, std::vector<evah_ctx *>{qs[g & 1]});
+      if (g == 0) {
+        done = ex->prepare_constants();
+        consts.resize(program.size());
+        for (TermId t = 0; t < program.size(); t++)
+          if (done[t]) consts[t] = ex->value(t);
+      } else {
+        for (TermId t = 0; t < program.size(); t++)
+          if (done[t]) ex->set_value(t, consts[t]);
+      }
       ex->set_inputs_batch(chunk);
-      if (free_eagerly) run_counted(program, *ex);
-      else run_serial(program, *ex);
+      run_counted(program, *ex, &done);
       drain();
       prev = std::move(ex);
       prev_n = n;
