@@ -23,7 +23,7 @@ def _random_program(seed, vec):
     with prog:
         names = [f'x{i}' for i in range(rng.randint(1, 3))]
         pool = [(Input(n), 0) for n in names]           # (expression, multiplicative depth)
-        for _ in range(rng.randint(6, 14)):
+        for _ in range(rng.randint(6, 14) if seed < 64 else rng.randint(10, 30)):
             kind = rng.choice(['add', 'add', 'sub', 'mul', 'mulc', 'mulc', 'addc', 'rot', 'neg', 'sq'])
             a, da = rng.choice(pool)
             b, db = rng.choice(pool)
@@ -59,7 +59,10 @@ def _same(a, b, what):
             assert np.array_equal(g[4], o[4]), f"{what}: output {name} differs"
 
 
-@pytest.mark.parametrize("seed", range(64))
+import os
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EVA_FUZZ_SEEDS", "64"))))
 def test_random_program_bit_exact(seed):
     prog, inputs = _random_program(seed, 64)
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
