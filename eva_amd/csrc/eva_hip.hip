@@ -740,7 +740,7 @@ static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size
   if (target_tab) ip.src_tab = *target_tab;
   ntt_inverse<OpPlain>(c, ip, n * l);
   OpKsDigit::Params dp{t.d, sc.d, l, (size_t)l * N, kb.scratch_bs, 0, l + 1};
-  if (c->fuse_mac && l <= 16) { // 128-bit accumulation of l products of a lazy (<16q) operand
+  if (c->fuse_mac) { // 128-bit accumulation of lazy (<16q) products, folded every 16 digits
     // Output limbs are processed in slices so that a slice's converted digits (ni * l * N words)
     // are still in L2 / Infinity Cache when the fused second pass consumes them.
     const int a = (c->logN + 1) / 2, b = c->logN / 2;

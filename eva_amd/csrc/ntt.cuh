@@ -375,7 +375,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
       for (int it = 0; it < NPAIR; it++) {
         const int idx = 2 * (threadIdx.x + it * T);
         const int sb = idx >> P, e = idx & (S - 1);
-        val[2 * it] = lds[sb * SP + lds_pad(e)];       // lazy [0,16q): fine for the 128-bit MAC (l <= 16)
+        val[2 * it] = lds[sb * SP + lds_pad(e)];       // lazy [0,16q): fine for the 128-bit MAC (folded every 16 digits)
         val[2 * it + 1] = lds[sb * SP + lds_pad(e + 1)];
       }
     }
@@ -385,6 +385,15 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
       acc128(acc0[2 * it + 1], val[2 * it + 1], k0r[it].y);
       acc128(acc1[2 * it], val[2 * it], k1r[it].x);
       acc128(acc1[2 * it + 1], val[2 * it + 1], k1r[it].y);
+    }
+    // 16 lazy products (each < 2^124) fill the 128-bit accumulators: with more digits than that,
+    // fold them back to one word every 16 (block-uniform, only ever taken when l > 16)
+    if ((J & 15u) == 15u && J + 1 < l) {
+#pragma unroll
+      for (int i = 0; i < NTT_R; i++) {
+        acc0[i] = {barrett128(acc0[i], pm), 0};
+        acc1[i] = {barrett128(acc1[i], pm), 0};
+      }
     }
   }
   u64 *p0 = prod + (size_t)I * N + gbase, *p1 = prod + ((size_t)(l + 1) + I) * N + gbase;

@@ -412,3 +412,25 @@ def test_level_batched_forms_equal_single_calls(cfg):
         assert np.array_equal(o.download(), e.o.rotate(h, s, keys[s]))
     with pytest.raises(backend.EvaHipError, match="zero steps"):
         e.g.rotate_pairs(cts[:1], [0])
+
+
+def test_more_than_16_limbs():
+    """More than 16 data limbs (possible at N >= 2^15 / 2^16 within the security tables): 16 lazy
+    products fill the fused kernel's 128-bit accumulators, so it folds them every 16 digits."""
+    e = Env(2048, [30] * 17 + [31, 31])   # 19 primes: 18 data limbs + the special prime
+    l = e.k - 1
+    assert l == 18
+    key = e.rand_key()
+    e.g.upload_relin_key(key)
+    a3 = e.rand(3, l)
+    A3 = e.g.upload_ct(a3, 2.0 ** 20)
+    relin = e.o.relinearize(a3, key)
+    assert np.array_equal(e.g.relinearize(A3).download(), relin)
+    assert np.array_equal(e.g.relinearize_rescale(A3, 10).download(), e.o.rescale(relin))
+    gk = e.rand_key()
+    e.g.upload_galois_key(e.g.galois_elt_from_step(-5), gk)
+    a2 = e.rand(2, l)
+    assert np.array_equal(e.g.rotate(e.g.upload_ct(a2, 2.0 ** 20), -5).download(), e.o.rotate(a2, -5, gk))
+    # and one level down, where l = 17 still exceeds 16
+    ms = e.g.mod_switch(A3)
+    assert np.array_equal(e.g.relinearize(ms).download(), e.o.relinearize(e.o.mod_switch(a3), key))
