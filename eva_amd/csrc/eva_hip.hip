@@ -28,6 +28,23 @@ namespace evah {
 
 static thread_local std::string g_err;
 
+// Contexts that exist: a buffer remembers the foreign queues that read it, and such a queue may
+// have been destroyed (after a sync) before the buffer is released.
+static std::mutex g_ctx_mu;
+static std::vector<const void *> g_live_ctx;
+static void ctx_register(const void *c) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  g_live_ctx.push_back(c);
+}
+static void ctx_unregister(const void *c) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), c), g_live_ctx.end());
+}
+static bool ctx_alive(const void *c) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  return std::find(g_live_ctx.begin(), g_live_ctx.end(), c) != g_live_ctx.end();
+}
+
 #define HIPCHK(x)                                                                                \
   do {                                                                                           \
     hipError_t e_ = (x);                                                                         \
@@ -567,7 +584,8 @@ static void acquire(evah_ctx *c, Buffer *b) {
 static void buf_unref(evah_ctx *c, Buffer *b) {
   (void)c;
   if (b && --b->refs == 0) {
-    for (evah_ctx *r : b->readers) stream_wait(b->owner, r); // recycle only after foreign reads
+    for (evah_ctx *r : b->readers)
+      if (ctx_alive(r)) stream_wait(b->owner, r); // recycle only after foreign reads (a destroyed queue was synchronised)
     b->pool->free(b->d, b->bytes);
     delete b;
   }
@@ -940,6 +958,7 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     evah_ctx_destroy(c);
     throw;
   }
+  ctx_register(c);
   *out = c;
   API_END
 }
@@ -968,12 +987,14 @@ int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
     evah_ctx_destroy(c);
     throw;
   }
+  ctx_register(c);
   *out = c;
   API_END
 }
 
 void evah_ctx_destroy(evah_ctx *c) {
   if (!c) return;
+  ctx_unregister(c);
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->pool.release_cached();

@@ -45,7 +45,8 @@ int evah_ctx_create(uint32_t poly_degree, uint32_t n_primes, const uint64_t *pri
  * through either), owns its own HIP stream and buffer pool.  Independent DAG nodes / independent
  * programs issued through different forks overlap on the GPU — the stream-level counterpart of
  * the reference's Galois worker threads (multicore_program_traversal.h:55-78).  A handle may be
- * read by any fork once the producing fork has been synchronised. */
+ * read by any fork once the producing fork has been synchronised.  Values produced through a
+ * fork live in that fork's pool: free them before destroying it (values it only read may outlive it). */
 int evah_ctx_fork(evah_ctx *parent, evah_ctx **out);
 void evah_ctx_destroy(evah_ctx *ctx);
 /* Launch on an external HIP stream (hipStream_t as void*); NULL restores the context's own. */
