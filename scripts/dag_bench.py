@@ -40,6 +40,9 @@ def run(name, prog, N, inputs=None, pad_primes=0):
         from evatest import oracle_execute
         t0 = time.perf_counter(); oracle_execute(pub, compiled, enc); tc = time.perf_counter() - t0
         line += f"\n  CPU oracle walk (1 core): {tc*1e3:.1f} ms   -> GPU speed-up {tc/min(ts):.1f}x"
+        nthr = min(os.cpu_count() or 1, 64)
+        t0 = time.perf_counter(); oracle_execute(pub, compiled, enc, threads=nthr); tp = time.perf_counter() - t0
+        line += f"\n  CPU oracle walk, node-parallel on {nthr} threads: {tp*1e3:.1f} ms   -> GPU speed-up {tp/min(ts):.1f}x"
     print(line, flush=True)
 
 from eva import EvaProgram, Input, Output

@@ -12,9 +12,9 @@ from eva.metric import valuation_mse
 from eva.seal import generate_keys, SEALValuation
 
 
-def oracle_execute(public_ctx, compiled, enc_inputs):
+def oracle_execute(public_ctx, compiled, enc_inputs, threads=1):
     from oracle_executor import OracleExecutor, Cipher, Plain
-    outs = OracleExecutor(public_ctx).execute(compiled, enc_inputs)
+    outs = OracleExecutor(public_ctx).execute(compiled, enc_inputs, threads=threads)
     val = SEALValuation()
     for name, v in outs.items():
         if isinstance(v, Cipher):

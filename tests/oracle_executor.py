@@ -33,7 +33,70 @@ class OracleExecutor:
         self.relin = public_ctx.relin_key()
         self.galois = public_ctx.galois_keys()
 
-    def execute(self, program, enc_inputs):
+    def _eval(self, program, d, vals):
+        """value of one node given its operands' values (SEALExecutor::operator(), :279-404)"""
+        from eva_amd import Op
+        t, op, a = d["id"], d["op"], d["operands"]
+        if op == Op.Constant:
+            c = d["constant"]
+            return list(c) * (program.vec_size // len(c))
+        elif op == Op.Encode:
+            data = self.pub._encode(vals[a[0]], d["encode_scale"], d["encode_level"])
+            return Plain(data, 2.0 ** d["encode_scale"])
+        elif op in (Op.Add, Op.Sub, Op.Mul):
+            x, y = vals[a[0]], vals[a[1]]
+            if isinstance(x, list) and isinstance(y, list):
+                f = {Op.Add: lambda u, v: u + v, Op.Sub: lambda u, v: u - v, Op.Mul: lambda u, v: u * v}[op]
+                return [f(u, v) for u, v in zip(x, y)]
+            elif op == Op.Add:
+                if not isinstance(x, Cipher):
+                    x, y = y, x
+                if isinstance(y, Cipher):
+                    return Cipher(self.o.add(x.data, y.data), x.scale)
+                else:
+                    return Cipher(self.o.add_plain(x.data, y.data), x.scale)
+            elif op == Op.Sub:
+                if isinstance(y, Cipher):
+                    return Cipher(self.o.sub(x.data, y.data), x.scale)
+                else:
+                    return Cipher(self.o.sub_plain(x.data, y.data), x.scale)
+            else:
+                same = a[0] == a[1]
+                if not isinstance(x, Cipher):
+                    x, y = y, x
+                if isinstance(y, Cipher):
+                    out = self.o.square(x.data) if same else self.o.multiply(x.data, y.data)
+                else:
+                    out = self.o.multiply_plain(x.data, y.data)
+                return Cipher(out, x.scale * y.scale)
+        elif op in (Op.RotateLeftConst, Op.RotateRightConst):
+            x = vals[a[0]]
+            if isinstance(x, list):
+                return _rot(x, d["rotation"], op == Op.RotateLeftConst)
+            else:
+                steps = d["rotation"] if op == Op.RotateLeftConst else -d["rotation"]
+                key = None
+                if steps != 0:
+                    key = self.galois[po.galois_elt_from_step(self.N, steps)]
+                return Cipher(self.o.rotate(x.data, steps, key), x.scale)
+        elif op == Op.Negate:
+            x = vals[a[0]]
+            return [-u for u in x] if isinstance(x, list) else Cipher(self.o.negate(x.data), x.scale)
+        elif op == Op.Relinearize:
+            x = vals[a[0]]
+            return Cipher(self.o.relinearize(x.data, self.relin), x.scale)
+        elif op == Op.ModSwitch:
+            x = vals[a[0]]
+            return Cipher(self.o.mod_switch(x.data), x.scale)
+        elif op == Op.Rescale:
+            x = vals[a[0]]
+            return Cipher(self.o.rescale(x.data), x.scale / 2.0 ** d["rescale_divisor"])
+        elif op == Op.Output:
+            return vals[a[0]]
+        else:
+            raise RuntimeError(f"Unhandled op {op}")
+
+    def execute(self, program, enc_inputs, threads=1):
         vals = {}
         inputs = {name: t.index for name, t in program.inputs.items()}
         for name in enc_inputs.names():
@@ -46,66 +109,51 @@ class OracleExecutor:
             else:
                 vals[t] = list(data) * (program.vec_size // len(data))
         from eva_amd import Op
-        for d in program._dump():
-            t, op, a = d["id"], d["op"], d["operands"]
-            if op == Op.Input:
-                continue
-            if op == Op.Constant:
-                c = d["constant"]
-                vals[t] = list(c) * (program.vec_size // len(c))
-            elif op == Op.Encode:
-                data = self.pub._encode(vals[a[0]], d["encode_scale"], d["encode_level"])
-                vals[t] = Plain(data, 2.0 ** d["encode_scale"])
-            elif op in (Op.Add, Op.Sub, Op.Mul):
-                x, y = vals[a[0]], vals[a[1]]
-                if isinstance(x, list) and isinstance(y, list):
-                    f = {Op.Add: lambda u, v: u + v, Op.Sub: lambda u, v: u - v, Op.Mul: lambda u, v: u * v}[op]
-                    vals[t] = [f(u, v) for u, v in zip(x, y)]
-                elif op == Op.Add:
-                    if not isinstance(x, Cipher):
-                        x, y = y, x
-                    if isinstance(y, Cipher):
-                        vals[t] = Cipher(self.o.add(x.data, y.data), x.scale)
-                    else:
-                        vals[t] = Cipher(self.o.add_plain(x.data, y.data), x.scale)
-                elif op == Op.Sub:
-                    if isinstance(y, Cipher):
-                        vals[t] = Cipher(self.o.sub(x.data, y.data), x.scale)
-                    else:
-                        vals[t] = Cipher(self.o.sub_plain(x.data, y.data), x.scale)
-                else:
-                    same = a[0] == a[1]
-                    if not isinstance(x, Cipher):
-                        x, y = y, x
-                    if isinstance(y, Cipher):
-                        out = self.o.square(x.data) if same else self.o.multiply(x.data, y.data)
-                    else:
-                        out = self.o.multiply_plain(x.data, y.data)
-                    vals[t] = Cipher(out, x.scale * y.scale)
-            elif op in (Op.RotateLeftConst, Op.RotateRightConst):
-                x = vals[a[0]]
-                if isinstance(x, list):
-                    vals[t] = _rot(x, d["rotation"], op == Op.RotateLeftConst)
-                else:
-                    steps = d["rotation"] if op == Op.RotateLeftConst else -d["rotation"]
-                    key = None
-                    if steps != 0:
-                        key = self.galois[po.galois_elt_from_step(self.N, steps)]
-                    vals[t] = Cipher(self.o.rotate(x.data, steps, key), x.scale)
-            elif op == Op.Negate:
-                x = vals[a[0]]
-                vals[t] = [-u for u in x] if isinstance(x, list) else Cipher(self.o.negate(x.data), x.scale)
-            elif op == Op.Relinearize:
-                x = vals[a[0]]
-                vals[t] = Cipher(self.o.relinearize(x.data, self.relin), x.scale)
-            elif op == Op.ModSwitch:
-                x = vals[a[0]]
-                vals[t] = Cipher(self.o.mod_switch(x.data), x.scale)
-            elif op == Op.Rescale:
-                x = vals[a[0]]
-                vals[t] = Cipher(self.o.rescale(x.data), x.scale / 2.0 ** d["rescale_divisor"])
-            elif op == Op.Output:
-                vals[t] = vals[a[0]]
-            else:
-                raise RuntimeError(f"Unhandled op {op}")
+        dump = program._dump()
+        if threads <= 1:
+            for d in dump:
+                if d["op"] != Op.Input:
+                    vals[d["id"]] = self._eval(program, d, vals)
+        else:
+            # node-level parallel walk (dependency counting over a thread pool; ctypes releases the
+            # GIL inside the oracle) — the CPU analogue of MulticoreProgramTraversal::forwardPass
+            import threading
+            from concurrent.futures import ThreadPoolExecutor
+            nodes = {d["id"]: d for d in dump if d["op"] != Op.Input}
+            waiting = {t: sum(1 for o in set(d["operands"]) if o in nodes) for t, d in nodes.items()}
+            users = {}
+            for t, d in nodes.items():
+                for o in set(d["operands"]):
+                    if o in nodes:
+                        users.setdefault(o, []).append(t)
+            lock, done = threading.Lock(), threading.Event()
+            left = [len(nodes)]
+            errors = []
+            pool = ThreadPoolExecutor(max_workers=threads)
+
+            def run(t):
+                try:
+                    v = self._eval(program, nodes[t], vals)
+                except Exception as e:  # noqa: BLE001
+                    errors.append(e)
+                    done.set()
+                    return
+                ready = []
+                with lock:
+                    vals[t] = v
+                    left[0] -= 1
+                    for u in users.get(t, ()):
+                        waiting[u] -= 1
+                        if waiting[u] == 0:
+                            ready.append(u)
+                    if left[0] == 0:
+                        done.set()
+                for u in ready:
+                    pool.submit(run, u)
+            for t in [t for t, w in waiting.items() if w == 0]:
+                pool.submit(run, t)
+            done.wait()
+            pool.shutdown(wait=True)
+            if errors:
+                raise errors[0]
         return {name: vals[t.index] for name, t in program.outputs.items()}

@@ -84,3 +84,23 @@ def test_random_programs_compile_and_decrypt_on_the_oracle(seed):
     from test_gpu_fuzz import _random_program
     prog, inputs = _random_program(100 + seed, 32)
     compile_and_check(prog, inputs, executor="oracle", seed=seed + 1)
+
+
+def test_threaded_oracle_walk_equals_serial_walk():
+    """The node-parallel CPU walk (the reported multi-core baseline of the DAG configs) produces the
+    serial walk's ciphertexts."""
+    import numpy as np
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    from evatest import oracle_execute
+    from test_compiler import _sobel
+    sob = _sobel(16, 16, 256)
+    sob.set_input_scales(25)
+    sob.set_output_ranges(10)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(sob)
+    pub, sec = generate_keys(params, 5)
+    enc = pub.encrypt({'image': [((37 * i) % 256) / 255.0 for i in range(256)]}, sig)
+    a, b = oracle_execute(pub, compiled, enc), oracle_execute(pub, compiled, enc, threads=4)
+    for name in a.names():
+        x, y = a.get(name), b.get(name)
+        assert x[:4] == y[:4] and np.array_equal(x[4], y[4])
