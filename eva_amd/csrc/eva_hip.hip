@@ -19,6 +19,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "hostmath.h"
@@ -2126,130 +2127,320 @@ int evah_test_ntt(evah_ctx *c, uint32_t prime_idx, int inverse, uint64_t *host) 
 }
 
 // Whole-DAG submit over a value table (include/eva_hip.h).  Dispatch rules follow
-// seal_executor.h:114-215; the calls below are the same entry points a per-node host loop uses.
+// seal_executor.h:114-215.  The op list is scheduled level by level (depth = longest path from the
+// caller-placed values): the ops of one level are independent, so its rotations, rescales,
+// relinearizations and ciphertext products go out through the batched entry points; a
+// Relinearize consumed only by a Rescale is evaluated with it; multiply_plain / add chains whose
+// partial sums have no other reader collapse into evah_weighted_sum.  Same ciphertexts as calling
+// the entry points one op at a time in list order.
 int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab, uint32_t n_vals) {
+  struct LazySum { // unevaluated sum of products; the handles are aliases owned here
+    std::vector<evah_ct *> cts;
+    std::vector<evah_pt *> pts;
+    uint32_t size = 0, limbs = 0;
+    double scale = 0;
+  };
+  struct State {
+    evah_ctx *c;
+    std::map<uint32_t, LazySum> sums;
+    std::map<uint32_t, evah_ct *> relins; // value -> alias of the size-3 operand of a deferred Relinearize
+    ~State() {
+      for (auto &kv : sums) {
+        for (evah_ct *h : kv.second.cts) evah_ct_free(c, h);
+        for (evah_pt *h : kv.second.pts) evah_pt_free(c, h);
+      }
+      for (auto &kv : relins) evah_ct_free(c, kv.second);
+    }
+  } st{c, {}, {}};
+  auto chk = [&](int rc) {
+    if (rc) throw std::runtime_error(g_err);
+  };
   auto slot = [&](uint32_t i) -> evah_val & {
     if (i >= n_vals) throw std::invalid_argument("value index out of range");
     return tab[i];
   };
-  auto ct_of = [&](uint32_t i) -> evah_ct * {
-    evah_val &v = slot(i);
-    if (v.kind != EVAH_VAL_CT || !v.h) throw std::invalid_argument("operand is not a ciphertext");
-    return static_cast<evah_ct *>(v.h);
-  };
+  auto alias_ct = [](evah_ct *a) { evah_ct *o = new evah_ct(*a); o->buf->refs++; return o; };
+  auto alias_pt = [](evah_pt *a) { evah_pt *o = new evah_pt(*a); o->buf->refs++; return o; };
   auto release = [&](uint32_t i) {
-    evah_val &v = slot(i);
+    evah_val &v = tab[i];
     if (v.kind == EVAH_VAL_CT) evah_ct_free(c, static_cast<evah_ct *>(v.h));
     else if (v.kind == EVAH_VAL_PT) evah_pt_free(c, static_cast<evah_pt *>(v.h));
     v.kind = EVAH_VAL_NONE;
     v.h = nullptr;
   };
-  auto chk = [&](int rc) {
-    if (rc) throw std::runtime_error(g_err);
-  };
   auto put = [&](uint32_t dst, evah_ct *o) {
-    evah_val &v = slot(dst);
-    if (v.kind != EVAH_VAL_NONE) release(dst);
-    v.kind = EVAH_VAL_CT;
-    v.h = o;
+    tab[dst].kind = EVAH_VAL_CT;
+    tab[dst].h = o;
   };
+  auto drop_sum = [&](uint32_t v) {
+    auto it = st.sums.find(v);
+    if (it == st.sums.end()) return;
+    for (evah_ct *h : it->second.cts) evah_ct_free(c, h);
+    for (evah_pt *h : it->second.pts) evah_pt_free(c, h);
+    st.sums.erase(it);
+  };
+  // a value as a device ciphertext: deferred forms are evaluated on first demand
+  auto ct_of = [&](uint32_t v) -> evah_ct * {
+    auto ls = st.sums.find(v);
+    if (ls != st.sums.end()) {
+      evah_ct *o = nullptr;
+      std::vector<const evah_ct *> cc(ls->second.cts.begin(), ls->second.cts.end());
+      std::vector<const evah_pt *> pp(ls->second.pts.begin(), ls->second.pts.end());
+      chk(evah_weighted_sum(c, cc.data(), pp.data(), (uint32_t)cc.size(), &o));
+      drop_sum(v);
+      put(v, o);
+    }
+    auto lr = st.relins.find(v);
+    if (lr != st.relins.end()) {
+      evah_ct *o = nullptr;
+      chk(evah_relinearize(c, lr->second, &o));
+      evah_ct_free(c, lr->second);
+      st.relins.erase(lr);
+      put(v, o);
+    }
+    evah_val &x = slot(v);
+    if (x.kind != EVAH_VAL_CT || !x.h) throw std::invalid_argument("operand is not a ciphertext");
+    return static_cast<evah_ct *>(x.h);
+  };
+  auto is_ct = [&](uint32_t v) { return slot(v).kind == EVAH_VAL_CT || st.sums.count(v) || st.relins.count(v); };
+  auto is_plain_ct = [&](uint32_t v) { return tab[v].kind == EVAH_VAL_CT && !st.sums.count(v) && !st.relins.count(v); };
+
   API_BEGIN
   use(c);
+  // ---- analysis: producers, readers, levels (the list is in topological order, single assignment)
+  const int NONE = -1;
+  std::vector<int> producer(n_vals, NONE), only_reader(n_vals, NONE);
+  std::vector<uint32_t> reads(n_vals, 0), level(n_ops, 0);
+  std::vector<char> freeable(n_vals, 0);
+  auto arity = [](uint32_t op) { return (op == 11 || op == 12 || op == 13) ? 2 : (op == 1 || op == 3 || op == 23) ? 0 : 1; };
+  uint32_t depth = 0;
   for (uint32_t i = 0; i < n_ops; i++) {
     const evah_op &o = ops[i];
-    evah_ct *out = nullptr;
-    switch (o.op) {
-    case 1: case 3: case 23: // Input / Constant / Encode: the caller placed the value
+    const int na = arity(o.op);
+    if (na == 0) {
       if (slot(o.dst).kind == EVAH_VAL_NONE) throw std::invalid_argument("input / plaintext slot is empty");
       continue;
-    case 2: { // Output
-      if (o.dst != o.src0) {
-        evah_val &d = slot(o.dst), &s0 = slot(o.src0);
-        if (d.kind != EVAH_VAL_NONE) release(o.dst);
-        d = s0;
-        s0.kind = EVAH_VAL_NONE;
-        s0.h = nullptr;
+    }
+    if (slot(o.dst).kind != EVAH_VAL_NONE || producer[o.dst] != NONE)
+      throw std::invalid_argument("every value slot is written by exactly one op (dst slots start empty)");
+    const uint32_t srcs[2] = {o.src0, o.src1};
+    for (int k = 0; k < na; k++) {
+      const uint32_t v = srcs[k];
+      if (v >= n_vals) throw std::invalid_argument("value index out of range");
+      if (producer[v] == NONE && tab[v].kind == EVAH_VAL_NONE) throw std::invalid_argument("operand is used before it is produced");
+      if (producer[v] != NONE) level[i] = std::max(level[i], level[producer[v]] + 1);
+      only_reader[v] = reads[v] == 0 ? (int)i : -2;
+      reads[v]++;
+      if (o.flags & (k == 0 ? EVAH_OPF_FREE_SRC0 : EVAH_OPF_FREE_SRC1)) freeable[v] = 1;
+    }
+    producer[o.dst] = (int)i;
+    depth = std::max(depth, level[i]);
+  }
+  std::vector<std::vector<uint32_t>> buckets(depth + 1);
+  for (uint32_t i = 0; i < n_ops; i++)
+    if (arity(ops[i].op)) buckets[level[i]].push_back(i);
+  // dst is an intermediate nobody else sees and its one reader is an op of kind `by`
+  auto feeds_only = [&](uint32_t dst, uint32_t by) {
+    return reads[dst] == 1 && only_reader[dst] >= 0 && ops[only_reader[dst]].op == by && freeable[dst];
+  };
+  auto shape = [&](uint32_t v, uint32_t &size, uint32_t &limbs, double &scale) {
+    auto ls = st.sums.find(v);
+    if (ls != st.sums.end()) { size = ls->second.size; limbs = ls->second.limbs; scale = ls->second.scale; return; }
+    chk(evah_ct_info(ct_of(v), &size, &limbs, &scale));
+  };
+
+  for (auto &lvl : buckets) {
+    std::map<uint32_t, std::vector<uint32_t>> rots, relins, muls;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<uint32_t>> rescales;
+    std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> fused;
+    // ---- one op through the ordinary entry points (seal_executor.h:114-215)
+    auto single = [&](const evah_op &o) {
+      evah_ct *out = nullptr;
+      switch (o.op) {
+      case 2: { // Output: dst names the same ciphertext
+        evah_val &s0 = slot(o.src0);
+        if (s0.kind == EVAH_VAL_PT) { tab[o.dst].kind = EVAH_VAL_PT; tab[o.dst].h = alias_pt(static_cast<evah_pt *>(s0.h)); return; }
+        out = alias_ct(ct_of(o.src0));
+        break;
       }
-      continue;
-    }
-    case 10: chk(evah_negate(c, ct_of(o.src0), &out)); break;
-    case 11: case 13: { // Add / Mul: a plaintext first operand goes behind the ciphertext
-      uint32_t a = o.src0, b = o.src1;
-      if (slot(a).kind != EVAH_VAL_CT) std::swap(a, b);
-      evah_ct *x = ct_of(a);
-      const evah_val &y = slot(b);
-      if (y.kind == EVAH_VAL_CT) {
-        if (o.op == 11) chk(evah_add(c, x, static_cast<evah_ct *>(y.h), &out));
-        else if (a == b) chk(evah_square(c, x, &out));
-        else chk(evah_multiply(c, x, static_cast<evah_ct *>(y.h), &out));
-      } else if (y.kind == EVAH_VAL_PT) {
-        if (o.op == 11) chk(evah_add_plain(c, x, static_cast<evah_pt *>(y.h), &out));
-        else chk(evah_multiply_plain(c, x, static_cast<evah_pt *>(y.h), &out));
-      } else {
-        throw std::runtime_error("Unsupported operation encountered");
+      case 10: chk(evah_negate(c, ct_of(o.src0), &out)); break;
+      case 11: case 13: { // Add / Mul: a plaintext first operand goes behind the ciphertext
+        uint32_t a = o.src0, b = o.src1;
+        if (!is_ct(a)) std::swap(a, b);
+        if (!is_ct(a)) throw std::runtime_error("Unsupported operation encountered");
+        if (is_ct(b)) {
+          if (o.op == 11) chk(evah_add(c, ct_of(a), ct_of(b), &out));
+          else if (a == b) chk(evah_square(c, ct_of(a), &out));
+          else chk(evah_multiply(c, ct_of(a), ct_of(b), &out));
+        } else if (slot(b).kind == EVAH_VAL_PT) {
+          if (o.op == 11) chk(evah_add_plain(c, ct_of(a), static_cast<evah_pt *>(tab[b].h), &out));
+          else chk(evah_multiply_plain(c, ct_of(a), static_cast<evah_pt *>(tab[b].h), &out));
+        } else {
+          throw std::runtime_error("Unsupported operation encountered");
+        }
+        break;
       }
-      break;
-    }
-    case 12: {
-      evah_ct *x = ct_of(o.src0);
-      const evah_val &y = slot(o.src1);
-      if (y.kind == EVAH_VAL_CT) chk(evah_sub(c, x, static_cast<evah_ct *>(y.h), &out));
-      else if (y.kind == EVAH_VAL_PT) chk(evah_sub_plain(c, x, static_cast<evah_pt *>(y.h), &out));
-      else throw std::runtime_error("Unsupported operation encountered");
-      break;
-    }
-    case 14: case 15: {
-      // a run of rotations of the same operand -> one wide launch set (steps 0 stay single calls)
-      auto steps_of = [](const evah_op &r) { return r.op == 14 ? r.imm : -r.imm; };
-      uint32_t n = 1;
-      while (i + n < n_ops && n < (uint32_t)KS_BATCH_MAX && (ops[i + n].op == 14 || ops[i + n].op == 15) &&
-             ops[i + n].src0 == o.src0 && !(ops[i + n - 1].flags & EVAH_OPF_FREE_SRC0))
-        n++;
-      bool all_nonzero = true;
-      for (uint32_t j = 0; j < n; j++) all_nonzero = all_nonzero && steps_of(ops[i + j]) != 0;
-      if (n > 1 && all_nonzero) {
-        std::vector<int32_t> st(n);
-        std::vector<evah_ct *> outs(n, nullptr);
-        for (uint32_t j = 0; j < n; j++) st[j] = steps_of(ops[i + j]);
-        chk(evah_rotate_many(c, ct_of(o.src0), st.data(), n, outs.data()));
-        for (uint32_t j = 0; j < n; j++) put(ops[i + j].dst, outs[j]);
-        if (ops[i + n - 1].flags & EVAH_OPF_FREE_SRC0) release(o.src0);
-        i += n - 1;
-        continue;
+      case 12:
+        if (is_ct(o.src1)) chk(evah_sub(c, ct_of(o.src0), ct_of(o.src1), &out));
+        else if (slot(o.src1).kind == EVAH_VAL_PT) chk(evah_sub_plain(c, ct_of(o.src0), static_cast<evah_pt *>(tab[o.src1].h), &out));
+        else throw std::runtime_error("Unsupported operation encountered");
+        break;
+      case 14: chk(evah_rotate(c, ct_of(o.src0), o.imm, &out)); break;
+      case 15: chk(evah_rotate(c, ct_of(o.src0), -o.imm, &out)); break; // seal_executor.h:188
+      case 20: chk(evah_relinearize(c, ct_of(o.src0), &out)); break;
+      case 21: chk(evah_mod_switch(c, ct_of(o.src0), &out)); break;
+      case 22: chk(evah_rescale(c, ct_of(o.src0), (uint32_t)o.imm, &out)); break;
+      default: throw std::runtime_error("Unhandled op " + std::to_string(o.op));
       }
-      chk(evah_rotate(c, ct_of(o.src0), steps_of(o), &out));
-      break;
-    }
-    case 20: {
-      // Relinearize whose result is consumed and released by the next op, a Rescale: fused form
-      if (i + 1 < n_ops && ops[i + 1].op == 22 && ops[i + 1].src0 == o.dst && o.dst != o.src0 &&
-          (ops[i + 1].flags & EVAH_OPF_FREE_SRC0)) {
-        chk(evah_relinearize_rescale(c, ct_of(o.src0), (uint32_t)ops[i + 1].imm, &out));
-        if (o.flags & EVAH_OPF_FREE_SRC0) release(o.src0);
-        put(ops[i + 1].dst, out);
-        i += 1;
-        continue;
-      }
-      chk(evah_relinearize(c, ct_of(o.src0), &out));
-      break;
-    }
-    case 21: chk(evah_mod_switch(c, ct_of(o.src0), &out)); break;
-    case 22: chk(evah_rescale(c, ct_of(o.src0), (uint32_t)o.imm, &out)); break;
-    default: throw std::runtime_error("Unhandled op " + std::to_string(o.op));
-    }
-    const bool binary = o.op == 11 || o.op == 12 || o.op == 13;
-    // the result is stored before operands are released (dst may reuse an operand's slot)
-    evah_val keep0 = slot(o.src0), keep1 = binary ? slot(o.src1) : evah_val{EVAH_VAL_NONE, nullptr};
-    const bool f0 = o.flags & EVAH_OPF_FREE_SRC0, f1 = binary && (o.flags & EVAH_OPF_FREE_SRC1) && o.src1 != o.src0;
-    if (f0) { slot(o.src0).kind = EVAH_VAL_NONE; slot(o.src0).h = nullptr; }
-    if (f1) { slot(o.src1).kind = EVAH_VAL_NONE; slot(o.src1).h = nullptr; }
-    put(o.dst, out);
-    auto drop = [&](const evah_val &v) {
-      if (v.kind == EVAH_VAL_CT) evah_ct_free(c, static_cast<evah_ct *>(v.h));
-      else if (v.kind == EVAH_VAL_PT) evah_pt_free(c, static_cast<evah_pt *>(v.h));
+      put(o.dst, out);
     };
-    if (f0) drop(keep0);
-    if (f1) drop(keep1);
+    // ---- classify
+    for (uint32_t i : lvl) {
+      const evah_op &o = ops[i];
+      uint32_t size = 0, limbs = 0;
+      double scale = 0;
+      if ((o.op == 14 || o.op == 15) && o.imm != 0 && is_ct(o.src0)) {
+        shape(o.src0, size, limbs, scale);
+        rots[limbs].push_back(i);
+      } else if (o.op == 22 && st.relins.count(o.src0)) {
+        chk(evah_ct_info(st.relins[o.src0], &size, &limbs, &scale));
+        fused[{limbs, (uint32_t)o.imm}].push_back(i);
+      } else if (o.op == 22 && is_ct(o.src0)) {
+        shape(o.src0, size, limbs, scale);
+        rescales[{size, limbs, (uint32_t)o.imm}].push_back(i);
+      } else if (o.op == 20 && is_ct(o.src0)) {
+        if (feeds_only(o.dst, 22)) {
+          st.relins[o.dst] = alias_ct(ct_of(o.src0)); // evaluated together with its Rescale
+        } else {
+          shape(o.src0, size, limbs, scale);
+          relins[limbs].push_back(i);
+        }
+      } else if (o.op == 13 && o.src0 != o.src1 && is_ct(o.src0) && is_ct(o.src1)) {
+        shape(o.src0, size, limbs, scale);
+        muls[limbs].push_back(i);
+      } else if (o.op == 13 && feeds_only(o.dst, 11) &&
+                 ((is_plain_ct(o.src0) && slot(o.src1).kind == EVAH_VAL_PT) || (is_plain_ct(o.src1) && slot(o.src0).kind == EVAH_VAL_PT))) {
+        const uint32_t a = is_plain_ct(o.src0) ? o.src0 : o.src1, b = a == o.src0 ? o.src1 : o.src0;
+        evah_ct *x = static_cast<evah_ct *>(tab[a].h);
+        evah_pt *w = static_cast<evah_pt *>(tab[b].h);
+        if (w->limbs != x->limbs) { single(o); continue; } // multiply_plain reports the mismatch
+        LazySum ls;
+        ls.size = x->size; ls.limbs = x->limbs; ls.scale = x->scale * w->scale;
+        ls.cts.push_back(alias_ct(x));
+        ls.pts.push_back(alias_pt(w));
+        st.sums[o.dst] = std::move(ls);
+      } else if (o.op == 11 && is_ct(o.src0) && is_ct(o.src1) && !st.relins.count(o.src0) && !st.relins.count(o.src1) &&
+                 (st.sums.count(o.src0) || st.sums.count(o.src1) || feeds_only(o.dst, 11))) {
+        uint32_t s0, l0, s1, l1;
+        double c0, c1;
+        shape(o.src0, s0, l0, c0);
+        shape(o.src1, s1, l1, c1);
+        size_t nterms = 0;
+        for (uint32_t v : {o.src0, o.src1}) nterms += st.sums.count(v) ? st.sums[v].cts.size() : 1;
+        if (s0 != s1 || l0 != l1 || c0 != c1 || nterms > (size_t)KS_BATCH_MAX) { single(o); continue; }
+        LazySum ls;
+        ls.size = s0; ls.limbs = l0; ls.scale = c0;
+        for (uint32_t v : {o.src0, o.src1}) {
+          auto it = st.sums.find(v);
+          if (it != st.sums.end()) {
+            for (evah_ct *h : it->second.cts) ls.cts.push_back(alias_ct(h));
+            for (evah_pt *h : it->second.pts) ls.pts.push_back(h ? alias_pt(h) : nullptr);
+          } else {
+            ls.cts.push_back(alias_ct(static_cast<evah_ct *>(tab[v].h)));
+            ls.pts.push_back(nullptr);
+          }
+        }
+        st.sums[o.dst] = std::move(ls);
+        if (!(feeds_only(o.dst, 11) && nterms < (size_t)KS_BATCH_MAX)) (void)ct_of(o.dst); // the chain ends here
+      } else {
+        single(o);
+      }
+    }
+    // ---- the batchable kinds of this level
+    auto each_chunk = [&](std::vector<uint32_t> &g, size_t cap, auto &&fn) {
+      if (g.size() == 1) { single(ops[g[0]]); return; }
+      for (size_t i = 0; i < g.size(); i += cap) fn(g.data() + i, (uint32_t)std::min(cap, g.size() - i));
+    };
+    auto store = [&](const uint32_t *is, uint32_t n, std::vector<evah_ct *> &outs) {
+      for (uint32_t j = 0; j < n; j++) put(ops[is[j]].dst, outs[j]);
+    };
+    for (auto &kv : rots)
+      each_chunk(kv.second, KS_BATCH_MAX, [&](const uint32_t *is, uint32_t n) {
+        std::vector<const evah_ct *> in(n);
+        std::vector<int32_t> steps(n);
+        std::vector<evah_ct *> outs(n, nullptr);
+        for (uint32_t j = 0; j < n; j++) {
+          in[j] = ct_of(ops[is[j]].src0);
+          steps[j] = ops[is[j]].op == 14 ? ops[is[j]].imm : -ops[is[j]].imm;
+        }
+        chk(evah_rotate_pairs(c, in.data(), steps.data(), n, outs.data()));
+        store(is, n, outs);
+      });
+    for (auto &kv : fused) {
+      auto fused_single = [&](uint32_t i) {
+        const evah_op &o = ops[i];
+        evah_ct *out = nullptr;
+        chk(evah_relinearize_rescale(c, st.relins[o.src0], (uint32_t)o.imm, &out));
+        evah_ct_free(c, st.relins[o.src0]);
+        st.relins.erase(o.src0);
+        put(o.dst, out);
+      };
+      if (kv.second.size() == 1) { fused_single(kv.second[0]); continue; }
+      for (size_t i0 = 0; i0 < kv.second.size(); i0 += KS_BATCH_MAX) {
+        const uint32_t n = (uint32_t)std::min<size_t>(KS_BATCH_MAX, kv.second.size() - i0);
+        const uint32_t *is = kv.second.data() + i0;
+        std::vector<const evah_ct *> in(n);
+        std::vector<evah_ct *> outs(n, nullptr);
+        for (uint32_t j = 0; j < n; j++) in[j] = st.relins[ops[is[j]].src0];
+        chk(evah_relinearize_rescale_many(c, in.data(), n, kv.first.second, outs.data()));
+        for (uint32_t j = 0; j < n; j++) {
+          evah_ct_free(c, st.relins[ops[is[j]].src0]);
+          st.relins.erase(ops[is[j]].src0);
+        }
+        store(is, n, outs);
+      }
+    }
+    for (auto &kv : rescales)
+      each_chunk(kv.second, (2 * KS_BATCH_MAX) / std::get<0>(kv.first), [&](const uint32_t *is, uint32_t n) {
+        std::vector<const evah_ct *> in(n);
+        std::vector<evah_ct *> outs(n, nullptr);
+        for (uint32_t j = 0; j < n; j++) in[j] = ct_of(ops[is[j]].src0);
+        chk(evah_rescale_many(c, in.data(), n, std::get<2>(kv.first), outs.data()));
+        store(is, n, outs);
+      });
+    for (auto &kv : relins)
+      each_chunk(kv.second, KS_BATCH_MAX, [&](const uint32_t *is, uint32_t n) {
+        std::vector<const evah_ct *> in(n);
+        std::vector<evah_ct *> outs(n, nullptr);
+        for (uint32_t j = 0; j < n; j++) in[j] = ct_of(ops[is[j]].src0);
+        chk(evah_relinearize_many(c, in.data(), n, outs.data()));
+        store(is, n, outs);
+      });
+    for (auto &kv : muls)
+      each_chunk(kv.second, KS_BATCH_MAX, [&](const uint32_t *is, uint32_t n) {
+        std::vector<const evah_ct *> ia(n), ib(n);
+        std::vector<evah_ct *> outs(n, nullptr);
+        for (uint32_t j = 0; j < n; j++) {
+          ia[j] = ct_of(ops[is[j]].src0);
+          ib[j] = ct_of(ops[is[j]].src1);
+        }
+        chk(evah_multiply_many(c, ia.data(), ib.data(), n, outs.data()));
+        store(is, n, outs);
+      });
+    // ---- operands whose last reader has run are released (deferred forms hold their own aliases)
+    for (uint32_t i : lvl) {
+      const evah_op &o = ops[i];
+      const uint32_t srcs[2] = {o.src0, o.src1};
+      for (int k = 0; k < arity(o.op); k++) {
+        const uint32_t v = srcs[k];
+        if (--reads[v] == 0 && freeable[v]) {
+          drop_sum(v);
+          auto lr = st.relins.find(v);
+          if (lr != st.relins.end()) { evah_ct_free(c, lr->second); st.relins.erase(lr); }
+          if (tab[v].kind != EVAH_VAL_NONE) release(v);
+        }
+      }
+    }
   }
   API_END
 }

@@ -187,16 +187,23 @@ int evah_mod_switch(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
  * (program_traversal.h:36-93, seal_executor.h:279-404) for the encrypted part of a program.
  *   op    : the reference's Op codes (eva/ir/ops.h:11-25): Negate 10, Add 11, Sub 12, Mul 13,
  *           RotateLeftConst 14, RotateRightConst 15, Relinearize 20, ModSwitch 21, Rescale 22,
- *           Output 2 (dst becomes an alias of src0; src0's slot is emptied)
+ *           Output 2 (dst names the same ciphertext as src0); Input 1 / Constant 3 / Encode 23 are
+ *           accepted as markers of caller-placed slots
  *   imm   : rotation steps (14/15), rescale divisor bits (22)
- *   flags : EVAH_OPF_FREE_SRC0/1 = release that operand after this op (its last use; the reference
- *           frees at last use under Galois, multicore_program_traversal.h:62-67)
+ *   flags : EVAH_OPF_FREE_SRC0/1 = the caller does not need that operand afterwards: it is released
+ *           once its last reader in the list has run (the reference frees at last use under
+ *           Galois, multicore_program_traversal.h:62-67)
+ * Single assignment: every dst slot starts empty and is written by exactly one op; inputs and
+ * encoded plaintexts (Encode / Constant nodes) are placed in the table by the caller; on return
+ * the slots written by ops hold new handles owned by the caller (unless released by a flag).
  * Operand kinds select the evaluator call exactly as seal_executor.h:114-175 does: Add/Mul swap a
  * plaintext first operand behind the ciphertext, Mul with src0 == src1 is square, Sub needs a
- * ciphertext first.  Inputs, encoded plaintexts (Encode/Constant nodes) are placed in the table
- * by the caller; on return the slots named by executed ops hold new handles owned by the caller.
- * Inside, Relinearize followed by the Rescale that consumes (and frees) it, and runs of rotations
- * of one operand, are issued through the fused / batched forms (same ciphertexts). */
+ * ciphertext first.
+ * Scheduling inside (same ciphertexts as running the list op by op): ops are taken level by level
+ * (depth from the caller-placed values — what MulticoreProgramTraversal's ready set holds), the
+ * independent rotations / rescales / relinearizations / ciphertext products of a level go out
+ * through the batched entry points, a Relinearize read only by a Rescale is evaluated with it,
+ * and multiply_plain / add chains without other readers become one evah_weighted_sum. */
 enum { EVAH_VAL_NONE = 0, EVAH_VAL_CT = 1, EVAH_VAL_PT = 2 };
 enum { EVAH_OPF_FREE_SRC0 = 1, EVAH_OPF_FREE_SRC1 = 2 };
 typedef struct evah_val { uint32_t kind; void *h; } evah_val;

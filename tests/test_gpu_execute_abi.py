@@ -123,6 +123,21 @@ def test_execute_sobel_n8192():
     assert sum(1 for o in ops if o[0] in (int(Op.RotateLeftConst), int(Op.RotateRightConst))) >= 8
 
 
+def test_execute_harris_level_batching():
+    """BASELINE config 3's DAG (three independent convolution chains) through the one-call submit:
+    its level scheduler batches them; results still equal the oracle walk."""
+    from test_gpu_e2e import _harris, _image
+    _check(_harris(), _image(4096), N=16384)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_execute_random_programs(seed):
+    """the generator of tests/test_gpu_fuzz.py through evah_execute"""
+    from test_gpu_fuzz import _random_program
+    prog, inputs = _random_program(1000 + seed, 64)
+    _check(prog, inputs)
+
+
 def test_execute_reports_errors():
     g = be.Context(1024, be.default_test_primes(1024)) if hasattr(be, "default_test_primes") else None
     if g is None:
@@ -130,8 +145,10 @@ def test_execute_reports_errors():
         g = be.Context(1024, coeff_modulus_create(1024, [30, 30, 30]))
     rng = np.random.default_rng(1)
     a = g.upload_ct(rng.integers(0, 1 << 20, size=(2, 2, 1024), dtype=np.uint64), 2.0 ** 10)
-    with pytest.raises(RuntimeError, match="not a ciphertext|out of range"):
+    with pytest.raises(RuntimeError, match="not a ciphertext|out of range|before it is produced"):
         g.execute([(int(Op.Negate), 1, 5, 0, 0, 0)], {0: a}, n_vals=3)
+    with pytest.raises(RuntimeError, match="written by exactly one op"):
+        g.execute([(int(Op.Negate), 1, 0, 0, 0, 0), (int(Op.Negate), 1, 0, 0, 0, 0)], {0: a}, n_vals=3)
     with pytest.raises(RuntimeError, match="Unhandled op"):
         g.execute([(99, 1, 0, 0, 0, 0)], {0: a}, n_vals=3)
     with pytest.raises(RuntimeError, match="relinearization key not present|size-3"):
