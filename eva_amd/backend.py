@@ -190,6 +190,11 @@ class Ciphertext:
         _chk(_lib.evah_ct_download(self.ctx.h, self.h, _p(out)))
         return out if b > 1 else out[0]
 
+    def write(self, data):
+        """overwrite the device words of this handle (same shape): refill of a captured graph's input"""
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        _chk(_lib.evah_ct_write(self.ctx.h, self.h, _p(data)))
+
     def unstack(self, b):
         h = C.c_void_p()
         _chk(_lib.evah_ct_unstack(self.ctx.h, self.h, int(b), C.byref(h)))
@@ -407,6 +412,21 @@ class Context:
         outs = (C.c_void_p * n)()
         _chk(_lib.evah_multiply_many(self.h, ia, ib, n, outs))
         return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n)]
+
+    # ---- graph capture of a sequence of calls on this context (single queue)
+    def capture_begin(self):
+        _chk(_lib.evah_capture_begin(self.h, None, 0))
+
+    def capture_end(self):
+        g = C.c_void_p()
+        _chk(_lib.evah_capture_end(self.h, None, 0, C.byref(g)))
+        return g
+
+    def graph_launch(self, g):
+        _chk(_lib.evah_graph_launch(self.h, g))
+
+    def graph_free(self, g):
+        _lib.evah_graph_free(g)
 
     def execute(self, ops, values, n_vals=None):
         """evah_execute: `ops` = [(op, dst, src0, src1, imm, flags)], `values` = {slot: Ciphertext |

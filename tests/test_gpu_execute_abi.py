@@ -138,6 +138,44 @@ def test_execute_random_programs(seed):
     _check(prog, inputs)
 
 
+def test_execute_captured_into_a_graph_and_replayed():
+    """evah_capture_begin / evah_execute / evah_capture_end: the whole program becomes one hipGraph;
+    refilling the input slot (evah_ct_write) and launching the graph gives the oracle's ciphertext
+    for the new input."""
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    from oracle_executor import OracleExecutor
+    sob = _sobel(32, 32, 1024)
+    sob.set_input_scales(25)
+    sob.set_output_ranges(10)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(sob)
+    pub, sec = generate_keys(params, 4)
+    g = be.Context(pub.poly_modulus_degree, list(pub.primes))
+    g.upload_relin_key(pub.relin_key())
+    for elt, key in pub.galois_keys().items():
+        g.upload_galois_key(elt, key)
+    img = lambda u: {'image': [((37 * i + 13 * u) % 256) / 255.0 for i in range(1024)]}
+    enc0, enc1 = pub.encrypt(img(0), sig), pub.encrypt(img(1), sig)
+    ops, values, outs = _lower(compiled, enc0, pub, g)
+    # the caller keeps its inputs: strip the release flags of caller-placed slots (none are set by _lower)
+    warm = g.execute(ops, dict(values))          # eager: builds permutation tables, fills the pool
+    for t, h in warm.items():
+        if t not in values:
+            h.free()
+    g.capture_begin()
+    res = g.execute(ops, dict(values))
+    graph = g.capture_end()
+    (name, t_out), = outs.items()
+    in_slot = compiled.inputs['image'].index
+    for enc in (enc0, enc1, enc0):
+        kind, size, limbs, scale, data = enc.get('image')
+        values[in_slot].write(data)
+        g.graph_launch(graph)
+        ref = OracleExecutor(pub).execute(compiled, enc)
+        assert np.array_equal(res[t_out].download(), ref[name].data)
+    g.graph_free(graph)
+
+
 def test_execute_reports_errors():
     g = be.Context(1024, be.default_test_primes(1024)) if hasattr(be, "default_test_primes") else None
     if g is None:
