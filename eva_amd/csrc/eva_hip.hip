@@ -2299,6 +2299,12 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
       const evah_op &o = ops[i];
       uint32_t size = 0, limbs = 0;
       double scale = 0;
+      // a batched handle already covers its instances in one launch set: the *_many forms take
+      // single ciphertexts, so its ops go through the ordinary entry points
+      if (tab[o.src0].kind == EVAH_VAL_CT && static_cast<evah_ct *>(tab[o.src0].h)->batch > 1 && !st.sums.count(o.src0)) {
+        single(o);
+        continue;
+      }
       if ((o.op == 14 || o.op == 15) && o.imm != 0 && is_ct(o.src0)) {
         shape(o.src0, size, limbs, scale);
         rots[limbs].push_back(i);

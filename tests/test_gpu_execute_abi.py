@@ -176,6 +176,34 @@ def test_execute_captured_into_a_graph_and_replayed():
     g.graph_free(graph)
 
 
+def test_execute_on_batched_handles():
+    """The same op list over batched input handles (three encryptions in one handle): every
+    instance of every output equals the oracle walk of that instance."""
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    from oracle_executor import OracleExecutor
+    sob = _sobel(32, 32, 1024)
+    sob.set_input_scales(25)
+    sob.set_output_ranges(10)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(sob)
+    pub, sec = generate_keys(params, 6)
+    g = be.Context(pub.poly_modulus_degree, list(pub.primes))
+    g.upload_relin_key(pub.relin_key())
+    for elt, key in pub.galois_keys().items():
+        g.upload_galois_key(elt, key)
+    encs = [pub.encrypt({'image': [((37 * i + 29 * u) % 256) / 255.0 for i in range(1024)]}, sig) for u in range(3)]
+    ops, values, outs = _lower(compiled, encs[0], pub, g)
+    in_slot = compiled.inputs['image'].index
+    datas = [e.get('image') for e in encs]
+    values[in_slot] = g.upload_ct_batch(np.stack([d[4] for d in datas]), datas[0][3])
+    res = g.execute(ops, values)
+    (name, t_out), = outs.items()
+    got = res[t_out].download()
+    assert got.shape[0] == 3
+    for u, enc in enumerate(encs):
+        assert np.array_equal(got[u], OracleExecutor(pub).execute(compiled, enc)[name].data), f"instance {u}"
+
+
 def test_execute_reports_errors():
     g = be.Context(1024, be.default_test_primes(1024)) if hasattr(be, "default_test_primes") else None
     if g is None:
