@@ -345,28 +345,38 @@ public:
         objects[t] = std::make_shared<CtHandle>(ctx, h);
       }
       break;
-    case Op::Relinearize: {
-      const auto &uses = x.uses;
-      if (fuse_relin_rescale && uses.size() == 1 && program.at(uses[0]).op == Op::Rescale) {
-        objects[t] = LazyRelin{a[0]};
-        queue_of[t] = queue_of[a[0]];
+    case Op::Relinearize:
+    case Op::ModSwitch:
+    case Op::Rescale:
+      if (is_raw(a[0])) {
+        // scale management of an unencrypted value: the reduction balancer can pair constants, and
+        // the rescaler then treats raw x raw like any product.  The reference's SEALExecutor would
+        // throw std::bad_variant_access here (seal_executor.h:197-215 take a Ciphertext); its
+        // semantic executor copies (reference_executor.cpp) — which is what the value means.
+        objects[t] = raw(a[0]);
         break;
       }
-      evah_ct *h = nullptr;
-      chk(evah_relinearize(ctx, ct(a[0]), &h));
-      objects[t] = std::make_shared<CtHandle>(ctx, h);
-    } break;
-    case Op::ModSwitch: {
-      evah_ct *h = nullptr;
-      chk(evah_mod_switch(ctx, ct(a[0]), &h));
-      objects[t] = std::make_shared<CtHandle>(ctx, h);
-    } break;
-    case Op::Rescale: {
-      evah_ct *h = nullptr;
-      if (auto *lz = std::get_if<LazyRelin>(&objects[a[0]])) chk(evah_relinearize_rescale(ctx, ct(lz->src), x.rescale_divisor, &h));
-      else chk(evah_rescale(ctx, ct(a[0]), x.rescale_divisor, &h));
-      objects[t] = std::make_shared<CtHandle>(ctx, h);
-    } break;
+      if (x.op == Op::Relinearize) {
+        const auto &uses = x.uses;
+        if (fuse_relin_rescale && uses.size() == 1 && program.at(uses[0]).op == Op::Rescale) {
+          objects[t] = LazyRelin{a[0]};
+          queue_of[t] = queue_of[a[0]];
+          break;
+        }
+        evah_ct *h = nullptr;
+        chk(evah_relinearize(ctx, ct(a[0]), &h));
+        objects[t] = std::make_shared<CtHandle>(ctx, h);
+      } else if (x.op == Op::ModSwitch) {
+        evah_ct *h = nullptr;
+        chk(evah_mod_switch(ctx, ct(a[0]), &h));
+        objects[t] = std::make_shared<CtHandle>(ctx, h);
+      } else {
+        evah_ct *h = nullptr;
+        if (auto *lz = std::get_if<LazyRelin>(&objects[a[0]])) chk(evah_relinearize_rescale(ctx, ct(lz->src), x.rescale_divisor, &h));
+        else chk(evah_rescale(ctx, ct(a[0]), x.rescale_divisor, &h));
+        objects[t] = std::make_shared<CtHandle>(ctx, h);
+      }
+      break;
     case Op::Output:
       if (std::holds_alternative<LazyPlain>(objects[a[0]])) (void)pt(a[0]);
       objects[t] = objects[a[0]];

@@ -82,6 +82,11 @@ class OracleExecutor:
         elif op == Op.Negate:
             x = vals[a[0]]
             return [-u for u in x] if isinstance(x, list) else Cipher(self.o.negate(x.data), x.scale)
+        elif op in (Op.Relinearize, Op.ModSwitch, Op.Rescale) and isinstance(vals[a[0]], list):
+            # a scale-management node on an unencrypted value (the reduction balancer can pair
+            # constants: raw x raw products the rescaler then treats like any product) is a copy,
+            # as in the reference's semantic executor (eva/common/reference_executor.cpp)
+            return vals[a[0]]
         elif op == Op.Relinearize:
             x = vals[a[0]]
             return Cipher(self.o.relinearize(x.data, self.relin), x.scale)

@@ -321,3 +321,9 @@ def test_execute_batch_equals_execute_per_instance():
     with pytest.raises(RuntimeError, match="batch_chunk"):
         pub.batch_chunk = 65
         pub.execute_batch(compiled, encs)
+
+
+def test_product_of_several_constants_with_a_ciphertext():
+    """see tests/test_host_e2e_cpu.py: a Rescale lands on an unencrypted constant product"""
+    from test_host_e2e_cpu import _constant_chain_program
+    compile_and_check(_constant_chain_program(), {'x': [i / 16.0 for i in range(16)]}, check_bit_exact=True)

@@ -52,6 +52,7 @@ def _lower(compiled, enc_inputs, pub, g):
             elif op == Op.Sub: raw[t] = [u - v for u, v in zip(*x)]
             elif op == Op.Mul: raw[t] = [u * v for u, v in zip(*x)]
             elif op == Op.Negate: raw[t] = [-u for u in x[0]]
+            elif op in (Op.Rescale, Op.Relinearize, Op.ModSwitch): raw[t] = list(x[0])  # scale management of a raw value: a copy
             else: raise RuntimeError("raw op not needed by these programs")
             continue
         imm = d.get("rotation", d.get("rescale_divisor", 0)) or 0

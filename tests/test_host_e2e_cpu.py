@@ -104,3 +104,30 @@ def test_threaded_oracle_walk_equals_serial_walk():
     for name in a.names():
         x, y = a.get(name), b.get(name)
         assert x[:4] == y[:4] and np.array_equal(x[4], y[4])
+
+
+def _constant_chain_program():
+    prog = EvaProgram('consts', vec_size=16)
+    with prog:
+        x = Input('x')
+        Output('y', x * 0.5 * 0.25 * 2.0 * 1.5 + x)
+    prog.set_input_scales(30)
+    prog.set_output_ranges(20)
+    return prog
+
+
+def test_product_of_several_constants_with_a_ciphertext():
+    """x*c1*c2*c3*c4: the reduction balancer pairs the constants (raw x raw products created after
+    type deduction), the rescaler then inserts a Rescale on an unencrypted value — found by the
+    randomised test (seed 418).  The reference's SEALExecutor cannot run that node
+    (seal_executor.h:209-215 takes a Ciphertext); here it is the copy its semantic executor makes."""
+    prog = _constant_chain_program()
+    compiled, params, sig = compile_and_check(prog, {'x': [i / 16.0 for i in range(16)]}, executor="oracle")
+    from eva import Op
+    dump = {d["id"]: d for d in compiled._dump()}
+
+    def unencrypted(t):
+        d = dump[t]
+        return d["op"] == Op.Constant or (d["op"] == Op.Mul and all(unencrypted(o) for o in d["operands"]))
+    assert any(d["op"] == Op.Rescale and unencrypted(d["operands"][0]) for d in dump.values()), \
+        "this program is meant to put a Rescale on a constant product"
