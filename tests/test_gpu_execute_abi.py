@@ -131,7 +131,7 @@ def test_execute_harris_level_batching():
     _check(_harris(), _image(4096), N=16384)
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EVA_FUZZ_SEEDS", "48"))))
 def test_execute_random_programs(seed):
     """the generator of tests/test_gpu_fuzz.py through evah_execute"""
     from test_gpu_fuzz import _random_program
