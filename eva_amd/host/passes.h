@@ -769,7 +769,15 @@ private:
       ms.finish();
     }
     forward_pass(p, TypeDeducer{p, types});
-    forward_pass(p, BackendLowering{p, types});
+    // Every term of a snapshot of the order is offered to the lowering.  (The reference runs it
+    // through ProgramTraversal, whose ready-list never reaches the Negate / Add it creates, so a
+    // second plaintext-minus-ciphertext downstream of a lowered one stays a Sub that its executor
+    // cannot run — seal_lowering.h:24-30, program_traversal.h:36-88; found by tests/test_gpu_fuzz.py.)
+    {
+      BackendLowering lower{p, types};
+      for (TermId t : p.topo_order()) lower(t);
+      p.gc();
+    }
     forward_pass(p, TypeDeducer{p, types});
   }
 

@@ -56,6 +56,8 @@ class OracleExecutor:
                 else:
                     return Cipher(self.o.add_plain(x.data, y.data), x.scale)
             elif op == Op.Sub:
+                if not isinstance(x, Cipher):  # seal_executor.h:139: std::get<Ciphertext>(args1)
+                    raise RuntimeError("Unsupported operation encountered")
                 if isinstance(y, Cipher):
                     return Cipher(self.o.sub(x.data, y.data), x.scale)
                 else:

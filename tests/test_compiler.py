@@ -198,3 +198,23 @@ def test_repeated_squaring_is_not_flattened():
     assert ops.count(Op.Relinearize) == 8
     assert sum(1 for d in compiled._dump() if d["op"] == Op.Mul and d["operands"][0] == d["operands"][1]) == 8
     assert len(params.prime_bits) == 10  # 8 rescale primes + one output prime + special
+
+
+def test_every_plain_minus_cipher_is_lowered():
+    """seal_lowering.h:24-30 turns plaintext - ciphertext into (-ciphertext) + plaintext; the
+    reference's traversal never reaches terms downstream of the Negate/Add it creates, so a second
+    such Sub further down survives there.  Here every one is lowered."""
+    from eva import EvaProgram, Input, Output, Op
+    from eva.ckks import CKKSCompiler
+    prog = EvaProgram('subs', vec_size=8)
+    with prog:
+        x = Input('x')
+        p = Input('p', False)
+        y = (p - x) + 0.5
+        Output('y', p - (y + y))
+    prog.set_input_scales(30)
+    prog.set_output_ranges(20)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    dump = {d["id"]: d for d in compiled._dump()}
+    assert not any(d["op"] == Op.Sub for d in dump.values())
+    assert sum(1 for d in dump.values() if d["op"] == Op.Negate) == 2

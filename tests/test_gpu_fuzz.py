@@ -20,11 +20,17 @@ pytestmark = pytest.mark.gpu
 def _random_program(seed, vec):
     rng = random.Random(seed)
     prog = EvaProgram(f'fuzz{seed}', vec_size=vec)
+    rich = seed >= 2000 or seed % 5 == 4   # also: unencrypted inputs, vector constants, powers
     with prog:
         names = [f'x{i}' for i in range(rng.randint(1, 3))]
         pool = [(Input(n), 0) for n in names]           # (expression, multiplicative depth)
+        plain_names = []
+        if rich and rng.random() < 0.5:
+            plain_names = ['p0']
+            pool.append((Input('p0', False), 0))         # an unencrypted input: encoded at run time
         for _ in range(rng.randint(6, 14) if seed < 64 else rng.randint(10, 30)):
-            kind = rng.choice(['add', 'add', 'sub', 'mul', 'mulc', 'mulc', 'addc', 'rot', 'neg', 'sq'])
+            kind = rng.choice(['add', 'add', 'sub', 'mul', 'mulc', 'mulc', 'addc', 'rot', 'neg', 'sq'] +
+                              (['mulv', 'addv', 'pow'] if rich else []))
             a, da = rng.choice(pool)
             b, db = rng.choice(pool)
             c = round(rng.uniform(-1, 1), 3)
@@ -36,17 +42,23 @@ def _random_program(seed, vec):
             elif kind == 'sq':
                 if da >= 1: continue
                 e, d = a * a, da + 1
+            elif kind == 'pow':
+                if da >= 1: continue
+                e, d = a ** 3, da + 2
             elif kind == 'mulc': e, d = a * c, da
             elif kind == 'addc': e, d = a + c, da
+            elif kind == 'mulv': e, d = a * [round(rng.uniform(-1, 1), 3) for _ in range(vec)], da
+            elif kind == 'addv': e, d = a + [round(rng.uniform(-1, 1), 3) for _ in range(vec)], da
             elif kind == 'rot': e, d = (a << rng.randint(1, 5)) if rng.random() < 0.7 else (a >> rng.randint(1, 3)), da
             else: e, d = -a, da
             pool.append((e, d))
-        outs = rng.sample(pool[len(names):], k=min(2, len(pool) - len(names)))
+        first = len(names) + len(plain_names)
+        outs = rng.sample(pool[first:], k=min(2, len(pool) - first))
         for i, (e, _) in enumerate(outs):
             Output(f'y{i}', e)
     prog.set_input_scales(30)
     prog.set_output_ranges(20)
-    inputs = {n: [rng.uniform(-1, 1) for _ in range(vec)] for n in names}
+    inputs = {n: [rng.uniform(-1, 1) for _ in range(vec)] for n in names + plain_names}
     return prog, inputs
 
 
@@ -79,7 +91,8 @@ def test_random_program_bit_exact(seed):
         out = pub.execute(compiled, enc)
     _same(out, ref, "graph replay")
     pub.batch_chunk = 2
-    other = {n: [v * 0.5 for v in x] for n, x in inputs.items()}
+    # unencrypted inputs are shared by the instances of a batch; the encrypted ones differ
+    other = {n: (x if n.startswith('p') else [v * 0.5 for v in x]) for n, x in inputs.items()}
     enc2 = pub.encrypt(other, sig)
     outs = pub.execute_batch(compiled, [enc, enc2, enc])
     _same(outs[0], ref, "execute_batch[0]")
