@@ -77,7 +77,13 @@ import os
 @pytest.mark.parametrize("seed", range(int(os.environ.get("EVA_FUZZ_SEEDS", "64"))))
 def test_random_program_bit_exact(seed):
     prog, inputs = _random_program(seed, 64)
-    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    config = {'warn_vec_size': 'false'}
+    if seed >= 3000:   # the general-purpose compiler configurations, chosen by the seed
+        rng = random.Random(seed)
+        config.update(rescaler=rng.choice(['lazy_waterline', 'eager_waterline']),
+                      lazy_relinearize=rng.choice(['true', 'false']),
+                      balance_reductions=rng.choice(['true', 'false']))
+    compiled, params, sig = CKKSCompiler(config=config).compile(prog)
     assert valuation_mse(evaluate(prog, inputs), evaluate(compiled, inputs)) < 1e-10
     if seed % 3 == 0:
         params.poly_modulus_degree = max(params.poly_modulus_degree, 4096)
