@@ -8,7 +8,7 @@ import random
 import numpy as np
 import pytest
 
-from eva import EvaProgram, Input, Output, evaluate
+from eva import EvaProgram, Input, Op, Output, evaluate
 from eva.ckks import CKKSCompiler
 from eva.metric import valuation_mse
 from eva.seal import generate_keys
@@ -30,7 +30,7 @@ def _random_program(seed, vec):
             pool.append((Input('p0', False), 0))         # an unencrypted input: encoded at run time
         for _ in range(rng.randint(6, 14) if seed < 64 else rng.randint(10, 30)):
             kind = rng.choice(['add', 'add', 'sub', 'mul', 'mulc', 'mulc', 'addc', 'rot', 'neg', 'sq'] +
-                              (['mulv', 'addv', 'pow'] if rich else []))
+                              (['mulv', 'addv', 'pow'] if rich else []) + (['hsum', 'id'] if seed >= 4200 else []))
             a, da = rng.choice(pool)
             b, db = rng.choice(pool)
             c = round(rng.uniform(-1, 1), 3)
@@ -49,6 +49,10 @@ def _random_program(seed, vec):
             elif kind == 'addc': e, d = a + c, da
             elif kind == 'mulv': e, d = a * [round(rng.uniform(-1, 1), 3) for _ in range(vec)], da
             elif kind == 'addv': e, d = a + [round(rng.uniform(-1, 1), 3) for _ in range(vec)], da
+            elif kind == 'hsum':
+                from eva.std.numeric import horizontal_sum
+                e, d = horizontal_sum(a), da
+            elif kind == 'id': e, d = a, da
             elif kind == 'rot': e, d = (a << rng.randint(1, 5)) if rng.random() < 0.7 else (a >> rng.randint(1, 3)), da
             else: e, d = -a, da
             pool.append((e, d))
@@ -56,8 +60,12 @@ def _random_program(seed, vec):
         outs = rng.sample(pool[first:], k=min(2, len(pool) - first))
         for i, (e, _) in enumerate(outs):
             Output(f'y{i}', e)
-    prog.set_input_scales(30)
-    prog.set_output_ranges(20)
+    if seed >= 4200:   # other fixed-point formats
+        prog.set_input_scales(rng.choice([25, 30, 40, 50]))
+        prog.set_output_ranges(rng.choice([10, 20, 30]))
+    else:
+        prog.set_input_scales(30)
+        prog.set_output_ranges(20)
     inputs = {n: [rng.uniform(-1, 1) for _ in range(vec)] for n in names + plain_names}
     return prog, inputs
 
@@ -104,4 +112,11 @@ def test_random_program_bit_exact(seed):
     _same(outs[0], ref, "execute_batch[0]")
     _same(outs[2], ref, "execute_batch[2]")
     _same(outs[1], oracle_execute(pub, compiled, enc2), "execute_batch[1]")
-    assert valuation_mse(sec.decrypt(out, sig), evaluate(compiled, inputs)) < 0.01
+    # decrypt accuracy (tests/common.py:34) where the fixed-point format can deliver it: modest
+    # values at >= 30 bits of scale.  (Seeds >= 4200 also draw 25-bit scales and horizontal sums
+    # that leave the declared range; there the bit-exact comparisons above are the check.)
+    expect = evaluate(compiled, inputs)
+    biggest = max(abs(v) for vals in expect.values() for v in vals)
+    if seed < 4200 or biggest < 8:
+        if seed < 4200 or all(d.get("encode_scale", 30) >= 30 for d in compiled._dump() if d["op"] == Op.Input):
+            assert valuation_mse(sec.decrypt(out, sig), expect) < 0.01
