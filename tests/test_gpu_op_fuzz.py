@@ -1,0 +1,83 @@
+"""Randomised parity of the C-ABI evaluator entry points: random ring degree, random prime
+chain (20- to 60-bit primes in any order, so the special prime and the prime being divided out
+may be much smaller or larger than the limb a kernel works on — the lazy fused loads switch on
+exactly those ratios), random level (mod-switched views) and size; every result must equal the
+CPU oracle's bit for bit."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from test_gpu_parity import Env
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EVA_FUZZ_SEEDS", "40"))))
+def test_random_parameters(seed):
+    rng = random.Random(seed)
+    logn = rng.randint(10, 13)
+    N = 1 << logn
+    k = rng.randint(2, 7)
+    bits = [rng.choice([20, 25, 30, 36, 40, 45, 50, 55, 58, 60]) for _ in range(k)]
+    bits = [max(b, logn + 3) for b in bits]
+    e = Env(N, bits)
+    l_top = k - 1
+    drop = rng.randint(0, max(0, l_top - 1))          # work on a mod-switched view `drop` levels down
+    l = l_top - drop
+    np_rng = np.random.default_rng(seed)
+    e.rng = np_rng
+
+    def up(h, scale=2.0 ** 8):
+        ct = e.g.upload_ct(h, scale)
+        for _ in range(drop):
+            ct = e.g.mod_switch(ct)
+        return ct
+
+    def host(size):
+        h = e.rand(size, l_top)
+        return h, h[:, :l, :].copy()
+
+    a2f, a2 = host(2)
+    b2f, b2 = host(2)
+    a3f, a3 = host(3)
+    A2, B2, A3 = up(a2f), up(b2f), up(a3f)
+    ptf = e.rand(1, l_top)[0]
+    pt = ptf[:l].copy()
+    PT = e.g.upload_pt(pt, 2.0 ** 8)
+    key = e.rand_key()
+    e.g.upload_relin_key(key)
+    assert np.array_equal(e.g.add(A2, A3).download(), e.o.add(a2, a3))
+    assert np.array_equal(e.g.sub(A3, B2).download(), e.o.sub(a3, b2))
+    assert np.array_equal(e.g.multiply(A2, B2).download(), e.o.multiply(a2, b2))
+    assert np.array_equal(e.g.square(B2).download(), e.o.square(b2))
+    assert np.array_equal(e.g.multiply_plain(A3, PT).download(), e.o.multiply_plain(a3, pt))
+    assert np.array_equal(e.g.add_plain(A2, PT).download(), e.o.add_plain(a2, pt))
+    relin = e.o.relinearize(a3, key)
+    assert np.array_equal(e.g.relinearize(A3).download(), relin)
+    steps = rng.choice([1, -1, 3, -7, N // 4, -(N // 2 - 1)])
+    gk = e.rand_key()
+    e.g.upload_galois_key(e.g.galois_elt_from_step(steps), gk)
+    rot = e.o.rotate(a2, steps, gk)
+    assert np.array_equal(e.g.rotate(A2, steps).download(), rot)
+    bare = up(e.rand(2, l_top), 2.0 ** 16)
+    bare_h = bare.download()
+    ws_ref = e.o.add(e.o.add(e.o.multiply_plain(a2, pt), e.o.multiply_plain(b2, pt)), bare_h)
+    assert np.array_equal(e.g.weighted_sum([A2, B2, bare], [PT, PT, None]).download(), ws_ref)
+    if l >= 2:
+        assert np.array_equal(e.g.rescale(A3, 3).download(), e.o.rescale(a3))
+        assert np.array_equal(e.g.relinearize_rescale(A3, 3).download(), e.o.rescale(relin))
+        many = e.g.relinearize_rescale_many([A3, up(a3f)], 3)
+        assert all(np.array_equal(m.download(), e.o.rescale(relin)) for m in many)
+        outs = e.g.rescale_many([A2, B2], 3)
+        assert np.array_equal(outs[0].download(), e.o.rescale(a2)) and np.array_equal(outs[1].download(), e.o.rescale(b2))
+    outs = e.g.relinearize_many([A3, up(a3f)])
+    assert all(np.array_equal(m.download(), relin) for m in outs)
+    outs = e.g.rotate_pairs([A2, B2], [steps, steps])
+    assert np.array_equal(outs[0].download(), rot) and np.array_equal(outs[1].download(), e.o.rotate(b2, steps, gk))
+    batch = e.g.stack([e.g.upload_ct(a3, 2.0 ** 8), e.g.upload_ct(a3, 2.0 ** 8)]) if drop == 0 else None
+    if batch is not None:
+        d = e.g.relinearize(batch).download()
+        assert np.array_equal(d[0], relin) and np.array_equal(d[1], relin)
