@@ -53,6 +53,10 @@ def _lower(compiled, enc_inputs, pub, g):
             elif op == Op.Mul: raw[t] = [u * v for u, v in zip(*x)]
             elif op == Op.Negate: raw[t] = [-u for u in x[0]]
             elif op in (Op.Rescale, Op.Relinearize, Op.ModSwitch): raw[t] = list(x[0])  # scale management of a raw value: a copy
+            elif op in (Op.RotateLeftConst, Op.RotateRightConst):
+                r = d["rotation"] % len(x[0])
+                raw[t] = x[0][r:] + x[0][:r] if op == Op.RotateLeftConst else x[0][len(x[0]) - r:] + x[0][:len(x[0]) - r]
+            elif op == Op.Output: raw[t] = x[0]
             else: raise RuntimeError("raw op not needed by these programs")
             continue
         imm = d.get("rotation", d.get("rescale_divisor", 0)) or 0
@@ -83,6 +87,8 @@ def _check(prog, inputs, N=None):
     from oracle_executor import OracleExecutor
     ref = OracleExecutor(pub).execute(compiled, enc)
     for name, t in outs.items():
+        if isinstance(ref[name], list):
+            continue   # an output that depends on unencrypted values only: host work, not part of the submit
         assert np.array_equal(res[t].download(), ref[name].data), f"output {name} differs from the oracle walk"
         assert res[t].scale == ref[name].scale
     # every intermediate was released at its last use: only caller-placed values and outputs remain
