@@ -97,3 +97,35 @@ def test_round_trips_are_exact(tmp_path):
     with pytest.raises(RuntimeError):
         open(f('bad'), 'wb').write(b'nonsense')
         load(f('bad'))
+
+
+@pytest.mark.parametrize("seed", [2001, 2004, 3002, 3005, 4201, 4203, 17, 29])
+def test_random_programs_survive_save_and_load(tmp_path, seed):
+    """Random programs (tests/test_gpu_fuzz.py's generator: constants, vector constants, rotations,
+    unencrypted inputs): the compiled program, its parameters, signature and an encrypted valuation
+    are unchanged by save -> load (same term dump, same prime bits / rotations, same words)."""
+    from test_gpu_fuzz import _random_program
+    prog, inputs = _random_program(seed, 32)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    p = lambda n: os.path.join(str(tmp_path), n)
+    save(compiled, p('c.eva')); save(params, p('c.evaparams')); save(sig, p('c.evasignature'))
+    c2, p2, s2 = load(p('c.eva')), load(p('c.evaparams')), load(p('c.evasignature'))
+
+    def shape(pr):  # ids may be renumbered by the round trip: compare the multiset of node descriptions
+        d = {x["id"]: x for x in pr._dump()}
+        def desc(x):
+            return (str(x["op"]), tuple(str(d[o]["op"]) for o in x["operands"]), x.get("rotation"), x.get("rescale_divisor"),
+                    x.get("encode_scale"), x.get("encode_level"), tuple(x.get("constant") or ()))
+        return sorted(map(desc, d.values()), key=repr)
+    assert shape(compiled) == shape(c2)
+    assert list(params.prime_bits) == list(p2.prime_bits) and set(params.rotations) == set(p2.rotations)
+    assert params.poly_modulus_degree == p2.poly_modulus_degree and sig.vec_size == s2.vec_size
+    assert valuation_mse(evaluate(compiled, inputs), evaluate(c2, inputs)) == 0
+    pub, sec = generate_keys(params, seed)
+    enc = pub.encrypt(inputs, sig)
+    save(enc, p('v.sealvals'))
+    enc2 = load(p('v.sealvals'))
+    for name in enc.names():
+        a, b = enc.get(name), enc2.get(name)
+        assert a[:4] == b[:4]
+        assert np.array_equal(np.asarray(a[4]), np.asarray(b[4]))
