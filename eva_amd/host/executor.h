@@ -872,11 +872,24 @@ public:
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
     HipExecutor ex(program, *host, queue_handles());
+    // constants (Constant / Encode nodes and arithmetic on them) are evaluated by the first walk
+    // of a program and stay resident: later walks only look them up
+    ConstCache &cc = const_cache[&program];
+    const uint64_t h = program_hash(program);
+    if (cc.values.size() != program.size() || cc.hash != h) {
+      cc.done = ex.prepare_constants();
+      cc.values.assign(program.size(), HipExecutor::RuntimeValue{});
+      for (TermId t = 0; t < program.size(); t++)
+        if (cc.done[t]) cc.values[t] = ex.value(t);
+      cc.hash = h;
+    } else {
+      for (TermId t = 0; t < program.size(); t++)
+        if (cc.done[t]) ex.set_value(t, cc.values[t]);
+    }
     ex.set_inputs(inputs);
     auto t1 = clk::now();
-    if (level_batching && num_queues <= 1) ex.run_levelled(nullptr, free_eagerly);
-    else if (free_eagerly) run_counted(program, ex);
-    else run_serial(program, ex);
+    if (level_batching && num_queues <= 1) ex.run_levelled(&cc.done, free_eagerly);
+    else run_counted(program, ex, &cc.done);
     auto t2 = clk::now();
     HipValuation out;
     ex.get_outputs(out);
@@ -945,12 +958,13 @@ public:
   }
 
   ~HipPublic() {
+    const_cache.clear();
     plans.clear();
     batch_fork.reset();
     forks.clear(); // queues go before the root context
     dev.reset();
   }
-  void drop_graphs() { plans.clear(); seen.clear(); }
+  void drop_graphs() { plans.clear(); seen.clear(); const_cache.clear(); }
 
 private:
   std::shared_ptr<DeviceCtx> dev;
@@ -1014,6 +1028,12 @@ private:
       return true;
     }
   };
+  struct ConstCache {
+    uint64_t hash = 0;
+    std::vector<char> done;
+    std::vector<HipExecutor::RuntimeValue> values;
+  };
+  std::unordered_map<const Program *, ConstCache> const_cache;
   std::unordered_map<const Program *, std::unique_ptr<GraphPlan>> plans;
   std::unordered_map<const Program *, int> seen;
 
