@@ -385,6 +385,57 @@ public:
     }
   }
 
+  // The default walk: host-side nodes (constants, arithmetic on unencrypted values, Encode) are
+  // evaluated here, every node that produces a ciphertext is lowered to an evah_op, and the whole
+  // encrypted part of the program goes to the library as ONE evah_execute — the level scheduler,
+  // the batched levels, the fused relinearize+rescale and the weighted sums live there
+  // (include/eva_hip.h).  `skip` marks nodes already evaluated (resident constants);
+  // free_values lets the library release intermediates after their last reader.
+  void run_library(const std::vector<char> *skip, bool free_values) {
+    const auto order = program.topo_order();
+    ctx = queues[0];
+    std::vector<char> produced(program.size(), 0); // ciphertext nodes computed by the submit
+    std::vector<evah_op> ops;
+    std::vector<evah_val> table(program.size(), evah_val{EVAH_VAL_NONE, nullptr});
+    auto cipher = [&](TermId t) { return produced[t] || is_device_ct(t); };
+    auto place = [&](TermId t) { // an operand that already exists on the device
+      if (produced[t] || table[t].kind != EVAH_VAL_NONE) return;
+      if (is_device_ct(t)) table[t] = evah_val{EVAH_VAL_CT, ct(t)};
+      else if (is_plain(t)) table[t] = evah_val{EVAH_VAL_PT, pt(t)};
+      else throw std::runtime_error("Unsupported operation encountered");
+    };
+    for (TermId t : order) {
+      if (skip && (*skip)[t]) continue;
+      const Term &x = program.at(t);
+      bool any_cipher = false;
+      for (TermId o : x.operands) any_cipher = any_cipher || cipher(o);
+      if (!any_cipher) { // Input, Constant, Encode, arithmetic on raw values, outputs of unencrypted values
+        (*this)(t);
+        continue;
+      }
+      evah_op op{};
+      op.op = (uint32_t)x.op;
+      op.dst = t;
+      op.src0 = x.operands[0];
+      op.src1 = x.operands.size() > 1 ? x.operands[1] : 0;
+      op.imm = (x.op == Op::RotateLeftConst || x.op == Op::RotateRightConst) ? (int32_t)x.rotation
+               : x.op == Op::Rescale                                         ? (int32_t)x.rescale_divisor
+                                                                             : 0;
+      for (size_t k = 0; k < x.operands.size() && k < 2; k++) {
+        place(x.operands[k]);
+        if (free_values && produced[x.operands[k]]) op.flags |= (k == 0 ? EVAH_OPF_FREE_SRC0 : EVAH_OPF_FREE_SRC1);
+      }
+      produced[t] = 1;
+      ops.push_back(op);
+    }
+    if (ops.empty()) return;
+    const int rc = evah_execute(ctx, ops.data(), (uint32_t)ops.size(), table.data(), (uint32_t)table.size());
+    // whatever the submit produced and did not release is owned here now (also after an error)
+    for (TermId t = 0; t < program.size(); t++)
+      if (produced[t] && table[t].kind == EVAH_VAL_CT) objects[t] = std::make_shared<CtHandle>(ctx, static_cast<evah_ct *>(table[t].h));
+    chk(rc);
+  }
+
   // Level-synchronous walk: nodes are taken by depth (longest path from the sources), so the nodes
   // of one level are mutually independent, and the key-switching / rescaling / ct x ct nodes of a
   // level go out together through the batched entry points (evah_rotate_pairs, _rescale_many,
@@ -888,7 +939,8 @@ public:
     }
     ex.set_inputs(inputs);
     auto t1 = clk::now();
-    if (level_batching && num_queues <= 1) ex.run_levelled(&cc.done, free_eagerly);
+    if (library_scheduler && num_queues <= 1) ex.run_library(&cc.done, free_eagerly);
+    else if (level_batching && num_queues <= 1) ex.run_levelled(&cc.done, free_eagerly);
     else run_counted(program, ex, &cc.done);
     auto t2 = clk::now();
     HipValuation out;
@@ -904,6 +956,8 @@ public:
   // one launch set — per group instead of per instance.  Results are those of execute() on each
   // valuation, bit for bit.  The reference has no counterpart: it loops SEALPublic::execute.
   // independent nodes of one DAG level through the batched entry points (EVA_LEVEL_BATCHING=0 disables)
+  // the encrypted part of a program as one evah_execute (EVA_LIBRARY_SCHEDULER=0: the host-side walks)
+  bool library_scheduler = std::getenv("EVA_LIBRARY_SCHEDULER") ? std::atoi(std::getenv("EVA_LIBRARY_SCHEDULER")) != 0 : true;
   bool level_batching = std::getenv("EVA_LEVEL_BATCHING") ? std::atoi(std::getenv("EVA_LEVEL_BATCHING")) != 0 : true;
   uint32_t batch_chunk = 32;
   std::vector<HipValuation> execute_batch(Program &program, const std::vector<const HipValuation *> &inputs) {
@@ -1088,7 +1142,8 @@ private:
     // capture the walk
     chk(evah_capture_begin(q0, q.data() + 1, (uint32_t)q.size() - 1));
     try {
-      if (level_batching) ex.run_levelled(&done, true);
+      if (library_scheduler) ex.run_library(&done, true);
+      else if (level_batching) ex.run_levelled(&done, true);
       else run_counted(program, ex, &done);
       for (auto &kv : program.outputs()) plan->outputs[kv.first] = ex.value(kv.second);
     } catch (...) {
