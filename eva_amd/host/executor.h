@@ -141,15 +141,7 @@ public:
   struct LazyRelin {
     TermId src;
   };
-  // A sum of ciphertext x plaintext products (and plain ciphertext terms) whose partial sums have
-  // no other consumer: the multiply_plain / add chain of a convolution window is evaluated as one
-  // evah_weighted_sum pass when its root is reached (same ciphertext, one launch instead of 2n-1).
-  struct LazySum {
-    std::vector<std::pair<std::shared_ptr<CtHandle>, std::shared_ptr<PtHandle>>> terms;
-    uint32_t size = 0, limbs = 0; // shape and scale every term (product) has
-    double scale = 0;
-  };
-  using RuntimeValue = std::variant<std::monostate, std::shared_ptr<CtHandle>, std::shared_ptr<PtHandle>, std::vector<double>, LazyPlain, LazyRelin, LazySum>;
+  using RuntimeValue = std::variant<std::monostate, std::shared_ptr<CtHandle>, std::shared_ptr<PtHandle>, std::vector<double>, LazyPlain, LazyRelin>;
 
   // queues: issue queues (HIP streams) of one device — queues[0] is the root context, the rest
   // are its forks.  Independent DAG nodes are spread over them (the GPU counterpart of the
@@ -290,10 +282,9 @@ public:
         std::vector<double> o(u.size());
         for (size_t i = 0; i < u.size(); i++) o[i] = x.op == Op::Add ? u[i] + v[i] : x.op == Op::Sub ? u[i] - v[i] : u[i] * v[i];
         objects[t] = std::move(o);
-      } else if (x.op == Op::Add) {
-        if (!try_lazy_add(t, a[0], a[1])) objects[t] = add(a[0], a[1]);
-      } else if (x.op == Op::Sub) objects[t] = sub(a[0], a[1]);
-      else if (!try_lazy_mul(t, a[0], a[1])) objects[t] = mul(a[0], a[1]);
+      } else if (x.op == Op::Add) objects[t] = add(a[0], a[1]);
+      else if (x.op == Op::Sub) objects[t] = sub(a[0], a[1]);
+      else objects[t] = mul(a[0], a[1]);
       break;
     case Op::RotateLeftConst:
     case Op::RotateRightConst:
@@ -436,128 +427,6 @@ public:
     chk(rc);
   }
 
-  // Level-synchronous walk: nodes are taken by depth (longest path from the sources), so the nodes
-  // of one level are mutually independent, and the key-switching / rescaling / ct x ct nodes of a
-  // level go out together through the batched entry points (evah_rotate_pairs, _rescale_many,
-  // _relinearize_many, _relinearize_rescale_many, _multiply_many): the three independent
-  // convolution chains of a Harris detector become one launch set per step instead of three.
-  // Same ciphertexts as the node-by-node walk; `skip` marks nodes already evaluated (constants of
-  // a captured plan); free_values releases operands after the level of their last consumer.
-  void run_levelled(const std::vector<char> *skip, bool free_values) {
-    auto order = program.topo_order();
-    std::vector<uint32_t> level(program.size(), 0), succ(program.size(), 0);
-    uint32_t depth = 0;
-    for (TermId t : order) {
-      uint32_t lv = 0;
-      for (TermId o : program.at(t).operands) {
-        lv = std::max(lv, level[o] + 1);
-        succ[o]++;
-      }
-      level[t] = lv;
-      depth = std::max(depth, lv);
-    }
-    std::vector<std::vector<TermId>> buckets(depth + 1);
-    for (TermId t : order) buckets[level[t]].push_back(t);
-    ctx = queues[0];
-    auto info = [&](evah_ct *h, uint32_t &size, uint32_t &limbs) {
-      double sc;
-      chk(evah_ct_info(h, &size, &limbs, &sc));
-    };
-    for (auto &nodes : buckets) {
-      // (group key, node) lists of the batchable kinds of this level
-      std::map<uint32_t, std::vector<TermId>> rots, relins, muls;
-      std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<TermId>> rescales; // (size, limbs, divisor)
-      std::map<std::pair<uint32_t, uint32_t>, std::vector<TermId>> fused;              // (limbs, divisor)
-      for (TermId t : nodes) {
-        if (skip && (*skip)[t]) continue;
-        const Term &x = program.at(t);
-        const auto &a = x.operands;
-        uint32_t size = 0, limbs = 0;
-        if ((x.op == Op::RotateLeftConst || x.op == Op::RotateRightConst) && is_cipher(a[0]) && x.rotation != 0) {
-          info(ct(a[0]), size, limbs);
-          rots[limbs].push_back(t);
-        } else if (x.op == Op::Rescale && std::holds_alternative<LazyRelin>(objects[a[0]])) {
-          info(ct(std::get<LazyRelin>(objects[a[0]]).src), size, limbs);
-          fused[{limbs, x.rescale_divisor}].push_back(t);
-        } else if (x.op == Op::Rescale && is_cipher(a[0])) {
-          info(ct(a[0]), size, limbs);
-          rescales[{size, limbs, x.rescale_divisor}].push_back(t);
-        } else if (x.op == Op::Relinearize && is_cipher(a[0]) &&
-                   !(fuse_relin_rescale && x.uses.size() == 1 && program.at(x.uses[0]).op == Op::Rescale)) {
-          info(ct(a[0]), size, limbs);
-          relins[limbs].push_back(t);
-        } else if (x.op == Op::Mul && a[0] != a[1] && is_cipher(a[0]) && is_cipher(a[1])) {
-          info(ct(a[0]), size, limbs);
-          muls[limbs].push_back(t);
-        } else {
-          (*this)(t);
-        }
-      }
-      // flush: groups of one take the ordinary path
-      auto each_chunk = [&](std::vector<TermId> &g, size_t cap, auto &&fn) {
-        if (g.size() == 1) { (*this)(g[0]); return; }
-        for (size_t i = 0; i < g.size(); i += cap) fn(g.data() + i, (uint32_t)std::min(cap, g.size() - i));
-      };
-      auto store = [&](const TermId *ts, uint32_t n, std::vector<evah_ct *> &outs) {
-        for (uint32_t i = 0; i < n; i++) objects[ts[i]] = std::make_shared<CtHandle>(ctx, outs[i]);
-      };
-      for (auto &kv : rots)
-        each_chunk(kv.second, 64, [&](const TermId *ts, uint32_t n) {
-          std::vector<const evah_ct *> in(n);
-          std::vector<int32_t> steps(n);
-          std::vector<evah_ct *> outs(n, nullptr);
-          for (uint32_t i = 0; i < n; i++) {
-            const Term &y = program.at(ts[i]);
-            in[i] = ct(y.operands[0]);
-            steps[i] = y.op == Op::RotateLeftConst ? y.rotation : -y.rotation; // seal_executor.h:188
-          }
-          chk(evah_rotate_pairs(ctx, in.data(), steps.data(), n, outs.data()));
-          store(ts, n, outs);
-        });
-      for (auto &kv : fused)
-        each_chunk(kv.second, 64, [&](const TermId *ts, uint32_t n) {
-          std::vector<const evah_ct *> in(n);
-          std::vector<evah_ct *> outs(n, nullptr);
-          for (uint32_t i = 0; i < n; i++) in[i] = ct(std::get<LazyRelin>(objects[program.at(ts[i]).operands[0]]).src);
-          chk(evah_relinearize_rescale_many(ctx, in.data(), n, kv.first.second, outs.data()));
-          store(ts, n, outs);
-        });
-      for (auto &kv : rescales)
-        each_chunk(kv.second, 128 / std::get<0>(kv.first), [&](const TermId *ts, uint32_t n) {
-          std::vector<const evah_ct *> in(n);
-          std::vector<evah_ct *> outs(n, nullptr);
-          for (uint32_t i = 0; i < n; i++) in[i] = ct(program.at(ts[i]).operands[0]);
-          chk(evah_rescale_many(ctx, in.data(), n, std::get<2>(kv.first), outs.data()));
-          store(ts, n, outs);
-        });
-      for (auto &kv : relins)
-        each_chunk(kv.second, 64, [&](const TermId *ts, uint32_t n) {
-          std::vector<const evah_ct *> in(n);
-          std::vector<evah_ct *> outs(n, nullptr);
-          for (uint32_t i = 0; i < n; i++) in[i] = ct(program.at(ts[i]).operands[0]);
-          chk(evah_relinearize_many(ctx, in.data(), n, outs.data()));
-          store(ts, n, outs);
-        });
-      for (auto &kv : muls)
-        each_chunk(kv.second, 64, [&](const TermId *ts, uint32_t n) {
-          std::vector<const evah_ct *> ia(n), ib(n);
-          std::vector<evah_ct *> outs(n, nullptr);
-          for (uint32_t i = 0; i < n; i++) {
-            ia[i] = ct(program.at(ts[i]).operands[0]);
-            ib[i] = ct(program.at(ts[i]).operands[1]);
-          }
-          chk(evah_multiply_many(ctx, ia.data(), ib.data(), n, outs.data()));
-          store(ts, n, outs);
-        });
-      if (free_values)
-        for (TermId t : nodes) {
-          if (skip && (*skip)[t]) continue;
-          for (TermId o : program.at(t).operands)
-            if (--succ[o] == 0) free(o);
-        }
-    }
-  }
-
   // ---- hooks used when an execution is captured into a graph
   const RuntimeValue &value(TermId t) const { return objects[t]; }
   void set_value(TermId t, RuntimeValue v) { objects[t] = std::move(v); }
@@ -653,7 +522,6 @@ private:
     const int bits = (int)std::ceil(std::log2(std::max(bound, 1.0))) + 1;
     return bits < 62 && bits < host.total_bits[limbs];
   }
-  bool fuse_sums = std::getenv("EVA_FUSE_SUMS") ? std::atoi(std::getenv("EVA_FUSE_SUMS")) != 0 : true;
 
   // Queue for node t: key-switching / rescaling consumers of a fanned-out value are spread
   // round-robin (they are independent and heavy); everything else follows its first
@@ -677,78 +545,14 @@ private:
     return q;
   }
 
-  bool is_cipher(TermId t) const {
-    return std::holds_alternative<std::shared_ptr<CtHandle>>(objects[t]) || std::holds_alternative<LazySum>(objects[t]);
-  }
+  bool is_cipher(TermId t) const { return std::holds_alternative<std::shared_ptr<CtHandle>>(objects[t]); }
   bool is_device_ct(TermId t) const { return std::holds_alternative<std::shared_ptr<CtHandle>>(objects[t]); }
-  // the only consumer of t is one operand slot of an Add: its value can stay an unevaluated sum
-  bool feeds_one_add(TermId t) const {
-    const auto &u = program.at(t).uses;
-    return u.size() == 1 && program.at(u[0]).op == Op::Add;
-  }
-  RuntimeValue weighted_sum(const LazySum &ls) {
-    const uint32_t n = (uint32_t)ls.terms.size();
-    std::vector<const evah_ct *> cts(n);
-    std::vector<const evah_pt *> pts(n);
-    for (uint32_t i = 0; i < n; i++) {
-      cts[i] = ls.terms[i].first->h;
-      pts[i] = ls.terms[i].second ? ls.terms[i].second->h : nullptr;
-    }
-    evah_ct *h = nullptr;
-    chk(evah_weighted_sum(ctx, cts.data(), pts.data(), n, &h));
-    return wrap(h);
-  }
-  // Mul(cipher, plain) feeding one Add: keep it as a one-term sum
-  bool try_lazy_mul(TermId t, TermId a, TermId b) {
-    if (!fuse_sums || !feeds_one_add(t)) return false;
-    if (!is_device_ct(a)) std::swap(a, b);
-    if (!is_device_ct(a) || !is_plain(b)) return false;
-    evah_pt *ph = pt(b); // materialises a lazily encoded plaintext
-    LazySum ls;
-    uint32_t pl = 0;
-    double ps = 0;
-    chk(evah_ct_info(ct(a), &ls.size, &ls.limbs, &ls.scale));
-    chk(evah_pt_info(ph, &pl, &ps));
-    if (pl != ls.limbs) return false; // let multiply_plain report the mismatch
-    ls.scale *= ps;
-    ls.terms.emplace_back(std::get<std::shared_ptr<CtHandle>>(objects[a]), std::get<std::shared_ptr<PtHandle>>(objects[b]));
-    objects[t] = std::move(ls);
-    return true;
-  }
-  // Add over sums / ciphertexts of one shape and scale: concatenate; evaluate when the chain ends
-  bool try_lazy_add(TermId t, TermId a, TermId b) {
-    if (!fuse_sums) return false;
-    const bool la = std::holds_alternative<LazySum>(objects[a]), lb = std::holds_alternative<LazySum>(objects[b]);
-    const bool ca = is_device_ct(a), cb = is_device_ct(b);
-    if (!((la || ca) && (lb || cb))) return false;              // a plaintext / raw operand: the ordinary add
-    if (!la && !lb && !feeds_one_add(t)) return false;          // an isolated ct + ct
-    LazySum ls;
-    bool first = true;
-    for (TermId o : {a, b}) {
-      uint32_t sz = 0, lm = 0;
-      double sc = 0;
-      if (auto *l = std::get_if<LazySum>(&objects[o])) {
-        sz = l->size; lm = l->limbs; sc = l->scale;
-        ls.terms.insert(ls.terms.end(), l->terms.begin(), l->terms.end());
-      } else {
-        chk(evah_ct_info(std::get<std::shared_ptr<CtHandle>>(objects[o])->h, &sz, &lm, &sc));
-        ls.terms.emplace_back(std::get<std::shared_ptr<CtHandle>>(objects[o]), nullptr);
-      }
-      if (first) { ls.size = sz; ls.limbs = lm; ls.scale = sc; first = false; }
-      else if (sz != ls.size || lm != ls.limbs || sc != ls.scale) return false; // mixed shapes: the ordinary add decides
-    }
-    if (ls.terms.size() > 64) return false;                     // (ct() evaluates the operands, then the ordinary add)
-    if (feeds_one_add(t) && ls.terms.size() < 64) objects[t] = std::move(ls);
-    else objects[t] = weighted_sum(ls);
-    return true;
-  }
   bool is_plain(TermId t) const {
     return std::holds_alternative<std::shared_ptr<PtHandle>>(objects[t]) || std::holds_alternative<LazyPlain>(objects[t]);
   }
   bool is_raw(TermId t) const { return std::holds_alternative<std::vector<double>>(objects[t]); }
   const std::vector<double> &raw(TermId t) const { return std::get<std::vector<double>>(objects[t]); }
   evah_ct *ct(TermId t) {
-    if (auto *ls = std::get_if<LazySum>(&objects[t])) objects[t] = weighted_sum(*ls);
     auto *p = std::get_if<std::shared_ptr<CtHandle>>(&objects[t]);
     if (!p) throw std::runtime_error("Unsupported operation encountered");
     return (*p)->h;
@@ -940,7 +744,6 @@ public:
     ex.set_inputs(inputs);
     auto t1 = clk::now();
     if (library_scheduler && num_queues <= 1) ex.run_library(&cc.done, free_eagerly);
-    else if (level_batching && num_queues <= 1) ex.run_levelled(&cc.done, free_eagerly);
     else run_counted(program, ex, &cc.done);
     auto t2 = clk::now();
     HipValuation out;
@@ -955,10 +758,8 @@ public:
   // `batch_chunk` at a time into batched device handles, so each DAG node is one backend call —
   // one launch set — per group instead of per instance.  Results are those of execute() on each
   // valuation, bit for bit.  The reference has no counterpart: it loops SEALPublic::execute.
-  // independent nodes of one DAG level through the batched entry points (EVA_LEVEL_BATCHING=0 disables)
   // the encrypted part of a program as one evah_execute (EVA_LIBRARY_SCHEDULER=0: the host-side walks)
   bool library_scheduler = std::getenv("EVA_LIBRARY_SCHEDULER") ? std::atoi(std::getenv("EVA_LIBRARY_SCHEDULER")) != 0 : true;
-  bool level_batching = std::getenv("EVA_LEVEL_BATCHING") ? std::atoi(std::getenv("EVA_LEVEL_BATCHING")) != 0 : true;
   uint32_t batch_chunk = 32;
   std::vector<HipValuation> execute_batch(Program &program, const std::vector<const HipValuation *> &inputs) {
     ensure_device();
@@ -1143,7 +944,6 @@ private:
     chk(evah_capture_begin(q0, q.data() + 1, (uint32_t)q.size() - 1));
     try {
       if (library_scheduler) ex.run_library(&done, true);
-      else if (level_batching) ex.run_levelled(&done, true);
       else run_counted(program, ex, &done);
       for (auto &kv : program.outputs()) plan->outputs[kv.first] = ex.value(kv.second);
     } catch (...) {

@@ -194,6 +194,7 @@ PYBIND11_MODULE(_eva, m) {
         return p.execute_batch(program, inputs);
       }, py::arg("program"), py::arg("inputs"),
            "execute() for a list of independent input valuations of one program; instances run batch_chunk at a time as batched device handles")
+      .def_readwrite("library_scheduler", &HipPublic::library_scheduler, "run the encrypted part of a program as one evah_execute (default) instead of the node-by-node host walk")
       .def_readwrite("batch_chunk", &HipPublic::batch_chunk, "instances per batched device handle in execute_batch (1..64)")
       .def_readwrite("device", &HipPublic::device)
       .def_readwrite("free_eagerly", &HipPublic::free_eagerly)

@@ -265,8 +265,9 @@ def test_graph_replay_matches_eager_and_oracle():
 
 
 def test_executor_options_give_identical_ciphertexts():
-    """Issue-queue count, rotation batching and relinearize+rescale fusion are scheduling choices:
-    every combination must produce the same output ciphertext as the plain serial walk."""
+    """Issue-queue count, the library scheduler vs the node-by-node host walk, rotation batching and
+    relinearize+rescale fusion are scheduling choices: every combination must produce the same
+    output ciphertext."""
     import numpy as np
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
@@ -280,15 +281,15 @@ def test_executor_options_give_identical_ciphertexts():
     for queues in (1, 3, 8):
         for batch in ("1", "0"):
             for fuse in ("1", "0"):
-                for sums in ("1", "0"):
+                for lib in ("1", "0"):
                     os.environ["EVA_BATCH_ROTATIONS"], os.environ["EVA_FUSE_RELIN_RESCALE"] = batch, fuse
-                    os.environ["EVA_FUSE_SUMS"] = sums
+                    pub.library_scheduler = lib == "1"
                     pub.num_queues = queues
                     out = pub.execute(compiled, enc).get('image')
                     if base is None:
                         base = out
-                    assert out[:4] == base[:4] and np.array_equal(out[4], base[4]), (queues, batch, fuse, sums)
-    os.environ.pop("EVA_BATCH_ROTATIONS"); os.environ.pop("EVA_FUSE_RELIN_RESCALE"); os.environ.pop("EVA_FUSE_SUMS")
+                    assert out[:4] == base[:4] and np.array_equal(out[4], base[4]), (queues, batch, fuse, lib)
+    os.environ.pop("EVA_BATCH_ROTATIONS"); os.environ.pop("EVA_FUSE_RELIN_RESCALE")
 
 
 def test_execute_batch_equals_execute_per_instance():
