@@ -2250,7 +2250,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
   };
 
   for (auto &lvl : buckets) {
-    std::map<uint32_t, std::vector<uint32_t>> rots, relins, muls;
+    std::map<uint32_t, std::vector<uint32_t>> rots, relins, muls, batched_rots;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<uint32_t>> rescales;
     std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> fused;
     // ---- one op through the ordinary entry points (seal_executor.h:114-215)
@@ -2300,9 +2300,27 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
       uint32_t size = 0, limbs = 0;
       double scale = 0;
       // a batched handle already covers its instances in one launch set: the *_many forms take
-      // single ciphertexts, so its ops go through the ordinary entry points
-      if (tab[o.src0].kind == EVAH_VAL_CT && static_cast<evah_ct *>(tab[o.src0].h)->batch > 1 && !st.sums.count(o.src0)) {
-        single(o);
+      // single ciphertexts, so on batched operands only sibling rotations are grouped (rotate_many
+      // accepts them) and the deferred forms below still apply
+      auto batched_val = [&](uint32_t v) {
+        return tab[v].kind == EVAH_VAL_CT && static_cast<evah_ct *>(tab[v].h)->batch > 1;
+      };
+      const bool batched = batched_val(o.src0) || ((o.op == 11 || o.op == 12 || o.op == 13) && batched_val(o.src1)) ||
+                           (st.relins.count(o.src0) && st.relins[o.src0]->batch > 1);
+      if (batched && (o.op == 14 || o.op == 15) && o.imm != 0) {
+        batched_rots[o.src0].push_back(i);
+        continue;
+      }
+      if (batched && (o.op == 22 || (o.op == 20 && !feeds_only(o.dst, 22)) || (o.op == 13 && o.src0 != o.src1 && is_ct(o.src0) && is_ct(o.src1)))) {
+        if (o.op == 22 && st.relins.count(o.src0)) { // deferred relinearize + this rescale, on the batched handle
+          evah_ct *out = nullptr;
+          chk(evah_relinearize_rescale(c, st.relins[o.src0], (uint32_t)o.imm, &out));
+          evah_ct_free(c, st.relins[o.src0]);
+          st.relins.erase(o.src0);
+          put(o.dst, out);
+        } else {
+          single(o);
+        }
         continue;
       }
       if ((o.op == 14 || o.op == 15) && o.imm != 0 && is_ct(o.src0)) {
@@ -2370,6 +2388,14 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     auto store = [&](const uint32_t *is, uint32_t n, std::vector<evah_ct *> &outs) {
       for (uint32_t j = 0; j < n; j++) put(ops[is[j]].dst, outs[j]);
     };
+    for (auto &kv : batched_rots)
+      each_chunk(kv.second, KS_BATCH_MAX, [&](const uint32_t *is, uint32_t n) {
+        std::vector<int32_t> steps(n);
+        std::vector<evah_ct *> outs(n, nullptr);
+        for (uint32_t j = 0; j < n; j++) steps[j] = ops[is[j]].op == 14 ? ops[is[j]].imm : -ops[is[j]].imm;
+        chk(evah_rotate_many(c, ct_of(kv.first), steps.data(), n, outs.data()));
+        store(is, n, outs);
+      });
     for (auto &kv : rots)
       each_chunk(kv.second, KS_BATCH_MAX, [&](const uint32_t *is, uint32_t n) {
         std::vector<const evah_ct *> in(n);

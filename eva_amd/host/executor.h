@@ -798,7 +798,8 @@ public:
           if (done[t]) ex->set_value(t, consts[t]);
       }
       ex->set_inputs_batch(chunk);
-      run_counted(program, *ex, &done);
+      if (library_scheduler) ex->run_library(&done, true);
+      else run_counted(program, *ex, &done);
       drain();
       prev = std::move(ex);
       prev_n = n;
