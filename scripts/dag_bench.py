@@ -1,7 +1,11 @@
 """execute() wall time for the BASELINE DAG configs on one GPU vs the CPU oracle walking the same
 compiled DAG (1 core): C1 README polynomial, C2 Sobel N=2^13, C3 Harris N=2^15, one instance of
 C4 (Sobel N=2^14) and C5 (3x3 convolution + depth-8 squaring chain, N=2^16, 13 primes).
-usage: dag_bench.py [reps] [--no-cpu]"""
+usage: dag_bench.py [reps] [--cpu]
+
+The GPU legs use only the product.  --cpu adds the reported CPU baseline of each DAG — the same role
+as bench.py's cpu_baseline leg — by walking the compiled DAG over the CPU oracle through the test
+helpers (tests/evatest.py, tests/oracle_executor.py); nothing of it is on the measured GPU path."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,7 +17,7 @@ from test_compiler import _sobel
 from test_gpu_e2e import _harris, _image
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
-no_cpu = "--no-cpu" in sys.argv
+no_cpu = "--cpu" not in sys.argv
 
 def run(name, prog, N, inputs=None, pad_primes=0):
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
