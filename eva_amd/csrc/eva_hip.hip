@@ -242,39 +242,53 @@ k_galois_perm_many(DevCtx cx, const u64 *a, size_t a_ps, PermTables pt, u64 *out
   st2(out + z * o_ps + (size_t)i * cx.N + n, v);
 }
 
-// ---- CKKS encoder on the device (SEAL CKKSEncoder::encode): values -> conjugate-
-// symmetric slot vector -> inverse special FFT (FP64, Gentleman-Sande, one launch per stage) ->
-// round(x * scale / N) -> residues.  Operation order and rounding are exactly those of the host
-// encoder (eva_amd/host/ckks_host.h encode_coeff) and FMA contraction is off, so the plaintext is
-// the same bit for bit.
+// ---- CKKS encoder on the device (SEAL 3.6 CKKSEncoder::encode_internal, reached from
+// seal_executor.h:242): values -> conjugate-symmetric slot vector -> inverse special FFT in FP64
+// (Gentleman-Sande, one launch per stage, roots in the order the stages consume them) with the
+// factor scale/N folded into the LAST stage exactly as SEAL's DWTHandler::transform_from_rev
+// does (sums scaled, differences times the pre-scaled root) -> round -> residues.  Each complex
+// product is four rounded multiplies, a rounded difference and a rounded sum; FMA contraction is
+// off, so the doubles — and the plaintext — are those of the host encoder and the CPU oracle.
 __global__ void __launch_bounds__(256)
 k_enc_scatter(const double *vals, uint32_t n_vals, const uint32_t *slot_map, double2 *c, uint32_t slots) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= slots) return;
   const double v = vals[i % n_vals]; // the vector is replicated over the N/2 slots (seal_executor.h:226-240)
   c[slot_map[i]] = make_double2(v, 0.0);
-  c[slot_map[slots + i]] = make_double2(v, 0.0); // conjugate of a real value
+  c[slot_map[slots + i]] = make_double2(v, -0.0); // conjugate of a real value
 }
+// stage with gap 2^log_gap: group g uses roots[root0 + g] (already conjugated)
 __global__ void __launch_bounds__(256)
-k_enc_fft_stage(double2 *c, const double2 *roots, uint32_t mm, uint32_t log_gap, uint32_t half_n) {
+k_enc_fft_stage(double2 *c, const double2 *roots, uint32_t root0, uint32_t log_gap, uint32_t half_n) {
 #pragma clang fp contract(off)
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= half_n) return;
   const uint32_t gap = 1u << log_gap, g = idx >> log_gap, j = idx & (gap - 1);
   const uint32_t a = 2 * g * gap + j, b = a + gap;
-  const double2 r = roots[mm + g];
-  const double wx = r.x, wy = -r.y; // conj(root)
+  const double2 r = roots[root0 + g];
   const double2 u = c[a], v = c[b];
   c[a] = make_double2(u.x + v.x, u.y + v.y);
   const double dx = u.x - v.x, dy = u.y - v.y;
-  c[b] = make_double2(dx * wx - dy * wy, dx * wy + dy * wx);
+  const double p = dx * r.x, q = dy * r.y, s = dx * r.y, t = dy * r.x;
+  c[b] = make_double2(p - q, s + t);
 }
+// last stage (one group, gap = N/2): x = (u + v) * fix, y = (u - v) * (root * fix)
 __global__ void __launch_bounds__(256)
-k_enc_round(DevCtx cx, const double2 *c, double fix, uint32_t limbs, u64 *out) {
+k_enc_fft_last(double2 *c, double2 scaled_root, double fix, uint32_t half_n) {
 #pragma clang fp contract(off)
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= half_n) return;
+  const double2 u = c[j], v = c[j + half_n];
+  c[j] = make_double2((u.x + v.x) * fix, (u.y + v.y) * fix);
+  const double dx = u.x - v.x, dy = u.y - v.y;
+  const double p = dx * scaled_root.x, q = dy * scaled_root.y, s = dx * scaled_root.y, t = dy * scaled_root.x;
+  c[j + half_n] = make_double2(p - q, s + t);
+}
+__global__ void __launch_bounds__(256)
+k_enc_round(DevCtx cx, const double2 *c, uint32_t limbs, u64 *out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cx.N) return;
-  const double t = c[j].x * fix;
+  const double t = c[j].x;
   const double x = fabs(t) < 4503599627370496.0 ? round(t) : t; // >= 2^52: already an integer
   const bool neg = signbit(x);
   const u64 mant = (u64)fabs(x); // |x| < 2^63 is guaranteed by the caller's bound
@@ -456,7 +470,8 @@ struct SharedDev {
   KeyDev relin;
   std::map<uint32_t, KeyDev> galois;
   std::map<uint32_t, uint32_t *> perms;
-  double2 *enc_roots = nullptr;     // CKKS encoder: zeta^br(j), zeta = exp(2 pi i / 2N)
+  double2 *enc_roots = nullptr;     // CKKS encoder: inverse-FFT roots in the order the stages consume them
+  double enc_last_root[2] = {0, 0}; // the single root of the last stage (scaled by fix on the host per call)
   uint32_t *enc_slot_map = nullptr; // slot i (and its conjugate, at slots + i) -> FFT input index
   ~SharedDev() {
     (void)hipSetDevice(device);
@@ -1383,15 +1398,15 @@ static void enc_tables(evah_ctx *c) {
     map[slots + i] = bitrev((uint32_t)((m - pos - 1) >> 1), c->logN);
     pos = (pos * 3) & (m - 1);
   }
+  // inverse-transform roots in consumption order, the doubles SEAL's ComplexRoots holds (hostmath.h)
+  const CkksRoots cr = ckks_roots(N);
   std::vector<double> roots(2 * (size_t)N);
-  const double PI2 = 6.283185307179586476925286766559;
-  roots[0] = 1.0;
-  roots[1] = 0.0;
-  for (uint32_t j = 1; j < N; j++) {
-    const double ang = PI2 * (double)bitrev(j, c->logN) / (double)m;
-    roots[2 * j] = std::cos(ang);
-    roots[2 * j + 1] = std::sin(ang);
+  for (uint32_t j = 0; j < N; j++) {
+    roots[2 * j] = cr.inv_seq[j].real();
+    roots[2 * j + 1] = cr.inv_seq[j].imag();
   }
+  c->sh->enc_last_root[0] = cr.inv_seq[N - 1].real();
+  c->sh->enc_last_root[1] = cr.inv_seq[N - 1].imag();
   HIPCHK(hipMalloc(&c->sh->enc_slot_map, sizeof(uint32_t) * N));
   HIPCHK(hipMalloc(&c->sh->enc_roots, sizeof(double2) * N));
   HIPCHK(hipMemcpy(c->sh->enc_slot_map, map.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
@@ -1418,9 +1433,13 @@ int evah_pt_encode(evah_ctx *c, const double *values, uint32_t n_values, uint32_
     ProfScope ps(c, KC_EW);
     hipLaunchKernelGGL(k_enc_scatter, dim3((slots + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const double *>(vals.d),
                        n_values, c->sh->enc_slot_map, cd, slots);
-    for (uint32_t mm = N >> 1, lg = 0; mm >= 1; mm >>= 1, lg++)
-      hipLaunchKernelGGL(k_enc_fft_stage, dim3((slots + 255) / 256), dim3(256), 0, c->stream, cd, c->sh->enc_roots, mm, lg, slots);
-    hipLaunchKernelGGL(k_enc_round, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->dev, cd, scale / (double)N, limbs, t->d);
+    const double fix = scale / (double)N;
+    for (uint32_t mm = N >> 1, lg = 0; mm > 1; mm >>= 1, lg++) // stage with mm groups starts at root N - 2mm + 1
+      hipLaunchKernelGGL(k_enc_fft_stage, dim3((slots + 255) / 256), dim3(256), 0, c->stream, cd, c->sh->enc_roots, N - 2 * mm + 1,
+                         lg, slots);
+    hipLaunchKernelGGL(k_enc_fft_last, dim3((slots + 255) / 256), dim3(256), 0, c->stream, cd,
+                       make_double2(c->sh->enc_last_root[0] * fix, c->sh->enc_last_root[1] * fix), fix, slots);
+    hipLaunchKernelGGL(k_enc_round, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->dev, cd, limbs, t->d);
     HIPCHK(hipGetLastError());
     OpPlain::Params p{t->d, t->d, 0, 0, limbs, 0, 0, {}};
     ntt_forward<OpPlain>(c, p, limbs);

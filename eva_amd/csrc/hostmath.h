@@ -5,6 +5,8 @@
 // minimal primitive 2N-th root per prime, bit-reversed root-power tables with Shoup quotients.
 // Shared by libeva_hip.so (table upload) and the host module (keygen / encrypt / decrypt).
 #pragma once
+#include <cmath>
+#include <complex>
 #include <cstdint>
 #include <stdexcept>
 #include <vector>
@@ -119,6 +121,44 @@ inline std::vector<u64> root_power_table(uint32_t N, u64 q, u64 psi) {
     p = mulmod(p, psi, q);
   }
   return rp;
+}
+
+// ---- complex roots of the CKKS encoder (FP64).  The encoder's bits depend on the exact doubles
+// used as roots, so they are produced the way SEAL 3.6's util::ComplexRoots produces them: the
+// first octant of the 2N-th roots from cos/sin(2*pi*i/2N), all others through the 8-fold
+// symmetry.  Only indices <= N (the upper half plane) are ever needed.
+struct CkksRoots {
+  std::vector<std::complex<double>> fwd;     // fwd[j] = zeta^br(j), j < N (forward special FFT, heap order)
+  std::vector<std::complex<double>> inv_seq; // inv_seq[i] = conj(zeta^(br(i-1)+1)), 1 <= i < N: the
+                                             // inverse transform's roots in the order its stages use them
+};
+inline CkksRoots ckks_roots(uint32_t N) {
+  const uint32_t logN = ilog2(N);
+  const size_t deg = 2 * (size_t)N, oct_n = deg / 8;
+  std::vector<std::complex<double>> oct(oct_n + 1);
+  const double pi = 3.1415926535897932384626433832795028842;
+  for (size_t i = 0; i <= oct_n; i++) {
+    const double theta = 2 * pi * (double)i / (double)deg;
+    oct[i] = std::complex<double>(std::cos(theta), std::sin(theta));
+  }
+  auto first_quadrant = [&](size_t idx) { // idx <= deg/4
+    if (idx <= oct_n) return oct[idx];
+    const std::complex<double> t = oct[deg / 4 - idx];
+    return std::complex<double>(t.imag(), t.real());
+  };
+  auto root = [&](size_t idx) { // idx <= deg/2
+    if (idx <= deg / 4) return first_quadrant(idx);
+    return -std::conj(first_quadrant(deg / 2 - idx));
+  };
+  CkksRoots r;
+  r.fwd.resize(N);
+  r.inv_seq.resize(N);
+  r.fwd[0] = 1.0;
+  for (uint32_t j = 1; j < N; j++) {
+    r.fwd[j] = root(bitrev(j, logN));
+    r.inv_seq[j] = std::conj(root((size_t)bitrev(j - 1, logN) + 1));
+  }
+  return r;
 }
 
 }  // namespace evah

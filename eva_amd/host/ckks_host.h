@@ -159,32 +159,52 @@ public:
     }
   }
 
-  // ---- CKKS encoder (A.9).  values: N/2 slots (already replicated by the caller).
+  // ---- CKKS encoder.  values: N/2 slots (already replicated by the caller).
   // Coefficient-form residues [limbs][N]; the forward NTT is done by the caller (device or host).
+  // Floating-point operation order is SEAL 3.6's (CKKSEncoder::encode_internal reached from
+  // /root/reference/eva/seal/seal_executor.h:242): Gentleman-Sande stages over the sequentially
+  // stored inverse roots, and the factor scale/N applied INSIDE the last stage — sums are scaled,
+  // differences are multiplied by the pre-scaled root — so the rounded coefficients are SEAL's.
+  static std::complex<double> cmul(const std::complex<double> &a, const std::complex<double> &b) {
+    // four rounded products, one rounded difference and sum (no fused multiply-add)
+    const double p = a.real() * b.real(), q = a.imag() * b.imag();
+    const double r = a.real() * b.imag(), t = a.imag() * b.real();
+    return {p - q, r + t};
+  }
   void encode_coeff(const double *values, double scale, uint32_t limbs, u64 *out) const {
     const uint32_t slots = N >> 1;
     std::vector<std::complex<double>> c(N);
     for (uint32_t i = 0; i < slots; i++) {
-      c[slot_map_[i]] = values[i];
-      c[slot_map_[slots + i]] = values[i]; // conj of a real value
+      c[slot_map_[i]] = std::complex<double>(values[i], 0.0);
+      c[slot_map_[slots + i]] = std::complex<double>(values[i], -0.0); // conj of a real value
     }
-    // inverse special FFT (Gentleman-Sande, zeta^-br(m+g))
-    for (uint32_t mm = N >> 1, gap = 1; mm >= 1; mm >>= 1, gap <<= 1)
-      for (uint32_t g = 0; g < mm; g++) {
-        const std::complex<double> w = std::conj(roots_[mm + g]);
-        std::complex<double> *a = c.data() + 2 * (size_t)g * gap, *b = a + gap;
+    const double fix = scale / (double)N;
+    size_t next_root = 1; // inv_seq_[1..N-1] in the order the stages consume them
+    uint32_t gap = 1;
+    for (uint32_t groups = N >> 1; groups > 1; groups >>= 1, gap <<= 1)
+      for (uint32_t g = 0; g < groups; g++) {
+        const std::complex<double> w = inv_seq_[next_root++];
+        std::complex<double> *lo = c.data() + 2 * (size_t)g * gap, *hi = lo + gap;
         for (uint32_t j = 0; j < gap; j++) {
-          std::complex<double> u = a[j], v = b[j];
-          a[j] = u + v;
-          b[j] = (u - v) * w;
+          const std::complex<double> u = lo[j], v = hi[j];
+          lo[j] = u + v;
+          hi[j] = cmul(u - v, w);
         }
       }
-    const double fix = scale / (double)N;
+    { // final stage: one group, gap = N/2, scaling folded in
+      const std::complex<double> w = inv_seq_[next_root], ws(w.real() * fix, w.imag() * fix);
+      std::complex<double> *lo = c.data(), *hi = lo + gap;
+      for (uint32_t j = 0; j < gap; j++) {
+        const std::complex<double> u = lo[j], v = hi[j], s = u + v;
+        lo[j] = std::complex<double>(s.real() * fix, s.imag() * fix);
+        hi[j] = cmul(u - v, ws);
+      }
+    }
     double max_coeff = 0;
-    for (uint32_t j = 0; j < N; j++) max_coeff = std::max(max_coeff, std::fabs(c[j].real() * fix));
+    for (uint32_t j = 0; j < N; j++) max_coeff = std::max(max_coeff, std::fabs(c[j].real()));
     int bitcount = (int)std::ceil(std::log2(std::max(max_coeff, 1.0))) + 1;
     if (bitcount >= total_bits[limbs]) throw std::invalid_argument("encoded values are too large");
-    for (uint32_t j = 0; j < N; j++) residues_of(std::round(c[j].real() * fix), limbs, out + j, N);
+    for (uint32_t j = 0; j < N; j++) residues_of(std::round(c[j].real()), limbs, out + j, N);
   }
   // residues of round(c*scale) per limb: the encoding of a uniform constant (every NTT slot)
   void encode_uniform(double value, double scale, uint32_t limbs, u64 *out) const {
@@ -279,7 +299,8 @@ public:
 private:
   std::vector<std::vector<u64>> pow2_;
   std::vector<uint32_t> slot_map_;
-  std::vector<std::complex<double>> roots_; // roots_[m+g] = zeta^br(m+g), zeta = exp(2 pi i / 2N)
+  std::vector<std::complex<double>> roots_;   // roots_[m+g] = zeta^br(m+g), zeta = exp(2 pi i / 2N)
+  std::vector<std::complex<double>> inv_seq_; // inverse-transform roots in consumption order
 
   void init_encoder() {
     const uint32_t slots = N >> 1, m = 2 * N;
@@ -290,13 +311,9 @@ private:
       slot_map_[slots + i] = evah::bitrev((uint32_t)((m - pos - 1) >> 1), logN);
       pos = (pos * 3) & (m - 1);
     }
-    roots_.resize(N);
-    const double PI2 = 6.283185307179586476925286766559;
-    for (uint32_t j = 1; j < N; j++) {
-      double ang = PI2 * (double)evah::bitrev(j, logN) / (double)m;
-      roots_[j] = std::complex<double>(std::cos(ang), std::sin(ang));
-    }
-    roots_[0] = 1.0;
+    evah::CkksRoots r = evah::ckks_roots(N); // SEAL ComplexRoots doubles (hostmath.h)
+    roots_ = std::move(r.fwd);
+    inv_seq_ = std::move(r.inv_seq);
   }
 
   // ---- tiny multiword helpers (little-endian u64 words)

@@ -531,54 +531,166 @@ void evo_rotate(const evo_ctx *c, uint32_t l, const uint64_t *a2, int32_t steps,
 
 /* ------------------------------------------------------------------ CKKS encoder */
 
-/* SEAL CKKSEncoder::encode_internal up to the integer coefficients.
- * values: N/2 slots.  coeffs: N rounded real coefficients. */
-void evo_encode_coeffs(uint32_t N, const double *values, double scale, double *coeffs) {
-  uint32_t logN = 0, slots = N >> 1, m = 2 * N;
-  while ((1u << logN) < N) logN++;
-  double *re = (double *)calloc((size_t)2 * N, sizeof(double)), *im = re + N;
-  u64 pos = 1;
-  for (uint32_t i = 0; i < slots; i++) {
-    uint32_t i1 = bitrev((uint32_t)((pos - 1) >> 1), logN);
-    uint32_t i2 = bitrev((uint32_t)((m - pos - 1) >> 1), logN);
-    re[i1] = values[i]; im[i1] = 0.0;
-    re[i2] = values[i]; im[i2] = -0.0;
-    pos = (pos * 3) & (m - 1);
+/* The encoder is FP64 code, so bits depend on the ORDER of floating-point operations.  What
+ * follows restates, routine by routine, Microsoft SEAL v3.6.x (absent from /root/reference; the
+ * call site is /root/reference/eva/seal/seal_executor.h:242 `encoder.encode(vec, parms_id,
+ * pow(2.0, scale), plaintext)`):
+ *   - util::ComplexRoots (native/src/seal/util/croots.cpp): one octant of the 2N-th roots from
+ *     std::polar(1.0, 2*PI_*i/2N), the rest by the 8-fold symmetry (get_root);
+ *   - CKKSEncoder::CKKSEncoder (ckks.cpp): matrix_reps_index_map_, and
+ *     inv_root_powers_[i] = conj(get_root(reverse_bits(i-1, logn) + 1)), i = 1..n-1, which
+ *     DWTHandler consumes SEQUENTIALLY (`*++roots`);
+ *   - util::DWTHandler::transform_from_rev (util/dwthandler.h) with the Arithmetic<complex<double>,
+ *     complex<double>, double> of ckks.h: Gentleman-Sande stages x = u+v, y = (u-v)*r, and the
+ *     LAST stage with the scalar fix = scale/n folded in: x = (u+v)*fix, y = (u-v)*(r*fix);
+ *   - CKKSEncoder::encode_internal (ckks.h): round (ties away), sign, residues, per-limb NTT.
+ * A complex product is evaluated as libgcc's __muldc3 does for finite operands — (a.re*b.re -
+ * a.im*b.im, a.re*b.im + a.im*b.re), each product rounded (no FMA: SEAL's stock build targets
+ * baseline x86-64; this file is compiled with -ffp-contract=off) — and complex*double scales both
+ * parts.  cos/sin come from the platform libm exactly as std::polar takes them. */
+typedef struct { double re, im; } cplx;
+static const double SEAL_PI = 3.1415926535897932384626433832795028842; /* ComplexRoots::PI_ */
+
+static inline cplx c_add(cplx a, cplx b) { return (cplx){a.re + b.re, a.im + b.im}; }
+static inline cplx c_sub(cplx a, cplx b) { return (cplx){a.re - b.re, a.im - b.im}; }
+static inline cplx c_mul(cplx a, cplx b) {
+  double ac = a.re * b.re, bd = a.im * b.im, ad = a.re * b.im, bc = a.im * b.re;
+  return (cplx){ac - bd, ad + bc};
+}
+static inline cplx c_scale(cplx a, double s) { return (cplx){a.re * s, a.im * s}; }
+
+/* ComplexRoots::get_root over the stored octant oct[0 .. degree/8] */
+static cplx croots_get(const cplx *oct, size_t degree, size_t index) {
+  index &= degree - 1;
+  if (index <= degree / 8) return oct[index];
+  if (index <= degree / 4) { /* mirror: swap real and imaginary parts */
+    cplx t = oct[degree / 4 - index];
+    return (cplx){t.im, t.re};
   }
-  /* inverse special FFT: Gentleman-Sande with zeta^-br(mm+i), zeta = exp(2 pi i / 2N) */
-  const double PI2 = 6.283185307179586476925286766559;
-  for (uint32_t mm = N >> 1, gap = 1; mm >= 1; mm >>= 1, gap <<= 1) {
-    for (uint32_t i = 0; i < mm; i++) {
-      uint32_t e = bitrev(mm + i, logN);
-      double ang = -PI2 * (double)e / (double)m;
-      double wr = cos(ang), wi = sin(ang);
-      size_t a = 2 * (size_t)i * gap, b = a + gap;
-      for (uint32_t j = 0; j < gap; j++) {
-        double xr = re[a + j], xi = im[a + j], yr = re[b + j], yi = im[b + j];
-        re[a + j] = xr + yr; im[a + j] = xi + yi;
-        double dr = xr - yr, di = xi - yi;
-        re[b + j] = dr * wr - di * wi;
-        im[b + j] = dr * wi + di * wr;
-      }
-    }
+  if (index <= degree / 2) { /* -conj */
+    cplx t = croots_get(oct, degree, degree / 2 - index);
+    return (cplx){-t.re, t.im};
   }
-  double fix = scale / (double)N;
-  for (uint32_t j = 0; j < N; j++) coeffs[j] = round(re[j] * fix);
-  free(re);
+  if (index <= 3 * degree / 4) { /* negation */
+    cplx t = croots_get(oct, degree, index - degree / 2);
+    return (cplx){-t.re, -t.im};
+  }
+  cplx t = croots_get(oct, degree, degree - index); /* conj */
+  return (cplx){t.re, -t.im};
 }
 
+/* inv_root_powers_ of CKKSEncoder for degree N (entry 0 unused), caller frees */
+static cplx *ckks_inv_root_powers(uint32_t N, uint32_t logN) {
+  size_t degree = (size_t)2 * N;
+  cplx *oct = (cplx *)malloc(sizeof(cplx) * (degree / 8 + 1));
+  for (size_t i = 0; i <= degree / 8; i++) {
+    double theta = 2 * SEAL_PI * (double)i / (double)degree;
+    oct[i] = (cplx){cos(theta), sin(theta)}; /* std::polar(1.0, theta) */
+  }
+  cplx *inv = (cplx *)malloc(sizeof(cplx) * N);
+  inv[0] = (cplx){0, 0};
+  for (uint32_t i = 1; i < N; i++) {
+    cplx r = croots_get(oct, degree, (size_t)bitrev(i - 1, logN) + 1);
+    inv[i] = (cplx){r.re, -r.im};
+  }
+  free(oct);
+  return inv;
+}
+
+/* CKKSEncoder::encode_internal up to the rounded real coefficients.
+ * values: N/2 slots (EVA replicates the vector first, seal_executor.h:226-240). */
+static void encode_reals(uint32_t N, const double *values, double scale, double *coeffs, int rounded) {
+  uint32_t logN = 0, slots = N >> 1, m = 2 * N;
+  while ((1u << logN) < N) logN++;
+  cplx *v = (cplx *)calloc(N, sizeof(cplx));
+  u64 pos = 1;
+  for (uint32_t i = 0; i < slots; i++) { /* matrix_reps_index_map_ */
+    uint32_t i1 = bitrev((uint32_t)((pos - 1) >> 1), logN);
+    uint32_t i2 = bitrev((uint32_t)((m - pos - 1) >> 1), logN);
+    v[i1] = (cplx){values[i], 0.0};
+    v[i2] = (cplx){values[i], -0.0}; /* std::conj of a real value */
+    pos = (pos * 3) & (m - 1);
+  }
+  cplx *inv = ckks_inv_root_powers(N, logN);
+  const cplx *roots = inv;
+  const double fix = scale / (double)N;
+  /* transform_from_rev(values, log_n, roots, &fix) */
+  size_t gap = 1, mm = N >> 1;
+  for (; mm > 1; mm >>= 1) {
+    size_t offset = 0;
+    for (size_t i = 0; i < mm; i++) {
+      cplx r = *++roots;
+      cplx *x = v + offset, *y = x + gap;
+      for (size_t j = 0; j < gap; j++) {
+        cplx u = *x, w = *y;
+        *x++ = c_add(u, w);
+        *y++ = c_mul(c_sub(u, w), r);
+      }
+      offset += gap << 1;
+    }
+    gap <<= 1;
+  }
+  {
+    cplx r = *++roots;
+    cplx scaled_r = c_scale(r, fix); /* mul_root_scalar */
+    cplx *x = v, *y = v + gap;
+    for (size_t j = 0; j < gap; j++) {
+      cplx u = *x, w = *y;
+      *x++ = c_scale(c_add(u, w), fix);
+      *y++ = c_mul(c_sub(u, w), scaled_r);
+    }
+  }
+  for (uint32_t j = 0; j < N; j++) coeffs[j] = rounded ? round(v[j].re) : v[j].re;
+  free(inv);
+  free(v);
+}
+void evo_encode_coeffs(uint32_t N, const double *values, double scale, double *coeffs) {
+  encode_reals(N, values, scale, coeffs, 1);
+}
+
+/* rest of encode_internal: |coefficient| -> base-2^64 words (exact: the double is an integer)
+ * -> residue per prime, negated for negative coefficients; then ntt_negacyclic_harvey per limb.
+ * returns -1 for "encoded values are too large" (max_coeff_bit_count >= total modulus bits). */
 int evo_encode(const evo_ctx *c, uint32_t l, const double *values, double scale, uint64_t *pt) {
   uint32_t N = c->N;
   double *co = (double *)malloc(sizeof(double) * N);
-  evo_encode_coeffs(N, values, scale, co);
-  int rc = 0;
-  for (uint32_t j = 0; j < N && rc == 0; j++) {
-    double a = fabs(co[j]);
-    if (!(a < 3.4028236692093846e38)) { rc = -1; break; } /* >= 2^128 unsupported */
-    u128 mag = (u128)a;
-    int neg = signbit(co[j]);
+  encode_reals(N, values, scale, co, 0);
+  double max_coeff = 0; /* over the unrounded real parts, as encode_internal does */
+  for (uint32_t j = 0; j < N; j++) max_coeff = fmax(max_coeff, fabs(co[j]));
+  for (uint32_t j = 0; j < N; j++) co[j] = round(co[j]);
+  /* total_coeff_modulus_bit_count at this level */
+  int total_bits = 0;
+  {
+    u64 w[64] = {1};
+    int nw = 1;
     for (uint32_t i = 0; i < l; i++) {
-      u64 q = c->m[i].q, r = (u64)(mag % q);
+      u64 carry = 0;
+      for (int t = 0; t < nw; t++) {
+        u128 p = (u128)w[t] * c->m[i].q + carry;
+        w[t] = (u64)p;
+        carry = (u64)(p >> 64);
+      }
+      if (carry) w[nw++] = carry;
+    }
+    total_bits = (nw - 1) * 64;
+    for (u64 top = w[nw - 1]; top; top >>= 1) total_bits++;
+  }
+  int bitcount = (int)ceil(log2(fmax(max_coeff, 1.0))) + 1;
+  int rc = bitcount >= total_bits ? -1 : 0;
+  for (uint32_t j = 0; j < N && rc == 0; j++) {
+    int neg = signbit(co[j]);
+    double a = fabs(co[j]);
+    /* words of the integer a, least significant first (fmod / divide by 2^64 are exact) */
+    u64 words[20];
+    int nw = 0;
+    const double two64 = 18446744073709551616.0;
+    while (a >= 1 && nw < 20) {
+      words[nw++] = (u64)fmod(a, two64);
+      a /= two64;
+    }
+    for (uint32_t i = 0; i < l; i++) {
+      u64 q = c->m[i].q, r = 0;
+      for (int t = nw - 1; t >= 0; t--) r = (u64)((((u128)r << 64) | words[t]) % q);
       pt[(size_t)i * N + j] = neg ? negm(r, q) : r;
     }
   }

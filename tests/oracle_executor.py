@@ -41,7 +41,14 @@ class OracleExecutor:
             c = d["constant"]
             return list(c) * (program.vec_size // len(c))
         elif op == Op.Encode:
-            data = self.pub._encode(vals[a[0]], d["encode_scale"], d["encode_level"])
+            # encoder.encode at 2^scale and the level's limb count (seal_executor.h:217-243), by the
+            # ORACLE's encoder: the walk borrows nothing from the product
+            v = list(vals[a[0]])
+            slots = self.N // 2
+            if not v or slots % len(v):
+                raise RuntimeError("Size must exactly divide slots")
+            limbs = self.k - 1 - d["encode_level"]
+            data = self.o.encode(limbs, np.array(v * (slots // len(v)), dtype=np.float64), 2.0 ** d["encode_scale"])
             return Plain(data, 2.0 ** d["encode_scale"])
         elif op in (Op.Add, Op.Sub, Op.Mul):
             x, y = vals[a[0]], vals[a[1]]
