@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""Writes the golden vectors as raw little-endian files for tools/seal_parity.cpp (which diffs
+them against a real Microsoft SEAL >= 3.6 — the reference's arithmetic, absent from the
+development container).
+
+  python tests/golden/export_seal_vectors.py OUT_DIR            # the committed N = 1024 set
+  python tests/golden/export_seal_vectors.py OUT_DIR N b0,b1,.. # a fresh set from the CPU oracle
+                                                                # (e.g. 65536 60,60,...,60)
+OUT_DIR/manifest.txt  : `key v0 v1 ...` lines (N, bits, scale_log2, rot_steps, enc_scale_bits)
+OUT_DIR/<name>.u64    : uint64 arrays, C order ([size][limbs][N] for ciphertexts,
+                        [digit][2][k][N] for keys); OUT_DIR/<name>.f64 : float64 arrays
+Test infrastructure only (it may import oracle/)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def fresh(N, bits, seed=20260927):
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as po
+    primes = po.coeff_modulus_create(N, bits)
+    o = po.Oracle(N, primes)
+    k, l = len(primes), len(primes) - 1
+    rng = np.random.default_rng(seed)
+
+    def rand(prefix, nl):
+        return np.stack([rng.integers(0, primes[i], size=prefix + (N,), dtype=np.uint64) for i in range(nl)], axis=len(prefix))
+    d = {"primes": np.array(primes, dtype=np.uint64), "psi": np.array([o.psi(i) for i in range(k)], dtype=np.uint64)}
+    d["a2"], d["b2"], d["a3"], d["pt"] = rand((2,), l), rand((2,), l), rand((3,), l), rand((), l)
+    d["relin_key"] = rand((l, 2), k)
+    d["rot_steps"] = np.array([1, -3, N // 2 - 1], dtype=np.int64)
+    for s in d["rot_steps"]:
+        d[f"galois_key_{int(s)}"] = rand((l, 2), k)
+    d["poly"] = rand((), 1)[0]
+    a2, b2, a3, pt = d["a2"], d["b2"], d["a3"], d["pt"]
+    d["out_ntt0"], d["out_intt0"] = o.ntt(0, d["poly"]), o.intt(0, d["poly"])
+    d["out_add"], d["out_add_32"] = o.add(a2, b2), o.add(a3, b2)
+    d["out_sub"], d["out_sub_23"] = o.sub(a2, b2), o.sub(a2, a3)
+    d["out_negate"] = o.negate(a3)
+    d["out_add_plain"], d["out_sub_plain"] = o.add_plain(a2, pt), o.sub_plain(a2, pt)
+    d["out_multiply"], d["out_square"] = o.multiply(a2, b2), o.square(a2)
+    d["out_multiply_plain"] = o.multiply_plain(a3, pt)
+    d["out_relinearize"] = o.relinearize(a3, d["relin_key"])
+    d["out_rescale"], d["out_rescale3"] = o.rescale(a2), o.rescale(a3)
+    d["out_relin_rescale"] = o.rescale(d["out_relinearize"])
+    d["out_mod_switch"] = o.mod_switch(a3)
+    for s in d["rot_steps"]:
+        d[f"out_rotate_{int(s)}"] = o.rotate(a2, int(s), d[f"galois_key_{int(s)}"])
+    d["out_triple"] = o.op_triple(a2, b2, d["relin_key"])
+    d["enc_scale_bits"] = np.array([20, 30, 40, 55, 60], dtype=np.int64)
+    for c, sb in enumerate(d["enc_scale_bits"]):
+        d[f"enc_values_{c}"] = rng.uniform(-3, 3, N // 2)
+        d[f"out_encode_{c}"] = o.encode(l, d[f"enc_values_{c}"], 2.0 ** int(sb))
+    return d, bits
+
+
+def main():
+    if len(sys.argv) < 2:
+        raise SystemExit(__doc__)
+    out = sys.argv[1]
+    os.makedirs(out, exist_ok=True)
+    if len(sys.argv) >= 4:
+        d, bits = fresh(int(sys.argv[2]), [int(b) for b in sys.argv[3].split(",")])
+        N = int(sys.argv[2])
+    else:
+        d, bits, N = dict(np.load(os.path.join(HERE, "ops_n1024.npz"))), [60, 40, 60], 1024
+    with open(os.path.join(out, "manifest.txt"), "w") as f:
+        f.write("# vectors for tools/seal_parity.cpp; every ciphertext / plaintext carries scale 2^scale_log2\n")
+        f.write(f"N {N}\nbits {' '.join(str(b) for b in bits)}\nscale_log2 10\n")
+        f.write("rot_steps " + " ".join(str(int(s)) for s in d["rot_steps"]) + "\n")
+        f.write("enc_scale_bits " + " ".join(str(int(s)) for s in d["enc_scale_bits"]) + "\n")
+    n = 0
+    for name, a in d.items():
+        if name in ("rot_steps", "enc_scale_bits"):
+            continue
+        ext = ".f64" if a.dtype == np.float64 else ".u64"
+        np.ascontiguousarray(a).astype("<f8" if ext == ".f64" else "<u8").tofile(os.path.join(out, name + ext))
+        n += 1
+    print(f"wrote {n} arrays + manifest.txt to {out}")
+
+
+if __name__ == "__main__":
+    main()

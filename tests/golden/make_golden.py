@@ -6,7 +6,10 @@
                       vectors the reference's own tests assert (/root/reference/tests/bug_fixes.py:68,
                       tests/features.py:129,133), with the program and configuration of each.
   ops_n1024.npz       inputs and expected outputs of every evaluator call on the path (N = 1024,
-                      primes [60, 40, 60] -> 2 data limbs + the special prime), from seeded inputs.
+                      primes [60, 40, 60] -> 2 data limbs + the special prime), from seeded inputs,
+                      and of CKKSEncoder::encode at five scales.  tests/golden/export_seal_vectors.py
+                      turns the same vectors into raw files for tools/seal_parity.cpp, which diffs
+                      them against a real SEAL >= 3.6 wherever one is installed.
 
 The reference itself cannot run in this container (SEAL, protobuf and Galois are absent: SURVEY.md
 §8(c)), so the ciphertext-level vectors are produced by this repo's CPU oracle (oracle/), whose
@@ -102,6 +105,13 @@ def main():
     for s in d["rot_steps"]:
         d[f"out_rotate_{int(s)}"] = o.rotate(a2, int(s), d[f"galois_key_{int(s)}"])
     d["out_triple"] = o.op_triple(a2, b2, d["relin_key"])
+    # CKKSEncoder::encode (seal_executor.h:242): full slot vectors at the first data level; drawn
+    # after everything else so the vectors above keep their values
+    d["psi"] = np.array([o.psi(i) for i in range(k)], dtype=np.uint64)
+    d["enc_scale_bits"] = np.array([20, 30, 40, 55, 60], dtype=np.int64)
+    for c, sb in enumerate(d["enc_scale_bits"]):
+        d[f"enc_values_{c}"] = rng.uniform(-3, 3, N // 2)
+        d[f"out_encode_{c}"] = o.encode(l, d[f"enc_values_{c}"], 2.0 ** int(sb))
     np.savez_compressed(os.path.join(HERE, "ops_n1024.npz"), **d)
     print("wrote", sorted(os.listdir(HERE)))
 

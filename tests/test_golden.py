@@ -58,6 +58,9 @@ def test_oracle_reproduces_golden_vectors(vec):
         assert np.array_equal(got, vec[name]), name
         n += 1
     assert n == 19
+    for c, sb in enumerate(vec["enc_scale_bits"]):  # CKKSEncoder::encode vectors
+        assert np.array_equal(o.encode(2, vec[f"enc_values_{c}"], 2.0 ** int(sb)), vec[f"out_encode_{c}"]), f"encode {c}"
+    assert [o.psi(i) for i in range(3)] == [int(x) for x in vec["psi"]]
 
 
 def test_reference_constants(consts):
@@ -132,3 +135,6 @@ def test_gpu_reproduces_golden_vectors(vec):
     outs = o.g.rotate_many(o._c(vec["a2"]), [int(s) for s in vec["rot_steps"]])
     for s, ct in zip(vec["rot_steps"], outs):
         assert np.array_equal(ct.download(), vec[f"out_rotate_{int(s)}"])
+    for c, sb in enumerate(vec["enc_scale_bits"]):  # the device encoder against the stored plaintexts
+        got = o.g.encode_pt(vec[f"enc_values_{c}"], 2, 2.0 ** int(sb)).download()
+        assert np.array_equal(got, vec[f"out_encode_{c}"]), f"encode {c}"

@@ -1,0 +1,79 @@
+"""BASELINE.json's DAG configurations at their stated sizes, output ciphertexts of
+public_ctx.execute / execute_batch compared bit for bit with the CPU oracle walking the same
+compiled DAG on the same encrypted inputs and keys (SURVEY.md section 8(d) describes the padding of
+the prime chain to the stated number of data limbs L):
+  C3  Harris corner detector (examples/image_processing.py:65-100), N = 2^15, L = 8
+  C4  256 independent Sobel DAGs (examples/image_processing.py:39-63), N = 2^14, L = 5 — execute_batch
+  C5  3x3 convolution + depth-8 squaring chain (tests/large_programs.py:10-53 style), N = 2^16, L = 12
+"""
+import numpy as np
+import pytest
+
+from eva import EvaProgram, Input, Output, evaluate
+from eva.ckks import CKKSCompiler
+from eva.metric import valuation_mse
+from eva.seal import generate_keys
+from evatest import compile_and_check, oracle_execute
+from test_compiler import _sobel
+from test_gpu_e2e import _harris, _image
+
+pytestmark = pytest.mark.gpu
+
+
+def pad_chain(params, n_primes, N):
+    """force N and pad prime_bits with 60-bit primes (after the output prime) up to
+    n_primes = L + 1; legal because the reference builds its context with sec_level none
+    (/root/reference/eva/seal/seal.cpp:169)."""
+    params.poly_modulus_degree = N
+    pb = list(params.prime_bits)
+    if len(pb) < n_primes:
+        params.prime_bits = pb[:1] + [60] * (n_primes - len(pb)) + pb[1:]
+
+
+def conv_depth8():
+    deep = EvaProgram('conv+depth8', vec_size=4096)
+    with deep:
+        image = Input('image')
+        acc = None
+        for i in range(3):
+            for j in range(3):
+                t = (image << (i * 64 + j)) * (1.0 / 9.0)
+                acc = t if acc is None else acc + t
+        for _ in range(8):
+            acc = acc * acc
+        Output('y', acc)
+    deep.set_input_scales(30)
+    deep.set_output_ranges(20)
+    return deep
+
+
+def test_config5_conv_depth8_n65536_l12_bit_exact():
+    _, params, _ = compile_and_check(conv_depth8(), _image(4096), check_bit_exact=True,
+                                     params_hook=lambda p: pad_chain(p, 13, 65536))
+    assert params.poly_modulus_degree == 65536 and len(params.prime_bits) == 13
+
+
+def test_config3_harris_n32768_l8_bit_exact():
+    _, params, _ = compile_and_check(_harris(), _image(4096), check_bit_exact=True,
+                                     params_hook=lambda p: pad_chain(p, 9, 32768))
+    assert params.poly_modulus_degree == 32768 and len(params.prime_bits) == 9 and len(params.rotations) == 9
+
+
+def test_config4_256_sobel_n16384_sampled_against_oracle():
+    sob = _sobel(64, 64, 4096)
+    sob.set_input_scales(25)
+    sob.set_output_ranges(10)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(sob)
+    pad_chain(params, 6, 16384)
+    pub, sec = generate_keys(params, 11)
+    imgs = [{'image': [((37 * i + 13 * u) % 256) / 255.0 for i in range(4096)]} for u in range(256)]
+    encs = [pub.encrypt(x, sig) for x in imgs]
+    outs = pub.execute_batch(compiled, encs)
+    assert len(outs) == 256
+    for u in (0, 1, 31, 32, 63, 64, 127, 200, 255):  # across batched handles and both issue queues
+        ref = oracle_execute(pub, compiled, encs[u])
+        for name in ref.names():
+            g, o = outs[u].get(name), ref.get(name)
+            assert g[:4] == o[:4]
+            assert np.array_equal(g[4], o[4]), f"instance {u}, output {name}: execute_batch differs from the oracle walk"
+        assert valuation_mse(sec.decrypt(outs[u], sig), evaluate(compiled, imgs[u])) < 0.01

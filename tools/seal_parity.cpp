@@ -1,0 +1,229 @@
+// seal_parity.cpp — diff this repository's CPU oracle (and therefore the HIP kernels that are
+// bit-exact against it) with the REAL Microsoft SEAL, bit for bit.
+//
+// The reference (microsoft/EVA) takes its arithmetic from Microsoft SEAL >= 3.6
+// (/root/reference/CMakeLists.txt:24 `find_package(SEAL 3.6 REQUIRED)`, README.md:28-36), which is
+// not present where this repository was developed.  This standalone program builds against an
+// installed SEAL 3.6.x ANYWHERE and checks, on the vectors written by
+// tests/golden/export_seal_vectors.py:
+//   1. CoeffModulus::Create(N, bits)                      == exported prime chain
+//   2. the minimal primitive 2N-th root per prime          == exported psi
+//   3. ntt_negacyclic_harvey / inverse_...                 == exported transforms
+//   4. every Evaluator call EVA's SEALExecutor makes (seal_executor.h:114-243) on the exported
+//      inputs and keys                                      == exported outputs
+//   5. CKKSEncoder::encode on the exported value vectors   == exported plaintexts
+// and prints one PASS/FAIL line per item plus a summary; exit status 0 only when all pass.
+// With --time-triple it also times multiply + relinearize + rescale_to_next (BASELINE.json's
+// metric) on one thread, so bench.py can report a `cpu_baseline` of kind "reference".
+//
+// build:  cmake -S tools -B build/seal_parity && cmake --build build/seal_parity
+//    or:  g++ -O2 -std=c++17 tools/seal_parity.cpp -I<seal include dir> -L<seal lib dir> -lseal-3.6 -o seal_parity
+// run:    python tests/golden/export_seal_vectors.py /tmp/vec && ./seal_parity /tmp/vec
+//
+// NOT compiled in the development container (no SEAL there): written against the SEAL 3.6 public
+// API as used by the reference itself (eva/seal/seal.cpp:148-203, seal_executor.h).
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "seal/seal.h"
+
+using namespace seal;
+using u64 = std::uint64_t;
+
+static std::string g_dir;
+static int g_fail = 0, g_pass = 0;
+
+static std::vector<u64> load_u64(const std::string &name) {
+  std::ifstream f(g_dir + "/" + name + ".u64", std::ios::binary | std::ios::ate);
+  if (!f) throw std::runtime_error("missing vector file " + name + ".u64");
+  const std::streamsize n = f.tellg();
+  std::vector<u64> v((size_t)n / 8);
+  f.seekg(0);
+  f.read(reinterpret_cast<char *>(v.data()), n);
+  return v;
+}
+static std::vector<double> load_f64(const std::string &name) {
+  std::ifstream f(g_dir + "/" + name + ".f64", std::ios::binary | std::ios::ate);
+  if (!f) throw std::runtime_error("missing vector file " + name + ".f64");
+  const std::streamsize n = f.tellg();
+  std::vector<double> v((size_t)n / 8);
+  f.seekg(0);
+  f.read(reinterpret_cast<char *>(v.data()), n);
+  return v;
+}
+static std::map<std::string, std::vector<long long>> load_manifest() {
+  std::ifstream f(g_dir + "/manifest.txt");
+  if (!f) throw std::runtime_error("missing manifest.txt in " + g_dir);
+  std::map<std::string, std::vector<long long>> m;
+  std::string line;
+  while (std::getline(f, line)) {
+    std::istringstream is(line);
+    std::string key;
+    if (!(is >> key) || key[0] == '#') continue;
+    long long v;
+    while (is >> v) m[key].push_back(v);
+  }
+  return m;
+}
+static void report(const std::string &what, bool ok) {
+  std::cout << (ok ? "PASS  " : "FAIL  ") << what << std::endl;
+  (ok ? g_pass : g_fail)++;
+}
+static bool same(const u64 *got, const std::vector<u64> &want) { return std::memcmp(got, want.data(), want.size() * 8) == 0; }
+
+int main(int argc, char **argv) {
+  if (argc < 2) {
+    std::cerr << "usage: seal_parity <vector dir> [--time-triple]" << std::endl;
+    return 2;
+  }
+  g_dir = argv[1];
+  const bool time_triple = argc > 2 && std::string(argv[2]) == "--time-triple";
+  auto mf = load_manifest();
+  const size_t N = (size_t)mf.at("N")[0];
+  std::vector<int> bits(mf.at("bits").begin(), mf.at("bits").end());
+  const double scale = std::pow(2.0, (double)mf.at("scale_log2")[0]);
+  const size_t k = bits.size(), l = k - 1;
+
+  std::cout << "SEAL " << SEAL_VERSION_MAJOR << "." << SEAL_VERSION_MINOR << "." << SEAL_VERSION_PATCH << ", N = " << N << ", k = " << k
+            << std::endl;
+
+  // ---- the context exactly as the reference builds it (eva/seal/seal.cpp:169, 179-182)
+  EncryptionParameters parms(scheme_type::ckks);
+  parms.set_poly_modulus_degree(N);
+  parms.set_coeff_modulus(CoeffModulus::Create(N, bits));
+  SEALContext context(parms, true, sec_level_type::none);
+  auto key_data = context.key_context_data();
+
+  // 1. primes   2. psi
+  {
+    auto want = load_u64("primes"), psi = load_u64("psi");
+    bool okp = true, okr = true;
+    auto &cm = key_data->parms().coeff_modulus();
+    for (size_t i = 0; i < k; i++) {
+      okp = okp && cm[i].value() == want[i];
+      okr = okr && key_data->small_ntt_tables()[i].get_root() == psi[i];
+    }
+    report("CoeffModulus::Create prime chain", okp);
+    report("minimal primitive 2N-th roots (NTTTables::get_root)", okr);
+  }
+  // 3. transforms under prime 0
+  {
+    auto poly = load_u64("poly");
+    auto f = poly, b = poly;
+    util::ntt_negacyclic_harvey(f.data(), key_data->small_ntt_tables()[0]);
+    util::inverse_ntt_negacyclic_harvey(b.data(), key_data->small_ntt_tables()[0]);
+    report("ntt_negacyclic_harvey", same(f.data(), load_u64("out_ntt0")));
+    report("inverse_ntt_negacyclic_harvey", same(b.data(), load_u64("out_intt0")));
+  }
+
+  // ---- values at the first data level (l limbs)
+  auto first = context.first_context_data();
+  const parms_id_type pid = first->parms_id();
+  auto make_ct = [&](const std::string &name, size_t size) {
+    auto d = load_u64(name);
+    Ciphertext ct;
+    ct.resize(context, pid, size);
+    ct.is_ntt_form() = true;
+    ct.scale() = scale;
+    if (d.size() != size * l * N) throw std::runtime_error("unexpected length of " + name);
+    std::memcpy(ct.data(), d.data(), d.size() * 8);
+    return ct;
+  };
+  auto make_pt = [&](const std::string &name) {
+    auto d = load_u64(name);
+    Plaintext pt;
+    pt.parms_id() = parms_id_zero;
+    pt.resize(l * N);
+    std::memcpy(pt.data(), d.data(), d.size() * 8);
+    pt.parms_id() = pid;
+    pt.scale() = scale;
+    return pt;
+  };
+  Ciphertext a2 = make_ct("a2", 2), b2 = make_ct("b2", 2), a3 = make_ct("a3", 3);
+  Plaintext pt = make_pt("pt");
+
+  // ---- keys: generate real key objects for their structure, then overwrite every residue with the
+  // exported uniform data (layout [digit][2][k][N] == SEAL's KSwitchKeys: one size-2 key-level
+  // ciphertext per digit)
+  KeyGenerator keygen(context);
+  RelinKeys rk;
+  keygen.create_relin_keys(rk);
+  {
+    auto d = load_u64("relin_key");
+    for (size_t J = 0; J < l; J++) std::memcpy(rk.data()[0][J].data().data(), d.data() + J * 2 * k * N, 2 * k * N * 8);
+  }
+  std::vector<int> steps(mf.at("rot_steps").begin(), mf.at("rot_steps").end());
+  GaloisKeys gk;
+  keygen.create_galois_keys(steps, gk);
+  for (int s : steps) {
+    auto d = load_u64("galois_key_" + std::to_string(s));
+    const std::uint32_t elt = key_data->galois_tool()->get_elt_from_step(s);
+    auto &kv = gk.data()[GaloisKeys::get_index(elt)];
+    for (size_t J = 0; J < l; J++) std::memcpy(kv[J].data().data(), d.data() + J * 2 * k * N, 2 * k * N * 8);
+  }
+
+  // 4. evaluator calls (seal_executor.h line in brackets)
+  Evaluator ev(context);
+  Ciphertext o;
+  ev.add(a2, b2, o);                   report("add 2+2 [:124]", same(o.data(), load_u64("out_add")));
+  ev.add(a3, b2, o);                   report("add 3+2 [:124]", same(o.data(), load_u64("out_add_32")));
+  ev.sub(a2, b2, o);                   report("sub 2-2 [:140]", same(o.data(), load_u64("out_sub")));
+  ev.sub(a2, a3, o);                   report("sub 2-3 [:140]", same(o.data(), load_u64("out_sub_23")));
+  ev.negate(a3, o);                    report("negate [:194]", same(o.data(), load_u64("out_negate")));
+  ev.add_plain(a2, pt, o);             report("add_plain [:127]", same(o.data(), load_u64("out_add_plain")));
+  ev.sub_plain(a2, pt, o);             report("sub_plain [:143]", same(o.data(), load_u64("out_sub_plain")));
+  ev.multiply(a2, b2, o);              report("multiply [:164]", same(o.data(), load_u64("out_multiply")));
+  ev.square(a2, o);                    report("square [:162]", same(o.data(), load_u64("out_square")));
+  ev.multiply_plain(a3, pt, o);        report("multiply_plain [:168]", same(o.data(), load_u64("out_multiply_plain")));
+  ev.relinearize(a3, rk, o);           report("relinearize [:200]", same(o.data(), load_u64("out_relinearize")));
+  { Ciphertext r; ev.rescale_to_next(o, r); report("rescale_to_next(relinearize) [:200,:213]", same(r.data(), load_u64("out_relin_rescale"))); }
+  ev.rescale_to_next(a2, o);           report("rescale_to_next size 2 [:213]", same(o.data(), load_u64("out_rescale")));
+  ev.rescale_to_next(a3, o);           report("rescale_to_next size 3 [:213]", same(o.data(), load_u64("out_rescale3")));
+  ev.mod_switch_to_next(a3, o);        report("mod_switch_to_next [:206]", same(o.data(), load_u64("out_mod_switch")));
+  for (int s : steps) {
+    ev.rotate_vector(a2, s, gk, o);
+    report("rotate_vector " + std::to_string(s) + " [:181,:188]", same(o.data(), load_u64("out_rotate_" + std::to_string(s))));
+  }
+  {
+    Ciphertext m, r, t;
+    ev.multiply(a2, b2, m);
+    ev.relinearize(m, rk, r);
+    ev.rescale_to_next(r, t);
+    report("op-triple multiply+relinearize+rescale", same(t.data(), load_u64("out_triple")));
+  }
+
+  // 5. encoder (seal_executor.h:242): full slot vectors at 2^scale_bits, first data level
+  CKKSEncoder encoder(context);
+  if (mf.count("enc_scale_bits")) {
+    auto &sb = mf.at("enc_scale_bits");
+    for (size_t c = 0; c < sb.size(); c++) {
+      auto vals = load_f64("enc_values_" + std::to_string(c));
+      Plaintext p;
+      encoder.encode(vals, pid, std::pow(2.0, (double)sb[c]), p);
+      report("CKKSEncoder::encode at 2^" + std::to_string(sb[c]) + " [:242]", same(p.data(), load_u64("out_encode_" + std::to_string(c))));
+    }
+  }
+
+  if (time_triple) {
+    Ciphertext m, r, t;
+    const int reps = 20;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps; i++) {
+      ev.multiply(a2, b2, m);
+      ev.relinearize(m, rk, r);
+      ev.rescale_to_next(r, t);
+    }
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cout << "TIMING op-triples/s " << reps / s << " threads 1 N " << N << " limbs " << l << std::endl;
+  }
+  std::cout << "SUMMARY " << g_pass << " passed, " << g_fail << " failed" << std::endl;
+  return g_fail ? 1 : 0;
+}
