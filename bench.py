@@ -3,18 +3,34 @@
 (multiply + relinearize + rescale) at N = 2^16, L = 10 data limbs (k = 11 key primes).
 
 One "step" = one batch of --batch independent op-triples through the C-ABI of libeva_hip.so
-(per group of --group triples: evah_multiply_many, then evah_relinearize_rescale_many =
-relinearize and rescale_to_next evaluated together, bit-identical to the separate calls), inputs and the relinearization key already
-resident in HBM.  One process per GPU; ranks run independent batches (the path shards over
-independent ciphertexts — no data-path collective), `value` = triples of all ranks / max time.
+(per group of --group triples: one evah_multiply_relinearize_rescale_many when the library has the
+fully fused form, else evah_multiply_many + evah_relinearize_rescale_many — bit-identical to the
+three separate SEAL calls), inputs and the relinearization key already resident in HBM.  One process
+per GPU; ranks run independent batches (the path shards over independent ciphertexts — no data-path
+collective), `value` = triples of all ranks / max time over ranks.
+
+`python bench.py --gpus N` with no torch.distributed environment launches the N ranks itself
+(python -m torch.distributed.run, 127.0.0.1); under torchrun it is one rank of the job.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline     — dominant kernel class by HIP-event time measured live in the timed region
-  cpu_baseline — the CPU oracle (kind "port") timed on one host core on a bounded sample
+  roofline     — SURVEY.md section 8(d) algorithmic bytes of the op-triple x value, over the 8 TB/s
+                 HBM peak (`frac`), plus the dominant kernel class by HIP-event time measured live
+                 inside the timed region on the launch stream
+  verified     — after the timed region one output per group is downloaded and compared, word for
+                 word, with the CPU oracle's multiply+relinearize+rescale of the same operands
+  execute_path — the same op-triples as a compiled EVA program through public_ctx.execute()
+                 (upload + graph replay + download: the PCIe-inclusive figure, never `value`)
+  dag          — Harris corner detector, N = 2^15, L = 8 (BASELINE config 3): execute() ms and the
+                 CPU walk of the same compiled DAG over the oracle (serial and all host cores),
+                 north_star's ">= 10x the CPU on Harris" driver-timed
+  cpu_baseline — the CPU oracle (kind "port"; "SEAL absent" unless a real SEAL is installed on the
+                 host) on one host core on a bounded sample, and on many cores
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,49 +41,155 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 
 def class_bytes(N, l, k, G=1):
-    """Compulsory HBM bytes (distinct inputs read once + outputs written once) per launch of each
-    kernel class for a group of G op-triples as bench.py issues it — evah_multiply_many, then
-    evah_relinearize_rescale_many (relinearize at l limbs fused with the rescale l -> l-1);
-    DESIGN.md §4.  Every launch covers the G triples of the group; the relinearization key is one
-    input of the fused key-switch launch however many triples share it, so it is counted once
-    per launch (the op-level figure below keeps SURVEY §8(d)'s per-op key bytes).
-    W = one limb of one polynomial = 8N bytes."""
+    """Distinct HBM bytes (inputs read once + outputs written once) per launch of each kernel class
+    for a group of G op-triples; the relinearization key is one input of the fused key-switch
+    launch however many triples share it.  W = one limb of one polynomial = 8N bytes.  These are
+    per-KERNEL figures (they include the l^2 converted digits that SURVEY 8(d) counts as NTT-internal)
+    and only feed `roofline.dominant`; the headline uses triple_bytes()."""
     W = 8 * N
     per_triple = {
-        "elementwise": [7 * l * W],                                   # multiply: 4 polys in, 3 out
-        "intt_pass1": [2 * l * W, 2 * 2 * W, (2 + 2 + 2 + 2) * W],   # digits; special limbs; t_K (a,prod,r in / t out)
-        "intt_pass2": [2 * l * W, 2 * 2 * W, (2 + 2 + 2 + 2) * W],
-        "ksdigit_pass1": [(l + l * l) * W],                           # l digits in, l^2 converted digits out
-        "ks_mac": [(l * l + l + 2 * (l + 1)) * W],                    # digits + target in, prod out (key: below)
-        "moddown_pass1": [(2 + 2 + 2 * (l - 1)) * W],                 # r, t in; intermediates out
-        "moddown_pass2": [(4 * 2 * (l - 1)) * W],                     # interm + a + prod in; out
+        "elementwise": 7 * l * W,
+        "intt_pass1": (2 * l * W + 2 * 2 * W + 8 * W) / 3, "intt_pass2": (2 * l * W + 2 * 2 * W + 8 * W) / 3,
+        "ksdigit_pass1": (l + l * l) * W,
+        "ks_mac": (l * l + l + 2 * (l + 1)) * W,
+        "moddown_pass1": (2 + 2 + 2 * (l - 1)) * W,
+        "moddown_pass2": (4 * 2 * (l - 1)) * W,
     }
-    out = {kk: (sum(v) / len(v)) * G for kk, v in per_triple.items()}
-    out["ks_mac"] += 2 * l * (l + 1) * W                              # the shared key, read once per launch
+    out = {kk: v * G for kk, v in per_triple.items()}
+    out["ks_mac"] += 2 * l * (l + 1) * W
     return out
 
 
 def triple_bytes(N, l):
-    """SURVEY.md §8(d): multiply 7P + relinearize 5P + 2l(l+1)N8 + rescale 2P + 2(l-1)N8."""
+    """SURVEY.md 8(d): multiply 7P + relinearize 5P + 2l(l+1)N8 + rescale 2P + 2(l-1)N8."""
     P = l * N * 8
     return 7 * P + 5 * P + 2 * l * (l + 1) * N * 8 + 2 * P + 2 * (l - 1) * N * 8
+
+
+def self_launch(args):
+    """--gpus N without a torch.distributed environment: start the N ranks here."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def execute_leg(N, l, n_products, reps):
+    """The op-triples as a compiled program through public_ctx.execute(): z_i = x_i * y_i with eager
+    relinearization, so every product is Mul -> Relinearize -> Rescale on l limbs."""
+    import numpy as np
+    from eva import EvaProgram, Input, Output
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    prog = EvaProgram('op_triples', vec_size=1024)
+    with prog:
+        for i in range(n_products):
+            Output(f'z{i}', Input(f'x{i}') * Input(f'y{i}'))
+    prog.set_input_scales(60)
+    prog.set_output_ranges(20)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false', 'lazy_relinearize': 'false'}).compile(prog)
+    params.poly_modulus_degree = N
+    params.prime_bits = [60] * (l + 1)
+    pub, sec = generate_keys(params, 17)
+    rng = np.random.default_rng(5)
+    inputs = {}
+    for i in range(n_products):
+        inputs[f'x{i}'] = list(rng.uniform(-1, 1, 1024))
+        inputs[f'y{i}'] = list(rng.uniform(-1, 1, 1024))
+    enc = pub.encrypt(inputs, sig)
+    out = pub.execute(compiled, enc)            # eager walk (device context, key upload, pool)
+    out = pub.execute(compiled, enc)            # graph capture
+    ts, parts = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = pub.execute(compiled, enc)
+        ts.append(time.perf_counter() - t0)
+        parts.append(list(pub.last_timing))
+    ts.sort()
+    med = ts[len(ts) // 2]
+    # check product 0 against the oracle's op-triple on the same encrypted inputs and key
+    from oracle import pyoracle as po  # checker only
+    o = po.Oracle(N, list(pub.primes))
+    want = o.op_triple(enc.get('x0')[4], enc.get('y0')[4], pub.relin_key())
+    ok = bool(np.array_equal(out.get('z0')[4], want))
+    from eva import Op
+    kinds = [str(d["op"]).split(".")[-1] for d in compiled._dump()]
+    pm = [sorted(p[j] for p in parts)[len(parts) // 2] for j in range(3)]
+    return {"program": f"{n_products} independent products z_i = x_i * y_i (Mul -> Relinearize -> Rescale), N=2^{N.bit_length() - 1}, L={l}",
+            "ms_per_execute": round(med * 1e3, 3), "triples_per_s": round(n_products / med, 1),
+            "includes": "input upload (PCIe), hipGraph replay, output download (PCIe)",
+            "ms_upload_enqueue_drain": [round(x, 3) for x in pm],
+            "ops": {kk: kinds.count(kk) for kk in ("Mul", "Relinearize", "Rescale")},
+            "bit_exact_vs_oracle": ok}
+
+
+def dag_leg(reps, cpu_threads):
+    """BASELINE config 3 / north_star's target: Harris corner detector at N = 2^15, L = 8."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    from test_gpu_e2e import _harris, _image
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
+    params.poly_modulus_degree = 32768
+    pb = list(params.prime_bits)
+    params.prime_bits = pb[:1] + [60] * (9 - len(pb)) + pb[1:]
+    pub, sec = generate_keys(params, 1)
+    enc = pub.encrypt(_image(4096), sig)
+    out = pub.execute(compiled, enc)
+    out = pub.execute(compiled, enc)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = pub.execute(compiled, enc)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    gpu_ms = ts[len(ts) // 2] * 1e3
+    # CPU: the same compiled DAG walked in C over the oracle (checker / reported baseline only)
+    from oracle_executor import c_walk
+    ref, t1 = c_walk(pub, compiled, enc, threads=1)
+    ok = all(np.array_equal(out.get(name)[4], ref[name]) for name in ref)
+    _, tn = c_walk(pub, compiled, enc, threads=cpu_threads)
+    kinds = [str(d["op"]).split(".")[-1] for d in compiled._dump()]
+    return {"workload": "Harris corner detector (examples/image_processing.py), 64x64 image, N=2^15, L=8 data limbs",
+            "terms": len(kinds), "rotations": kinds.count("RotateLeftConst") + kinds.count("RotateRightConst"),
+            "relinearize": kinds.count("Relinearize"), "rescale": kinds.count("Rescale"),
+            "gpu_execute_ms": round(gpu_ms, 3), "gpu_includes": "input upload, hipGraph replay, output download",
+            "cpu_walk_ms": {"1": round(t1 * 1e3, 1), str(cpu_threads): round(tn * 1e3, 1)},
+            "cpu_walk": "oracle/eva_oracle_dag.c: serial forwardPass / dependency-counting traversal on pthreads",
+            "speedup_vs_cpu": {"1": round(t1 * 1e3 / gpu_ms, 1), str(cpu_threads): round(tn * 1e3 / gpu_ms, 1)},
+            "bit_exact_vs_oracle": bool(ok)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="independent op-triples per step")
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--limbs", type=int, default=10)
     ap.add_argument("--streams", type=int, default=1,
                     help="issue queues (forked contexts = HIP streams) the independent triples are spread over")
     ap.add_argument("--group", type=int, default=32,
-                    help="triples handed to one evah_relinearize_rescale_many call (wide launches, shared key)")
+                    help="triples handed to one batched call (wide launches, shared key)")
+    ap.add_argument("--unfused", action="store_true", help="multiply_many + relinearize_rescale_many instead of the fully fused call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the execute()-path and DAG legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import numpy as np
     # torch first (inside Dist): the HIP runtime torch bundles must be the one every library shares
@@ -79,7 +201,7 @@ def main():
                          "the product path has no CPU fallback")
     dist = Dist(backend="nccl")
     rank, world, local = dist.rank, dist.world, dist.local_rank
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from eva_amd import backend
@@ -90,8 +212,9 @@ def main():
     primes = coeff_modulus_create(N, [60] * k)
     g = backend.Context(N, primes, device=local)
     queues = [g] + [g.fork() for _ in range(max(1, args.streams) - 1)]
+    fused = (not args.unfused) and hasattr(g, "multiply_relinearize_rescale_many")
 
-    # synthetic inputs (SURVEY.md §8d): uniform residues; every triple of a step has its own
+    # synthetic inputs (SURVEY.md 8d): uniform residues; every triple of a step has its own
     # operand pair (distinct HBM data: no triple finds its inputs in cache because another used them)
     rng = np.random.default_rng(0xE7A + rank)
 
@@ -102,35 +225,42 @@ def main():
     key_host = rand((l, 2), k)
     g.upload_relin_key(key_host)
     npairs = args.batch
-    host_pairs, pairs = [], []
+    G = max(1, min(args.group, 64, args.batch))
+    host_pairs, pairs = {}, []
     for i in range(npairs):
         a, b = rand((2,), l), rand((2,), l)
         pairs.append((g.upload_ct(a, 2.0 ** 40), g.upload_ct(b, 2.0 ** 40)))
-        if i < 4:
-            host_pairs.append((a, b))  # the CPU baseline leg runs the first four
+        if i % G == 0 or i < 4:
+            host_pairs[i] = (a, b)  # verification (first of each group) and the CPU baseline leg
 
     PROF_EVERY = 8  # HIP-event brackets on every 8th triple only: keeps the timed region honest
 
-    G = max(1, min(args.group, 64, args.batch))
+    def run_group(q, idx):
+        """-> (handles to free, outputs)"""
+        As, Bs = [pairs[i % npairs][0] for i in idx], [pairs[i % npairs][1] for i in idx]
+        if len(idx) > 1:
+            if fused:
+                outs = q.multiply_relinearize_rescale_many(As, Bs, 60)
+                return outs, outs
+            ms = q.multiply_many(As, Bs)
+            outs = q.relinearize_rescale_many(ms, 60)
+            return ms + outs, outs
+        m = q.multiply(As[0], Bs[0])
+        o = q.relinearize_rescale(m, 60)
+        return [m, o], [o]
 
-    def step(profile=False):
-        # the batch is issued in groups of G independent triples per queue: G multiplies, then one
-        # relinearize_rescale_many (== rescale(relinearize(m)) for each m) as one wide launch set
+    def step(profile=False, keep=None):
         for gi, i0 in enumerate(range(0, args.batch, G)):
             q = queues[gi % len(queues)]
             sample = profile and (gi % max(1, PROF_EVERY // G) == 0)
             if sample:
                 q.profile(True)
-            idx = range(i0, min(i0 + G, args.batch))
-            if len(idx) > 1:
-                ms = q.multiply_many([pairs[i % npairs][0] for i in idx], [pairs[i % npairs][1] for i in idx])
-                outs = q.relinearize_rescale_many(ms, 60)
-            else:
-                ms = [q.multiply(*pairs[i0 % npairs])]
-                outs = [q.relinearize_rescale(ms[0], 60)]
+            hs, outs = run_group(q, range(i0, min(i0 + G, args.batch)))
             if sample:
                 q.profile(False)
-            for h in ms + outs:
+            if keep is not None:
+                keep[i0] = outs[0].download()
+            for h in hs:
                 h.free()
 
     def barrier():
@@ -158,72 +288,73 @@ def main():
     triples = args.steps * args.batch * world
     value = triples / dt
 
-    # after the timed region: the same groups on ONE queue with nothing else in flight, so each
-    # kernel has the chip to itself (the timed region overlaps two queues, which stretches every
-    # launch it brackets); reported beside the timed-region figures, never instead of them
-    iso = {}
-    q0 = queues[0]
-    q0.profile_reset()
-    q0.profile(True)
-    for _ in range(3):
-        if G > 1:
-            ms = q0.multiply_many([pairs[i % npairs][0] for i in range(G)], [pairs[i % npairs][1] for i in range(G)])
-            outs = q0.relinearize_rescale_many(ms, 60)
-        else:
-            ms = [q0.multiply(*pairs[0])]
-            outs = [q0.relinearize_rescale(ms[0], 60)]
-        for h in ms + outs:
-            h.free()
-    q0.profile(False)
-    q0.sync()
-    iso = q0.profile_get()
+    # ---- outside the timed region: one more step whose first output per group is downloaded and
+    # compared with the CPU oracle on the same operands
+    got = {}
+    step(keep=got)
+    barrier()
+    verified = None
+    if rank == 0:
+        from oracle import pyoracle as po  # checker only
+        o = po.Oracle(N, primes)
+        verified = {"triples_checked": len(got), "bit_exact_vs_oracle":
+                    bool(all(np.array_equal(got[i], o.op_triple(host_pairs[i][0], host_pairs[i][1], key_host)) for i in got))}
+        if not verified["bit_exact_vs_oracle"]:
+            raise SystemExit("bench.py: the timed path's output differs from the CPU oracle — number withheld")
 
     if rank == 0:
         cb = class_bytes(N, l, k, G)
-        dom = max(prof, key=lambda c: prof[c][1])
-        n_l, ms = prof[dom]
-        avg_us = ms * 1e3 / max(n_l, 1)
-        ach = cb[dom] / (avg_us * 1e-6) / 1e9 if dom in cb and n_l else 0.0
-        kern_total_ms = sum(v[1] for v in prof.values())
-        traffic = None  # PMC bytes per launch of the dominant kernel, from the committed rocprofv3 passes
-        tpath = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
-        if os.path.exists(tpath):
+        dom = max(prof, key=lambda c: prof[c][1]) if prof else None
+        roofline = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "achieved": round(triple_bytes(N, l) * value / world / 1e9, 1),
+                    "frac": round(triple_bytes(N, l) * value / world / 1e9 / HBM_PEAK_GBPS, 4),
+                    "bytes_per_unit": triple_bytes(N, l),
+                    "basis": "SURVEY.md 8(d) algorithmic bytes of one op-triple (inputs, outputs and key read/written "
+                             "once; NTT-internal passes count as zero) x op-triples/s per GPU"}
+        if dom:
+            n_l, ms = prof[dom]
+            avg_us = ms * 1e3 / max(n_l, 1)
+            kern_total_ms = sum(v[1] for v in prof.values())
+            traffic = None  # PMC bytes per launch of the dominant kernel, from the committed rocprofv3 passes
+            tpath = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath))["by_class"].get(dom, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline["kernel"] = dom
+            roofline["traffic"] = traffic
+            roofline["dominant"] = {
+                "kernel": dom, "avg_launch_us": round(avg_us, 2), "launches_sampled": n_l,
+                "distinct_bytes_per_launch": int(cb.get(dom, 0)),
+                "achieved": round(cb.get(dom, 0) / (avg_us * 1e-6) / 1e9, 1) if avg_us else None,
+                "sampling": (f"HIP events on the launch stream around every launch of 1 in {max(1, PROF_EVERY // G)} "
+                             f"groups of {G} triples inside the timed region")}
+            roofline["by_class_us"] = {c: round(v[1] * 1e3 / max(v[0], 1), 2) for c, v in prof.items() if v[0]}
+            roofline["by_class_share"] = {c: round(v[1] / kern_total_ms, 3) for c, v in prof.items() if v[0]}
+
+        legs = {}
+        if world == 1 and not args.no_legs:
             try:
-                traffic = json.load(open(tpath))["by_class"].get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {
-            "bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "avg_launch_us": round(avg_us, 2), "launches_sampled": n_l,
-            "sampling": (f"HIP events around every launch of 1 in {max(1, PROF_EVERY // G)} groups of {G} triples "
-                         "inside the timed region"),
-            "bytes_per_launch": int(cb.get(dom, 0)),
-            "op_level": {  # SURVEY.md §8(d) figure: 198.2 MB per op-triple at N=2^16, l=10
-                "bytes_per_triple": triple_bytes(N, l),
-                "achieved": round(triple_bytes(N, l) * value / world / 1e9, 1),
-                "frac": round(triple_bytes(N, l) * value / world / 1e9 / HBM_PEAK_GBPS, 4)},
-            "isolated": {  # same launches, one queue, nothing overlapping (outside the timed region)
-                "kernel": dom,
-                "avg_launch_us": round(iso[dom][1] * 1e3 / max(iso[dom][0], 1), 2) if dom in iso else None,
-                "achieved": round(cb[dom] / (iso[dom][1] * 1e-3 / max(iso[dom][0], 1)) / 1e9, 1)
-                if dom in iso and iso[dom][1] > 0 and dom in cb else None,
-                "by_class_us": {c: round(v[1] * 1e3 / max(v[0], 1), 2) for c, v in iso.items() if v[0]}},
-            "by_class_us": {c: round(v[1] * 1e3 / max(v[0], 1), 2) for c, v in prof.items() if v[0]},
-            "by_class_share": {c: round(v[1] / kern_total_ms, 3) for c, v in prof.items() if v[0]},
-        }
+                legs["execute_path"] = execute_leg(N, l, 8, 15)
+            except Exception as e:  # noqa: BLE001 — a leg must not cost the headline line
+                legs["execute_path"] = {"error": repr(e)}
+            try:
+                legs["dag"] = dag_leg(15, max(1, min(os.cpu_count() or 1, 64)))
+            except Exception as e:  # noqa: BLE001
+                legs["dag"] = {"error": repr(e)}
+
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
-            from oracle import pyoracle as po  # checker / reported baseline only
-            o = po.Oracle(N, primes)
-            a, b = host_pairs[0]
+            hp = [host_pairs[i] for i in sorted(host_pairs)][:4]
+            a, b = hp[0]
             t1 = time.perf_counter()
             o.op_triple(a, b, key_host)
             one = time.perf_counter() - t1
             n = max(1, min(50, int(args.cpu_seconds / max(one, 1e-3))))
             t1 = time.perf_counter()
             for i in range(n):
-                a, b = host_pairs[i % len(host_pairs)]
+                a, b = hp[i % len(hp)]
                 o.op_triple(a, b, key_host)
             cdt = time.perf_counter() - t1
             # the same port on many host cores at once (independent triples, one per thread; ctypes
@@ -233,7 +364,7 @@ def main():
             done = []
 
             def worker(i):
-                a_, b_ = host_pairs[i % len(host_pairs)]
+                a_, b_ = hp[i % len(hp)]
                 o.op_triple(a_, b_, key_host)
                 done.append(i)
             ths = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
@@ -243,7 +374,15 @@ def main():
             for t in ths:
                 t.join()
             mdt = time.perf_counter() - t1
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            try:
+                import seal_probe
+                seal = seal_probe.probe()
+            except Exception:  # noqa: BLE001
+                seal = {"present": False}
             cpu = {"value": round(n / cdt, 3), "unit": "op-triples/s", "cores": 1, "kind": "port",
+                   "seal": "present: " + ",".join(seal.get("paths", [])[:2]) if seal.get("present") else
+                           "SEAL absent on this host (tools/seal_probe.py): the oracle restatement is the baseline",
                    "all_cores": {"value": round(len(done) / mdt, 2), "cores": threads,
                                  "sample": f"{threads} op-triples, one per thread, concurrently"},
                    "sample": f"{n} op-triples (multiply+relinearize+rescale) at N=2^{args.logn}, "
@@ -260,9 +399,12 @@ def main():
                                    f"{args.batch} independent triples per step per GPU",
                        "poly_modulus_degree": N, "limbs": l, "batch_per_gpu": args.batch,
                        "streams_per_gpu": len(queues), "triples_per_call": G,
+                       "entry_point": "evah_multiply_relinearize_rescale_many" if fused else
+                                      "evah_multiply_many + evah_relinearize_rescale_many",
                        "parallelism": f"independent ciphertexts sharded over {world} GPU(s), no collective"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "verified": verified, "cpu_baseline": cpu,
         }
+        line.update(legs)
         print(json.dumps(line), flush=True)
     # orderly teardown: values, then forked queues, then the root context
     for a, b in pairs:

@@ -84,10 +84,10 @@ inline std::vector<u64> coeff_modulus_create(uint32_t N, const std::vector<int> 
   size_t cnt[64] = {0}, used[64] = {0};
   std::vector<u64> table[64];
   for (int b : bit_sizes) {
-    if (b < 2 || b > 61) throw std::invalid_argument("bit_sizes is invalid");
+    if (b < 2 || b > 60) throw std::invalid_argument("bit_sizes is invalid"); // SEAL_USER_MOD_BIT_COUNT_MAX = 60
     cnt[b]++;
   }
-  for (int b = 2; b <= 61; b++)
+  for (int b = 2; b <= 60; b++)
     if (cnt[b]) table[b] = ntt_primes_descending(N, b, cnt[b]);
   std::vector<u64> out;
   for (int b : bit_sizes) out.push_back(table[b][cnt[b] - 1 - used[b]++]);
@@ -137,9 +137,14 @@ inline CkksRoots ckks_roots(uint32_t N) {
   const size_t deg = 2 * (size_t)N, oct_n = deg / 8;
   std::vector<std::complex<double>> oct(oct_n + 1);
   const double pi = 3.1415926535897932384626433832795028842;
+  // cos and sin through volatile pointers: GCC would fuse the pair into one sincos() call, and
+  // glibc's sincos() is not bit-identical to sin() (2N = 8192, i = 487 differs in the last place);
+  // the reference recommends clang (README.md:21-25), which makes the two separate libm calls
+  double (*volatile libm_cos)(double) = static_cast<double (*)(double)>(std::cos);
+  double (*volatile libm_sin)(double) = static_cast<double (*)(double)>(std::sin);
   for (size_t i = 0; i <= oct_n; i++) {
     const double theta = 2 * pi * (double)i / (double)deg;
-    oct[i] = std::complex<double>(std::cos(theta), std::sin(theta));
+    oct[i] = std::complex<double>(libm_cos(theta), libm_sin(theta));
   }
   auto first_quadrant = [&](size_t idx) { // idx <= deg/4
     if (idx <= oct_n) return oct[idx];

@@ -10,10 +10,12 @@
 #include <cmath>
 #include <complex>
 #include <cstdint>
+#include <memory>
 #include <random>
 #include <stdexcept>
 #include <vector>
 
+#include "csprng.h"
 #include "hostmath.h"
 #include "../../include/eva_hip.h"
 
@@ -268,13 +270,13 @@ public:
   }
 
   // ---- sampling
-  void sample_ternary(std::mt19937_64 &rng, std::vector<int8_t> &out) const {
+  void sample_ternary(SecureRng &rng, std::vector<int8_t> &out) const {
     out.resize(N);
     std::uniform_int_distribution<int> d(-1, 1);
     for (auto &v : out) v = (int8_t)d(rng);
   }
   // centered binomial, 21 + 21 bits: sigma ~ 3.24 (SEAL sample_poly_cbd)
-  void sample_error(std::mt19937_64 &rng, std::vector<int8_t> &out) const {
+  void sample_error(SecureRng &rng, std::vector<int8_t> &out) const {
     out.resize(N);
     for (auto &v : out) {
       u64 r = rng();
@@ -286,7 +288,7 @@ public:
     for (uint32_t j = 0; j < N; j++) out[j] = s[j] < 0 ? q - (u64)(-s[j]) : (u64)s[j];
     ntt(prime_idx, out);
   }
-  void sample_uniform(std::mt19937_64 &rng, uint32_t prime_idx, u64 *out) const {
+  void sample_uniform(SecureRng &rng, uint32_t prime_idx, u64 *out) const {
     u64 q = primes[prime_idx];
     u64 lim = ~(u64)0 - (~(u64)0 % q) - 1; // rejection bound
     for (uint32_t j = 0; j < N; j++) {
@@ -389,10 +391,21 @@ struct PublicKey {
 class KeyGenerator {
 public:
   const HostContext &cx;
-  std::mt19937_64 rng;
+  // two independent ChaCha20 streams: `secret` draws the secret key and the error polynomials,
+  // `pub` the uniform polynomials that are published as part of every key — nothing an observer of
+  // the keys sees comes from the stream that produced the secret.  seed == 0: both keyed from the
+  // OS (getrandom); seed != 0 is the reproducible test hook (csprng.h).
+  std::unique_ptr<SecureRng> secret, pub;
   SecretKey sk;
-  KeyGenerator(const HostContext &c, uint64_t seed) : cx(c), rng(seed) {
-    cx.sample_ternary(rng, sk.s);
+  KeyGenerator(const HostContext &c, uint64_t seed) : cx(c) {
+    if (seed) {
+      secret = std::make_unique<SecureRng>(seed, 1);
+      pub = std::make_unique<SecureRng>(seed, 2);
+    } else {
+      secret = std::make_unique<SecureRng>();
+      pub = std::make_unique<SecureRng>();
+    }
+    cx.sample_ternary(*secret, sk.s);
     sk.s_ntt.resize((size_t)cx.k * cx.N);
     for (uint32_t i = 0; i < cx.k; i++) cx.small_to_ntt(sk.s, i, sk.s_ntt.data() + (size_t)i * cx.N);
   }
@@ -445,12 +458,12 @@ private:
   void encrypt_zero_symmetric(u64 *c0, u64 *c1) {
     const uint32_t N = cx.N;
     std::vector<int8_t> e;
-    cx.sample_error(rng, e);
+    cx.sample_error(*secret, e);
     std::vector<u64> en(N);
     for (uint32_t i = 0; i < cx.k; i++) {
       const u64 q = cx.primes[i];
       u64 *a = c1 + (size_t)i * N, *b = c0 + (size_t)i * N;
-      cx.sample_uniform(rng, i, a);
+      cx.sample_uniform(*pub, i, a);
       cx.small_to_ntt(e, i, en.data());
       const u64 *s = sk.s_ntt.data() + (size_t)i * N;
       for (uint32_t j = 0; j < N; j++) b[j] = evah::negmod(evah::addmod(cx.mulm(a[j], s[j], i), en[j], q), q);
@@ -497,7 +510,7 @@ struct HostPlain {
 
 // Public-key encryption of an NTT-form plaintext at `limbs` data limbs (A.10): encrypt zero one
 // level up (limbs+1 primes), divide-and-round by that extra prime, add the plaintext to c0.
-inline HostCipher encrypt(const HostContext &cx, const PublicKey &pk, const HostPlain &pt, std::mt19937_64 &rng) {
+inline HostCipher encrypt(const HostContext &cx, const PublicKey &pk, const HostPlain &pt, SecureRng &rng) {
   const uint32_t N = cx.N, l = pt.limbs, up = l + 1;
   if (up > cx.k) throw std::invalid_argument("plaintext level is not valid for encryption");
   std::vector<int8_t> u, e0, e1;

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <set>
 #include <memory>
 #include <tuple>
 #include <random>
@@ -679,7 +680,7 @@ public:
     if (slots < (size_t)sig.vec_size) throw std::runtime_error("Vector size cannot be larger than slot count");
     if (slots % sig.vec_size) throw std::runtime_error("Vector size must exactly divide the slot count");
     HipValuation out;
-    std::mt19937_64 rng(std::random_device{}());
+    SecureRng rng; // a fresh ChaCha20 stream keyed with 256 bits from the OS for this call (csprng.h)
     for (auto &kv : inputs) {
       const auto &v = kv.second;
       if (v.size() != (size_t)sig.vec_size) throw std::runtime_error("Input size does not match program vector size");
@@ -714,9 +715,19 @@ public:
     ensure_device();
     if (graphs_enabled() && graphable(program, inputs)) {
       auto it = plans.find(&program);
-      if (it == plans.end()) {
+      if (it == plans.end() && !no_graph.count(&program)) {
         seen[&program]++;
-        if (seen[&program] >= 2) it = plans.emplace(&program, build_plan(program, inputs)).first;
+        if (seen[&program] >= 2) {
+          // capture can fail (out of memory for the second buffer set, a runtime refusing the
+          // capture or the instantiation, a first-use table build inside it): the eager walk that
+          // served the first call still works, so remember the program as not graphable and go on
+          try {
+            it = plans.emplace(&program, build_plan(program, inputs)).first;
+          } catch (const std::exception &e) {
+            no_graph.insert(&program);
+            if (std::getenv("EVA_VERBOSE")) std::fprintf(stderr, "EVA: graph capture disabled for this program: %s\n", e.what());
+          }
+        }
       }
       if (it != plans.end()) {
         if (it->second->matches(program, inputs)) return run_plan(*it->second, inputs);
@@ -820,7 +831,7 @@ public:
     forks.clear(); // queues go before the root context
     dev.reset();
   }
-  void drop_graphs() { plans.clear(); seen.clear(); const_cache.clear(); }
+  void drop_graphs() { plans.clear(); seen.clear(); no_graph.clear(); const_cache.clear(); }
 
 private:
   std::shared_ptr<DeviceCtx> dev;
@@ -892,6 +903,7 @@ private:
   std::unordered_map<const Program *, ConstCache> const_cache;
   std::unordered_map<const Program *, std::unique_ptr<GraphPlan>> plans;
   std::unordered_map<const Program *, int> seen;
+  std::set<const Program *> no_graph; // programs whose capture failed once: always walked eagerly
 
   bool graphs_enabled() const {
     if (const char *e = std::getenv("EVA_GRAPH")) return std::atoi(e) != 0;
@@ -1046,8 +1058,7 @@ generate_keys(const CKKSParameters &params, uint64_t seed = 0) {
   if (bits.size() < 2) throw std::invalid_argument("need at least two primes (data + special)");
   auto primes = evah::coeff_modulus_create(params.poly_modulus_degree, bits);
   auto host = std::make_shared<HostContext>(params.poly_modulus_degree, primes);
-  if (!seed) seed = ((uint64_t)std::random_device{}() << 32) ^ std::random_device{}();
-  KeyGenerator kg(*host, seed);
+  KeyGenerator kg(*host, seed); // seed == 0: keyed from the OS; otherwise the reproducible test hook
   auto pub = std::make_shared<HipPublic>();
   auto sec = std::make_shared<HipSecret>();
   pub->host = host;

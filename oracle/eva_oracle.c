@@ -579,13 +579,21 @@ static cplx croots_get(const cplx *oct, size_t degree, size_t index) {
   return (cplx){t.re, -t.im};
 }
 
+/* std::polar(1.0, theta) is (cos(theta), sin(theta)) from libm.  GCC fuses such a pair into ONE
+ * sincos() call, and glibc 2.35's sincos() is not bit-identical to sin(): at 2N = 8192 the octant
+ * angle i = 487 differs in the last place.  The reference recommends building SEAL with clang
+ * (/root/reference/README.md:21-25), which keeps the two separate calls; calling through volatile
+ * pointers keeps them separate under any compiler, so oracle, host and device tables agree. */
+static double (*volatile libm_cos)(double) = cos;
+static double (*volatile libm_sin)(double) = sin;
+
 /* inv_root_powers_ of CKKSEncoder for degree N (entry 0 unused), caller frees */
 static cplx *ckks_inv_root_powers(uint32_t N, uint32_t logN) {
   size_t degree = (size_t)2 * N;
   cplx *oct = (cplx *)malloc(sizeof(cplx) * (degree / 8 + 1));
   for (size_t i = 0; i <= degree / 8; i++) {
     double theta = 2 * SEAL_PI * (double)i / (double)degree;
-    oct[i] = (cplx){cos(theta), sin(theta)}; /* std::polar(1.0, theta) */
+    oct[i] = (cplx){libm_cos(theta), libm_sin(theta)}; /* std::polar(1.0, theta) */
   }
   cplx *inv = (cplx *)malloc(sizeof(cplx) * N);
   inv[0] = (cplx){0, 0};

@@ -109,6 +109,20 @@ void evo_encode_coeffs(uint32_t N, const double *values, double scale, double *c
 void evo_op_triple(const evo_ctx *c, uint32_t l, const uint64_t *a2, const uint64_t *b2,
                    const uint64_t *relin_key, uint64_t *out2 /* [2][l-1][N] */);
 
+/* ---- eva_oracle_dag.c: walk of a compiled program's encrypted part (the CPU baseline of the DAG
+ * configurations).  op codes are the reference's (eva/ir/ops.h:11-25); Input / Constant / Encode
+ * entries mark caller-placed slots.  vals[v].kind: 0 empty, 1 ciphertext [size][limbs][N],
+ * 2 plaintext [limbs][N].  Slots written by the walk get malloc'ed data (release with
+ * evo_dag_free unless `alias` is set: an Output shares its operand's data); intermediates are
+ * freed at their last use.  threads <= 1: ProgramTraversal::forwardPass; > 1: the
+ * dependency-counting MulticoreProgramTraversal analogue on that many pthreads. */
+typedef struct { uint32_t op, dst, src0, src1; int32_t imm; } evo_dag_op;
+typedef struct { uint32_t kind, size, limbs, alias; uint64_t *data; } evo_dag_val;
+int evo_dag_walk(const evo_ctx *c, const evo_dag_op *ops, uint32_t n_ops, evo_dag_val *vals, uint32_t n_vals,
+                 const uint64_t *relin_key, const uint32_t *galois_elts, const uint64_t *const *galois_keys,
+                 uint32_t n_galois, int threads);
+void evo_dag_free(uint64_t *data);
+
 #ifdef __cplusplus
 }
 #endif

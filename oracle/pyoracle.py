@@ -14,9 +14,18 @@ _LIB = os.path.join(_HERE, "libeva_oracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "eva_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("eva_oracle.c", "eva_oracle_dag.c", "eva_oracle.h")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+class DagOp(C.Structure):  # evo_dag_op
+    _fields_ = [("op", C.c_uint32), ("dst", C.c_uint32), ("src0", C.c_uint32), ("src1", C.c_uint32), ("imm", C.c_int32)]
+
+
+class DagVal(C.Structure):  # evo_dag_val
+    _fields_ = [("kind", C.c_uint32), ("size", C.c_uint32), ("limbs", C.c_uint32), ("alias", C.c_uint32),
+                ("data", C.POINTER(C.c_uint64))]
 
 
 def _load():
@@ -59,6 +68,9 @@ def _load():
         "evo_encode": (C.c_int, [vp, C.c_uint32, dblp, C.c_double, u64p]),
         "evo_encode_coeffs": (None, [C.c_uint32, dblp, C.c_double, dblp]),
         "evo_op_triple": (None, [vp, C.c_uint32, u64p, u64p, u64p, u64p]),
+        "evo_dag_walk": (C.c_int, [vp, C.POINTER(DagOp), C.c_uint32, C.POINTER(DagVal), C.c_uint32, u64p, u32p,
+                                   C.POINTER(u64p), C.c_uint32, C.c_int]),
+        "evo_dag_free": (None, [u64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -207,6 +219,43 @@ class Oracle:
         if rc != 0:
             raise ValueError("encoded values are too large")
         return pt
+
+    def dag_walk(self, ops, values, n_vals, relin_key, galois_keys, threads=1):
+        """Walks a flat op list [(op, dst, src0, src1, imm)] (the reference's op codes) over the
+        evaluator, in C: threads <= 1 the serial forwardPass, > 1 the dependency-counting traversal
+        on that many pthreads.  values: {slot: ("ct", array [size][l][N]) | ("pt", array [l][N])}.
+        Returns ({slot: array} for every slot the walk left filled, seconds spent inside the walk)."""
+        import time
+        arr = (DagOp * len(ops))(*[DagOp(*[int(x) for x in o[:5]]) for o in ops])
+        vals = (DagVal * n_vals)()
+        keep = []
+        for t, (kind, a) in values.items():
+            a = np.ascontiguousarray(a, dtype=np.uint64)
+            keep.append(a)
+            vals[t].kind = 1 if kind == "ct" else 2
+            vals[t].size = a.shape[0] if kind == "ct" else 1
+            vals[t].limbs = a.shape[-2]
+            vals[t].data = _p(a)
+        elts = sorted(galois_keys)
+        gk = [np.ascontiguousarray(galois_keys[e], dtype=np.uint64) for e in elts]
+        elt_arr = (C.c_uint32 * max(1, len(elts)))(*elts)
+        key_arr = (_u64p * max(1, len(elts)))(*[_p(k) for k in gk])
+        rk = _p(relin_key) if relin_key is not None else None
+        t0 = time.perf_counter()
+        rc = lib.evo_dag_walk(self._c, arr, len(ops), vals, n_vals, rk, elt_arr, key_arr, len(elts), int(threads))
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError(f"evo_dag_walk failed ({rc})")
+        out = {}
+        for t in range(n_vals):
+            v = vals[t]
+            if v.kind == 1 and t not in values:
+                n = v.size * v.limbs * self.N
+                out[t] = np.ctypeslib.as_array(v.data, shape=(n,)).reshape(v.size, v.limbs, self.N).copy()
+        for t in range(n_vals):
+            if vals[t].kind == 1 and t not in values and not vals[t].alias:
+                lib.evo_dag_free(vals[t].data)
+        return out, dt
 
     def op_triple(self, a2, b2, key):
         l = a2.shape[1]

@@ -171,3 +171,57 @@ class OracleExecutor:
             if errors:
                 raise errors[0]
         return {name: vals[t.index] for name, t in program.outputs.items()}
+
+
+def lower(program, enc_inputs, oracle, N, k):
+    """compiled program -> (ops, values, outputs) for Oracle.dag_walk: the encrypted part as a flat
+    list of the reference's op codes; unencrypted (vector<double>) nodes are evaluated here as
+    SEALExecutor does on the host (seal_executor.h:63-112), Encode nodes by the oracle's encoder."""
+    from eva_amd import Op
+    dump = program._dump()
+    raw, values, ops = {}, {}, []
+    inputs = {name: t.index for name, t in program.inputs.items()}
+    for name in enc_inputs.names():
+        kind, size, limbs, scale, data = enc_inputs.get(name)
+        t = inputs[name]
+        if kind == "cipher":
+            values[t] = ("ct", data)
+        elif kind == "plain":
+            values[t] = ("pt", data)
+        else:
+            raw[t] = list(data) * (program.vec_size // len(data))
+    slots = N // 2
+    for d in dump:
+        t, op, a = d["id"], d["op"], d["operands"]
+        if op == Op.Input:
+            continue
+        if op == Op.Constant:
+            raw[t] = list(d["constant"]) * (program.vec_size // len(d["constant"]))
+        elif op == Op.Encode:
+            v = raw[a[0]]
+            limbs = k - 1 - d["encode_level"]
+            values[t] = ("pt", oracle.encode(limbs, np.array(v * (slots // len(v)), dtype=np.float64), 2.0 ** d["encode_scale"]))
+        elif all(x in raw for x in a):
+            x = [raw[i] for i in a]
+            if op == Op.Add: raw[t] = [u + v for u, v in zip(*x)]
+            elif op == Op.Sub: raw[t] = [u - v for u, v in zip(*x)]
+            elif op == Op.Mul: raw[t] = [u * v for u, v in zip(*x)]
+            elif op == Op.Negate: raw[t] = [-u for u in x[0]]
+            elif op in (Op.RotateLeftConst, Op.RotateRightConst): raw[t] = _rot(x[0], d["rotation"], op == Op.RotateLeftConst)
+            else: raw[t] = list(x[0])  # Output / scale management of an unencrypted value: a copy
+        else:
+            imm = d.get("rotation", d.get("rescale_divisor", 0)) or 0
+            ops.append((int(op), t, a[0], a[1] if len(a) > 1 else 0, int(imm)))
+    outs = {name: t.index for name, t in program.outputs.items()}
+    return ops, values, outs, max(d["id"] for d in dump) + 1
+
+
+def c_walk(public_ctx, program, enc_inputs, threads=1):
+    """The compiled DAG walked in C over the oracle (oracle/eva_oracle_dag.c): serial forwardPass or
+    the dependency-counting multicore traversal.  Returns ({output name: ciphertext array}, seconds
+    inside the walk — lowering and encoding excluded, as key / plaintext preparation is for the GPU)."""
+    N, primes = public_ctx.poly_modulus_degree, list(public_ctx.primes)
+    o = po.Oracle(N, primes)
+    ops, values, outs, n_vals = lower(program, enc_inputs, o, N, len(primes))
+    res, dt = o.dag_walk(ops, values, n_vals, public_ctx.relin_key(), public_ctx.galois_keys(), threads)
+    return {name: res[t] for name, t in outs.items() if t in res}, dt

@@ -131,3 +131,29 @@ def test_product_of_several_constants_with_a_ciphertext():
         return d["op"] == Op.Constant or (d["op"] == Op.Mul and all(unencrypted(o) for o in d["operands"]))
     assert any(d["op"] == Op.Rescale and unencrypted(d["operands"][0]) for d in dump.values()), \
         "this program is meant to put a Rescale on a constant product"
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_c_dag_walk_equals_python_walk(threads):
+    """oracle/eva_oracle_dag.c (the CPU baseline of the DAG configs: serial forwardPass and the
+    dependency-counting multicore traversal) gives the ciphertexts of the node-by-node Python walk."""
+    import numpy as np
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    from oracle_executor import OracleExecutor, c_walk
+    from test_compiler import _sobel
+    for prog, inputs in ((_sobel(16, 16, 256), {'image': [((37 * i) % 256) / 255.0 for i in range(256)]}),
+                         (_constant_chain_program(), {'x': [i / 16.0 for i in range(16)]})):
+        if prog.name != 'chain':
+            prog.set_input_scales(25)
+            prog.set_output_ranges(10)
+        compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+        pub, sec = generate_keys(params, 5)
+        enc = pub.encrypt(inputs, sig)
+        ref = OracleExecutor(pub).execute(compiled, enc)
+        got, dt = c_walk(pub, compiled, enc, threads=threads)
+        assert dt > 0
+        for name, v in ref.items():
+            if isinstance(v, list):
+                continue
+            assert np.array_equal(got[name], v.data), name
