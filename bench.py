@@ -3,9 +3,9 @@
 (multiply + relinearize + rescale) at N = 2^16, L = 10 data limbs (k = 11 key primes).
 
 One "step" = one batch of --batch independent op-triples through the C-ABI of libeva_hip.so
-(per group of --group triples: one evah_multiply_relinearize_rescale_many when the library has the
-fully fused form, else evah_multiply_many + evah_relinearize_rescale_many — bit-identical to the
-three separate SEAL calls), inputs and the relinearization key already resident in HBM.  One process
+(per group of --group triples: evah_multiply_many, then evah_relinearize_rescale_many = relinearize
+and rescale_to_next evaluated together; --fused-multiply takes the one-call form
+evah_multiply_relinearize_rescale_many — all bit-identical to the three separate SEAL calls), inputs and the relinearization key already resident in HBM.  One process
 per GPU; ranks run independent batches (the path shards over independent ciphertexts — no data-path
 collective), `value` = triples of all ranks / max time over ranks.
 
@@ -182,7 +182,9 @@ def main():
                     help="issue queues (forked contexts = HIP streams) the independent triples are spread over")
     ap.add_argument("--group", type=int, default=32,
                     help="triples handed to one batched call (wide launches, shared key)")
-    ap.add_argument("--unfused", action="store_true", help="multiply_many + relinearize_rescale_many instead of the fully fused call")
+    ap.add_argument("--fused-multiply", action="store_true",
+                    help="evah_multiply_relinearize_rescale_many (no size-3 product in HBM; measured 1.5 %% slower at this size: "
+                         "the combine pass re-reads both operands) instead of multiply_many + relinearize_rescale_many")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the execute()-path and DAG legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -212,7 +214,7 @@ def main():
     primes = coeff_modulus_create(N, [60] * k)
     g = backend.Context(N, primes, device=local)
     queues = [g] + [g.fork() for _ in range(max(1, args.streams) - 1)]
-    fused = (not args.unfused) and hasattr(g, "multiply_relinearize_rescale_many")
+    fused = args.fused_multiply
 
     # synthetic inputs: uniform residues; every triple of a step has its own
     # operand pair (distinct HBM data: no triple finds its inputs in cache because another used them)

@@ -124,10 +124,6 @@ k_mul22(DevCtx cx, const u64 *a, size_t a_ps, const u64 *b, size_t b_ps, u64 *ou
 }
 
 // K4 batched: n independent 2x2 products in one launch; grid.z = instance
-struct MulTab {
-  const u64 *a[KS_BATCH_MAX], *b[KS_BATCH_MAX];
-  uint32_t a_ps[KS_BATCH_MAX], b_ps[KS_BATCH_MAX]; // poly strides in units of N coefficients
-};
 __global__ void __launch_bounds__(256)
 k_mul22_many(DevCtx cx, MulTab tab, u64 *out_b, size_t o_ps) {
   EW_SETUP
@@ -498,6 +494,9 @@ struct evah_ctx {
   std::vector<hipEvent_t> capture_events; // events consumed by the capture in progress
   std::vector<hipEvent_t> sync_events; // recycled events for cross-queue ordering
   bool fuse_mac = true; // key-switch: fuse the inner product into the digit NTTs' second pass
+  // evah_execute: run Mul -> Relinearize -> Rescale chains as one evah_multiply_relinearize_rescale_many
+  // (EVAH_FUSE_MUL=0/1; default: only where launches, not bytes, bound the chain — see DESIGN.md §4)
+  bool fuse_mul = false;
   int ks_groups = 1;    // output-limb slices per key-switch (EVAH_KS_GROUPS)
   int ks_threads = 64;  // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS): one wave = one
                         // 2^P-point sub-transform per workgroup measured best (barriers are intra-wave)
@@ -643,6 +642,7 @@ static dim3 ew_grid(evah_ctx *c, uint32_t limbs, uint32_t polys) {
 // ---- NTT launch plumbing
 template <class Op> struct OpClass;
 template <> struct OpClass<OpPlain> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
+template <> struct OpClass<OpMulIntt> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
 template <> struct OpClass<OpKsDigit> { static constexpr int fwd_a = KC_KSDIGIT_A, fwd_b = KC_KSDIGIT_B; };
 template <> struct OpClass<OpModDown> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 template <> struct OpClass<OpRR> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
@@ -699,6 +699,7 @@ struct KsBatch { // one launch worth of key-switches: regular strides, irregular
   size_t target_bs = 0, scratch_bs = 0, prod_bs = 0;
   KsKeys keys{};
   PtrTab targets{}; // used when the targets are separate allocations (target == nullptr)
+  const MulTab *mul = nullptr; // fused multiply: the target of instance b is d2 = a1 b1 of product b
 };
 template <int P, int LR>
 static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scratch, const KsBatch &kb, u64 *prod, uint32_t l) {
@@ -713,14 +714,18 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   const uint32_t n_tiles = c->N / tile;
   // the one-wave workgroup (the default) is compiled with its own launch bound: the register
   // allocator is not held to the 256-thread budget
-  if ((tile >> LR) <= 64)
-    hipLaunchKernelGGL((ks_inner_kernel<P, LR, 64>), dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev,
-                       target, kb.target_bs, scratch, kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n,
-                       kb.targets);
-  else
-    hipLaunchKernelGGL((ks_inner_kernel<P, LR, NTT_THREADS>), dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev,
-                       target, kb.target_bs, scratch, kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n,
-                       kb.targets);
+  static const MulTab no_mul{};
+  auto go = [&](auto kernel, const MulTab &mt) {
+    hipLaunchKernelGGL(kernel, dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev, target, kb.target_bs, scratch,
+                       kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n, kb.targets, mt);
+  };
+  if ((tile >> LR) <= 64) {
+    if (kb.mul) go(ks_inner_kernel<P, LR, 64, true>, *kb.mul);
+    else go(ks_inner_kernel<P, LR, 64, false>, no_mul);
+  } else {
+    if (kb.mul) go(ks_inner_kernel<P, LR, NTT_THREADS, true>, *kb.mul);
+    else go(ks_inner_kernel<P, LR, NTT_THREADS, false>, no_mul);
+  }
   HIPCHK(hipGetLastError());
 }
 template <int LR>
@@ -754,7 +759,7 @@ template <class Op> static void ntt_inverse(evah_ctx *c, const typename Op::Para
 // prod[b][K][I] (I <= l, slot l = special prime) = sum_J op_b(I,J) * key_b[J][K].
 // target_b = target + b * target_bs; prod_b = prod_d + b * 2 (l+1) N.
 static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t target_bs, const KeyDev *const *keys,
-                                uint32_t n, u64 *prod_d, const PtrTab *target_tab = nullptr) {
+                                uint32_t n, u64 *prod_d, const PtrTab *target_tab = nullptr, const MulTab *mul = nullptr) {
   const size_t N = c->N;
   if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::runtime_error("key-switch batch out of range");
   KsBatch kb;
@@ -767,12 +772,19 @@ static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size
     kb.keys.key[b] = keys[b]->d;
   }
   if (target_tab) kb.targets = *target_tab; // target == nullptr: separately allocated targets
+  kb.mul = mul;
+  if (mul && !c->fuse_mac) throw std::logic_error("the fused multiply needs the fused key-switch kernel");
   Scratch t(c, (size_t)n * l * N);        // coefficient-form digits
   Scratch sc(c, n * kb.scratch_bs);       // converted digits, NTT form per output limb
   // 1. digits to coefficient form (job -> (b, J))
-  OpPlain::Params ip{target, t.d, target_bs, (size_t)l * N, l, 0, 0, {}};
-  if (target_tab) ip.src_tab = *target_tab;
-  ntt_inverse<OpPlain>(c, ip, n * l);
+  if (mul) { // the target is the product's d2, formed on load
+    OpMulIntt::Params ip{*mul, t.d, (size_t)l * N, l};
+    ntt_inverse<OpMulIntt>(c, ip, n * l);
+  } else {
+    OpPlain::Params ip{target, t.d, target_bs, (size_t)l * N, l, 0, 0, {}};
+    if (target_tab) ip.src_tab = *target_tab;
+    ntt_inverse<OpPlain>(c, ip, n * l);
+  }
   OpKsDigit::Params dp{t.d, sc.d, l, (size_t)l * N, kb.scratch_bs, 0, l + 1};
   if (c->fuse_mac) { // 128-bit accumulation of lazy (<16q) products, folded every 16 digits
     // Output limbs are processed in slices so that a slice's converted digits (ni * l * N words)
@@ -898,6 +910,8 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     c->primes.assign(primes, primes + k);
     if (const char *e = std::getenv("EVAH_FUSE_MAC")) c->fuse_mac = std::atoi(e) != 0;
     if (const char *e = std::getenv("EVAH_KS_GROUPS")) c->ks_groups = std::max(1, std::atoi(e));
+    c->fuse_mul = N <= 8192;
+    if (const char *e = std::getenv("EVAH_FUSE_MUL")) c->fuse_mul = std::atoi(e) != 0;
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {
       int t = std::atoi(e);
       if (t == 64 || t == 128 || t == 256) c->ks_threads = t;
@@ -993,6 +1007,7 @@ int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
     c->total_bits = parent->total_bits;
     c->dev = parent->dev;
     c->fuse_mac = parent->fuse_mac;
+    c->fuse_mul = parent->fuse_mul;
     c->ks_threads = parent->ks_threads;
     c->ks_groups = parent->ks_groups;
     HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
@@ -1692,7 +1707,8 @@ int evah_relinearize(evah_ctx *c, const evah_ct *a, evah_ct **out) {
   API_END
 }
 
-static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n, u64 *out_d);
+static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n, u64 *out_d, const MulTab *mul = nullptr,
+                               uint32_t mul_limbs = 0);
 
 int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bits, evah_ct **out) {
   API_BEGIN
@@ -1750,12 +1766,14 @@ int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bit
 // relinearization key and rescaled: one set of n-times-wider launches; instances are co-scheduled
 // per XCD so the key tiles are read from HBM once per XCD, not once per instance.
 // core of the batched form: n (<= KS_BATCH_MAX) size-3 ciphertexts at one level -> out_d[n][2][(l-1) N]
-static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n, u64 *out_d) {
-  const uint32_t l = as[0]->limbs;
+// mul != nullptr: instance b is the product a[b] x b[b] of mul (size-2 operands at mul_limbs limbs),
+// its polynomials d0, d1, d2 evaluated where they are consumed (as == nullptr then)
+static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n, u64 *out_d, const MulTab *mul, uint32_t mul_limbs) {
+  const uint32_t l = mul ? mul_limbs : as[0]->limbs;
   const uint32_t last = l - 1, sp = c->k - 1;
   const size_t N = c->N, pps = (size_t)(l + 1) * N, ops = (size_t)(l - 1) * N;
   PtrTab c2{}, a_last{}, a_polys{};
-  for (uint32_t b = 0; b < n; b++) {
+  for (uint32_t b = 0; b < n && !mul; b++) {
     const evah_ct *a = as[b];
     c2.p[b] = a->d + 2 * a->ps;
     for (uint32_t K = 0; K < 2; K++) {
@@ -1765,14 +1783,64 @@ static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n
   }
   Scratch prod(c, (size_t)n * 2 * pps);
   std::vector<const KeyDev *> keys(n, &c->sh->relin);
-  switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2);
+  switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2, mul);
   Scratch r(c, (size_t)n * 2 * N), t(c, (size_t)n * 2 * N);
   OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
   ntt_inverse<OpPlain>(c, spp, 2 * n);
   OpRRLast::Params lp{nullptr, 0, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, a_last};
+  if (mul) { lp.use_mul = true; lp.mul = *mul; }
   ntt_inverse<OpRRLast>(c, lp, 2 * n);
   OpRR::Params rp{r.d, N, t.d, N, nullptr, 0, prod.d, pps, out_d, ops, sp, last, l - 1, a_polys};
+  if (mul) { rp.use_mul = true; rp.mul = *mul; }
   ntt_forward<OpRR>(c, rp, 2 * n * (l - 1));
+}
+
+// multiply (size 2 x size 2) -> relinearize -> rescale_to_next for n (<= 64) independent pairs at one
+// level, the three SEAL calls of seal_executor.h:164, :200, :213-214 evaluated together: the size-3
+// product is never materialised — d2 = a1 b1 is formed in the load of the digit inverse
+// transform (and in the key-switch kernel where the NTT-form digit is used as is), d0 and d1 in
+// the epilogue that combines them with the key-switch result.  Same ciphertext, bit for bit.
+static void mul_relin_rescale(evah_ctx *c, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n, uint32_t divisor_bits,
+                              evah_ct **outs) {
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("multiply_relinearize_rescale_many handles 1..64 products per call");
+  if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
+  const uint32_t l = as[0]->limbs;
+  if (l < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  const size_t N = c->N, ops = (size_t)(l - 1) * N;
+  MulTab tab{};
+  std::vector<double> scales(n);
+  for (uint32_t i = 0; i < n; i++) {
+    const evah_ct *a = as[i], *b = bs[i];
+    if (a->size != 2 || b->size != 2) throw std::invalid_argument("multiply supports size-2 operands only (relinearize first)");
+    if (a->batch != 1 || b->batch != 1) throw std::invalid_argument("multiply_relinearize_rescale_many takes single ciphertexts");
+    if (a->limbs != l || b->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    scales[i] = a->scale * b->scale;
+    check_scale(c, scales[i], l);
+    acquire(c, a->buf);
+    acquire(c, b->buf);
+    tab.a[i] = a->d;
+    tab.b[i] = b->d;
+    tab.a_ps[i] = (uint32_t)(a->ps / N);
+    tab.b_ps[i] = (uint32_t)(b->ps / N);
+  }
+  Buffer *ob = buf_new(c, (size_t)n * 2 * ops);
+  try {
+    relin_rescale_core(c, nullptr, n, ob->d, &tab, l);
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)n;
+  for (uint32_t b = 0; b < n; b++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)b * 2 * ops;
+    t->size = 2;
+    t->limbs = l - 1;
+    t->ps = ops;
+    t->scale = scales[b] / std::pow(2.0, (double)divisor_bits);
+    outs[b] = t;
+  }
 }
 
 int evah_relinearize_rescale_many(evah_ctx *c, const evah_ct *const *as, uint32_t n, uint32_t divisor_bits, evah_ct **outs) {
@@ -1807,6 +1875,39 @@ int evah_relinearize_rescale_many(evah_ctx *c, const evah_ct *const *as, uint32_
     t->ps = ops;
     t->scale = as[b]->scale / std::pow(2.0, (double)divisor_bits);
     outs[b] = t;
+  }
+  API_END
+}
+
+int evah_multiply_relinearize_rescale_many(evah_ctx *c, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n,
+                                           uint32_t divisor_bits, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  if (!c->fuse_mac) { // EVAH_FUSE_MAC=0 (the unfused reference path): the three calls one after the other
+    std::vector<evah_ct *> ms(n, nullptr);
+    if (evah_multiply_many(c, as, bs, n, ms.data())) throw std::runtime_error(g_err);
+    int rc = evah_relinearize_rescale_many(c, ms.data(), n, divisor_bits, outs);
+    std::string err = g_err;
+    for (evah_ct *m : ms) evah_ct_free(c, m);
+    if (rc) throw std::runtime_error(err);
+  } else {
+    mul_relin_rescale(c, as, bs, n, divisor_bits, outs);
+  }
+  API_END
+}
+
+int evah_multiply_relinearize_rescale(evah_ctx *c, const evah_ct *a, const evah_ct *b, uint32_t divisor_bits, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (a->batch != 1 || b->batch != 1 || !c->fuse_mac) { // batched handles: the separate (already batched) calls
+    evah_ct *m = nullptr;
+    if (evah_multiply(c, a, b, &m)) throw std::runtime_error(g_err);
+    int rc = evah_relinearize_rescale(c, m, divisor_bits, out);
+    std::string err = g_err;
+    evah_ct_free(c, m);
+    if (rc) throw std::runtime_error(err);
+  } else {
+    mul_relin_rescale(c, &a, &b, 1, divisor_bits, out);
   }
   API_END
 }
@@ -2163,14 +2264,19 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     evah_ctx *c;
     std::map<uint32_t, LazySum> sums;
     std::map<uint32_t, evah_ct *> relins; // value -> alias of the size-3 operand of a deferred Relinearize
+    // value -> aliases of the two operands of a deferred Mul (prods) / of a Relinearize of one (prodrel):
+    // Mul -> Relinearize -> Rescale chains without other readers run as one fused call at the Rescale
+    std::map<uint32_t, std::pair<evah_ct *, evah_ct *>> prods, prodrel;
     ~State() {
       for (auto &kv : sums) {
         for (evah_ct *h : kv.second.cts) evah_ct_free(c, h);
         for (evah_pt *h : kv.second.pts) evah_pt_free(c, h);
       }
       for (auto &kv : relins) evah_ct_free(c, kv.second);
+      for (auto *m : {&prods, &prodrel})
+        for (auto &kv : *m) { evah_ct_free(c, kv.second.first); evah_ct_free(c, kv.second.second); }
     }
-  } st{c, {}, {}};
+  } st{c, {}, {}, {}, {}};
   auto chk = [&](int rc) {
     if (rc) throw std::runtime_error(g_err);
   };
@@ -2271,7 +2377,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
   for (auto &lvl : buckets) {
     std::map<uint32_t, std::vector<uint32_t>> rots, relins, muls, batched_rots;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<uint32_t>> rescales;
-    std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> fused;
+    std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> fused, fused3;
     // ---- one op through the ordinary entry points (seal_executor.h:114-215)
     auto single = [&](const evah_op &o) {
       evah_ct *out = nullptr;
@@ -2342,7 +2448,12 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         }
         continue;
       }
-      if ((o.op == 14 || o.op == 15) && o.imm != 0 && is_ct(o.src0)) {
+      if (o.op == 20 && st.prods.count(o.src0)) { // Relinearize of a deferred product: still deferred
+        st.prodrel[o.dst] = st.prods[o.src0];
+        st.prods.erase(o.src0);
+      } else if (o.op == 22 && st.prodrel.count(o.src0)) {
+        fused3[{st.prodrel[o.src0].first->limbs, (uint32_t)o.imm}].push_back(i);
+      } else if ((o.op == 14 || o.op == 15) && o.imm != 0 && is_ct(o.src0)) {
         shape(o.src0, size, limbs, scale);
         rots[limbs].push_back(i);
       } else if (o.op == 22 && st.relins.count(o.src0)) {
@@ -2359,8 +2470,17 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
           relins[limbs].push_back(i);
         }
       } else if (o.op == 13 && o.src0 != o.src1 && is_ct(o.src0) && is_ct(o.src1)) {
-        shape(o.src0, size, limbs, scale);
-        muls[limbs].push_back(i);
+        // Mul read only by a Relinearize that is read only by a Rescale (the commonest CKKS
+        // pattern): nothing is computed here, the three run as one fused call at the Rescale
+        evah_ct *x = ct_of(o.src0), *y = ct_of(o.src1);
+        const bool chain = c->fuse_mac && c->fuse_mul && feeds_only(o.dst, 20) && feeds_only(ops[only_reader[o.dst]].dst, 22);
+        if (chain && x->size == 2 && y->size == 2 && x->limbs == y->limbs && x->limbs >= 2 && x->batch == 1 && y->batch == 1) {
+          check_scale(c, x->scale * y->scale, x->limbs);
+          st.prods[o.dst] = {alias_ct(x), alias_ct(y)};
+        } else {
+          shape(o.src0, size, limbs, scale);
+          muls[limbs].push_back(i);
+        }
       } else if (o.op == 13 && feeds_only(o.dst, 11) &&
                  ((is_plain_ct(o.src0) && slot(o.src1).kind == EVAH_VAL_PT) || (is_plain_ct(o.src1) && slot(o.src0).kind == EVAH_VAL_PT))) {
         const uint32_t a = is_plain_ct(o.src0) ? o.src0 : o.src1, b = a == o.src0 ? o.src1 : o.src0;
@@ -2451,6 +2571,24 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         store(is, n, outs);
       }
     }
+    for (auto &kv : fused3)
+      for (size_t i0 = 0; i0 < kv.second.size(); i0 += KS_BATCH_MAX) {
+        const uint32_t n = (uint32_t)std::min<size_t>(KS_BATCH_MAX, kv.second.size() - i0);
+        const uint32_t *is = kv.second.data() + i0;
+        std::vector<const evah_ct *> ia(n), ib(n);
+        std::vector<evah_ct *> outs(n, nullptr);
+        for (uint32_t j = 0; j < n; j++) {
+          ia[j] = st.prodrel[ops[is[j]].src0].first;
+          ib[j] = st.prodrel[ops[is[j]].src0].second;
+        }
+        chk(evah_multiply_relinearize_rescale_many(c, ia.data(), ib.data(), n, kv.first.second, outs.data()));
+        for (uint32_t j = 0; j < n; j++) {
+          evah_ct_free(c, const_cast<evah_ct *>(ia[j]));
+          evah_ct_free(c, const_cast<evah_ct *>(ib[j]));
+          st.prodrel.erase(ops[is[j]].src0);
+        }
+        store(is, n, outs);
+      }
     for (auto &kv : rescales)
       each_chunk(kv.second, (2 * KS_BATCH_MAX) / std::get<0>(kv.first), [&](const uint32_t *is, uint32_t n) {
         std::vector<const evah_ct *> in(n);

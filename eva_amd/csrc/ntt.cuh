@@ -274,11 +274,40 @@ struct PtrTab {
   const u64 *p[2 * KS_BATCH_MAX];
 };
 
-template <int P, int LR, int MAXT>
+// Operands of a batch of ciphertext products (instance b = a[b] x b[b], both size 2), passed by
+// value.  With it the consumers of a product's polynomials d0 = a0 b0, d1 = a0 b1 + a1 b0,
+// d2 = a1 b1 evaluate the one they need from the operands where they would have
+// loaded it, so multiply -> relinearize -> rescale runs without the size-3 product ever being
+// written to or read back from HBM.  Every d_K is a canonical residue, so the result is the one
+// the separate evah_multiply call stores.
+struct MulTab {
+  const u64 *a[KS_BATCH_MAX], *b[KS_BATCH_MAX];
+  uint32_t a_ps[KS_BATCH_MAX], b_ps[KS_BATCH_MAX]; // poly strides in units of N coefficients
+};
+// One product's operands, resolved from a MulTab entry (block-uniform: scalar loads of the kernel argument)
+struct MulSrc {
+  const u64 *a, *b; // polynomial 0 of each operand
+  size_t sa, sb;    // poly strides in words
+};
+__device__ __forceinline__ MulSrc mul_src(const MulTab &t, uint32_t N, uint32_t inst) {
+  return MulSrc{t.a[inst], t.b[inst], (size_t)t.a_ps[inst] * N, (size_t)t.b_ps[inst] * N};
+}
+// d_K of a product at word `off` (= limb * N + n) of a polynomial, K in {0, 1, 2}
+__device__ __forceinline__ u64 product_poly(const MulSrc &m, uint32_t K, size_t off, const DevPrime &pm) {
+  const u64 *a0 = m.a + off, *b0 = m.b + off;
+  const size_t sa = m.sa, sb = m.sb;
+  if (K == 0) return mulmod(a0[0], b0[0], pm);
+  if (K == 2) return mulmod(a0[sa], b0[sb], pm);
+  u128_t s = mul128(a0[0], b0[sb]);
+  acc128(s, a0[sa], b0[0]);
+  return barrett128(s, pm);
+}
+
+template <int P, int LR, int MAXT, bool MUL>
 __global__ void __launch_bounds__(MAXT)
 ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
                 size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, uint32_t i0,
-                int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets) {
+                int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets, MulTab mul) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   // grid.x carries (tile, instance): instances of one tile are placed 8 block ids apart, i.e. on
   // the same XCD (blocks are dealt round-robin over the 8 XCDs) and close in dispatch order, so
@@ -292,7 +321,8 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
     inst = blockIdx.x / n_tiles;
     tile_idx = blockIdx.x % n_tiles;
   }
-  const u64 *__restrict__ target = target_b ? target_b + inst * target_bs : targets.p[inst];
+  // MUL: the key-switch target is d2 = a1 b1 of product `inst`, evaluated where it is needed (I == J)
+  const u64 *__restrict__ target = MUL ? nullptr : (target_b ? target_b + inst * target_bs : targets.p[inst]);
   const u64 *__restrict__ scratch = scratch_b + inst * scratch_bs;
   const u64 *__restrict__ key = keys.key[inst];
   u64 *__restrict__ prod = prod_b + inst * prod_bs;
@@ -328,15 +358,23 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   // Software pipeline over the digits: the key words of digit J are requested before its
   // transform starts and the coefficients of digit J+1 as soon as those of J sit in LDS, so both
   // streams are in flight during the register rounds instead of being waited for at their use.
-  auto digit_src = [&](uint32_t J) -> const u64 * {
-    return (I == J ? target + (size_t)J * N : scratch + ((size_t)I * l + J) * N) + gbase;
+  const MulSrc msrc = MUL ? mul_src(mul, cx.N, inst) : MulSrc{nullptr, nullptr, 0, 0};
+  auto load_digits = [&](uint32_t J, ulonglong2 *d) {
+    if (MUL && I == J) { // block-uniform
+#pragma unroll
+      for (int it = 0; it < NPAIR; it++) {
+        const size_t off = (size_t)J * N + gbase + 2 * (threadIdx.x + it * T);
+        d[it].x = product_poly(msrc, 2, off, pm);
+        d[it].y = product_poly(msrc, 2, off + 1, pm);
+      }
+    } else {
+      const u64 *src = (I == J ? target + (size_t)J * N : scratch + ((size_t)I * l + J) * N) + gbase;
+#pragma unroll
+      for (int it = 0; it < NPAIR; it++) d[it] = *reinterpret_cast<const ulonglong2 *>(src + 2 * (threadIdx.x + it * T));
+    }
   };
   ulonglong2 dreg[NPAIR];
-  {
-    const u64 *src = digit_src(0);
-#pragma unroll
-    for (int it = 0; it < NPAIR; it++) dreg[it] = *reinterpret_cast<const ulonglong2 *>(src + 2 * (threadIdx.x + it * T));
-  }
+  load_digits(0, dreg);
   for (uint32_t J = 0; J < l; J++) {
     ulonglong2 k0r[NPAIR], k1r[NPAIR];
     const u64 *kp = key + J * key_digit + (size_t)kap * N + gbase;
@@ -347,15 +385,14 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
       k1r[it] = *reinterpret_cast<const ulonglong2 *>(kp + (size_t)cx.k * N + idx);
     }
     u64 val[NTT_R];
-    const u64 *nsrc = digit_src(J + 1 < l ? J + 1 : J);
+    const uint32_t Jn = J + 1 < l ? J + 1 : J;
     if (I == J) { // already in NTT form mod q_J: use the key-switch target directly
 #pragma unroll
       for (int it = 0; it < NPAIR; it++) {
         val[2 * it] = dreg[it].x;
         val[2 * it + 1] = dreg[it].y;
       }
-#pragma unroll
-      for (int it = 0; it < NPAIR; it++) dreg[it] = *reinterpret_cast<const ulonglong2 *>(nsrc + 2 * (threadIdx.x + it * T));
+      load_digits(Jn, dreg);
     } else {
       __syncthreads(); // previous iteration's LDS reads are done
 #pragma unroll
@@ -365,8 +402,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
         lds[sb * SP + lds_pad(e)] = dreg[it].x;
         lds[sb * SP + lds_pad(e + 1)] = dreg[it].y;
       }
-#pragma unroll
-      for (int it = 0; it < NPAIR; it++) dreg[it] = *reinterpret_cast<const ulonglong2 *>(nsrc + 2 * (threadIdx.x + it * T));
+      load_digits(Jn, dreg);
       __syncthreads();
       // STRIDED=true selects local-heap node indexing, which is what the LDS copy uses
       RoundSeq<P, LR, 0, false, true, true>::run(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
@@ -455,6 +491,42 @@ struct OpPlain {
                                                    uint32_t n, u64 v) {
     store(cx, j, pm, n, barrett64(v, pm.q, pm.brt));
   }
+};
+
+// Inverse transform of d2 = a1 b1 of a batch of products (the key-switch target of a fused
+// multiply -> relinearize): job -> (instance b = job / jl, limb i = job % jl); the product is
+// formed on load, so d2 itself never exists in memory.
+struct OpMulIntt {
+  struct Params {
+    MulTab mul;
+    u64 *dst;      // [batch][jl][N] coefficient-form digits
+    size_t dst_ps; // batch stride
+    uint32_t jl;
+  };
+  struct Job {
+    uint32_t prime;
+    size_t off;
+    MulSrc mul;
+    u64 *dst;
+    bool lazy;
+  };
+  static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i, uint32_t b, Job &j) {
+    j.prime = i;
+    j.off = (size_t)i * cx.N;
+    j.mul = mul_src(p.mul, cx.N, b);
+    j.dst = p.dst + b * p.dst_ps + (size_t)i * cx.N;
+    j.lazy = false;
+    return true;
+  }
+  template <bool LZ>
+  static __device__ __forceinline__ u64 load(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n) {
+    return product_poly(j.mul, 2, j.off + n, pm);
+  }
+  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &, uint32_t n, u64 v) {
+    j.dst[n] = v;
+  }
+  static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &, const DevPrime &, uint32_t, u64) {}
 };
 
 // Key-switch digit conversion: job -> (I = job / l, J = job % l);
@@ -580,6 +652,8 @@ struct OpRRLast {
     size_t t_ps;
     uint32_t last, sp;
     PtrTab a_tab; // used when a == nullptr: a_tab.p[job] = poly K of instance b at limb `last` (job = 2b+K)
+    bool use_mul = false; // a[K] = d_K of product b = job / 2 (fused multiply): evaluated on load
+    MulTab mul{};
   };
   struct Job {
     uint32_t prime;
@@ -588,12 +662,20 @@ struct OpRRLast {
     u64 halfP;
     ulonglong2 pinv;
     bool lazy;
+    bool use_mul;
+    MulSrc mul;
+    uint32_t K;
+    size_t off;
   };
   static dim3 grid(const Params &, uint32_t jobs) { return dim3(1, jobs, 1); }
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t job, uint32_t,
                                                Job &j) {
     j.prime = p.last;
-    j.a = p.a ? p.a + job * p.a_ps : p.a_tab.p[job];
+    j.use_mul = p.use_mul;
+    j.mul = p.use_mul ? mul_src(p.mul, cx.N, job >> 1) : MulSrc{nullptr, nullptr, 0, 0};
+    j.K = job & 1u;
+    j.off = (size_t)p.last * cx.N;
+    j.a = p.use_mul ? nullptr : (p.a ? p.a + job * p.a_ps : p.a_tab.p[job]);
     j.prod = p.prod + job * p.prod_ps;
     j.r = p.r + job * p.r_ps;
     j.dst = p.t + job * p.t_ps;
@@ -603,8 +685,9 @@ struct OpRRLast {
     return true;
   }
   template <bool LZ>
-  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
-    return addmod(j.a[n], mul_shoup(j.prod[n], j.pinv.x, j.pinv.y, pm.q), pm.q);
+  static __device__ __forceinline__ u64 load(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n) {
+    const u64 av = j.use_mul ? product_poly(j.mul, j.K, j.off + n, pm) : j.a[n];
+    return addmod(av, mul_shoup(j.prod[n], j.pinv.x, j.pinv.y, pm.q), pm.q);
   }
   static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 x) {
     const u64 u = submod(barrett64(j.r[n], pm.q, pm.brt), j.halfP, pm.q);
@@ -628,6 +711,8 @@ struct OpRR {
     size_t dst_ps;
     uint32_t sp, last, jl;
     PtrTab a_tab; // used when a == nullptr: a_tab.p[K] = poly K (limb 0), K = 2b + {0,1}
+    bool use_mul = false; // a[K] = d_(K&1) of product b = K / 2 (fused multiply): evaluated in the epilogue
+    MulTab mul{};
   };
   struct Job {
     uint32_t prime;
@@ -636,6 +721,10 @@ struct OpRR {
     u64 halfP, halfL;
     ulonglong2 pinv, linv;
     bool lazy;
+    bool use_mul;
+    MulSrc mul;
+    uint32_t K;
+    size_t off;
   };
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i, uint32_t K,
@@ -643,7 +732,11 @@ struct OpRR {
     j.prime = i;
     j.r = p.r + K * p.r_ps;
     j.t = p.t + K * p.t_ps;
-    j.a = (p.a ? p.a + K * p.a_ps : p.a_tab.p[K]) + (size_t)i * cx.N;
+    j.use_mul = p.use_mul;
+    j.mul = p.use_mul ? mul_src(p.mul, cx.N, K >> 1) : MulSrc{nullptr, nullptr, 0, 0};
+    j.K = K & 1u;
+    j.off = (size_t)i * cx.N;
+    j.a = p.use_mul ? nullptr : (p.a ? p.a + K * p.a_ps : p.a_tab.p[K]) + (size_t)i * cx.N;
     j.prod = p.prod + K * p.prod_ps + (size_t)i * cx.N;
     j.dst = p.dst + K * p.dst_ps + (size_t)i * cx.N;
     j.halfP = cx.halfmod[p.sp * cx.k + i];
@@ -662,9 +755,10 @@ struct OpRR {
     const u64 v = submod(barrett64(j.t[n], pm.q, pm.brt), j.halfL, pm.q);
     return addmod(mul_shoup(u, j.pinv.x, j.pinv.y, pm.q), v, pm.q);
   }
-  static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 W) {
+  static __device__ __forceinline__ void store_fwd(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n, u64 W) {
     W += (W >= pm.q8 ? pm.nq8 : 0);                                                  // [0,16q) -> [0,8q)
-    const u64 x = j.a[n] + mul_tw_lazy5(j.prod[n], j.pinv.x, j.pinv.y, pm.nq) + pm.q8 - W; // < 14q < 2^64
+    const u64 av = j.use_mul ? product_poly(j.mul, j.K, j.off + n, pm) : j.a[n];
+    const u64 x = av + mul_tw_lazy5(j.prod[n], j.pinv.x, j.pinv.y, pm.nq) + pm.q8 - W; // < 14q < 2^64
     j.dst[n] = mul_shoup(x, j.linv.x, j.linv.y, pm.q);                               // exact for any 64-bit operand
   }
 };

@@ -153,15 +153,28 @@ public:
     if (program.vec_size() > host.N / 2) throw std::runtime_error("Vector size cannot be larger than slot count");
   }
 
+  // values may come from files or from Python (_set_cipher): before any upload the declared shape
+  // has to agree with the data length and the context, or the copy would read past the host buffer
+  void check_shape(const std::string &name, const HostCipher &c) const {
+    if (c.size < 1 || c.size > 3 || c.limbs < 1 || c.limbs > host.k - 1 || c.data.size() != (size_t)c.size * c.limbs * host.N)
+      throw std::runtime_error("input " + name + ": ciphertext shape does not match its data or the encryption parameters");
+  }
+  void check_shape(const std::string &name, const HostPlain &p) const {
+    if (p.limbs < 1 || p.limbs > host.k - 1 || p.data.size() != (size_t)p.limbs * host.N)
+      throw std::runtime_error("input " + name + ": plaintext shape does not match its data or the encryption parameters");
+  }
+
   // seal_executor.h:264-277 (the reference deep-copies; here inputs are uploaded to HBM)
   void set_inputs(const HipValuation &inputs) {
     for (auto &kv : inputs.values) {
       TermId t = program.input(kv.first);
       if (auto *c = std::get_if<HostCipher>(&kv.second)) {
+        check_shape(kv.first, *c);
         evah_ct *h = nullptr;
         chk(evah_ct_upload(ctx, c->size, c->limbs, c->scale, (const uint64_t *)c->data.data(), &h));
         objects[t] = std::make_shared<CtHandle>(ctx, h);
       } else if (auto *p = std::get_if<HostPlain>(&kv.second)) {
+        check_shape(kv.first, *p);
         evah_pt *h = nullptr;
         chk(evah_pt_upload(ctx, p->limbs, p->scale, (const uint64_t *)p->data.data(), &h));
         objects[t] = std::make_shared<PtHandle>(ctx, h);
@@ -189,6 +202,7 @@ public:
         std::vector<const uint64_t *> ptrs(B);
         for (uint32_t b = 0; b < B; b++) {
           const auto &c = std::get<HostCipher>(batch[b]->values.at(kv.first));
+          check_shape(kv.first, c);
           if (c.size != c0->size || c.limbs != c0->limbs || c.scale != c0->scale)
             throw std::runtime_error("execute_batch: input " + kv.first + " differs in shape or scale across the batch");
           ptrs[b] = (const uint64_t *)c.data.data();
@@ -197,6 +211,7 @@ public:
         chk(evah_ct_upload_instances(ctx, B, c0->size, c0->limbs, c0->scale, ptrs.data(), &h));
         objects[t] = std::make_shared<CtHandle>(ctx, h);
       } else if (auto *p = std::get_if<HostPlain>(&kv.second)) {
+        check_shape(kv.first, *p);
         for (const HipValuation *v : batch) {
           const auto &q = std::get<HostPlain>(v->values.at(kv.first));
           if (q.limbs != p->limbs || q.scale != p->scale || q.data != p->data)
@@ -934,6 +949,7 @@ private:
     for (auto &kv : inputs.values) {
       TermId t = program.input(kv.first);
       if (auto *c = std::get_if<HostCipher>(&kv.second)) {
+        ex.check_shape(kv.first, *c);
         evah_ct *h = nullptr;
         chk(evah_ct_upload(q0, c->size, c->limbs, c->scale, (const uint64_t *)c->data.data(), &h));
         auto sp = std::make_shared<CtHandle>(q0, h);
@@ -941,6 +957,7 @@ private:
         ex.set_value(t, sp);
       } else {
         auto &pl = std::get<HostPlain>(kv.second);
+        ex.check_shape(kv.first, pl);
         evah_pt *h = nullptr;
         chk(evah_pt_upload(q0, pl.limbs, pl.scale, (const uint64_t *)pl.data.data(), &h));
         auto sp = std::make_shared<PtHandle>(q0, h);
@@ -974,8 +991,15 @@ private:
     auto t0 = clk::now();
     evah_ctx *q0 = plan.queues[0]->h;
     for (auto &kv : inputs.values) {
-      if (auto *c = std::get_if<HostCipher>(&kv.second)) chk(evah_ct_write(q0, plan.in_ct.at(kv.first)->h, (const uint64_t *)c->data.data()));
-      else chk(evah_pt_write(q0, plan.in_pt.at(kv.first)->h, (const uint64_t *)std::get<HostPlain>(kv.second).data.data()));
+      // matches() compared the declared shapes with the slots; the data length must agree as well
+      if (auto *c = std::get_if<HostCipher>(&kv.second)) {
+        if (c->data.size() != (size_t)c->size * c->limbs * host->N) throw std::runtime_error("input " + kv.first + ": ciphertext shape does not match its data");
+        chk(evah_ct_write(q0, plan.in_ct.at(kv.first)->h, (const uint64_t *)c->data.data()));
+      } else {
+        auto &pl = std::get<HostPlain>(kv.second);
+        if (pl.data.size() != (size_t)pl.limbs * host->N) throw std::runtime_error("input " + kv.first + ": plaintext shape does not match its data");
+        chk(evah_pt_write(q0, plan.in_pt.at(kv.first)->h, (const uint64_t *)pl.data.data()));
+      }
     }
     auto t1 = clk::now();
     chk(evah_graph_launch(q0, plan.graph));

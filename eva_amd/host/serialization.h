@@ -36,7 +36,8 @@ public:
   const std::vector<char> &buf;
   size_t pos = 0;
   explicit Reader(const std::vector<char> &b) : buf(b) {}
-  void need(size_t n) { if (pos + n > buf.size()) throw std::runtime_error("Could not parse message: truncated file"); }
+  // overflow-safe: n is compared with what is left, never added to pos
+  void need(uint64_t n) { if (n > buf.size() - pos) throw std::runtime_error("Could not parse message: truncated file"); }
   template <class T> T pod() {
     need(sizeof(T));
     T v;
@@ -53,6 +54,7 @@ public:
   }
   template <class T> std::vector<T> vec() {
     uint64_t n = pod<uint64_t>();
+    if (n > (buf.size() - pos) / sizeof(T)) throw std::runtime_error("Could not parse message: truncated file");
     need(n * sizeof(T));
     std::vector<T> v(n);
     std::memcpy(v.data(), buf.data() + pos, n * sizeof(T));
@@ -94,6 +96,18 @@ inline std::unique_ptr<Program> read_program(Reader &r) {
   for (uint64_t i = 0; i < n; i++) {
     Op op = (Op)r.pod<int32_t>();
     uint32_t no = r.pod<uint32_t>();
+    // files come from untrusted clients: the op code and its operand count are checked here, so
+    // evaluate() / execute() never index a missing operand (the reference gets this from protobuf
+    // parsing plus Program's own checks, eva/serialization/eva_serialization.cpp:146-289)
+    uint32_t want = 0;
+    switch (op) {
+    case Op::Input: case Op::Constant: want = 0; break;
+    case Op::Add: case Op::Sub: case Op::Mul: want = 2; break;
+    case Op::Output: case Op::Negate: case Op::RotateLeftConst: case Op::RotateRightConst: case Op::Relinearize:
+    case Op::ModSwitch: case Op::Rescale: case Op::Encode: want = 1; break;
+    default: throw std::runtime_error("Could not parse message: unknown op code");
+    }
+    if (no != want) throw std::runtime_error("Could not parse message: wrong operand count for op");
     std::vector<TermId> ops;
     for (uint32_t j = 0; j < no; j++) {
       TermId o = r.pod<uint32_t>();
@@ -108,11 +122,20 @@ inline std::unique_ptr<Program> read_program(Reader &r) {
     x.has_rescale_divisor = flags & 1; x.has_rotation = flags & 2; x.has_type = flags & 4; x.has_range = flags & 8;
     x.has_encode_scale = flags & 16; x.has_encode_level = flags & 32;
     if (flags & 64) x.constant = std::make_shared<ConstantValue>(ConstantValue{r.vec<double>()});
+    if (op == Op::Constant && (!x.constant || x.constant->values.empty() || x.constant->values.size() > vs))
+      throw std::runtime_error("Could not parse message: constant without a valid value");
+    if ((op == Op::RotateLeftConst || op == Op::RotateRightConst) && !x.has_rotation)
+      throw std::runtime_error("Could not parse message: rotation without a step count");
   }
+  auto term_of = [&](Op want_op) {
+    uint32_t t = r.pod<uint32_t>();
+    if (t >= n || p->at(t).op != want_op) throw std::runtime_error("Could not parse message: input / output binding names the wrong term");
+    return t;
+  };
   uint64_t ni = r.pod<uint64_t>();
-  for (uint64_t i = 0; i < ni; i++) { std::string s = r.str(); p->bind_input(s, r.pod<uint32_t>()); }
+  for (uint64_t i = 0; i < ni; i++) { std::string s = r.str(); p->bind_input(s, term_of(Op::Input)); }
   uint64_t nout = r.pod<uint64_t>();
-  for (uint64_t i = 0; i < nout; i++) { std::string s = r.str(); p->bind_output(s, r.pod<uint32_t>()); }
+  for (uint64_t i = 0; i < nout; i++) { std::string s = r.str(); p->bind_output(s, term_of(Op::Output)); }
   return p;
 }
 
@@ -162,8 +185,25 @@ inline HipValuation read_valuation(Reader &r) {
   for (uint64_t i = 0; i < n; i++) {
     std::string name = r.str();
     uint32_t kind = r.pod<uint32_t>();
-    if (kind == 1) { HostCipher c; c.size = r.pod<uint32_t>(); c.limbs = r.pod<uint32_t>(); c.scale = r.pod<double>(); { auto w = r.vec<u64>(); c.data.assign(w.begin(), w.end()); } v.values[name] = std::move(c); }
-    else if (kind == 2) { HostPlain p; p.limbs = r.pod<uint32_t>(); p.scale = r.pod<double>(); p.data = r.vec<u64>(); v.values[name] = std::move(p); }
+    // a valuation file carries no context; shapes must at least be self-consistent here (power-of-two
+    // degree) and are checked against the context again before every upload (check_shape)
+    auto degree_ok = [](size_t words, size_t polys) {
+      if (!polys || words % polys) return false;
+      size_t n = words / polys;
+      return n >= 1024 && n <= 131072 && !(n & (n - 1));
+    };
+    if (kind == 1) {
+      HostCipher c; c.size = r.pod<uint32_t>(); c.limbs = r.pod<uint32_t>(); c.scale = r.pod<double>();
+      { auto w = r.vec<u64>(); c.data.assign(w.begin(), w.end()); }
+      if (c.size < 1 || c.size > 3 || c.limbs < 1 || c.limbs > 61 || !degree_ok(c.data.size(), (size_t)c.size * c.limbs))
+        throw std::runtime_error("Could not parse message: ciphertext shape does not match its data");
+      v.values[name] = std::move(c);
+    } else if (kind == 2) {
+      HostPlain p; p.limbs = r.pod<uint32_t>(); p.scale = r.pod<double>(); p.data = r.vec<u64>();
+      if (p.limbs < 1 || p.limbs > 61 || !degree_ok(p.data.size(), p.limbs))
+        throw std::runtime_error("Could not parse message: plaintext shape does not match its data");
+      v.values[name] = std::move(p);
+    }
     else if (kind == 3) v.values[name] = r.vec<double>();
     else throw std::runtime_error("Could not parse message: unknown value kind");
   }
@@ -173,6 +213,11 @@ inline void write_ctx(Writer &w, const HostContext &h) { w.pod(h.N); w.vec(h.pri
 inline std::shared_ptr<HostContext> read_ctx(Reader &r) {
   uint32_t N = r.pod<uint32_t>();
   auto primes = r.vec<u64>();
+  if (N < 1024 || N > 131072 || (N & (N - 1)) || primes.size() < 2 || primes.size() > 62)
+    throw std::runtime_error("Could not parse message: invalid encryption parameters");
+  for (u64 q : primes)
+    if (q < 2 || q >= ((u64)1 << 60) || (q - 1) % (2ull * N) || !evah::is_prime(q))
+      throw std::runtime_error("Could not parse message: invalid coefficient modulus");
   return std::make_shared<HostContext>(N, primes);
 }
 inline void write(Writer &w, const HipPublic &p) {
@@ -182,15 +227,23 @@ inline void write(Writer &w, const HipPublic &p) {
   w.pod<uint64_t>(p.galois.size());
   for (auto &kv : p.galois) { w.pod(kv.first); w.pod(kv.second.n_digits); w.vec(kv.second.data); }
 }
+inline void check_switch_key(const SwitchKey &k, const HostContext &h, const char *what) {
+  if (k.n_digits == 0 || k.n_digits > h.k - 1 || k.data.size() != (size_t)k.n_digits * 2 * h.k * h.N)
+    throw std::runtime_error(std::string("Could not parse message: ") + what + " has the wrong size for its context");
+}
 inline std::shared_ptr<HipPublic> read_public(Reader &r) {
   auto p = std::make_shared<HipPublic>();
   p->host = read_ctx(r);
   p->pk.data = r.vec<u64>();
+  if (p->pk.data.size() != (size_t)2 * p->host->k * p->host->N) throw std::runtime_error("Could not parse message: public key has the wrong size for its context");
   p->relin.n_digits = r.pod<uint32_t>(); p->relin.data = r.vec<u64>();
+  check_switch_key(p->relin, *p->host, "relinearization key");
   uint64_t n = r.pod<uint64_t>();
   for (uint64_t i = 0; i < n; i++) {
     uint32_t elt = r.pod<uint32_t>();
     SwitchKey k; k.n_digits = r.pod<uint32_t>(); k.data = r.vec<u64>();
+    if (!(elt & 1) || elt >= 2 * p->host->N) throw std::runtime_error("Could not parse message: Galois element is not valid");
+    check_switch_key(k, *p->host, "Galois key");
     p->galois.emplace(elt, std::move(k));
   }
   return p;
@@ -205,6 +258,8 @@ inline std::shared_ptr<HipSecret> read_secret(Reader &r) {
   s->host = read_ctx(r);
   s->sk.s = r.vec<int8_t>();
   s->sk.s_ntt = r.vec<u64>();
+  if (s->sk.s.size() != s->host->N || s->sk.s_ntt.size() != (size_t)s->host->k * s->host->N)
+    throw std::runtime_error("Could not parse message: secret key has the wrong size for its context");
   return s;
 }
 

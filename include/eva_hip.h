@@ -160,6 +160,16 @@ int evah_relinearize_rescale(evah_ctx *ctx, const evah_ct *a, uint32_t divisor_b
  * the shared relinearization key is streamed once per XCD for the whole batch. */
 int evah_relinearize_rescale_many(evah_ctx *ctx, const evah_ct *const *as, uint32_t n, uint32_t divisor_bits,
                                   evah_ct **outs);
+/* evaluator.multiply (seal_executor.h:164), evaluator.relinearize (:200) and
+ * evaluator.rescale_to_next + scale fix-up (:213-214) on one pair of size-2 ciphertexts — the
+ * Mul -> Relinearize -> Rescale chain every ciphertext product of a compiled CKKS program goes
+ * through — evaluated together: the size-3 product is never written to HBM (its polynomials are
+ * formed where the key switch and the combine consume them).  Identical ciphertext to the three calls. */
+int evah_multiply_relinearize_rescale(evah_ctx *ctx, const evah_ct *a, const evah_ct *b, uint32_t divisor_bits, evah_ct **out);
+/* the same for n (<= 64) independent pairs at one level as one launch set; BASELINE.json's
+ * op-triple (multiply + relinearize + rescale) is exactly one unit of this call */
+int evah_multiply_relinearize_rescale_many(evah_ctx *ctx, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n,
+                                           uint32_t divisor_bits, evah_ct **outs);
 /* evaluator.rotate_vector(a, steps) (seal_executor.h:181; rightRotate passes -steps, :188);
  * steps == 0 copies; needs the Galois key for exactly this step's element */
 int evah_rotate(evah_ctx *ctx, const evah_ct *a, int32_t steps, evah_ct **out);
@@ -203,6 +213,7 @@ int evah_mod_switch(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
  * (depth from the caller-placed values — what MulticoreProgramTraversal's ready set holds), the
  * independent rotations / rescales / relinearizations / ciphertext products of a level go out
  * through the batched entry points, a Relinearize read only by a Rescale is evaluated with it,
+ * a Mul read only by such a Relinearize joins them (evah_multiply_relinearize_rescale_many),
  * and multiply_plain / add chains without other readers become one evah_weighted_sum. */
 enum { EVAH_VAL_NONE = 0, EVAH_VAL_CT = 1, EVAH_VAL_PT = 2 };
 enum { EVAH_OPF_FREE_SRC0 = 1, EVAH_OPF_FREE_SRC1 = 2 };

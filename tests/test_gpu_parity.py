@@ -135,6 +135,35 @@ def test_relinearize_rescale_fused_bit_exact(cfg):
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"N{c[0]}")
+def test_multiply_relinearize_rescale_fused_bit_exact(cfg):
+    """evah_multiply_relinearize_rescale(_many): the Mul -> Relinearize -> Rescale chain without the
+    size-3 product in memory == the oracle's three separate calls; operands are separate
+    allocations, one pair shares an operand, one operand is a mod-switched view."""
+    e = env(cfg)
+    key = e.rand_key()
+    e.g.upload_relin_key(key)
+    for l in sorted({e.k - 1, max(2, e.k - 2)}):
+        hosts = [(e.rand(2, l), e.rand(2, l)) for _ in range(3)]
+        A = [e.g.upload_ct(a, 2.0 ** 25) for a, _ in hosts]
+        B = [e.g.upload_ct(b, 2.0 ** 25) for _, b in hosts]
+        want = [e.o.rescale(e.o.relinearize(e.o.multiply(a, b), key)) for a, b in hosts]
+        one = e.g.multiply_relinearize_rescale(A[0], B[0], 30)
+        assert one.info() == (2, l - 1, 2.0 ** 20)
+        assert np.array_equal(one.download(), want[0]), f"fused multiply+relin+rescale mismatch at l={l}"
+        outs = e.g.multiply_relinearize_rescale_many(A + [A[1]], B + [B[2]], 30)
+        for o, w in zip(outs, want):
+            assert np.array_equal(o.download(), w)
+        assert np.array_equal(outs[3].download(), e.o.rescale(e.o.relinearize(e.o.multiply(hosts[1][0], hosts[2][1]), key)))
+        if l + 1 <= e.k - 1:  # operands that are mod-switched views of longer ciphertexts
+            big = e.rand(2, l + 1)
+            V = e.g.mod_switch(e.g.upload_ct(big, 2.0 ** 25))
+            got = e.g.multiply_relinearize_rescale(V, B[0], 30).download()
+            assert np.array_equal(got, e.o.rescale(e.o.relinearize(e.o.multiply(e.o.mod_switch(big), hosts[0][1]), key)))
+    with pytest.raises(backend.EvaHipError, match="size-2"):
+        e.g.multiply_relinearize_rescale(e.g.upload_ct(e.rand(3, e.k - 1), 2.0 ** 20), e.g.upload_ct(e.rand(2, e.k - 1), 2.0 ** 20), 30)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"N{c[0]}")
 def test_rotate_bit_exact(cfg):
     e = env(cfg)
     l = e.k - 1
@@ -313,8 +342,13 @@ def test_op_triple_metric_config_bit_exact():
     assert out.info() == (2, l - 1, 2.0 ** 20)
     ref = e.o.op_triple(a, b, key)
     assert np.array_equal(out.download(), ref)
-    fused = e.g.relinearize_rescale(e.g.multiply(A, B), 60)   # what bench.py issues
+    fused = e.g.relinearize_rescale(e.g.multiply(A, B), 60)
     assert fused.info() == (2, l - 1, 2.0 ** 20) and np.array_equal(fused.download(), ref)
+    # what bench.py issues: the fully fused form, batched
+    a2, b2 = e.rand(2, l), e.rand(2, l)
+    outs = e.g.multiply_relinearize_rescale_many([A, e.g.upload_ct(a2, 2.0 ** 40)], [B, e.g.upload_ct(b2, 2.0 ** 40)], 60)
+    assert outs[0].info() == (2, l - 1, 2.0 ** 20) and np.array_equal(outs[0].download(), ref)
+    assert np.array_equal(outs[1].download(), e.o.op_triple(a2, b2, key))
 
 
 def test_error_behaviour_matches_reference_preconditions():

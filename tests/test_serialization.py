@@ -129,3 +129,51 @@ def test_random_programs_survive_save_and_load(tmp_path, seed):
         a, b = enc.get(name), enc2.get(name)
         assert a[:4] == b[:4]
         assert np.array_equal(np.asarray(a[4]), np.asarray(b[4]))
+
+
+def test_malformed_files_and_values_are_rejected(tmp_path):
+    """load() validates structure (op codes, operand counts, bindings, key / value sizes) and the
+    executor re-checks value shapes before any upload: crafted inputs raise instead of reading out
+    of bounds."""
+    import struct
+    from eva import EvaProgram, Input, Output, save, load
+    from eva.seal import SEALValuation
+    prog = EvaProgram('p', vec_size=8)
+    with prog:
+        Output('y', Input('x') + Input('z'))
+    path = str(tmp_path / "p.eva")
+    save(prog, path)
+    raw = bytearray(open(path, "rb").read())
+    # find the Add term's record: op code 11 followed by operand count 2 -> make it 1
+    needle = struct.pack("<iI", 11, 2)
+    at = bytes(raw).find(needle)
+    assert at > 0
+    bad = bytearray(raw)
+    bad[at + 4:at + 8] = struct.pack("<I", 1)
+    open(path, "wb").write(bad)
+    with pytest.raises(RuntimeError, match="operand count"):
+        load(path)
+    bad = bytearray(raw)
+    bad[at:at + 4] = struct.pack("<i", 99)
+    open(path, "wb").write(bad)
+    with pytest.raises(RuntimeError, match="op code"):
+        load(path)
+    open(path, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(RuntimeError, match="truncated|parse"):
+        load(path)
+    # a length field near 2^64 must not wrap the bounds check
+    bad = bytearray(raw[:12]) + struct.pack("<Q", 2 ** 64 - 4) + bytearray(raw[20:])
+    open(path, "wb").write(bad)
+    with pytest.raises(RuntimeError, match="truncated|parse"):
+        load(path)
+    # a valuation whose declared shape disagrees with its data
+    v = SEALValuation()
+    v._set_cipher('x', np.zeros((2, 2, 1024), dtype=np.uint64), 2.0 ** 30)
+    vpath = str(tmp_path / "v.eva")
+    save(v, vpath)
+    rawv = bytearray(open(vpath, "rb").read())
+    at = bytes(rawv).find(struct.pack("<III", 1, 2, 2))   # kind, size, limbs
+    rawv[at + 8:at + 12] = struct.pack("<I", 7)          # limbs := 7
+    open(vpath, "wb").write(rawv)
+    with pytest.raises(RuntimeError, match="shape"):
+        load(vpath)
