@@ -14,114 +14,114 @@ from . import _eva
 
 __version__ = "0.1.0"
 
-_current_program = None
+class _Scope:
+    """The one EvaProgram a `with` block has made current (Input / Output / constants go there)."""
+    active = None
+
+    @classmethod
+    def program(cls):
+        if cls.active is None:
+            raise RuntimeError("Input / Output / constants need an enclosing `with EvaProgram(...)` block")
+        return cls.active
 
 
-def _curr():
-    """ Returns the EvaProgram that is currently in context """
-    if _current_program is None:
-        raise RuntimeError("No Program in context")
-    return _current_program
-
-
-def _py_to_term(x, program):
-    """ Maps supported types into native terms """
-    if isinstance(x, Expr):
-        return x.term
-    elif isinstance(x, list):
-        return program._make_dense_constant(x)
-    elif isinstance(x, numbers.Number):
-        return program._make_uniform_constant(x)
-    elif isinstance(x, _eva.Term):
-        return x
-    raise TypeError("No conversion to Term available for " + str(x))
+def _as_term(value, program):
+    """native Term for an Expr, a Term, a list (dense constant) or a number (uniform constant)"""
+    if isinstance(value, Expr):
+        return value.term
+    if isinstance(value, _eva.Term):
+        return value
+    if isinstance(value, list):
+        return program._make_dense_constant(value)
+    if isinstance(value, numbers.Number):
+        return program._make_uniform_constant(value)
+    raise TypeError(f"cannot use a {type(value).__name__} as an EVA term: {value!r}")
 
 
 def py_to_eva(x, program=None):
-    """ Maps supported types (Expr, Term, list, number) into Expr; constants are created in
-    `program` (default: the program currently in context). """
+    """Expr for an Expr, Term, list or number; constants are created in `program` (default: the
+    program of the enclosing `with` block)."""
     if isinstance(x, Expr):
         return x
-    if program is None:
-        program = _curr()
-    return Expr(_py_to_term(x, program), program)
+    target = program if program is not None else _Scope.program()
+    return Expr(_as_term(x, target), target)
 
 
-class Expr():
-    """ Wrapper for a native Term with operator overloads that create terms in the
-    associated EvaProgram. """
+class Expr:
+    """A value of an EvaProgram under construction: a native Term plus the program it belongs to.
+    Python arithmetic on it appends terms to that program (lists and numbers become constants)."""
 
     def __init__(self, term, program):
         self.term = term
         self.program = program
 
-    def _bin(self, op, a, b):
-        return Expr(self.program._make_term(op, [a, b]), self.program)
+    def _node(self, op, *operands):
+        terms = [_as_term(o, self.program) for o in operands]
+        return Expr(self.program._make_term(op, terms), self.program)
 
     def __add__(self, other):
-        return self._bin(Op.Add, self.term, _py_to_term(other, self.program))
+        return self._node(Op.Add, self, other)
 
     def __radd__(self, other):
-        return self._bin(Op.Add, _py_to_term(other, self.program), self.term)
+        return self._node(Op.Add, other, self)
 
     def __sub__(self, other):
-        return self._bin(Op.Sub, self.term, _py_to_term(other, self.program))
+        return self._node(Op.Sub, self, other)
 
     def __rsub__(self, other):
-        return self._bin(Op.Sub, _py_to_term(other, self.program), self.term)
+        return self._node(Op.Sub, other, self)
 
     def __mul__(self, other):
-        return self._bin(Op.Mul, self.term, _py_to_term(other, self.program))
+        return self._node(Op.Mul, self, other)
 
     def __rmul__(self, other):
-        return self._bin(Op.Mul, _py_to_term(other, self.program), self.term)
-
-    def __pow__(self, exponent):
-        """ Exponentiation as nested multiplication terms """
-        if exponent < 1:
-            raise ValueError("exponent must be greater than zero, got " + str(exponent))
-        result = self.term
-        for _ in range(exponent - 1):
-            result = self.program._make_term(Op.Mul, [result, self.term])
-        return Expr(result, self.program)
-
-    def __lshift__(self, rotation):
-        return Expr(self.program._make_left_rotation(self.term, rotation), self.program)
-
-    def __rshift__(self, rotation):
-        return Expr(self.program._make_right_rotation(self.term, rotation), self.program)
+        return self._node(Op.Mul, other, self)
 
     def __neg__(self):
-        return Expr(self.program._make_term(Op.Negate, [self.term]), self.program)
+        return self._node(Op.Negate, self)
+
+    def __pow__(self, exponent):
+        """x ** n for a positive integer n: a left-leaning chain of n - 1 products (the compiler's
+        reduction balancer reshapes it); the reference lowers powers the same way"""
+        if not isinstance(exponent, int) or exponent < 1:
+            raise ValueError(f"only positive integer powers are supported, got {exponent!r}")
+        power = self
+        for _ in range(exponent - 1):
+            power = power * self
+        return power
+
+    def __lshift__(self, steps):
+        return Expr(self.program._make_left_rotation(self.term, steps), self.program)
+
+    def __rshift__(self, steps):
+        return Expr(self.program._make_right_rotation(self.term, steps), self.program)
 
 
 class EvaProgram(Program):
-    """ Native Program that also acts as a context manager selecting the program the Input
-    and Output free functions operate on. """
+    """Program that can be made current with `with`: inside the block Input, Output and constants
+    refer to it."""
 
     def __init__(self, name, vec_size):
         super().__init__(name, vec_size)
 
     def __enter__(self):
-        global _current_program
-        if _current_program is not None:
-            raise RuntimeError("There is already an EVA Program in context")
-        _current_program = self
+        if _Scope.active is not None:
+            raise RuntimeError("`with EvaProgram` blocks do not nest: another program is already current")
+        _Scope.active = self
 
     def __exit__(self, exc_type, exc_value, exc_traceback):
-        global _current_program
-        if _current_program is not self:
-            raise RuntimeError("This program is not currently in context")
-        _current_program = None
+        if _Scope.active is not self:
+            raise RuntimeError("leaving a `with EvaProgram` block that is not the current one")
+        _Scope.active = None
 
 
 def Input(name, is_encrypted=True):
-    """ Create a new named input term in the current EvaProgram """
-    program = _curr()
+    """A named input of the current program: encrypted (Cipher) unless is_encrypted is False (Raw)."""
+    program = _Scope.program()
     return Expr(program._make_input(name, Type.Cipher if is_encrypted else Type.Raw), program)
 
 
 def Output(name, expr):
-    """ Create a new named output term in the current EvaProgram """
-    program = _curr()
-    program._make_output(name, _py_to_term(expr, program))
+    """Names `expr` as an output of the current program."""
+    program = _Scope.program()
+    program._make_output(name, _as_term(expr, program))

@@ -29,14 +29,34 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm to build the gfx950 backend)")
 
 
+HIP_UNITS = ("runtime.hip", "evaluator.hip", "scheduler.hip")
+HIP_HEADERS = ("internal.hip.h", "ntt.hip.h", "devmath.hip.h", "hostmath.h")
+
+
 def build_hip(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in ("eva_hip.hip", "ntt.cuh", "devmath.cuh", "hostmath.h")]
+    """The three translation units of libeva_hip.so are compiled concurrently (only evaluator.hip
+    holds device code) and linked into one shared library."""
+    units = [os.path.join(CSRC, f) for f in HIP_UNITS]
+    srcs = units + [os.path.join(CSRC, f) for f in HIP_HEADERS]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "eva_hip.h"))
     if not force and not _newer(HIP_LIB, srcs):
         return HIP_LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", HIP_LIB, os.path.join(CSRC, "eva_hip.hip")]
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    procs, objs = [], []
+    for u in units:
+        o = os.path.join(objdir, os.path.basename(u)[:-4] + ".o")
+        objs.append(o)
+        cmd = [_hipcc()] + flags + ["-c", u, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1,4 +1,4 @@
-// devmath.cuh — 64-bit modular arithmetic for gfx950 (CDNA4).
+// devmath.hip.h — 64-bit modular arithmetic for gfx950 (CDNA4).
 //
 // All ciphertext data are residues < q < 2^61.  CDNA4 has no 64x64->128 multiply; every
 // product below lowers to v_mad_u64_u32 / v_mul_hi_u32 chains, so the instruction budget is

@@ -1,57 +1,11 @@
-// eva_hip.hip — libeva_hip.so: C-ABI + HIP kernels of the MI355X CKKS evaluation backend.
-//
-// Replaces, for EVA's execute() hot path, every seal::Evaluator call made by
-// SEALExecutor::operator() (/root/reference/eva/seal/seal_executor.h:279-404) — see
-// include/eva_hip.h for the per-entry-point mapping.  gfx950 only; no CPU fallback: every entry
-// point needs a HIP device and fails with an error otherwise.
-#include "../../include/eva_hip.h"
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <map>
-#include <mutex>
-#include <unordered_map>
-#include <memory>
-#include <stdexcept>
-#include <string>
-#include <tuple>
-#include <vector>
-
-#include "hostmath.h"
-#include "ntt.cuh"
+// evaluator.hip — libeva_hip.so: HIP kernels + one C-ABI entry point per seal::Evaluator call made by
+// SEALExecutor::operator() (/root/reference/eva/seal/seal_executor.h:279-404), the device CKKS
+// encoder (:217-243), and the fused / batched forms the level scheduler uses.  include/eva_hip.h
+// names the reference line each entry point replaces.
+#include "internal.hip.h"
+#include "ntt.hip.h"
 
 namespace evah {
-
-static thread_local std::string g_err;
-
-// Contexts that exist: a buffer remembers the foreign queues that read it, and such a queue may
-// have been destroyed (after a sync) before the buffer is released.
-static std::mutex g_ctx_mu;
-static std::vector<const void *> g_live_ctx;
-static void ctx_register(const void *c) {
-  std::lock_guard<std::mutex> lk(g_ctx_mu);
-  g_live_ctx.push_back(c);
-}
-static void ctx_unregister(const void *c) {
-  std::lock_guard<std::mutex> lk(g_ctx_mu);
-  g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), c), g_live_ctx.end());
-}
-static bool ctx_alive(const void *c) {
-  std::lock_guard<std::mutex> lk(g_ctx_mu);
-  return std::find(g_live_ctx.begin(), g_live_ctx.end(), c) != g_live_ctx.end();
-}
-
-#define HIPCHK(x)                                                                                \
-  do {                                                                                           \
-    hipError_t e_ = (x);                                                                         \
-    if (e_ != hipSuccess)                                                                        \
-      throw std::runtime_error(std::string(#x) + " failed: " + hipGetErrorString(e_));          \
-  } while (0)
 
 // ------------------------------------------------------------------------------- kernels
 
@@ -355,290 +309,6 @@ k_ks_mac(DevCtx cx, const u64 *target, const u64 *scratch, const u64 *key, u64 *
   st2(prod + ((size_t)(l + 1) + I) * N + n, r1);
 }
 
-// ------------------------------------------------------------------------------- host state
-
-struct Pool {
-  std::map<size_t, std::vector<void *>> free_;
-  size_t in_use = 0, cached = 0;
-  void *alloc(size_t bytes) {
-    bytes = (bytes + 255) & ~(size_t)255;
-    auto it = free_.find(bytes);
-    void *p = nullptr;
-    if (it != free_.end() && !it->second.empty()) {
-      p = it->second.back();
-      it->second.pop_back();
-      cached -= bytes;
-    } else {
-      hipError_t e = hipMalloc(&p, bytes);
-      if (e != hipSuccess) {
-        release_cached();
-        HIPCHK(hipMalloc(&p, bytes));
-      }
-    }
-    in_use += bytes;
-    return p;
-  }
-  void free(void *p, size_t bytes) {
-    bytes = (bytes + 255) & ~(size_t)255;
-    free_[bytes].push_back(p);
-    in_use -= bytes;
-    cached += bytes;
-  }
-  void release_cached() {
-    for (auto &kv : free_)
-      for (void *p : kv.second) (void)hipFree(p);
-    free_.clear();
-    cached = 0;
-  }
-};
-
-struct Buffer {
-  u64 *d;
-  size_t bytes;
-  int refs;
-  Pool *pool;                       // owning queue's pool (handles may be freed through any fork)
-  evah_ctx *owner;                  // queue whose stream produced / will recycle this buffer
-  bool ready_everywhere;            // contents were synchronised with the host (uploads)
-  std::vector<evah_ctx *> synced;   // foreign queues that already wait for the producer
-  std::vector<evah_ctx *> readers;  // foreign queues that have enqueued reads
-};
-
-// Kernel classes for the optional per-launch HIP-event profile (bench.py's roofline leg).
-enum KClass {
-  KC_EW = 0,        // elementwise add/sub/negate/mul/square/mul_plain/perm/fill
-  KC_INTT_A,        // inverse pass 1 (contig)
-  KC_INTT_B,        // inverse pass 2 (strided)
-  KC_KSDIGIT_A,     // key-switch digit conversion, forward pass 1 (strided, fused base conversion)
-  KC_KSDIGIT_B,     // key-switch digit conversion, forward pass 2 (contig)
-  KC_KSMAC,         // key-switch inner product
-  KC_MODDOWN_A,     // rescale / mod-down forward pass 1 (fused reduce - half)
-  KC_MODDOWN_B,     // rescale / mod-down forward pass 2 (fused combine)
-  KC_NTT_A,         // plain forward pass 1
-  KC_NTT_B,         // plain forward pass 2
-  KC_COUNT
-};
-static const char *const kclass_names[KC_COUNT] = {
-    "elementwise", "intt_pass1", "intt_pass2", "ksdigit_pass1", "ksdigit_pass2", "ks_mac",
-    "moddown_pass1", "moddown_pass2", "ntt_pass1", "ntt_pass2"};
-
-struct ProfRec {
-  hipEvent_t e0, e1;
-  int cls;
-};
-
-struct KeyDev {
-  u64 *d = nullptr;
-  uint32_t n_digits = 0;
-  size_t bytes = 0;
-};
-
-} // namespace evah
-
-using namespace evah;
-
-struct evah_ct {
-  Buffer *buf;
-  u64 *d;
-  uint32_t size, limbs;
-  size_t ps; // poly stride in elements
-  double scale;
-  // `batch` independent ciphertexts of identical shape in one handle: instance b starts at
-  // d + b * size * ps, i.e. the handle is batch * size polynomials at a uniform stride.  Every
-  // evaluator entry point applies to all instances in one launch set (plaintext operands and keys
-  // are shared); this is how a batch of independent DAG instances is run (BASELINE config 4).
-  uint32_t batch = 1;
-};
-struct evah_pt {
-  Buffer *buf;
-  u64 *d;
-  uint32_t limbs;
-  double scale;
-};
-struct evah_graph {
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-};
-
-// Device state shared by a context and its forks: tables, keys, permutation tables.
-struct SharedDev {
-  int device = 0;
-  void *d_tables = nullptr;
-  KeyDev relin;
-  std::map<uint32_t, KeyDev> galois;
-  std::map<uint32_t, uint32_t *> perms;
-  double2 *enc_roots = nullptr;     // CKKS encoder: inverse-FFT roots in the order the stages consume them
-  double enc_last_root[2] = {0, 0}; // the single root of the last stage (scaled by fix on the host per call)
-  uint32_t *enc_slot_map = nullptr; // slot i (and its conjugate, at slots + i) -> FFT input index
-  ~SharedDev() {
-    (void)hipSetDevice(device);
-    if (enc_roots) (void)hipFree(enc_roots);
-    if (enc_slot_map) (void)hipFree(enc_slot_map);
-    if (relin.d) (void)hipFree(relin.d);
-    for (auto &kv : galois) (void)hipFree(kv.second.d);
-    for (auto &kv : perms) (void)hipFree(kv.second);
-    if (d_tables) (void)hipFree(d_tables);
-  }
-};
-
-struct evah_ctx {
-  std::shared_ptr<SharedDev> sh;
-  int device = 0;
-  uint32_t N = 0, logN = 0, k = 0;
-  std::vector<u64> primes;
-  std::vector<int> total_bits; // total_bits[l] = bit length of prod primes[0..l)
-  DevCtx dev{};
-  hipStream_t own = nullptr, stream = nullptr;
-  Pool pool;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool capturing = false;              // inside evah_capture_begin/end: no syncs, no profiling events
-  std::vector<hipEvent_t> capture_events; // events consumed by the capture in progress
-  std::vector<hipEvent_t> sync_events; // recycled events for cross-queue ordering
-  bool fuse_mac = true; // key-switch: fuse the inner product into the digit NTTs' second pass
-  // evah_execute: run Mul -> Relinearize -> Rescale chains as one evah_multiply_relinearize_rescale_many
-  // (EVAH_FUSE_MUL=0/1; default: only where launches, not bytes, bound the chain — see DESIGN.md §4)
-  bool fuse_mul = false;
-  int ks_groups = 1;    // output-limb slices per key-switch (EVAH_KS_GROUPS)
-  int ks_threads = 64;  // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS): one wave = one
-                        // 2^P-point sub-transform per workgroup measured best (barriers are intra-wave)
-  // per-launch profile
-  bool prof_on = false;
-  std::vector<ProfRec> prof_recs;
-  std::vector<hipEvent_t> prof_free;
-  double prof_ms[KC_COUNT] = {0};
-  uint64_t prof_n[KC_COUNT] = {0};
-};
-
-namespace evah {
-
-static void use(evah_ctx *c) { HIPCHK(hipSetDevice(c->device)); }
-
-static hipEvent_t prof_event(evah_ctx *c) {
-  if (!c->prof_free.empty()) {
-    hipEvent_t e = c->prof_free.back();
-    c->prof_free.pop_back();
-    return e;
-  }
-  hipEvent_t e;
-  HIPCHK(hipEventCreate(&e));
-  return e;
-}
-static void prof_drain(evah_ctx *c) {
-  for (auto &r : c->prof_recs) {
-    float ms = 0;
-    HIPCHK(hipEventSynchronize(r.e1));
-    HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
-    c->prof_ms[r.cls] += ms;
-    c->prof_n[r.cls]++;
-    c->prof_free.push_back(r.e0);
-    c->prof_free.push_back(r.e1);
-  }
-  c->prof_recs.clear();
-}
-struct ProfScope { // brackets one kernel launch with HIP events on the launch stream
-  evah_ctx *c;
-  int cls;
-  hipEvent_t e0 = nullptr;
-  ProfScope(evah_ctx *c_, int cls_) : c(c_), cls(cls_) {
-    if (c->prof_on && !c->capturing) {
-      if (c->prof_recs.size() >= 8192) prof_drain(c);
-      e0 = prof_event(c);
-      HIPCHK(hipEventRecord(e0, c->stream));
-    }
-  }
-  ~ProfScope() {
-    if (e0) {
-      hipEvent_t e1 = prof_event(c);
-      (void)hipEventRecord(e1, c->stream);
-      c->prof_recs.push_back({e0, e1, cls});
-    }
-  }
-};
-
-static Buffer *buf_new(evah_ctx *c, size_t elems) {
-  Buffer *b = new Buffer;
-  b->bytes = elems * sizeof(u64);
-  b->d = (u64 *)c->pool.alloc(b->bytes);
-  b->refs = 1;
-  b->pool = &c->pool;
-  b->owner = c;
-  b->ready_everywhere = false;
-  return b;
-}
-static hipEvent_t sync_event(evah_ctx *c) {
-  if (!c->capturing && !c->sync_events.empty()) {
-    hipEvent_t e = c->sync_events.back();
-    c->sync_events.pop_back();
-    return e;
-  }
-  hipEvent_t e;
-  HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  return e;
-}
-// make `waiter`'s stream wait for everything enqueued so far on `signaller`'s stream
-static void stream_wait(evah_ctx *waiter, evah_ctx *signaller) {
-  if (waiter == signaller || waiter->stream == signaller->stream) return;
-  hipEvent_t e = sync_event(waiter);
-  HIPCHK(hipEventRecord(e, signaller->stream));
-  HIPCHK(hipStreamWaitEvent(waiter->stream, e, 0));
-  // eager mode: the wait captured this record, so the event can be re-recorded right away.
-  // While capturing, an event is used for exactly one record/wait pair of the graph (re-recording
-  // one inside a capture has produced cyclic graphs with the ROCm 7.2 runtime).
-  if (waiter->capturing || signaller->capturing) waiter->capture_events.push_back(e);
-  else waiter->sync_events.push_back(e);
-}
-// Called before queue `c` enqueues a read of `b`: orders the read after the producer and
-// remembers the reader so the buffer is not recycled under it.
-static void acquire(evah_ctx *c, Buffer *b) {
-  if (!b || b->owner == c) return;
-  if (!b->ready_everywhere && std::find(b->synced.begin(), b->synced.end(), c) == b->synced.end()) {
-    stream_wait(c, b->owner);
-    b->synced.push_back(c);
-  }
-  if (std::find(b->readers.begin(), b->readers.end(), c) == b->readers.end()) b->readers.push_back(c);
-}
-static void buf_unref(evah_ctx *c, Buffer *b) {
-  (void)c;
-  if (b && --b->refs == 0) {
-    for (evah_ctx *r : b->readers)
-      if (ctx_alive(r)) stream_wait(b->owner, r); // recycle only after foreign reads (a destroyed queue was synchronised)
-    b->pool->free(b->d, b->bytes);
-    delete b;
-  }
-}
-static evah_ct *ct_new(evah_ctx *c, uint32_t size, uint32_t limbs, double scale, uint32_t batch = 1) {
-  evah_ct *t = new evah_ct;
-  t->batch = batch;
-  t->buf = buf_new(c, (size_t)batch * size * limbs * c->N);
-  t->d = t->buf->d;
-  t->size = size;
-  t->limbs = limbs;
-  t->ps = (size_t)limbs * c->N;
-  t->scale = scale;
-  return t;
-}
-static evah_pt *pt_new(evah_ctx *c, uint32_t limbs, double scale) {
-  evah_pt *t = new evah_pt;
-  t->buf = buf_new(c, (size_t)limbs * c->N);
-  t->d = t->buf->d;
-  t->limbs = limbs;
-  t->scale = scale;
-  return t;
-}
-
-struct Scratch { // pool-backed temporary, returned on scope exit (stream-ordered reuse)
-  evah_ctx *c;
-  u64 *d;
-  size_t bytes;
-  Scratch(evah_ctx *c_, size_t elems) : c(c_), bytes(elems * sizeof(u64)) {
-    d = (u64 *)c->pool.alloc(bytes);
-  }
-  ~Scratch() { c->pool.free(d, bytes); }
-};
-
-static dim3 ew_grid(evah_ctx *c, uint32_t limbs, uint32_t polys) {
-  return dim3(c->N / 512, limbs, polys);
-}
-
 // ---- NTT launch plumbing
 template <class Op> struct OpClass;
 template <> struct OpClass<OpPlain> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
@@ -829,562 +499,9 @@ static void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev 
   ntt_forward<OpModDown>(c, mp, 2 * l);
 }
 
-static int bitlen_of_product(const std::vector<u64> &primes, uint32_t count) {
-  std::vector<u64> w{1};
-  for (uint32_t i = 0; i < count; i++) {
-    u64 carry = 0;
-    for (auto &x : w) {
-      u128 t = (u128)x * primes[i] + carry;
-      x = (u64)t;
-      carry = (u64)(t >> 64);
-    }
-    if (carry) w.push_back(carry);
-  }
-  int bits = (int)(w.size() - 1) * 64;
-  u64 top = w.back();
-  while (top) { bits++; top >>= 1; }
-  return bits;
-}
-
-static void check_scale(evah_ctx *c, double scale, uint32_t limbs) {
-  // SEAL is_scale_within_bounds: 0 < scale, log2(scale) < total coeff modulus bits at the level
-  if (!(scale > 0) || (int)std::log2(scale) >= c->total_bits[limbs])
-    throw std::invalid_argument("scale out of bounds");
-}
-static bool same_scale(double a, double b) {
-  // SEAL util::are_close<double>
-  double scale_factor = std::max({std::fabs(a), std::fabs(b), 1.0});
-  return std::fabs(a - b) < 2.220446049250313e-16 * scale_factor;
-}
-
 } // namespace evah
 
-// ------------------------------------------------------------------------------- C-ABI
-
-#define EW_LAUNCH(...) do { ProfScope ps_(c, KC_EW); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
-#define API_BEGIN try {
-#define API_END                                                                                  \
-  g_err.clear();                                                                                 \
-  return 0;                                                                                      \
-  }                                                                                              \
-  catch (const std::exception &e) {                                                              \
-    g_err = e.what();                                                                            \
-    return 1;                                                                                    \
-  }                                                                                              \
-  catch (...) {                                                                                  \
-    g_err = "unknown error";                                                                     \
-    return 1;                                                                                    \
-  }
-
 extern "C" {
-
-const char *evah_last_error(void) { return g_err.c_str(); }
-int evah_abi_version(void) { return 1; }
-
-int evah_device_count(int *count) {
-  API_BEGIN
-  int n = 0;
-  hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    n = 0;
-  }
-  *count = n;
-  API_END
-}
-
-int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, evah_ctx **out) {
-  API_BEGIN
-  if (N < 1024 || N > 131072 || (N & (N - 1))) throw std::invalid_argument("poly_modulus_degree must be a power of two in [1024, 131072]");
-  if (k < 2 || k > 62) throw std::invalid_argument("need at least one data prime and one special prime");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-    throw std::runtime_error("libeva_hip: no HIP device available (this backend has no CPU fallback)");
-  if (device < 0 || device >= ndev) throw std::invalid_argument("invalid device index");
-  auto *c = new evah_ctx;
-  try {
-    c->device = device;
-    c->N = N;
-    c->logN = ilog2(N);
-    c->k = k;
-    c->primes.assign(primes, primes + k);
-    if (const char *e = std::getenv("EVAH_FUSE_MAC")) c->fuse_mac = std::atoi(e) != 0;
-    if (const char *e = std::getenv("EVAH_KS_GROUPS")) c->ks_groups = std::max(1, std::atoi(e));
-    c->fuse_mul = N <= 8192;
-    if (const char *e = std::getenv("EVAH_FUSE_MUL")) c->fuse_mul = std::atoi(e) != 0;
-    if (const char *e = std::getenv("EVAH_KS_THREADS")) {
-      int t = std::atoi(e);
-      if (t == 64 || t == 128 || t == 256) c->ks_threads = t;
-    }
-    for (u64 q : c->primes)
-      if (q >= ((u64)1 << 60) || (q - 1) % (2ull * N) || !is_prime(q)) // SEAL_USER_MOD_BIT_COUNT_MAX = 60
-        throw std::invalid_argument("coeff modulus primes must be at most 60 bits, prime and 1 mod 2N");
-    for (uint32_t l = 0; l <= k; l++) c->total_bits.push_back(l ? bitlen_of_product(c->primes, l) : 0);
-    use(c);
-    HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
-    c->stream = c->own;
-    HIPCHK(hipEventCreate(&c->ev0));
-    HIPCHK(hipEventCreate(&c->ev1));
-    // ---- tables: [primes k][tw_fwd k*N][tw_inv k*N][invq k*k][halfmod k*k]
-    const size_t sz_pr = sizeof(DevPrime) * k, sz_tw = sizeof(ulonglong2) * (size_t)k * N,
-                 sz_iq = sizeof(ulonglong2) * (size_t)k * k, sz_hm = sizeof(u64) * (size_t)k * k;
-    const size_t total = sz_pr + 2 * sz_tw + sz_iq + sz_hm;
-    std::vector<unsigned char> host(total);
-    auto *hp = reinterpret_cast<DevPrime *>(host.data());
-    auto *hf = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr);
-    auto *hi = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr + sz_tw);
-    auto *hq = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr + 2 * sz_tw);
-    auto *hh = reinterpret_cast<u64 *>(host.data() + sz_pr + 2 * sz_tw + sz_iq);
-    for (uint32_t i = 0; i < k; i++) {
-      const u64 q = c->primes[i];
-      const u64 psi = minimal_primitive_root(N, q), psi_inv = invmod(psi, q);
-      std::vector<u64> rp = root_power_table(N, q, psi), irp = root_power_table(N, q, psi_inv);
-      for (uint32_t j = 0; j < N; j++) {
-        hf[(size_t)i * N + j] = make_ulonglong2(rp[j], shoup(rp[j], q));
-        hi[(size_t)i * N + j] = make_ulonglong2(irp[j], shoup(irp[j], q));
-      }
-      DevPrime &d = hp[i];
-      d.q = q;
-      d.brt = (u64)((((u128)1) << 64) / q);
-      u128 ratio = (~(u128)0) / q;
-      d.r0 = (u64)ratio;
-      d.r1 = (u64)(ratio >> 64);
-      d.ninv = invmod(N % q, q);
-      d.ninv_s = shoup(d.ninv, q);
-      d.w0ninv = mulmod(irp[1], d.ninv, q);
-      d.w0ninv_s = shoup(d.w0ninv, q);
-      d.nq = 0ull - q;
-      d.q5 = 5 * q;
-      d.q4 = 4 * q;
-      d.q8 = 8 * q;
-      d.nq5 = 0ull - 5 * q;
-      d.nq8 = 0ull - 8 * q;
-      for (uint32_t a = 0; a < k; a++) {
-        const u64 qa = c->primes[a];
-        if (a == i) {
-          hq[a * k + i] = make_ulonglong2(0, 0);
-          hh[a * k + i] = 0;
-        } else {
-          u64 inv = invmod(qa % q, q);
-          hq[a * k + i] = make_ulonglong2(inv, shoup(inv, q));
-          hh[a * k + i] = (qa >> 1) % q;
-        }
-      }
-    }
-    c->sh = std::make_shared<SharedDev>();
-    c->sh->device = device;
-    HIPCHK(hipMalloc(&c->sh->d_tables, total));
-    HIPCHK(hipMemcpy(c->sh->d_tables, host.data(), total, hipMemcpyHostToDevice));
-    auto *base = reinterpret_cast<unsigned char *>(c->sh->d_tables);
-    c->dev.primes = reinterpret_cast<const DevPrime *>(base);
-    c->dev.tw_fwd = reinterpret_cast<const ulonglong2 *>(base + sz_pr);
-    c->dev.tw_inv = reinterpret_cast<const ulonglong2 *>(base + sz_pr + sz_tw);
-    c->dev.invq = reinterpret_cast<const ulonglong2 *>(base + sz_pr + 2 * sz_tw);
-    c->dev.halfmod = reinterpret_cast<const u64 *>(base + sz_pr + 2 * sz_tw + sz_iq);
-    c->dev.N = N;
-    c->dev.logN = c->logN;
-    c->dev.k = k;
-  } catch (...) {
-    evah_ctx_destroy(c);
-    throw;
-  }
-  ctx_register(c);
-  *out = c;
-  API_END
-}
-
-int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
-  API_BEGIN
-  use(parent);
-  auto *c = new evah_ctx;
-  try {
-    c->sh = parent->sh;
-    c->device = parent->device;
-    c->N = parent->N;
-    c->logN = parent->logN;
-    c->k = parent->k;
-    c->primes = parent->primes;
-    c->total_bits = parent->total_bits;
-    c->dev = parent->dev;
-    c->fuse_mac = parent->fuse_mac;
-    c->fuse_mul = parent->fuse_mul;
-    c->ks_threads = parent->ks_threads;
-    c->ks_groups = parent->ks_groups;
-    HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
-    c->stream = c->own;
-    HIPCHK(hipEventCreate(&c->ev0));
-    HIPCHK(hipEventCreate(&c->ev1));
-  } catch (...) {
-    evah_ctx_destroy(c);
-    throw;
-  }
-  ctx_register(c);
-  *out = c;
-  API_END
-}
-
-void evah_ctx_destroy(evah_ctx *c) {
-  if (!c) return;
-  ctx_unregister(c);
-  (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->pool.release_cached();
-  c->sh.reset(); // tables and keys go when the last fork goes
-  for (auto &r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-  for (auto e : c->prof_free) (void)hipEventDestroy(e);
-  for (auto e : c->sync_events) (void)hipEventDestroy(e);
-  for (auto e : c->capture_events) (void)hipEventDestroy(e);
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->own) (void)hipStreamDestroy(c->own);
-  delete c;
-}
-
-int evah_ctx_set_stream(evah_ctx *c, void *s) {
-  API_BEGIN
-  use(c);
-  HIPCHK(hipStreamSynchronize(c->stream)); // pool reuse is ordered per stream
-  c->stream = s ? (hipStream_t)s : c->own;
-  API_END
-}
-
-int evah_ctx_sync(evah_ctx *c) {
-  API_BEGIN
-  use(c);
-  HIPCHK(hipStreamSynchronize(c->stream));
-  API_END
-}
-
-int evah_ctx_mem_info(evah_ctx *c, size_t *in_use, size_t *cached) {
-  API_BEGIN
-  *in_use = c->pool.in_use;
-  *cached = c->pool.cached;
-  API_END
-}
-
-int evah_galois_elt_from_step(evah_ctx *c, int32_t steps, uint32_t *elt) {
-  API_BEGIN
-  const uint32_t N = c->N, m = 2 * N;
-  if (steps == 0) {
-    *elt = m - 1;
-  } else {
-    uint32_t pos = steps < 0 ? (uint32_t)(-(int64_t)steps) : (uint32_t)steps;
-    if (pos >= (N >> 1)) throw std::invalid_argument("step count too large");
-    uint32_t s = steps < 0 ? (N >> 1) - pos : pos, e = 1;
-    for (uint32_t i = 0; i < s; i++) e = (e * 3u) & (m - 1);
-    *elt = e;
-  }
-  API_END
-}
-
-int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digits, const uint64_t *data) {
-  API_BEGIN
-  use(c);
-  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
-  if (n_digits == 0 || n_digits > c->k - 1) throw std::invalid_argument("invalid key digit count");
-  KeyDev kd;
-  kd.n_digits = n_digits;
-  kd.bytes = sizeof(u64) * (size_t)n_digits * 2 * c->k * c->N;
-  HIPCHK(hipMalloc(&kd.d, kd.bytes));
-  HIPCHK(hipMemcpy(kd.d, data, kd.bytes, hipMemcpyHostToDevice));
-  if (kind == EVAH_KEY_RELIN) {
-    if (c->sh->relin.d) (void)hipFree(c->sh->relin.d);
-    c->sh->relin = kd;
-  } else if (kind == EVAH_KEY_GALOIS) {
-    if (!(galois_elt & 1) || galois_elt >= 2 * c->N) {
-      (void)hipFree(kd.d);
-      throw std::invalid_argument("Galois element is not valid");
-    }
-    auto it = c->sh->galois.find(galois_elt);
-    if (it != c->sh->galois.end()) (void)hipFree(it->second.d);
-    c->sh->galois[galois_elt] = kd;
-  } else {
-    (void)hipFree(kd.d);
-    throw std::invalid_argument("unknown key kind");
-  }
-  API_END
-}
-
-// Pinned (page-locked) host memory for the values that cross the boundary: copies from it are
-// DMA transfers at PCIe rate instead of the runtime's staged pageable path (~10 GB/s on one
-// core).  Blocks are recycled by size — pinning is far too slow to do per value.
-namespace {
-std::mutex g_host_mu;
-std::unordered_multimap<size_t, void *> g_host_free; // size -> idle pinned block
-std::unordered_map<void *, size_t> g_host_live;       // block handed out -> size
-size_t g_host_cached = 0;
-} // namespace
-void *evah_host_alloc(size_t bytes) {
-  if (!bytes) return nullptr;
-  std::lock_guard<std::mutex> lk(g_host_mu);
-  auto it = g_host_free.find(bytes);
-  void *p = nullptr;
-  if (it != g_host_free.end()) {
-    p = it->second;
-    g_host_free.erase(it);
-    g_host_cached -= bytes;
-  } else if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr; // no device / no memory: the caller falls back to ordinary memory
-  }
-  g_host_live.emplace(p, bytes);
-  return p;
-}
-void evah_host_free(void *p) {
-  if (!p) return;
-  std::lock_guard<std::mutex> lk(g_host_mu);
-  auto it = g_host_live.find(p);
-  if (it == g_host_live.end()) return;
-  const size_t bytes = it->second;
-  g_host_live.erase(it);
-  if (g_host_cached + bytes > ((size_t)4 << 30)) { // keep at most 4 GiB idle
-    (void)hipHostFree(p);
-    return;
-  }
-  g_host_free.emplace(bytes, p);
-  g_host_cached += bytes;
-}
-
-// Host <-> device copies of the instances of a batched handle, back to back on the context's
-// stream.  (Measured on MI355X: splitting them over 4 host threads with a copy stream each is
-// slower — 5.1 k vs 6.9 k Sobel DAGs/s — the pageable staging path of the runtime serialises.)
-static void io_copy(evah_ctx *c, uint32_t n, const std::function<hipError_t(uint32_t, hipStream_t)> &copy_one) {
-  for (uint32_t b = 0; b < n; b++) HIPCHK(copy_one(b, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-}
-
-int evah_ct_upload(evah_ctx *c, uint32_t size, uint32_t limbs, double scale, const uint64_t *data, evah_ct **out) {
-  API_BEGIN
-  use(c);
-  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
-  if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
-  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
-  evah_ct *t = ct_new(c, size, limbs, scale);
-  HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)size * limbs * c->N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  t->buf->ready_everywhere = true;
-  *out = t;
-  API_END
-}
-
-// `batch` ciphertexts of one shape as ONE handle; data = [batch][size][limbs][N]
-int evah_ct_upload_batch(evah_ctx *c, uint32_t batch, uint32_t size, uint32_t limbs, double scale, const uint64_t *data,
-                         evah_ct **out) {
-  API_BEGIN
-  use(c);
-  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
-  if (batch < 1 || batch > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("batch must be 1..64");
-  if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
-  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
-  evah_ct *t = ct_new(c, size, limbs, scale, batch);
-  HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)batch * size * limbs * c->N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  t->buf->ready_everywhere = true;
-  *out = t;
-  API_END
-}
-
-// the same from `batch` separate host arrays (each [size][limbs][N]): no host-side concatenation
-int evah_ct_upload_instances(evah_ctx *c, uint32_t batch, uint32_t size, uint32_t limbs, double scale,
-                             const uint64_t *const *data, evah_ct **out) {
-  API_BEGIN
-  use(c);
-  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
-  if (batch < 1 || batch > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("batch must be 1..64");
-  if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
-  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
-  evah_ct *t = ct_new(c, size, limbs, scale, batch);
-  const size_t each = (size_t)size * limbs * c->N;
-  try {
-    io_copy(c, batch, [&](uint32_t b, hipStream_t st) {
-      return hipMemcpyAsync(t->d + each * b, data[b], sizeof(u64) * each, hipMemcpyHostToDevice, st);
-    });
-  } catch (...) {
-    evah_ct_free(c, t);
-    throw;
-  }
-  *out = t;
-  API_END
-}
-
-// instance b of a batched handle -> out[b] ([size][limbs][N] each), all instances in one call
-int evah_ct_download_instances(evah_ctx *c, const evah_ct *ct, uint64_t *const *out) {
-  API_BEGIN
-  use(c);
-  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
-  acquire(c, ct->buf);
-  const size_t row = sizeof(u64) * (size_t)ct->limbs * c->N;
-  const bool dense = ct->ps == (size_t)ct->limbs * c->N; // not a mod-switched view: one linear copy per instance
-  io_copy(c, ct->batch, [&](uint32_t b, hipStream_t st) {
-    const u64 *src = ct->d + (size_t)b * ct->size * ct->ps;
-    if (dense) return hipMemcpyAsync(out[b], src, row * ct->size, hipMemcpyDeviceToHost, st);
-    return hipMemcpy2DAsync(out[b], row, src, sizeof(u64) * ct->ps, row, ct->size, hipMemcpyDeviceToHost, st);
-  });
-  API_END
-}
-
-int evah_ct_batch(const evah_ct *ct, uint32_t *batch) {
-  API_BEGIN
-  *batch = ct->batch;
-  API_END
-}
-
-// n single ciphertexts of one shape and scale -> one batched handle (device copies)
-int evah_ct_stack(evah_ctx *c, const evah_ct *const *cts, uint32_t n, evah_ct **out) {
-  API_BEGIN
-  use(c);
-  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("batch must be 1..64");
-  const evah_ct *f = cts[0];
-  for (uint32_t i = 0; i < n; i++) {
-    if (cts[i]->batch != 1) throw std::invalid_argument("stack takes single ciphertexts");
-    if (cts[i]->size != f->size || cts[i]->limbs != f->limbs) throw std::invalid_argument("encrypted parameter mismatch in batch");
-    if (!same_scale(cts[i]->scale, f->scale)) throw std::invalid_argument("scale mismatch");
-    acquire(c, cts[i]->buf);
-  }
-  evah_ct *o = ct_new(c, f->size, f->limbs, f->scale, n);
-  const size_t row = sizeof(u64) * (size_t)f->limbs * c->N;
-  for (uint32_t i = 0; i < n; i++)
-    HIPCHK(hipMemcpy2DAsync(o->d + (size_t)i * o->size * o->ps, sizeof(u64) * o->ps, cts[i]->d, sizeof(u64) * cts[i]->ps, row,
-                            f->size, hipMemcpyDeviceToDevice, c->stream));
-  *out = o;
-  API_END
-}
-
-// instance b of a batched handle as a single-ciphertext view (shares the buffer)
-int evah_ct_unstack(evah_ctx *c, const evah_ct *ct, uint32_t b, evah_ct **out) {
-  API_BEGIN
-  (void)c;
-  if (b >= ct->batch) throw std::invalid_argument("instance index out of range");
-  evah_ct *o = new evah_ct(*ct);
-  o->d = ct->d + (size_t)b * ct->size * ct->ps;
-  o->batch = 1;
-  o->buf->refs++;
-  *out = o;
-  API_END
-}
-
-int evah_ct_write(evah_ctx *c, evah_ct *ct, const uint64_t *data) {
-  API_BEGIN
-  use(c);
-  if (c->capturing) throw std::logic_error("evah_ct_write cannot be captured into a graph");
-  if (ct->ps != (size_t)ct->limbs * c->N) throw std::invalid_argument("cannot write into a mod-switched view");
-  acquire(c, ct->buf);
-  HIPCHK(hipMemcpyAsync(ct->d, data, sizeof(u64) * (size_t)ct->batch * ct->size * ct->limbs * c->N, hipMemcpyHostToDevice,
-                        c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream)); // pageable source: the caller may reuse it after return
-  API_END
-}
-
-int evah_pt_write(evah_ctx *c, evah_pt *pt, const uint64_t *data) {
-  API_BEGIN
-  use(c);
-  if (c->capturing) throw std::logic_error("evah_pt_write cannot be captured into a graph");
-  acquire(c, pt->buf);
-  HIPCHK(hipMemcpyAsync(pt->d, data, sizeof(u64) * (size_t)pt->limbs * c->N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  API_END
-}
-
-int evah_capture_begin(evah_ctx *q0, evah_ctx **others, uint32_t n_others) {
-  API_BEGIN
-  use(q0);
-  HIPCHK(hipStreamSynchronize(q0->stream));
-  for (uint32_t i = 0; i < n_others; i++) HIPCHK(hipStreamSynchronize(others[i]->stream));
-  HIPCHK(hipStreamBeginCapture(q0->stream, hipStreamCaptureModeRelaxed));
-  q0->capturing = true;
-  for (uint32_t i = 0; i < n_others; i++) { // fork: every queue joins the capture
-    stream_wait(others[i], q0);
-    others[i]->capturing = true;
-  }
-  API_END
-}
-
-int evah_capture_end(evah_ctx *q0, evah_ctx **others, uint32_t n_others, evah_graph **out) {
-  API_BEGIN
-  use(q0);
-  for (uint32_t i = 0; i < n_others; i++) { // join
-    stream_wait(q0, others[i]);
-    others[i]->capturing = false;
-  }
-  q0->capturing = false;
-  auto *g = new evah_graph;
-  hipError_t e = hipStreamEndCapture(q0->stream, &g->graph);
-  if (e != hipSuccess) {
-    delete g;
-    throw std::runtime_error(std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
-  }
-  for (uint32_t i = 0; i <= n_others; i++) { // events of this capture may be recycled now
-    evah_ctx *q = i ? others[i - 1] : q0;
-    q->sync_events.insert(q->sync_events.end(), q->capture_events.begin(), q->capture_events.end());
-    q->capture_events.clear();
-  }
-  e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-  if (e != hipSuccess) {
-    (void)hipGraphDestroy(g->graph);
-    delete g;
-    throw std::runtime_error(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e));
-  }
-  *out = g;
-  API_END
-}
-
-int evah_graph_launch(evah_ctx *q0, evah_graph *g) {
-  API_BEGIN
-  use(q0);
-  HIPCHK(hipGraphLaunch(g->exec, q0->stream));
-  API_END
-}
-
-void evah_graph_free(evah_graph *g) {
-  if (!g) return;
-  if (g->exec) (void)hipGraphExecDestroy(g->exec);
-  if (g->graph) (void)hipGraphDestroy(g->graph);
-  delete g;
-}
-
-int evah_ct_info(const evah_ct *ct, uint32_t *size, uint32_t *limbs, double *scale) {
-  API_BEGIN
-  if (size) *size = ct->size;
-  if (limbs) *limbs = ct->limbs;
-  if (scale) *scale = ct->scale;
-  API_END
-}
-
-int evah_ct_download(evah_ctx *c, const evah_ct *ct, uint64_t *out) {
-  API_BEGIN
-  use(c);
-  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
-  acquire(c, ct->buf);
-  const size_t row = sizeof(u64) * (size_t)ct->limbs * c->N;
-  // a batched handle downloads as [batch][size][limbs][N]; a dense handle (not a mod-switched
-  // view) is one linear copy — 2-D copies into pageable memory are several times slower
-  if (ct->ps == (size_t)ct->limbs * c->N)
-    HIPCHK(hipMemcpyAsync(out, ct->d, row * ct->size * ct->batch, hipMemcpyDeviceToHost, c->stream));
-  else
-    HIPCHK(hipMemcpy2DAsync(out, row, ct->d, sizeof(u64) * ct->ps, row, (size_t)ct->size * ct->batch, hipMemcpyDeviceToHost,
-                            c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  API_END
-}
-
-void evah_ct_free(evah_ctx *c, evah_ct *ct) {
-  if (!ct) return;
-  buf_unref(c, ct->buf);
-  delete ct;
-}
-
-int evah_pt_upload(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *data, evah_pt **out) {
-  API_BEGIN
-  use(c);
-  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
-  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
-  evah_pt *t = pt_new(c, limbs, scale);
-  HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)limbs * c->N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  t->buf->ready_everywhere = true;
-  *out = t;
-  API_END
-}
 
 int evah_pt_upload_coeff(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *data, evah_pt **out) {
   API_BEGIN
@@ -1480,29 +597,6 @@ int evah_pt_uniform(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *v
   HIPCHK(hipGetLastError());
   *out = t;
   API_END
-}
-
-int evah_pt_info(const evah_pt *pt, uint32_t *limbs, double *scale) {
-  API_BEGIN
-  if (limbs) *limbs = pt->limbs;
-  if (scale) *scale = pt->scale;
-  API_END
-}
-
-int evah_pt_download(evah_ctx *c, const evah_pt *pt, uint64_t *out) {
-  API_BEGIN
-  use(c);
-  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
-  acquire(c, pt->buf);
-  HIPCHK(hipMemcpyAsync(out, pt->d, sizeof(u64) * (size_t)pt->limbs * c->N, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  API_END
-}
-
-void evah_pt_free(evah_ctx *c, evah_pt *pt) {
-  if (!pt) return;
-  buf_unref(c, pt->buf);
-  delete pt;
 }
 
 // ---- evaluator
@@ -2243,434 +1337,6 @@ int evah_test_ntt(evah_ctx *c, uint32_t prime_idx, int inverse, uint64_t *host) 
   else ntt_forward<OpPlain>(c, p, 1);
   HIPCHK(hipMemcpyAsync(host, s.d, sizeof(u64) * c->N, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  API_END
-}
-
-// Whole-DAG submit over a value table (include/eva_hip.h).  Dispatch rules follow
-// seal_executor.h:114-215.  The op list is scheduled level by level (depth = longest path from the
-// caller-placed values): the ops of one level are independent, so its rotations, rescales,
-// relinearizations and ciphertext products go out through the batched entry points; a
-// Relinearize consumed only by a Rescale is evaluated with it; multiply_plain / add chains whose
-// partial sums have no other reader collapse into evah_weighted_sum.  Same ciphertexts as calling
-// the entry points one op at a time in list order.
-int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab, uint32_t n_vals) {
-  struct LazySum { // unevaluated sum of products; the handles are aliases owned here
-    std::vector<evah_ct *> cts;
-    std::vector<evah_pt *> pts;
-    uint32_t size = 0, limbs = 0;
-    double scale = 0;
-  };
-  struct State {
-    evah_ctx *c;
-    std::map<uint32_t, LazySum> sums;
-    std::map<uint32_t, evah_ct *> relins; // value -> alias of the size-3 operand of a deferred Relinearize
-    // value -> aliases of the two operands of a deferred Mul (prods) / of a Relinearize of one (prodrel):
-    // Mul -> Relinearize -> Rescale chains without other readers run as one fused call at the Rescale
-    std::map<uint32_t, std::pair<evah_ct *, evah_ct *>> prods, prodrel;
-    ~State() {
-      for (auto &kv : sums) {
-        for (evah_ct *h : kv.second.cts) evah_ct_free(c, h);
-        for (evah_pt *h : kv.second.pts) evah_pt_free(c, h);
-      }
-      for (auto &kv : relins) evah_ct_free(c, kv.second);
-      for (auto *m : {&prods, &prodrel})
-        for (auto &kv : *m) { evah_ct_free(c, kv.second.first); evah_ct_free(c, kv.second.second); }
-    }
-  } st{c, {}, {}, {}, {}};
-  auto chk = [&](int rc) {
-    if (rc) throw std::runtime_error(g_err);
-  };
-  auto slot = [&](uint32_t i) -> evah_val & {
-    if (i >= n_vals) throw std::invalid_argument("value index out of range");
-    return tab[i];
-  };
-  auto alias_ct = [](evah_ct *a) { evah_ct *o = new evah_ct(*a); o->buf->refs++; return o; };
-  auto alias_pt = [](evah_pt *a) { evah_pt *o = new evah_pt(*a); o->buf->refs++; return o; };
-  auto release = [&](uint32_t i) {
-    evah_val &v = tab[i];
-    if (v.kind == EVAH_VAL_CT) evah_ct_free(c, static_cast<evah_ct *>(v.h));
-    else if (v.kind == EVAH_VAL_PT) evah_pt_free(c, static_cast<evah_pt *>(v.h));
-    v.kind = EVAH_VAL_NONE;
-    v.h = nullptr;
-  };
-  auto put = [&](uint32_t dst, evah_ct *o) {
-    tab[dst].kind = EVAH_VAL_CT;
-    tab[dst].h = o;
-  };
-  auto drop_sum = [&](uint32_t v) {
-    auto it = st.sums.find(v);
-    if (it == st.sums.end()) return;
-    for (evah_ct *h : it->second.cts) evah_ct_free(c, h);
-    for (evah_pt *h : it->second.pts) evah_pt_free(c, h);
-    st.sums.erase(it);
-  };
-  // a value as a device ciphertext: deferred forms are evaluated on first demand
-  auto ct_of = [&](uint32_t v) -> evah_ct * {
-    auto ls = st.sums.find(v);
-    if (ls != st.sums.end()) {
-      evah_ct *o = nullptr;
-      std::vector<const evah_ct *> cc(ls->second.cts.begin(), ls->second.cts.end());
-      std::vector<const evah_pt *> pp(ls->second.pts.begin(), ls->second.pts.end());
-      chk(evah_weighted_sum(c, cc.data(), pp.data(), (uint32_t)cc.size(), &o));
-      drop_sum(v);
-      put(v, o);
-    }
-    auto lr = st.relins.find(v);
-    if (lr != st.relins.end()) {
-      evah_ct *o = nullptr;
-      chk(evah_relinearize(c, lr->second, &o));
-      evah_ct_free(c, lr->second);
-      st.relins.erase(lr);
-      put(v, o);
-    }
-    evah_val &x = slot(v);
-    if (x.kind != EVAH_VAL_CT || !x.h) throw std::invalid_argument("operand is not a ciphertext");
-    return static_cast<evah_ct *>(x.h);
-  };
-  auto is_ct = [&](uint32_t v) { return slot(v).kind == EVAH_VAL_CT || st.sums.count(v) || st.relins.count(v); };
-  auto is_plain_ct = [&](uint32_t v) { return tab[v].kind == EVAH_VAL_CT && !st.sums.count(v) && !st.relins.count(v); };
-
-  API_BEGIN
-  use(c);
-  // ---- analysis: producers, readers, levels (the list is in topological order, single assignment)
-  const int NONE = -1;
-  std::vector<int> producer(n_vals, NONE), only_reader(n_vals, NONE);
-  std::vector<uint32_t> reads(n_vals, 0), level(n_ops, 0);
-  std::vector<char> freeable(n_vals, 0);
-  auto arity = [](uint32_t op) { return (op == 11 || op == 12 || op == 13) ? 2 : (op == 1 || op == 3 || op == 23) ? 0 : 1; };
-  uint32_t depth = 0;
-  for (uint32_t i = 0; i < n_ops; i++) {
-    const evah_op &o = ops[i];
-    const int na = arity(o.op);
-    if (na == 0) {
-      if (slot(o.dst).kind == EVAH_VAL_NONE) throw std::invalid_argument("input / plaintext slot is empty");
-      continue;
-    }
-    if (slot(o.dst).kind != EVAH_VAL_NONE || producer[o.dst] != NONE)
-      throw std::invalid_argument("every value slot is written by exactly one op (dst slots start empty)");
-    const uint32_t srcs[2] = {o.src0, o.src1};
-    for (int k = 0; k < na; k++) {
-      const uint32_t v = srcs[k];
-      if (v >= n_vals) throw std::invalid_argument("value index out of range");
-      if (producer[v] == NONE && tab[v].kind == EVAH_VAL_NONE) throw std::invalid_argument("operand is used before it is produced");
-      if (producer[v] != NONE) level[i] = std::max(level[i], level[producer[v]] + 1);
-      only_reader[v] = reads[v] == 0 ? (int)i : -2;
-      reads[v]++;
-      if (o.flags & (k == 0 ? EVAH_OPF_FREE_SRC0 : EVAH_OPF_FREE_SRC1)) freeable[v] = 1;
-    }
-    producer[o.dst] = (int)i;
-    depth = std::max(depth, level[i]);
-  }
-  std::vector<std::vector<uint32_t>> buckets(depth + 1);
-  for (uint32_t i = 0; i < n_ops; i++)
-    if (arity(ops[i].op)) buckets[level[i]].push_back(i);
-  // dst is an intermediate nobody else sees and its one reader is an op of kind `by`
-  auto feeds_only = [&](uint32_t dst, uint32_t by) {
-    return reads[dst] == 1 && only_reader[dst] >= 0 && ops[only_reader[dst]].op == by && freeable[dst];
-  };
-  auto shape = [&](uint32_t v, uint32_t &size, uint32_t &limbs, double &scale) {
-    auto ls = st.sums.find(v);
-    if (ls != st.sums.end()) { size = ls->second.size; limbs = ls->second.limbs; scale = ls->second.scale; return; }
-    chk(evah_ct_info(ct_of(v), &size, &limbs, &scale));
-  };
-
-  for (auto &lvl : buckets) {
-    std::map<uint32_t, std::vector<uint32_t>> rots, relins, muls, batched_rots;
-    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<uint32_t>> rescales;
-    std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> fused, fused3;
-    // ---- one op through the ordinary entry points (seal_executor.h:114-215)
-    auto single = [&](const evah_op &o) {
-      evah_ct *out = nullptr;
-      switch (o.op) {
-      case 2: { // Output: dst names the same ciphertext
-        evah_val &s0 = slot(o.src0);
-        if (s0.kind == EVAH_VAL_PT) { tab[o.dst].kind = EVAH_VAL_PT; tab[o.dst].h = alias_pt(static_cast<evah_pt *>(s0.h)); return; }
-        out = alias_ct(ct_of(o.src0));
-        break;
-      }
-      case 10: chk(evah_negate(c, ct_of(o.src0), &out)); break;
-      case 11: case 13: { // Add / Mul: a plaintext first operand goes behind the ciphertext
-        uint32_t a = o.src0, b = o.src1;
-        if (!is_ct(a)) std::swap(a, b);
-        if (!is_ct(a)) throw std::runtime_error("Unsupported operation encountered");
-        if (is_ct(b)) {
-          if (o.op == 11) chk(evah_add(c, ct_of(a), ct_of(b), &out));
-          else if (a == b) chk(evah_square(c, ct_of(a), &out));
-          else chk(evah_multiply(c, ct_of(a), ct_of(b), &out));
-        } else if (slot(b).kind == EVAH_VAL_PT) {
-          if (o.op == 11) chk(evah_add_plain(c, ct_of(a), static_cast<evah_pt *>(tab[b].h), &out));
-          else chk(evah_multiply_plain(c, ct_of(a), static_cast<evah_pt *>(tab[b].h), &out));
-        } else {
-          throw std::runtime_error("Unsupported operation encountered");
-        }
-        break;
-      }
-      case 12:
-        if (is_ct(o.src1)) chk(evah_sub(c, ct_of(o.src0), ct_of(o.src1), &out));
-        else if (slot(o.src1).kind == EVAH_VAL_PT) chk(evah_sub_plain(c, ct_of(o.src0), static_cast<evah_pt *>(tab[o.src1].h), &out));
-        else throw std::runtime_error("Unsupported operation encountered");
-        break;
-      case 14: chk(evah_rotate(c, ct_of(o.src0), o.imm, &out)); break;
-      case 15: chk(evah_rotate(c, ct_of(o.src0), -o.imm, &out)); break; // seal_executor.h:188
-      case 20: chk(evah_relinearize(c, ct_of(o.src0), &out)); break;
-      case 21: chk(evah_mod_switch(c, ct_of(o.src0), &out)); break;
-      case 22: chk(evah_rescale(c, ct_of(o.src0), (uint32_t)o.imm, &out)); break;
-      default: throw std::runtime_error("Unhandled op " + std::to_string(o.op));
-      }
-      put(o.dst, out);
-    };
-    // ---- classify
-    for (uint32_t i : lvl) {
-      const evah_op &o = ops[i];
-      uint32_t size = 0, limbs = 0;
-      double scale = 0;
-      // a batched handle already covers its instances in one launch set: the *_many forms take
-      // single ciphertexts, so on batched operands only sibling rotations are grouped (rotate_many
-      // accepts them) and the deferred forms below still apply
-      auto batched_val = [&](uint32_t v) {
-        return tab[v].kind == EVAH_VAL_CT && static_cast<evah_ct *>(tab[v].h)->batch > 1;
-      };
-      const bool batched = batched_val(o.src0) || ((o.op == 11 || o.op == 12 || o.op == 13) && batched_val(o.src1)) ||
-                           (st.relins.count(o.src0) && st.relins[o.src0]->batch > 1);
-      if (batched && (o.op == 14 || o.op == 15) && o.imm != 0) {
-        batched_rots[o.src0].push_back(i);
-        continue;
-      }
-      if (batched && (o.op == 22 || (o.op == 20 && !feeds_only(o.dst, 22)) || (o.op == 13 && o.src0 != o.src1 && is_ct(o.src0) && is_ct(o.src1)))) {
-        if (o.op == 22 && st.relins.count(o.src0)) { // deferred relinearize + this rescale, on the batched handle
-          evah_ct *out = nullptr;
-          chk(evah_relinearize_rescale(c, st.relins[o.src0], (uint32_t)o.imm, &out));
-          evah_ct_free(c, st.relins[o.src0]);
-          st.relins.erase(o.src0);
-          put(o.dst, out);
-        } else {
-          single(o);
-        }
-        continue;
-      }
-      if (o.op == 20 && st.prods.count(o.src0)) { // Relinearize of a deferred product: still deferred
-        st.prodrel[o.dst] = st.prods[o.src0];
-        st.prods.erase(o.src0);
-      } else if (o.op == 22 && st.prodrel.count(o.src0)) {
-        fused3[{st.prodrel[o.src0].first->limbs, (uint32_t)o.imm}].push_back(i);
-      } else if ((o.op == 14 || o.op == 15) && o.imm != 0 && is_ct(o.src0)) {
-        shape(o.src0, size, limbs, scale);
-        rots[limbs].push_back(i);
-      } else if (o.op == 22 && st.relins.count(o.src0)) {
-        chk(evah_ct_info(st.relins[o.src0], &size, &limbs, &scale));
-        fused[{limbs, (uint32_t)o.imm}].push_back(i);
-      } else if (o.op == 22 && is_ct(o.src0)) {
-        shape(o.src0, size, limbs, scale);
-        rescales[{size, limbs, (uint32_t)o.imm}].push_back(i);
-      } else if (o.op == 20 && is_ct(o.src0)) {
-        if (feeds_only(o.dst, 22)) {
-          st.relins[o.dst] = alias_ct(ct_of(o.src0)); // evaluated together with its Rescale
-        } else {
-          shape(o.src0, size, limbs, scale);
-          relins[limbs].push_back(i);
-        }
-      } else if (o.op == 13 && o.src0 != o.src1 && is_ct(o.src0) && is_ct(o.src1)) {
-        // Mul read only by a Relinearize that is read only by a Rescale (the commonest CKKS
-        // pattern): nothing is computed here, the three run as one fused call at the Rescale
-        evah_ct *x = ct_of(o.src0), *y = ct_of(o.src1);
-        const bool chain = c->fuse_mac && c->fuse_mul && feeds_only(o.dst, 20) && feeds_only(ops[only_reader[o.dst]].dst, 22);
-        if (chain && x->size == 2 && y->size == 2 && x->limbs == y->limbs && x->limbs >= 2 && x->batch == 1 && y->batch == 1) {
-          check_scale(c, x->scale * y->scale, x->limbs);
-          st.prods[o.dst] = {alias_ct(x), alias_ct(y)};
-        } else {
-          shape(o.src0, size, limbs, scale);
-          muls[limbs].push_back(i);
-        }
-      } else if (o.op == 13 && feeds_only(o.dst, 11) &&
-                 ((is_plain_ct(o.src0) && slot(o.src1).kind == EVAH_VAL_PT) || (is_plain_ct(o.src1) && slot(o.src0).kind == EVAH_VAL_PT))) {
-        const uint32_t a = is_plain_ct(o.src0) ? o.src0 : o.src1, b = a == o.src0 ? o.src1 : o.src0;
-        evah_ct *x = static_cast<evah_ct *>(tab[a].h);
-        evah_pt *w = static_cast<evah_pt *>(tab[b].h);
-        if (w->limbs != x->limbs) { single(o); continue; } // multiply_plain reports the mismatch
-        LazySum ls;
-        ls.size = x->size; ls.limbs = x->limbs; ls.scale = x->scale * w->scale;
-        ls.cts.push_back(alias_ct(x));
-        ls.pts.push_back(alias_pt(w));
-        st.sums[o.dst] = std::move(ls);
-      } else if (o.op == 11 && is_ct(o.src0) && is_ct(o.src1) && !st.relins.count(o.src0) && !st.relins.count(o.src1) &&
-                 (st.sums.count(o.src0) || st.sums.count(o.src1) || feeds_only(o.dst, 11))) {
-        uint32_t s0, l0, s1, l1;
-        double c0, c1;
-        shape(o.src0, s0, l0, c0);
-        shape(o.src1, s1, l1, c1);
-        size_t nterms = 0;
-        for (uint32_t v : {o.src0, o.src1}) nterms += st.sums.count(v) ? st.sums[v].cts.size() : 1;
-        if (s0 != s1 || l0 != l1 || c0 != c1 || nterms > (size_t)KS_BATCH_MAX) { single(o); continue; }
-        LazySum ls;
-        ls.size = s0; ls.limbs = l0; ls.scale = c0;
-        for (uint32_t v : {o.src0, o.src1}) {
-          auto it = st.sums.find(v);
-          if (it != st.sums.end()) {
-            for (evah_ct *h : it->second.cts) ls.cts.push_back(alias_ct(h));
-            for (evah_pt *h : it->second.pts) ls.pts.push_back(h ? alias_pt(h) : nullptr);
-          } else {
-            ls.cts.push_back(alias_ct(static_cast<evah_ct *>(tab[v].h)));
-            ls.pts.push_back(nullptr);
-          }
-        }
-        st.sums[o.dst] = std::move(ls);
-        if (!(feeds_only(o.dst, 11) && nterms < (size_t)KS_BATCH_MAX)) (void)ct_of(o.dst); // the chain ends here
-      } else {
-        single(o);
-      }
-    }
-    // ---- the batchable kinds of this level
-    auto each_chunk = [&](std::vector<uint32_t> &g, size_t cap, auto &&fn) {
-      if (g.size() == 1) { single(ops[g[0]]); return; }
-      for (size_t i = 0; i < g.size(); i += cap) fn(g.data() + i, (uint32_t)std::min(cap, g.size() - i));
-    };
-    auto store = [&](const uint32_t *is, uint32_t n, std::vector<evah_ct *> &outs) {
-      for (uint32_t j = 0; j < n; j++) put(ops[is[j]].dst, outs[j]);
-    };
-    for (auto &kv : batched_rots)
-      each_chunk(kv.second, KS_BATCH_MAX, [&](const uint32_t *is, uint32_t n) {
-        std::vector<int32_t> steps(n);
-        std::vector<evah_ct *> outs(n, nullptr);
-        for (uint32_t j = 0; j < n; j++) steps[j] = ops[is[j]].op == 14 ? ops[is[j]].imm : -ops[is[j]].imm;
-        chk(evah_rotate_many(c, ct_of(kv.first), steps.data(), n, outs.data()));
-        store(is, n, outs);
-      });
-    for (auto &kv : rots)
-      each_chunk(kv.second, KS_BATCH_MAX, [&](const uint32_t *is, uint32_t n) {
-        std::vector<const evah_ct *> in(n);
-        std::vector<int32_t> steps(n);
-        std::vector<evah_ct *> outs(n, nullptr);
-        for (uint32_t j = 0; j < n; j++) {
-          in[j] = ct_of(ops[is[j]].src0);
-          steps[j] = ops[is[j]].op == 14 ? ops[is[j]].imm : -ops[is[j]].imm;
-        }
-        chk(evah_rotate_pairs(c, in.data(), steps.data(), n, outs.data()));
-        store(is, n, outs);
-      });
-    for (auto &kv : fused) {
-      auto fused_single = [&](uint32_t i) {
-        const evah_op &o = ops[i];
-        evah_ct *out = nullptr;
-        chk(evah_relinearize_rescale(c, st.relins[o.src0], (uint32_t)o.imm, &out));
-        evah_ct_free(c, st.relins[o.src0]);
-        st.relins.erase(o.src0);
-        put(o.dst, out);
-      };
-      if (kv.second.size() == 1) { fused_single(kv.second[0]); continue; }
-      for (size_t i0 = 0; i0 < kv.second.size(); i0 += KS_BATCH_MAX) {
-        const uint32_t n = (uint32_t)std::min<size_t>(KS_BATCH_MAX, kv.second.size() - i0);
-        const uint32_t *is = kv.second.data() + i0;
-        std::vector<const evah_ct *> in(n);
-        std::vector<evah_ct *> outs(n, nullptr);
-        for (uint32_t j = 0; j < n; j++) in[j] = st.relins[ops[is[j]].src0];
-        chk(evah_relinearize_rescale_many(c, in.data(), n, kv.first.second, outs.data()));
-        for (uint32_t j = 0; j < n; j++) {
-          evah_ct_free(c, st.relins[ops[is[j]].src0]);
-          st.relins.erase(ops[is[j]].src0);
-        }
-        store(is, n, outs);
-      }
-    }
-    for (auto &kv : fused3)
-      for (size_t i0 = 0; i0 < kv.second.size(); i0 += KS_BATCH_MAX) {
-        const uint32_t n = (uint32_t)std::min<size_t>(KS_BATCH_MAX, kv.second.size() - i0);
-        const uint32_t *is = kv.second.data() + i0;
-        std::vector<const evah_ct *> ia(n), ib(n);
-        std::vector<evah_ct *> outs(n, nullptr);
-        for (uint32_t j = 0; j < n; j++) {
-          ia[j] = st.prodrel[ops[is[j]].src0].first;
-          ib[j] = st.prodrel[ops[is[j]].src0].second;
-        }
-        chk(evah_multiply_relinearize_rescale_many(c, ia.data(), ib.data(), n, kv.first.second, outs.data()));
-        for (uint32_t j = 0; j < n; j++) {
-          evah_ct_free(c, const_cast<evah_ct *>(ia[j]));
-          evah_ct_free(c, const_cast<evah_ct *>(ib[j]));
-          st.prodrel.erase(ops[is[j]].src0);
-        }
-        store(is, n, outs);
-      }
-    for (auto &kv : rescales)
-      each_chunk(kv.second, (2 * KS_BATCH_MAX) / std::get<0>(kv.first), [&](const uint32_t *is, uint32_t n) {
-        std::vector<const evah_ct *> in(n);
-        std::vector<evah_ct *> outs(n, nullptr);
-        for (uint32_t j = 0; j < n; j++) in[j] = ct_of(ops[is[j]].src0);
-        chk(evah_rescale_many(c, in.data(), n, std::get<2>(kv.first), outs.data()));
-        store(is, n, outs);
-      });
-    for (auto &kv : relins)
-      each_chunk(kv.second, KS_BATCH_MAX, [&](const uint32_t *is, uint32_t n) {
-        std::vector<const evah_ct *> in(n);
-        std::vector<evah_ct *> outs(n, nullptr);
-        for (uint32_t j = 0; j < n; j++) in[j] = ct_of(ops[is[j]].src0);
-        chk(evah_relinearize_many(c, in.data(), n, outs.data()));
-        store(is, n, outs);
-      });
-    for (auto &kv : muls)
-      each_chunk(kv.second, KS_BATCH_MAX, [&](const uint32_t *is, uint32_t n) {
-        std::vector<const evah_ct *> ia(n), ib(n);
-        std::vector<evah_ct *> outs(n, nullptr);
-        for (uint32_t j = 0; j < n; j++) {
-          ia[j] = ct_of(ops[is[j]].src0);
-          ib[j] = ct_of(ops[is[j]].src1);
-        }
-        chk(evah_multiply_many(c, ia.data(), ib.data(), n, outs.data()));
-        store(is, n, outs);
-      });
-    // ---- operands whose last reader has run are released (deferred forms hold their own aliases)
-    for (uint32_t i : lvl) {
-      const evah_op &o = ops[i];
-      const uint32_t srcs[2] = {o.src0, o.src1};
-      for (int k = 0; k < arity(o.op); k++) {
-        const uint32_t v = srcs[k];
-        if (--reads[v] == 0 && freeable[v]) {
-          drop_sum(v);
-          auto lr = st.relins.find(v);
-          if (lr != st.relins.end()) { evah_ct_free(c, lr->second); st.relins.erase(lr); }
-          if (tab[v].kind != EVAH_VAL_NONE) release(v);
-        }
-      }
-    }
-  }
-  API_END
-}
-
-int evah_profile_enable(evah_ctx *c, int on) {
-  API_BEGIN
-  use(c);
-  c->prof_on = on != 0; // no host wait here: the records are resolved by evah_profile_get/_reset
-  API_END
-}
-int evah_profile_reset(evah_ctx *c) {
-  API_BEGIN
-  use(c);
-  prof_drain(c);
-  for (int i = 0; i < KC_COUNT; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
-  API_END
-}
-int evah_profile_classes(void) { return KC_COUNT; }
-const char *evah_profile_class_name(int cls) { return (cls >= 0 && cls < KC_COUNT) ? kclass_names[cls] : ""; }
-int evah_profile_get(evah_ctx *c, int cls, uint64_t *launches, double *total_ms) {
-  API_BEGIN
-  use(c);
-  if (cls < 0 || cls >= KC_COUNT) throw std::invalid_argument("kernel class out of range");
-  prof_drain(c);
-  *launches = c->prof_n[cls];
-  *total_ms = c->prof_ms[cls];
-  API_END
-}
-
-int evah_timer_start(evah_ctx *c) {
-  API_BEGIN
-  use(c);
-  HIPCHK(hipEventRecord(c->ev0, c->stream));
-  API_END
-}
-int evah_timer_stop(evah_ctx *c, float *ms) {
-  API_BEGIN
-  use(c);
-  HIPCHK(hipEventRecord(c->ev1, c->stream));
-  HIPCHK(hipEventSynchronize(c->ev1));
-  HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
   API_END
 }
 

@@ -1,0 +1,385 @@
+// internal.hip.h — state shared by the translation units of libeva_hip.so (not part of the ABI):
+// device pool, buffers with cross-queue ordering, handle and context structs, profiling scopes.
+//   runtime.hip    contexts, forks (issue queues), keys, pinned host memory, uploads / downloads,
+//                  graph capture, profiling hooks                       (no kernels)
+//   evaluator.hip  kernels + one C-ABI entry point per SEAL Evaluator call (elementwise, encoder,
+//                  key switching, rescale, rotations, the fused and batched forms)
+//   scheduler.hip  evah_execute: the whole-DAG submit (level scheduler, peepholes)   (no kernels)
+#pragma once
+#include "../../include/eva_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "devmath.hip.h"
+#include "hostmath.h"
+
+namespace evah {
+
+extern thread_local std::string g_err; // last error of the calling thread (runtime.hip)
+
+// Contexts that exist: a buffer remembers the foreign queues that read it, and such a queue may
+// have been destroyed (after a sync) before the buffer is released.  (runtime.hip)
+void ctx_register(const void *c);
+void ctx_unregister(const void *c);
+bool ctx_alive(const void *c);
+
+#define HIPCHK(x)                                                                                \
+  do {                                                                                           \
+    hipError_t e_ = (x);                                                                         \
+    if (e_ != hipSuccess)                                                                        \
+      throw std::runtime_error(std::string(#x) + " failed: " + hipGetErrorString(e_));          \
+  } while (0)
+
+#ifndef EVAH_KS_BATCH_MAX_DEFINED
+#define EVAH_KS_BATCH_MAX_DEFINED
+constexpr int KS_BATCH_MAX = 64; // instances per batched launch set / batched handle
+#endif
+
+
+struct Pool {
+  std::map<size_t, std::vector<void *>> free_;
+  size_t in_use = 0, cached = 0;
+  void *alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = free_.find(bytes);
+    void *p = nullptr;
+    if (it != free_.end() && !it->second.empty()) {
+      p = it->second.back();
+      it->second.pop_back();
+      cached -= bytes;
+    } else {
+      hipError_t e = hipMalloc(&p, bytes);
+      if (e != hipSuccess) {
+        release_cached();
+        HIPCHK(hipMalloc(&p, bytes));
+      }
+    }
+    in_use += bytes;
+    return p;
+  }
+  void free(void *p, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    free_[bytes].push_back(p);
+    in_use -= bytes;
+    cached += bytes;
+  }
+  void release_cached() {
+    for (auto &kv : free_)
+      for (void *p : kv.second) (void)hipFree(p);
+    free_.clear();
+    cached = 0;
+  }
+};
+
+struct Buffer {
+  u64 *d;
+  size_t bytes;
+  int refs;
+  Pool *pool;                       // owning queue's pool (handles may be freed through any fork)
+  evah_ctx *owner;                  // queue whose stream produced / will recycle this buffer
+  bool ready_everywhere;            // contents were synchronised with the host (uploads)
+  std::vector<evah_ctx *> synced;   // foreign queues that already wait for the producer
+  std::vector<evah_ctx *> readers;  // foreign queues that have enqueued reads
+};
+
+// Kernel classes for the optional per-launch HIP-event profile (bench.py's roofline leg).
+enum KClass {
+  KC_EW = 0,        // elementwise add/sub/negate/mul/square/mul_plain/perm/fill
+  KC_INTT_A,        // inverse pass 1 (contig)
+  KC_INTT_B,        // inverse pass 2 (strided)
+  KC_KSDIGIT_A,     // key-switch digit conversion, forward pass 1 (strided, fused base conversion)
+  KC_KSDIGIT_B,     // key-switch digit conversion, forward pass 2 (contig)
+  KC_KSMAC,         // key-switch inner product
+  KC_MODDOWN_A,     // rescale / mod-down forward pass 1 (fused reduce - half)
+  KC_MODDOWN_B,     // rescale / mod-down forward pass 2 (fused combine)
+  KC_NTT_A,         // plain forward pass 1
+  KC_NTT_B,         // plain forward pass 2
+  KC_COUNT
+};
+static const char *const kclass_names[KC_COUNT] = {
+    "elementwise", "intt_pass1", "intt_pass2", "ksdigit_pass1", "ksdigit_pass2", "ks_mac",
+    "moddown_pass1", "moddown_pass2", "ntt_pass1", "ntt_pass2"};
+
+struct ProfRec {
+  hipEvent_t e0, e1;
+  int cls;
+};
+
+struct KeyDev {
+  u64 *d = nullptr;
+  uint32_t n_digits = 0;
+  size_t bytes = 0;
+};
+
+} // namespace evah
+
+using namespace evah;
+
+struct evah_ct {
+  Buffer *buf;
+  u64 *d;
+  uint32_t size, limbs;
+  size_t ps; // poly stride in elements
+  double scale;
+  // `batch` independent ciphertexts of identical shape in one handle: instance b starts at
+  // d + b * size * ps, i.e. the handle is batch * size polynomials at a uniform stride.  Every
+  // evaluator entry point applies to all instances in one launch set (plaintext operands and keys
+  // are shared); this is how a batch of independent DAG instances is run (BASELINE config 4).
+  uint32_t batch = 1;
+};
+struct evah_pt {
+  Buffer *buf;
+  u64 *d;
+  uint32_t limbs;
+  double scale;
+};
+struct evah_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+// Device state shared by a context and its forks: tables, keys, permutation tables.
+struct SharedDev {
+  int device = 0;
+  void *d_tables = nullptr;
+  KeyDev relin;
+  std::map<uint32_t, KeyDev> galois;
+  std::map<uint32_t, uint32_t *> perms;
+  double2 *enc_roots = nullptr;     // CKKS encoder: inverse-FFT roots in the order the stages consume them
+  double enc_last_root[2] = {0, 0}; // the single root of the last stage (scaled by fix on the host per call)
+  uint32_t *enc_slot_map = nullptr; // slot i (and its conjugate, at slots + i) -> FFT input index
+  ~SharedDev() {
+    (void)hipSetDevice(device);
+    if (enc_roots) (void)hipFree(enc_roots);
+    if (enc_slot_map) (void)hipFree(enc_slot_map);
+    if (relin.d) (void)hipFree(relin.d);
+    for (auto &kv : galois) (void)hipFree(kv.second.d);
+    for (auto &kv : perms) (void)hipFree(kv.second);
+    if (d_tables) (void)hipFree(d_tables);
+  }
+};
+
+struct evah_ctx {
+  std::shared_ptr<SharedDev> sh;
+  int device = 0;
+  uint32_t N = 0, logN = 0, k = 0;
+  std::vector<u64> primes;
+  std::vector<int> total_bits; // total_bits[l] = bit length of prod primes[0..l)
+  DevCtx dev{};
+  hipStream_t own = nullptr, stream = nullptr;
+  Pool pool;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool capturing = false;              // inside evah_capture_begin/end: no syncs, no profiling events
+  std::vector<hipEvent_t> capture_events; // events consumed by the capture in progress
+  std::vector<hipEvent_t> sync_events; // recycled events for cross-queue ordering
+  bool fuse_mac = true; // key-switch: fuse the inner product into the digit NTTs' second pass
+  // evah_execute: run Mul -> Relinearize -> Rescale chains as one evah_multiply_relinearize_rescale_many
+  // (EVAH_FUSE_MUL=0/1; default: only where launches, not bytes, bound the chain — see DESIGN.md §4)
+  bool fuse_mul = false;
+  int ks_groups = 1;    // output-limb slices per key-switch (EVAH_KS_GROUPS)
+  int ks_threads = 64;  // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS): one wave = one
+                        // 2^P-point sub-transform per workgroup measured best (barriers are intra-wave)
+  // per-launch profile
+  bool prof_on = false;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> prof_free;
+  double prof_ms[KC_COUNT] = {0};
+  uint64_t prof_n[KC_COUNT] = {0};
+};
+
+namespace evah {
+
+inline void use(evah_ctx *c) { HIPCHK(hipSetDevice(c->device)); }
+
+inline hipEvent_t prof_event(evah_ctx *c) {
+  if (!c->prof_free.empty()) {
+    hipEvent_t e = c->prof_free.back();
+    c->prof_free.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIPCHK(hipEventCreate(&e));
+  return e;
+}
+inline void prof_drain(evah_ctx *c) {
+  for (auto &r : c->prof_recs) {
+    float ms = 0;
+    HIPCHK(hipEventSynchronize(r.e1));
+    HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
+    c->prof_ms[r.cls] += ms;
+    c->prof_n[r.cls]++;
+    c->prof_free.push_back(r.e0);
+    c->prof_free.push_back(r.e1);
+  }
+  c->prof_recs.clear();
+}
+struct ProfScope { // brackets one kernel launch with HIP events on the launch stream
+  evah_ctx *c;
+  int cls;
+  hipEvent_t e0 = nullptr;
+  ProfScope(evah_ctx *c_, int cls_) : c(c_), cls(cls_) {
+    if (c->prof_on && !c->capturing) {
+      if (c->prof_recs.size() >= 8192) prof_drain(c);
+      e0 = prof_event(c);
+      HIPCHK(hipEventRecord(e0, c->stream));
+    }
+  }
+  ~ProfScope() {
+    if (e0) {
+      hipEvent_t e1 = prof_event(c);
+      (void)hipEventRecord(e1, c->stream);
+      c->prof_recs.push_back({e0, e1, cls});
+    }
+  }
+};
+
+inline Buffer *buf_new(evah_ctx *c, size_t elems) {
+  Buffer *b = new Buffer;
+  b->bytes = elems * sizeof(u64);
+  b->d = (u64 *)c->pool.alloc(b->bytes);
+  b->refs = 1;
+  b->pool = &c->pool;
+  b->owner = c;
+  b->ready_everywhere = false;
+  return b;
+}
+inline hipEvent_t sync_event(evah_ctx *c) {
+  if (!c->capturing && !c->sync_events.empty()) {
+    hipEvent_t e = c->sync_events.back();
+    c->sync_events.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return e;
+}
+// make `waiter`'s stream wait for everything enqueued so far on `signaller`'s stream
+inline void stream_wait(evah_ctx *waiter, evah_ctx *signaller) {
+  if (waiter == signaller || waiter->stream == signaller->stream) return;
+  hipEvent_t e = sync_event(waiter);
+  HIPCHK(hipEventRecord(e, signaller->stream));
+  HIPCHK(hipStreamWaitEvent(waiter->stream, e, 0));
+  // eager mode: the wait captured this record, so the event can be re-recorded right away.
+  // While capturing, an event is used for exactly one record/wait pair of the graph (re-recording
+  // one inside a capture has produced cyclic graphs with the ROCm 7.2 runtime).
+  if (waiter->capturing || signaller->capturing) waiter->capture_events.push_back(e);
+  else waiter->sync_events.push_back(e);
+}
+// Called before queue `c` enqueues a read of `b`: orders the read after the producer and
+// remembers the reader so the buffer is not recycled under it.
+inline void acquire(evah_ctx *c, Buffer *b) {
+  if (!b || b->owner == c) return;
+  if (!b->ready_everywhere && std::find(b->synced.begin(), b->synced.end(), c) == b->synced.end()) {
+    stream_wait(c, b->owner);
+    b->synced.push_back(c);
+  }
+  if (std::find(b->readers.begin(), b->readers.end(), c) == b->readers.end()) b->readers.push_back(c);
+}
+inline void buf_unref(evah_ctx *c, Buffer *b) {
+  (void)c;
+  if (b && --b->refs == 0) {
+    if (!ctx_alive(b->owner)) {
+      // the queue that produced the buffer is gone (it was synchronised when destroyed, and its pool
+      // with it): nothing to order against and no pool to return to
+      (void)hipFree(b->d);
+      delete b;
+      return;
+    }
+    for (evah_ctx *r : b->readers)
+      if (ctx_alive(r)) stream_wait(b->owner, r); // recycle only after foreign reads (a destroyed queue was synchronised)
+    b->pool->free(b->d, b->bytes);
+    delete b;
+  }
+}
+inline evah_ct *ct_new(evah_ctx *c, uint32_t size, uint32_t limbs, double scale, uint32_t batch = 1) {
+  evah_ct *t = new evah_ct;
+  t->batch = batch;
+  t->buf = buf_new(c, (size_t)batch * size * limbs * c->N);
+  t->d = t->buf->d;
+  t->size = size;
+  t->limbs = limbs;
+  t->ps = (size_t)limbs * c->N;
+  t->scale = scale;
+  return t;
+}
+inline evah_pt *pt_new(evah_ctx *c, uint32_t limbs, double scale) {
+  evah_pt *t = new evah_pt;
+  t->buf = buf_new(c, (size_t)limbs * c->N);
+  t->d = t->buf->d;
+  t->limbs = limbs;
+  t->scale = scale;
+  return t;
+}
+
+struct Scratch { // pool-backed temporary, returned on scope exit (stream-ordered reuse)
+  evah_ctx *c;
+  u64 *d;
+  size_t bytes;
+  Scratch(evah_ctx *c_, size_t elems) : c(c_), bytes(elems * sizeof(u64)) {
+    d = (u64 *)c->pool.alloc(bytes);
+  }
+  ~Scratch() { c->pool.free(d, bytes); }
+};
+
+inline dim3 ew_grid(evah_ctx *c, uint32_t limbs, uint32_t polys) {
+  return dim3(c->N / 512, limbs, polys);
+}
+
+inline int bitlen_of_product(const std::vector<u64> &primes, uint32_t count) {
+  std::vector<u64> w{1};
+  for (uint32_t i = 0; i < count; i++) {
+    u64 carry = 0;
+    for (auto &x : w) {
+      u128 t = (u128)x * primes[i] + carry;
+      x = (u64)t;
+      carry = (u64)(t >> 64);
+    }
+    if (carry) w.push_back(carry);
+  }
+  int bits = (int)(w.size() - 1) * 64;
+  u64 top = w.back();
+  while (top) { bits++; top >>= 1; }
+  return bits;
+}
+
+inline void check_scale(evah_ctx *c, double scale, uint32_t limbs) {
+  // SEAL is_scale_within_bounds: 0 < scale, log2(scale) < total coeff modulus bits at the level
+  if (!(scale > 0) || (int)std::log2(scale) >= c->total_bits[limbs])
+    throw std::invalid_argument("scale out of bounds");
+}
+inline bool same_scale(double a, double b) {
+  // SEAL util::are_close<double>
+  double scale_factor = std::max({std::fabs(a), std::fabs(b), 1.0});
+  return std::fabs(a - b) < 2.220446049250313e-16 * scale_factor;
+}
+
+} // namespace evah
+
+#define EW_LAUNCH(...) do { ProfScope ps_(c, KC_EW); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+#define API_BEGIN try {
+#define API_END                                                                                  \
+  g_err.clear();                                                                                 \
+  return 0;                                                                                      \
+  }                                                                                              \
+  catch (const std::exception &e) {                                                              \
+    g_err = e.what();                                                                            \
+    return 1;                                                                                    \
+  }                                                                                              \
+  catch (...) {                                                                                  \
+    g_err = "unknown error";                                                                     \
+    return 1;                                                                                    \
+  }

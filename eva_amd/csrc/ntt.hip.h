@@ -1,4 +1,4 @@
-// ntt.cuh — two-pass negacyclic NTT / INTT over 64-bit RNS primes for gfx950.
+// ntt.hip.h — two-pass negacyclic NTT / INTT over 64-bit RNS primes for gfx950.
 //
 // Replaces SEAL's ntt_negacyclic_harvey / inverse_ntt_negacyclic_harvey as reached from
 // /root/reference/eva/seal/seal_executor.h:200 (relinearize), :181/:188 (rotate_vector) and
@@ -26,7 +26,7 @@
 // offset are fused into the transforms instead of being separate HBM round trips; the ops work
 // on lazy values where the moduli allow it (no Barrett reduction on the way in or out).
 #pragma once
-#include "devmath.cuh"
+#include "devmath.hip.h"
 #include <type_traits>
 
 namespace evah {
@@ -265,7 +265,11 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC_rt, int log_tiles) 
 // 128-bit register accumulators.  The l^2 N converted digits are therefore never written back:
 // HBM sees the pass-1 intermediates once, the key once and prod[2][l+1][N] once.
 // Keys of a batch of key-switches issued as one launch (sibling rotations of one ciphertext).
+// KS_BATCH_MAX (instances per batched launch): internal.hip.h / defined below when this header is used alone
+#ifndef EVAH_KS_BATCH_MAX_DEFINED
+#define EVAH_KS_BATCH_MAX_DEFINED
 constexpr int KS_BATCH_MAX = 64;
+#endif
 struct KsKeys {
   const u64 *key[KS_BATCH_MAX];
 };

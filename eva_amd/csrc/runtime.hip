@@ -1,0 +1,602 @@
+// runtime.hip — libeva_hip.so: contexts, issue queues, keys, value transfer, graph capture,
+// profiling hooks.  Replaces, for EVA's execute() hot path, the SEALContext / key objects and the
+// setInputs / getOutputs copies of SEALExecutor (/root/reference/eva/seal/seal.h:52-66,
+// seal_executor.h:264-277, 420-435) — see include/eva_hip.h for the per-entry-point mapping.
+// gfx950 only; no CPU fallback: every entry point needs a HIP device and fails otherwise.
+#include "internal.hip.h"
+
+namespace evah {
+
+thread_local std::string g_err;
+
+static std::mutex g_ctx_mu;
+static std::vector<const void *> g_live_ctx;
+void ctx_register(const void *c) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  g_live_ctx.push_back(c);
+}
+void ctx_unregister(const void *c) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), c), g_live_ctx.end());
+}
+bool ctx_alive(const void *c) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  return std::find(g_live_ctx.begin(), g_live_ctx.end(), c) != g_live_ctx.end();
+}
+
+} // namespace evah
+
+extern "C" {
+
+const char *evah_last_error(void) { return g_err.c_str(); }
+int evah_abi_version(void) { return 1; }
+
+int evah_device_count(int *count) {
+  API_BEGIN
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  API_END
+}
+
+int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, evah_ctx **out) {
+  API_BEGIN
+  if (N < 1024 || N > 131072 || (N & (N - 1))) throw std::invalid_argument("poly_modulus_degree must be a power of two in [1024, 131072]");
+  if (k < 2 || k > 62) throw std::invalid_argument("need at least one data prime and one special prime");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    throw std::runtime_error("libeva_hip: no HIP device available (this backend has no CPU fallback)");
+  if (device < 0 || device >= ndev) throw std::invalid_argument("invalid device index");
+  auto *c = new evah_ctx;
+  try {
+    c->device = device;
+    c->N = N;
+    c->logN = ilog2(N);
+    c->k = k;
+    c->primes.assign(primes, primes + k);
+    if (const char *e = std::getenv("EVAH_FUSE_MAC")) c->fuse_mac = std::atoi(e) != 0;
+    if (const char *e = std::getenv("EVAH_KS_GROUPS")) c->ks_groups = std::max(1, std::atoi(e));
+    c->fuse_mul = N <= 8192;
+    if (const char *e = std::getenv("EVAH_FUSE_MUL")) c->fuse_mul = std::atoi(e) != 0;
+    if (const char *e = std::getenv("EVAH_KS_THREADS")) {
+      int t = std::atoi(e);
+      if (t == 64 || t == 128 || t == 256) c->ks_threads = t;
+    }
+    for (u64 q : c->primes)
+      if (q >= ((u64)1 << 60) || (q - 1) % (2ull * N) || !is_prime(q)) // SEAL_USER_MOD_BIT_COUNT_MAX = 60
+        throw std::invalid_argument("coeff modulus primes must be at most 60 bits, prime and 1 mod 2N");
+    for (uint32_t l = 0; l <= k; l++) c->total_bits.push_back(l ? bitlen_of_product(c->primes, l) : 0);
+    use(c);
+    HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
+    c->stream = c->own;
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    // ---- tables: [primes k][tw_fwd k*N][tw_inv k*N][invq k*k][halfmod k*k]
+    const size_t sz_pr = sizeof(DevPrime) * k, sz_tw = sizeof(ulonglong2) * (size_t)k * N,
+                 sz_iq = sizeof(ulonglong2) * (size_t)k * k, sz_hm = sizeof(u64) * (size_t)k * k;
+    const size_t total = sz_pr + 2 * sz_tw + sz_iq + sz_hm;
+    std::vector<unsigned char> host(total);
+    auto *hp = reinterpret_cast<DevPrime *>(host.data());
+    auto *hf = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr);
+    auto *hi = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr + sz_tw);
+    auto *hq = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr + 2 * sz_tw);
+    auto *hh = reinterpret_cast<u64 *>(host.data() + sz_pr + 2 * sz_tw + sz_iq);
+    for (uint32_t i = 0; i < k; i++) {
+      const u64 q = c->primes[i];
+      const u64 psi = minimal_primitive_root(N, q), psi_inv = invmod(psi, q);
+      std::vector<u64> rp = root_power_table(N, q, psi), irp = root_power_table(N, q, psi_inv);
+      for (uint32_t j = 0; j < N; j++) {
+        hf[(size_t)i * N + j] = make_ulonglong2(rp[j], shoup(rp[j], q));
+        hi[(size_t)i * N + j] = make_ulonglong2(irp[j], shoup(irp[j], q));
+      }
+      DevPrime &d = hp[i];
+      d.q = q;
+      d.brt = (u64)((((u128)1) << 64) / q);
+      u128 ratio = (~(u128)0) / q;
+      d.r0 = (u64)ratio;
+      d.r1 = (u64)(ratio >> 64);
+      d.ninv = invmod(N % q, q);
+      d.ninv_s = shoup(d.ninv, q);
+      d.w0ninv = mulmod(irp[1], d.ninv, q);
+      d.w0ninv_s = shoup(d.w0ninv, q);
+      d.nq = 0ull - q;
+      d.q5 = 5 * q;
+      d.q4 = 4 * q;
+      d.q8 = 8 * q;
+      d.nq5 = 0ull - 5 * q;
+      d.nq8 = 0ull - 8 * q;
+      for (uint32_t a = 0; a < k; a++) {
+        const u64 qa = c->primes[a];
+        if (a == i) {
+          hq[a * k + i] = make_ulonglong2(0, 0);
+          hh[a * k + i] = 0;
+        } else {
+          u64 inv = invmod(qa % q, q);
+          hq[a * k + i] = make_ulonglong2(inv, shoup(inv, q));
+          hh[a * k + i] = (qa >> 1) % q;
+        }
+      }
+    }
+    c->sh = std::make_shared<SharedDev>();
+    c->sh->device = device;
+    HIPCHK(hipMalloc(&c->sh->d_tables, total));
+    HIPCHK(hipMemcpy(c->sh->d_tables, host.data(), total, hipMemcpyHostToDevice));
+    auto *base = reinterpret_cast<unsigned char *>(c->sh->d_tables);
+    c->dev.primes = reinterpret_cast<const DevPrime *>(base);
+    c->dev.tw_fwd = reinterpret_cast<const ulonglong2 *>(base + sz_pr);
+    c->dev.tw_inv = reinterpret_cast<const ulonglong2 *>(base + sz_pr + sz_tw);
+    c->dev.invq = reinterpret_cast<const ulonglong2 *>(base + sz_pr + 2 * sz_tw);
+    c->dev.halfmod = reinterpret_cast<const u64 *>(base + sz_pr + 2 * sz_tw + sz_iq);
+    c->dev.N = N;
+    c->dev.logN = c->logN;
+    c->dev.k = k;
+  } catch (...) {
+    evah_ctx_destroy(c);
+    throw;
+  }
+  ctx_register(c);
+  *out = c;
+  API_END
+}
+
+int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
+  API_BEGIN
+  use(parent);
+  auto *c = new evah_ctx;
+  try {
+    c->sh = parent->sh;
+    c->device = parent->device;
+    c->N = parent->N;
+    c->logN = parent->logN;
+    c->k = parent->k;
+    c->primes = parent->primes;
+    c->total_bits = parent->total_bits;
+    c->dev = parent->dev;
+    c->fuse_mac = parent->fuse_mac;
+    c->fuse_mul = parent->fuse_mul;
+    c->ks_threads = parent->ks_threads;
+    c->ks_groups = parent->ks_groups;
+    HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
+    c->stream = c->own;
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+  } catch (...) {
+    evah_ctx_destroy(c);
+    throw;
+  }
+  ctx_register(c);
+  *out = c;
+  API_END
+}
+
+void evah_ctx_destroy(evah_ctx *c) {
+  if (!c) return;
+  ctx_unregister(c);
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->pool.release_cached();
+  c->sh.reset(); // tables and keys go when the last fork goes
+  for (auto &r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto e : c->prof_free) (void)hipEventDestroy(e);
+  for (auto e : c->sync_events) (void)hipEventDestroy(e);
+  for (auto e : c->capture_events) (void)hipEventDestroy(e);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own) (void)hipStreamDestroy(c->own);
+  delete c;
+}
+
+int evah_ctx_set_stream(evah_ctx *c, void *s) {
+  API_BEGIN
+  use(c);
+  HIPCHK(hipStreamSynchronize(c->stream)); // pool reuse is ordered per stream
+  c->stream = s ? (hipStream_t)s : c->own;
+  API_END
+}
+
+int evah_ctx_sync(evah_ctx *c) {
+  API_BEGIN
+  use(c);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  API_END
+}
+
+int evah_ctx_mem_info(evah_ctx *c, size_t *in_use, size_t *cached) {
+  API_BEGIN
+  *in_use = c->pool.in_use;
+  *cached = c->pool.cached;
+  API_END
+}
+
+int evah_galois_elt_from_step(evah_ctx *c, int32_t steps, uint32_t *elt) {
+  API_BEGIN
+  const uint32_t N = c->N, m = 2 * N;
+  if (steps == 0) {
+    *elt = m - 1;
+  } else {
+    uint32_t pos = steps < 0 ? (uint32_t)(-(int64_t)steps) : (uint32_t)steps;
+    if (pos >= (N >> 1)) throw std::invalid_argument("step count too large");
+    uint32_t s = steps < 0 ? (N >> 1) - pos : pos, e = 1;
+    for (uint32_t i = 0; i < s; i++) e = (e * 3u) & (m - 1);
+    *elt = e;
+  }
+  API_END
+}
+
+int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digits, const uint64_t *data) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  if (n_digits == 0 || n_digits > c->k - 1) throw std::invalid_argument("invalid key digit count");
+  KeyDev kd;
+  kd.n_digits = n_digits;
+  kd.bytes = sizeof(u64) * (size_t)n_digits * 2 * c->k * c->N;
+  HIPCHK(hipMalloc(&kd.d, kd.bytes));
+  HIPCHK(hipMemcpy(kd.d, data, kd.bytes, hipMemcpyHostToDevice));
+  if (kind == EVAH_KEY_RELIN) {
+    if (c->sh->relin.d) (void)hipFree(c->sh->relin.d);
+    c->sh->relin = kd;
+  } else if (kind == EVAH_KEY_GALOIS) {
+    if (!(galois_elt & 1) || galois_elt >= 2 * c->N) {
+      (void)hipFree(kd.d);
+      throw std::invalid_argument("Galois element is not valid");
+    }
+    auto it = c->sh->galois.find(galois_elt);
+    if (it != c->sh->galois.end()) (void)hipFree(it->second.d);
+    c->sh->galois[galois_elt] = kd;
+  } else {
+    (void)hipFree(kd.d);
+    throw std::invalid_argument("unknown key kind");
+  }
+  API_END
+}
+
+// Pinned (page-locked) host memory for the values that cross the boundary: copies from it are
+// DMA transfers at PCIe rate instead of the runtime's staged pageable path (~10 GB/s on one
+// core).  Blocks are recycled by size — pinning is far too slow to do per value.
+namespace {
+std::mutex g_host_mu;
+std::unordered_multimap<size_t, void *> g_host_free; // size -> idle pinned block
+std::unordered_map<void *, size_t> g_host_live;       // block handed out -> size
+size_t g_host_cached = 0;
+} // namespace
+void *evah_host_alloc(size_t bytes) {
+  if (!bytes) return nullptr;
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  auto it = g_host_free.find(bytes);
+  void *p = nullptr;
+  if (it != g_host_free.end()) {
+    p = it->second;
+    g_host_free.erase(it);
+    g_host_cached -= bytes;
+  } else if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr; // no device / no memory: the caller falls back to ordinary memory
+  }
+  g_host_live.emplace(p, bytes);
+  return p;
+}
+void evah_host_free(void *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  auto it = g_host_live.find(p);
+  if (it == g_host_live.end()) return;
+  const size_t bytes = it->second;
+  g_host_live.erase(it);
+  if (g_host_cached + bytes > ((size_t)4 << 30)) { // keep at most 4 GiB idle
+    (void)hipHostFree(p);
+    return;
+  }
+  g_host_free.emplace(bytes, p);
+  g_host_cached += bytes;
+}
+
+// Host <-> device copies of the instances of a batched handle, back to back on the context's
+// stream.  (Measured on MI355X: splitting them over 4 host threads with a copy stream each is
+// slower — 5.1 k vs 6.9 k Sobel DAGs/s — the pageable staging path of the runtime serialises.)
+static void io_copy(evah_ctx *c, uint32_t n, const std::function<hipError_t(uint32_t, hipStream_t)> &copy_one) {
+  for (uint32_t b = 0; b < n; b++) HIPCHK(copy_one(b, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+}
+
+int evah_ct_upload(evah_ctx *c, uint32_t size, uint32_t limbs, double scale, const uint64_t *data, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
+  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
+  evah_ct *t = ct_new(c, size, limbs, scale);
+  HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)size * limbs * c->N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  t->buf->ready_everywhere = true;
+  *out = t;
+  API_END
+}
+
+// `batch` ciphertexts of one shape as ONE handle; data = [batch][size][limbs][N]
+int evah_ct_upload_batch(evah_ctx *c, uint32_t batch, uint32_t size, uint32_t limbs, double scale, const uint64_t *data,
+                         evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  if (batch < 1 || batch > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("batch must be 1..64");
+  if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
+  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
+  evah_ct *t = ct_new(c, size, limbs, scale, batch);
+  HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)batch * size * limbs * c->N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  t->buf->ready_everywhere = true;
+  *out = t;
+  API_END
+}
+
+// the same from `batch` separate host arrays (each [size][limbs][N]): no host-side concatenation
+int evah_ct_upload_instances(evah_ctx *c, uint32_t batch, uint32_t size, uint32_t limbs, double scale,
+                             const uint64_t *const *data, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  if (batch < 1 || batch > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("batch must be 1..64");
+  if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
+  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
+  evah_ct *t = ct_new(c, size, limbs, scale, batch);
+  const size_t each = (size_t)size * limbs * c->N;
+  try {
+    io_copy(c, batch, [&](uint32_t b, hipStream_t st) {
+      return hipMemcpyAsync(t->d + each * b, data[b], sizeof(u64) * each, hipMemcpyHostToDevice, st);
+    });
+  } catch (...) {
+    evah_ct_free(c, t);
+    throw;
+  }
+  *out = t;
+  API_END
+}
+
+// instance b of a batched handle -> out[b] ([size][limbs][N] each), all instances in one call
+int evah_ct_download_instances(evah_ctx *c, const evah_ct *ct, uint64_t *const *out) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  acquire(c, ct->buf);
+  const size_t row = sizeof(u64) * (size_t)ct->limbs * c->N;
+  const bool dense = ct->ps == (size_t)ct->limbs * c->N; // not a mod-switched view: one linear copy per instance
+  io_copy(c, ct->batch, [&](uint32_t b, hipStream_t st) {
+    const u64 *src = ct->d + (size_t)b * ct->size * ct->ps;
+    if (dense) return hipMemcpyAsync(out[b], src, row * ct->size, hipMemcpyDeviceToHost, st);
+    return hipMemcpy2DAsync(out[b], row, src, sizeof(u64) * ct->ps, row, ct->size, hipMemcpyDeviceToHost, st);
+  });
+  API_END
+}
+
+int evah_ct_batch(const evah_ct *ct, uint32_t *batch) {
+  API_BEGIN
+  *batch = ct->batch;
+  API_END
+}
+
+// n single ciphertexts of one shape and scale -> one batched handle (device copies)
+int evah_ct_stack(evah_ctx *c, const evah_ct *const *cts, uint32_t n, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("batch must be 1..64");
+  const evah_ct *f = cts[0];
+  for (uint32_t i = 0; i < n; i++) {
+    if (cts[i]->batch != 1) throw std::invalid_argument("stack takes single ciphertexts");
+    if (cts[i]->size != f->size || cts[i]->limbs != f->limbs) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    if (!same_scale(cts[i]->scale, f->scale)) throw std::invalid_argument("scale mismatch");
+    acquire(c, cts[i]->buf);
+  }
+  evah_ct *o = ct_new(c, f->size, f->limbs, f->scale, n);
+  const size_t row = sizeof(u64) * (size_t)f->limbs * c->N;
+  for (uint32_t i = 0; i < n; i++)
+    HIPCHK(hipMemcpy2DAsync(o->d + (size_t)i * o->size * o->ps, sizeof(u64) * o->ps, cts[i]->d, sizeof(u64) * cts[i]->ps, row,
+                            f->size, hipMemcpyDeviceToDevice, c->stream));
+  *out = o;
+  API_END
+}
+
+// instance b of a batched handle as a single-ciphertext view (shares the buffer)
+int evah_ct_unstack(evah_ctx *c, const evah_ct *ct, uint32_t b, evah_ct **out) {
+  API_BEGIN
+  (void)c;
+  if (b >= ct->batch) throw std::invalid_argument("instance index out of range");
+  evah_ct *o = new evah_ct(*ct);
+  o->d = ct->d + (size_t)b * ct->size * ct->ps;
+  o->batch = 1;
+  o->buf->refs++;
+  *out = o;
+  API_END
+}
+
+int evah_ct_write(evah_ctx *c, evah_ct *ct, const uint64_t *data) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("evah_ct_write cannot be captured into a graph");
+  if (ct->ps != (size_t)ct->limbs * c->N) throw std::invalid_argument("cannot write into a mod-switched view");
+  acquire(c, ct->buf);
+  HIPCHK(hipMemcpyAsync(ct->d, data, sizeof(u64) * (size_t)ct->batch * ct->size * ct->limbs * c->N, hipMemcpyHostToDevice,
+                        c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream)); // pageable source: the caller may reuse it after return
+  API_END
+}
+
+int evah_pt_write(evah_ctx *c, evah_pt *pt, const uint64_t *data) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("evah_pt_write cannot be captured into a graph");
+  acquire(c, pt->buf);
+  HIPCHK(hipMemcpyAsync(pt->d, data, sizeof(u64) * (size_t)pt->limbs * c->N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  API_END
+}
+
+int evah_capture_begin(evah_ctx *q0, evah_ctx **others, uint32_t n_others) {
+  API_BEGIN
+  use(q0);
+  HIPCHK(hipStreamSynchronize(q0->stream));
+  for (uint32_t i = 0; i < n_others; i++) HIPCHK(hipStreamSynchronize(others[i]->stream));
+  HIPCHK(hipStreamBeginCapture(q0->stream, hipStreamCaptureModeRelaxed));
+  q0->capturing = true;
+  for (uint32_t i = 0; i < n_others; i++) { // fork: every queue joins the capture
+    stream_wait(others[i], q0);
+    others[i]->capturing = true;
+  }
+  API_END
+}
+
+int evah_capture_end(evah_ctx *q0, evah_ctx **others, uint32_t n_others, evah_graph **out) {
+  API_BEGIN
+  use(q0);
+  for (uint32_t i = 0; i < n_others; i++) { // join
+    stream_wait(q0, others[i]);
+    others[i]->capturing = false;
+  }
+  q0->capturing = false;
+  auto *g = new evah_graph;
+  hipError_t e = hipStreamEndCapture(q0->stream, &g->graph);
+  if (e != hipSuccess) {
+    delete g;
+    throw std::runtime_error(std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
+  }
+  for (uint32_t i = 0; i <= n_others; i++) { // events of this capture may be recycled now
+    evah_ctx *q = i ? others[i - 1] : q0;
+    q->sync_events.insert(q->sync_events.end(), q->capture_events.begin(), q->capture_events.end());
+    q->capture_events.clear();
+  }
+  e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    throw std::runtime_error(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e));
+  }
+  *out = g;
+  API_END
+}
+
+int evah_graph_launch(evah_ctx *q0, evah_graph *g) {
+  API_BEGIN
+  use(q0);
+  HIPCHK(hipGraphLaunch(g->exec, q0->stream));
+  API_END
+}
+
+void evah_graph_free(evah_graph *g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+}
+
+int evah_ct_info(const evah_ct *ct, uint32_t *size, uint32_t *limbs, double *scale) {
+  API_BEGIN
+  if (size) *size = ct->size;
+  if (limbs) *limbs = ct->limbs;
+  if (scale) *scale = ct->scale;
+  API_END
+}
+
+int evah_ct_download(evah_ctx *c, const evah_ct *ct, uint64_t *out) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  acquire(c, ct->buf);
+  const size_t row = sizeof(u64) * (size_t)ct->limbs * c->N;
+  // a batched handle downloads as [batch][size][limbs][N]; a dense handle (not a mod-switched
+  // view) is one linear copy — 2-D copies into pageable memory are several times slower
+  if (ct->ps == (size_t)ct->limbs * c->N)
+    HIPCHK(hipMemcpyAsync(out, ct->d, row * ct->size * ct->batch, hipMemcpyDeviceToHost, c->stream));
+  else
+    HIPCHK(hipMemcpy2DAsync(out, row, ct->d, sizeof(u64) * ct->ps, row, (size_t)ct->size * ct->batch, hipMemcpyDeviceToHost,
+                            c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  API_END
+}
+
+void evah_ct_free(evah_ctx *c, evah_ct *ct) {
+  if (!ct) return;
+  buf_unref(c, ct->buf);
+  delete ct;
+}
+
+int evah_pt_upload(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *data, evah_pt **out) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
+  evah_pt *t = pt_new(c, limbs, scale);
+  HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)limbs * c->N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  t->buf->ready_everywhere = true;
+  *out = t;
+  API_END
+}
+
+int evah_pt_info(const evah_pt *pt, uint32_t *limbs, double *scale) {
+  API_BEGIN
+  if (limbs) *limbs = pt->limbs;
+  if (scale) *scale = pt->scale;
+  API_END
+}
+
+int evah_pt_download(evah_ctx *c, const evah_pt *pt, uint64_t *out) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  acquire(c, pt->buf);
+  HIPCHK(hipMemcpyAsync(out, pt->d, sizeof(u64) * (size_t)pt->limbs * c->N, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  API_END
+}
+
+void evah_pt_free(evah_ctx *c, evah_pt *pt) {
+  if (!pt) return;
+  buf_unref(c, pt->buf);
+  delete pt;
+}
+
+int evah_profile_enable(evah_ctx *c, int on) {
+  API_BEGIN
+  use(c);
+  c->prof_on = on != 0; // no host wait here: the records are resolved by evah_profile_get/_reset
+  API_END
+}
+int evah_profile_reset(evah_ctx *c) {
+  API_BEGIN
+  use(c);
+  prof_drain(c);
+  for (int i = 0; i < KC_COUNT; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+  API_END
+}
+int evah_profile_classes(void) { return KC_COUNT; }
+const char *evah_profile_class_name(int cls) { return (cls >= 0 && cls < KC_COUNT) ? kclass_names[cls] : ""; }
+int evah_profile_get(evah_ctx *c, int cls, uint64_t *launches, double *total_ms) {
+  API_BEGIN
+  use(c);
+  if (cls < 0 || cls >= KC_COUNT) throw std::invalid_argument("kernel class out of range");
+  prof_drain(c);
+  *launches = c->prof_n[cls];
+  *total_ms = c->prof_ms[cls];
+  API_END
+}
+
+int evah_timer_start(evah_ctx *c) {
+  API_BEGIN
+  use(c);
+  HIPCHK(hipEventRecord(c->ev0, c->stream));
+  API_END
+}
+int evah_timer_stop(evah_ctx *c, float *ms) {
+  API_BEGIN
+  use(c);
+  HIPCHK(hipEventRecord(c->ev1, c->stream));
+  HIPCHK(hipEventSynchronize(c->ev1));
+  HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  API_END
+}
+
+} // extern "C"
