@@ -21,7 +21,7 @@ class _Scope:
     @classmethod
     def program(cls):
         if cls.active is None:
-            raise RuntimeError("Input / Output / constants need an enclosing `with EvaProgram(...)` block")
+            raise RuntimeError("No Program in context (Input, Output and constants need an enclosing `with EvaProgram(...)` block)")
         return cls.active
 
 
