@@ -85,14 +85,28 @@ _SIGS = {
     "evah_profile_get": [_vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
     "evah_timer_start": [_vp],
     "evah_timer_stop": [_vp, C.POINTER(C.c_float)],
+    # limb-sharded execution
+    "evah_ctx_set_shard": [_vp, C.c_uint32, C.c_uint32],
+    "evah_ctx_shard_info": [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
+    "evah_buf_alloc": [_vp, C.c_size_t, _vpp],
+    "evah_buf_copy": [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t],
+    "evah_buf_download": [_vp, _vp, C.c_size_t, C.c_size_t, _u64p],
+    "evah_buf_upload": [_vp, _vp, C.c_size_t, C.c_size_t, _u64p],
+    "evah_shard_galois_perm": [_vp, _vp, C.c_uint32, _vpp],
+    "evah_shard_ks_digits": [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32],
+    "evah_shard_ks_products": [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_int, C.c_uint32, _vp, _vp],
+    "evah_shard_ks_finish": [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_double, _vpp],
+    "evah_shard_rescale_last": [_vp, _vp, C.c_uint32, _vp],
+    "evah_shard_rescale_finish": [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vpp],
 }
 _VOID = {
     "evah_ctx_destroy": [_vp],
     "evah_ct_free": [_vp, _vp],
     "evah_pt_free": [_vp, _vp],
     "evah_graph_free": [_vp],
+    "evah_buf_free": [_vp, _vp],
 }
-EXPORTED_SYMBOLS = sorted(list(_SIGS) + list(_VOID) + ["evah_host_alloc", "evah_host_free"] + [
+EXPORTED_SYMBOLS = sorted(list(_SIGS) + list(_VOID) + ["evah_host_alloc", "evah_host_free", "evah_buf_ptr", "evah_buf_words"] + [
     "evah_last_error", "evah_abi_version", "evah_profile_classes", "evah_profile_class_name"])
 
 
@@ -140,6 +154,10 @@ def load():
     lib.evah_profile_classes.argtypes = []
     lib.evah_profile_class_name.restype = C.c_char_p
     lib.evah_profile_class_name.argtypes = [C.c_int]
+    lib.evah_buf_ptr.restype = C.c_void_p
+    lib.evah_buf_ptr.argtypes = [_vp]
+    lib.evah_buf_words.restype = C.c_size_t
+    lib.evah_buf_words.argtypes = [_vp]
     _lib = lib
     return lib
 
@@ -250,6 +268,51 @@ class Plaintext:
             pass
 
 
+class DeviceBuffer:
+    """Device memory for the exchange steps of limb-sharded execution (evah_buf).  Exposes
+    __cuda_array_interface__, so torch.as_tensor(buf, device='cuda') views it without a copy (RCCL
+    collectives then run directly on it)."""
+
+    def __init__(self, ctx, words):
+        self.ctx, self.words = ctx, int(words)
+        h = C.c_void_p()
+        _chk(_lib.evah_buf_alloc(ctx.h, self.words, C.byref(h)))
+        self.h = h
+
+    @property
+    def ptr(self):
+        return _lib.evah_buf_ptr(self.h)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.words,), "typestr": "<i8", "data": (self.ptr, False), "version": 2}
+
+    def copy_from(self, src, dst_off, src_off, words):
+        """device (or peer) copy on this buffer's queue, ordered after the producer of src"""
+        _chk(_lib.evah_buf_copy(self.ctx.h, self.h, int(dst_off), src.h, int(src_off), int(words)))
+
+    def download(self, off=0, words=None):
+        words = self.words - off if words is None else words
+        out = np.empty(words, dtype=np.uint64)
+        _chk(_lib.evah_buf_download(self.ctx.h, self.h, int(off), int(words), _p(out)))
+        return out
+
+    def upload(self, data, off=0):
+        data = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1)
+        _chk(_lib.evah_buf_upload(self.ctx.h, self.h, int(off), data.size, _p(data)))
+
+    def free(self):
+        if self.h and self.ctx.h:
+            _lib.evah_buf_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Context:
     """evah_ctx: N, key-level prime chain (special prime last), tables and keys on one GPU."""
 
@@ -283,6 +346,37 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    # ---- limb-sharded execution (include/eva_hip.h): this context as shard `shard` of `n_shards`
+    def set_shard(self, shard, n_shards):
+        _chk(_lib.evah_ctx_set_shard(self.h, int(shard), int(n_shards)))
+
+    def buffer(self, words):
+        return DeviceBuffer(self, words)
+
+    def shard_galois_perm(self, a, elt):
+        return self._ct1(_lib.evah_shard_galois_perm, a, C.c_uint32(int(elt)))
+
+    def shard_ks_digits(self, a, poly, l, digits, rows):
+        _chk(_lib.evah_shard_ks_digits(self.h, a.h, int(poly), int(l), digits.h, int(rows)))
+
+    def shard_ks_products(self, a, poly, l, digits, rows, key_kind, elt, prod, r):
+        _chk(_lib.evah_shard_ks_products(self.h, a.h if a is not None else None, int(poly), int(l), digits.h, int(rows),
+                                         int(key_kind), int(elt), prod.h, r.h))
+
+    def shard_ks_finish(self, l, prod, r, add, add_polys, scale):
+        h = C.c_void_p()
+        _chk(_lib.evah_shard_ks_finish(self.h, int(l), prod.h, r.h, add.h if add is not None else None, int(add_polys),
+                                       float(scale), C.byref(h)))
+        return Ciphertext(self, h)
+
+    def shard_rescale_last(self, a, l, r):
+        _chk(_lib.evah_shard_rescale_last(self.h, a.h, int(l), r.h))
+
+    def shard_rescale_finish(self, a, l, r, divisor_bits):
+        h = C.c_void_p()
+        _chk(_lib.evah_shard_rescale_finish(self.h, a.h, int(l), r.h, int(divisor_bits), C.byref(h)))
+        return Ciphertext(self, h)
 
     # ---- plumbing
     def set_stream(self, stream_ptr):

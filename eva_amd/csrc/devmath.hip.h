@@ -38,6 +38,12 @@ struct DevCtx {
   const ulonglong2 *invq;      // [k][k]  invq[a*k+b] = (q_a^-1 mod q_b, Shoup quotient)
   const u64 *halfmod;          // [k][k]  (q_a >> 1) mod q_b
   uint32_t N, logN, k;
+  // Limb -> prime map of the context's values: limb j of a ciphertext / plaintext is modulo
+  // primes[p0 + j * pstep].  An ordinary context has (0, 1).  A limb-sharded context (shard s of G,
+  // "limb i of every poly lives on GPU i mod G") has (s, G): its values hold
+  // only the limbs i = s, s + G, ... and every per-limb kernel works on them unchanged.
+  uint32_t p0, pstep;
+  __host__ __device__ uint32_t prime_of(uint32_t limb) const { return p0 + limb * pstep; }
 };
 
 __device__ __forceinline__ u128_t mul128(u64 a, u64 b) {

@@ -13,7 +13,7 @@ namespace evah {
 #define EW_SETUP                                                                                 \
   const uint32_t p = blockIdx.z, i = blockIdx.y;                                                 \
   const size_t off = (size_t)i * cx.N + 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);    \
-  const DevPrime pm = cx.primes[i];                                                              \
+  const DevPrime pm = cx.primes[cx.prime_of(i)];                                                 \
   (void)p;
 
 __device__ __forceinline__ ulonglong2 ld2(const u64 *p) { return *reinterpret_cast<const ulonglong2 *>(p); }
@@ -243,7 +243,7 @@ k_enc_round(DevCtx cx, const double2 *c, uint32_t limbs, u64 *out) {
   const bool neg = signbit(x);
   const u64 mant = (u64)fabs(x); // |x| < 2^63 is guaranteed by the caller's bound
   for (uint32_t i = 0; i < limbs; i++) {
-    const DevPrime pm = cx.primes[i];
+    const DevPrime pm = cx.primes[cx.prime_of(i)];
     const u64 r = barrett64(mant, pm.q, pm.brt);
     out[(size_t)i * cx.N + j] = (neg && r) ? pm.q - r : r;
   }
@@ -370,6 +370,7 @@ struct KsBatch { // one launch worth of key-switches: regular strides, irregular
   KsKeys keys{};
   PtrTab targets{}; // used when the targets are separate allocations (target == nullptr)
   const MulTab *mul = nullptr; // fused multiply: the target of instance b is d2 = a1 b1 of product b
+  uint32_t istep = 1, nout = 0; // output limbs I = i0 + y * istep; nout = rows per polynomial of prod (0: l + 1)
 };
 template <int P, int LR>
 static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scratch, const KsBatch &kb, u64 *prod, uint32_t l) {
@@ -387,7 +388,8 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   static const MulTab no_mul{};
   auto go = [&](auto kernel, const MulTab &mt) {
     hipLaunchKernelGGL(kernel, dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev, target, kb.target_bs, scratch,
-                       kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n, kb.targets, mt);
+                       kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n, kb.targets, mt, kb.istep,
+                       kb.nout ? kb.nout : l + 1);
   };
   if ((tile >> LR) <= 64) {
     if (kb.mul) go(ks_inner_kernel<P, LR, 64, true>, *kb.mul);
@@ -1341,3 +1343,5 @@ int evah_test_ntt(evah_ctx *c, uint32_t prime_idx, int inverse, uint64_t *host) 
 }
 
 } // extern "C"
+
+#include "shard.hip.h"

@@ -311,7 +311,7 @@ template <int P, int LR, int MAXT, bool MUL>
 __global__ void __launch_bounds__(MAXT)
 ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
                 size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, uint32_t i0,
-                int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets, MulTab mul) {
+                int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets, MulTab mul, uint32_t istep, uint32_t nout) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   // grid.x carries (tile, instance): instances of one tile are placed 8 block ids apart, i.e. on
   // the same XCD (blocks are dealt round-robin over the 8 XCDs) and close in dispatch order, so
@@ -332,7 +332,10 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   u64 *__restrict__ prod = prod_b + inst * prod_bs;
   constexpr int NTT_R = 1 << LR, NPAIR = NTT_R / 2;
   constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
-  const uint32_t I = i0 + blockIdx.y;
+  // output limb of this workgroup: I = i0 + blockIdx.y * istep.  istep == 1: the rows of scratch /
+  // prod / target are indexed by I itself (nout = l + 1); istep == G (a shard's limbs): by blockIdx.y
+  const uint32_t I = i0 + blockIdx.y * istep;
+  const uint32_t Irow = istep > 1 ? blockIdx.y : I;
   const uint32_t kap = (I == l) ? cx.k - 1 : I;
   const DevPrime pm = cx.primes[kap];
   const ulonglong2 *tw = cx.tw_fwd + (size_t)kap * cx.N;
@@ -372,7 +375,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
         d[it].y = product_poly(msrc, 2, off + 1, pm);
       }
     } else {
-      const u64 *src = (I == J ? target + (size_t)J * N : scratch + ((size_t)I * l + J) * N) + gbase;
+      const u64 *src = (I == J ? target + (size_t)Irow * N : scratch + ((size_t)Irow * l + J) * N) + gbase;
 #pragma unroll
       for (int it = 0; it < NPAIR; it++) d[it] = *reinterpret_cast<const ulonglong2 *>(src + 2 * (threadIdx.x + it * T));
     }
@@ -436,7 +439,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
       }
     }
   }
-  u64 *p0 = prod + (size_t)I * N + gbase, *p1 = prod + ((size_t)(l + 1) + I) * N + gbase;
+  u64 *p0 = prod + (size_t)Irow * N + gbase, *p1 = prod + ((size_t)nout + Irow) * N + gbase;
 #pragma unroll
   for (int it = 0; it < NPAIR; it++) {
     const int idx = 2 * (threadIdx.x + it * T);
@@ -463,6 +466,7 @@ struct OpPlain {
     uint32_t jl, prime0;
     int addhalf;
     PtrTab src_tab; // used when src == nullptr: polynomial pp starts at src_tab.p[pp]
+    uint32_t pstep = 1; // limb i is modulo primes[prime0 + i * pstep] (limb-sharded values: the shard count)
   };
   struct Job {
     uint32_t prime;
@@ -475,7 +479,7 @@ struct OpPlain {
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i,
                                                uint32_t pp, Job &j) {
-    j.prime = p.prime0 + i;
+    j.prime = p.prime0 + i * p.pstep;
     j.src = (p.src ? p.src + pp * p.src_ps : p.src_tab.p[pp]) + (size_t)i * cx.N;
     j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
     j.addhalf = p.addhalf;
@@ -516,7 +520,7 @@ struct OpMulIntt {
   };
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i, uint32_t b, Job &j) {
-    j.prime = i;
+    j.prime = cx.prime_of(i);
     j.off = (size_t)i * cx.N;
     j.mul = mul_src(p.mul, cx.N, b);
     j.dst = p.dst + b * p.dst_ps + (size_t)i * cx.N;
@@ -541,7 +545,10 @@ struct OpKsDigit {
     u64 *scratch;   // [batch][l+1][l][N]
     uint32_t l;
     size_t t_bs, scratch_bs; // batch strides
-    uint32_t i0, ni;         // output-limb slice [i0, i0+ni) handled by this launch
+    uint32_t i0, ni;         // output limbs handled by this launch: I = i0 + iy * istep, iy < ni (I == l: special prime)
+    uint32_t istep = 1;      // 1: a slice of all limbs; G: the limbs a shard of G owns (scratch rows are then local: iy)
+    uint32_t t_split = 1, t_rows = 0; // digit J sits at row (J % t_split) * t_rows + J / t_split of t (an all-gathered
+                                      // buffer is shard-major); t_split == 1: row J
   };
   struct Job {
     uint32_t prime;
@@ -553,13 +560,15 @@ struct OpKsDigit {
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(p.l, p.ni, jobs / (p.ni * p.l)); }
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t J, uint32_t iy,
                                                uint32_t b, Job &j) {
-    const uint32_t I = p.i0 + iy;
+    const uint32_t I = p.i0 + iy * p.istep;
     if (I == J) return false;
     j.prime = (I == p.l) ? cx.k - 1 : I;
     // t_J < q_J: when q_J <= 8 q_kappa the digit is already a valid lazy input (< 12 q_kappa)
     j.lazy = cx.primes[J].q <= cx.primes[j.prime].q8;
-    j.src = p.t + b * p.t_bs + (size_t)J * cx.N;
-    j.dst = p.scratch + b * p.scratch_bs + ((size_t)I * p.l + J) * cx.N;
+    const uint32_t row = p.t_split > 1 ? (J % p.t_split) * p.t_rows + J / p.t_split : J;
+    j.src = p.t + b * p.t_bs + (size_t)row * cx.N;
+    const uint32_t Irow = p.istep > 1 ? iy : I;
+    j.dst = p.scratch + b * p.scratch_bs + ((size_t)Irow * p.l + J) * cx.N;
     return true;
   }
   template <bool LZ>
@@ -605,7 +614,7 @@ struct OpModDown {
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i,
                                                uint32_t pp, Job &j) {
-    j.prime = i;
+    j.prime = cx.prime_of(i); // limb i of the values (c, add, dst) — the prime itself on an ordinary context
     j.src = p.r + pp * p.r_ps;
     j.c = (p.c ? p.c + pp * p.c_ps : p.c_tab.p[pp]) + (size_t)i * cx.N;
     if (p.use_add_tab) {
@@ -616,9 +625,9 @@ struct OpModDown {
       j.add = use_add ? p.add + add_off + (size_t)i * cx.N : nullptr;
     }
     j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
-    j.halfm = cx.halfmod[p.a * cx.k + i];
-    j.inv = cx.invq[p.a * cx.k + i];
-    j.lazy = cx.primes[p.a].q <= cx.primes[i].q8; // r < q_a: r + (q_i - halfm) < 9 q_i
+    j.halfm = cx.halfmod[p.a * cx.k + j.prime];
+    j.inv = cx.invq[p.a * cx.k + j.prime];
+    j.lazy = cx.primes[p.a].q <= cx.primes[j.prime].q8; // r < q_a: r + (q_i - halfm) < 9 q_i
     return true;
   }
   template <bool LZ>

@@ -134,6 +134,8 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     c->dev.N = N;
     c->dev.logN = c->logN;
     c->dev.k = k;
+    c->dev.p0 = 0;
+    c->dev.pstep = 1;
   } catch (...) {
     evah_ctx_destroy(c);
     throw;

@@ -23,8 +23,12 @@ class Dist:
             backend = "nccl" if self.on_gpu else "gloo"
         self.backend = backend
         self.owns_group = False
+        # one GPU per rank under RCCL; under gloo several ranks may share a device (tests on a 1-GPU box)
+        self.device_index = self.local_rank
+        if self.on_gpu and backend != "nccl":
+            self.device_index = self.local_rank % max(torch.cuda.device_count(), 1)
         if self.on_gpu:
-            torch.cuda.set_device(self.local_rank)
+            torch.cuda.set_device(self.device_index)
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")

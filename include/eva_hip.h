@@ -221,6 +221,46 @@ typedef struct evah_val { uint32_t kind; void *h; } evah_val;
 typedef struct evah_op { uint32_t op, dst, src0, src1; int32_t imm; uint32_t flags; } evah_op;
 int evah_execute(evah_ctx *ctx, const evah_op *ops, uint32_t n_ops, evah_val *table, uint32_t n_vals);
 
+/* ---- limb-sharded execution (BASELINE config 5) --------------------------
+ * The RNS limbs of every value are dealt over G shards — limb i on shard i mod G — one shard per
+ * GPU (one process per GPU, RCCL between them) or several shards in one process.  A shard is an
+ * evah_ctx with a limb -> prime map: after evah_ctx_set_shard(ctx, s, G) the context's values hold
+ * only the limbs s, s+G, ... (`limbs` of a handle is then the LOCAL count) and every per-limb entry
+ * point above works on them unchanged; evah_mod_switch is called on the owner of the dropped limb
+ * only.  The reference has no counterpart (its parallelism is node-level,
+ * multicore_program_traversal.h:55-78): these entry points split the SEAL calls that mix limbs —
+ * switch_key_inplace behind relinearize / rotate_vector (seal_executor.h:200, :181/:188) and
+ * rescale_to_next (:213) — into phases with ONE exchange step between phases, done by the caller:
+ *   key switch   ks_digits -> all-gather of the coefficient-form digits -> ks_products ->
+ *                broadcast of r from the owner of the special limb (shard l mod G) -> ks_finish
+ *   rescale      rescale_last on the owner of limb l-1 -> broadcast of r -> rescale_finish
+ * `l` is the GLOBAL limb count of the level.  evah_buf is device memory for the exchange steps;
+ * evah_buf_ptr exposes the device address (for torch / RCCL), evah_buf_copy is the in-process exchange. */
+typedef struct evah_buf evah_buf;
+int evah_ctx_set_shard(evah_ctx *ctx, uint32_t shard, uint32_t n_shards);
+int evah_ctx_shard_info(evah_ctx *ctx, uint32_t *shard, uint32_t *n_shards);
+int evah_buf_alloc(evah_ctx *ctx, size_t words, evah_buf **out);
+void evah_buf_free(evah_ctx *ctx, evah_buf *buf);
+void *evah_buf_ptr(evah_buf *buf);
+size_t evah_buf_words(const evah_buf *buf);
+int evah_buf_copy(evah_ctx *dst_ctx, evah_buf *dst, size_t dst_off, const evah_buf *src, size_t src_off, size_t words);
+int evah_buf_download(evah_ctx *ctx, const evah_buf *buf, size_t off, size_t words, uint64_t *host);
+int evah_buf_upload(evah_ctx *ctx, evah_buf *buf, size_t off, size_t words, const uint64_t *host);
+/* (perm(c0), perm(c1)) on the local limbs: the NTT-domain Galois automorphism of rotate_vector */
+int evah_shard_galois_perm(evah_ctx *ctx, const evah_ct *a, uint32_t galois_elt, evah_ct **out);
+/* digits: [G][rows][N] words, rows >= ceil(l / G); row [s][j] = INTT of local limb j of polynomial `poly` */
+int evah_shard_ks_digits(evah_ctx *ctx, const evah_ct *a, uint32_t poly, uint32_t l, evah_buf *digits, uint32_t rows);
+/* prod: [2][ni][N] with ni = local data limbs (+1 on the owner of the special limb); r: [2][N] */
+int evah_shard_ks_products(evah_ctx *ctx, const evah_ct *a, uint32_t poly, uint32_t l, const evah_buf *digits, uint32_t rows,
+                           int key_kind, uint32_t galois_elt, evah_buf *prod, evah_buf *r);
+/* out = (add's first add_polys polynomials, or nothing) + mod-down of prod, size 2, at `scale` */
+int evah_shard_ks_finish(evah_ctx *ctx, uint32_t l, const evah_buf *prod, const evah_buf *r, const evah_ct *add,
+                         uint32_t add_polys, double scale, evah_ct **out);
+/* r: [size][N] */
+int evah_shard_rescale_last(evah_ctx *ctx, const evah_ct *a, uint32_t l, evah_buf *r);
+int evah_shard_rescale_finish(evah_ctx *ctx, const evah_ct *a, uint32_t l, const evah_buf *r, uint32_t divisor_bits,
+                              evah_ct **out);
+
 /* ---- whole-DAG capture ------------------------------------------------------------------------
  * Replaces the per-call DAG walk of SEALPublic::execute (seal.cpp:104-122) for repeated
  * executions of one compiled program: every evaluator call issued on `q0` and `others` (forks of

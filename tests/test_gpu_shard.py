@@ -1,0 +1,134 @@
+"""Limb-sharded execution on the MI355X backend (eva_amd/shard.py over the evah_shard_* entry
+points; SURVEY.md 8(e) row 3, BASELINE config 5).  On the single GPU of the test box the G shards
+are G contexts (own queues, shared tables and keys) and the exchange steps are device copies; the
+assembled ciphertexts must equal the UNSHARDED oracle's bit for bit for G = 2, 3, 4, 8, at every
+level of the chain, and for the config-5 DAG at its stated size.  The two-rank test runs one shard
+per process with the exchange steps through torch.distributed (gloo, staged through host memory:
+two processes cannot share one GPU under RCCL)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from eva_amd.shard import ShardedEvaluator, execute_sharded
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rand(rng, primes, N, prefix, nl):
+    return np.stack([rng.integers(0, primes[i], size=prefix + (N,), dtype=np.uint64) for i in range(nl)], axis=len(prefix))
+
+
+@pytest.mark.parametrize("cfg", [(4096, [60, 30, 60, 60, 60], 2), (4096, [60, 30, 60, 60, 60], 3), (8192, [60, 40, 60, 60, 60, 60, 60], 4),
+                                 (16384, [60] * 6, 8), (65536, [60] * 11, 8), (1024, [30, 30, 30, 31], 2)],
+                         ids=lambda c: f"N{c[0]}_k{len(c[1])}_G{c[2]}")
+def test_sharded_ops_bit_exact(cfg):
+    N, bits, G = cfg
+    primes = po.coeff_modulus_create(N, bits)
+    k, l = len(primes), len(primes) - 1
+    o = po.Oracle(N, primes)
+    ev = ShardedEvaluator.in_process(N, primes, G)
+    rng = np.random.default_rng(N + G)
+    relin = _rand(rng, primes, N, (l, 2), k)
+    ev.upload_relin_key(relin)
+    a2, b2, pt = _rand(rng, primes, N, (2,), l), _rand(rng, primes, N, (2,), l), _rand(rng, primes, N, (), l)
+    A, B, P = ev.upload_ct(a2, 2.0 ** 20), ev.upload_ct(b2, 2.0 ** 20), ev.upload_pt(pt, 2.0 ** 20)
+    assert np.array_equal(ev.download(A), a2)
+    assert np.array_equal(ev.download(ev.add(A, B)), o.add(a2, b2))
+    assert np.array_equal(ev.download(ev.sub_plain(A, P)), o.sub_plain(a2, pt))
+    assert np.array_equal(ev.download(ev.multiply_plain(A, P)), o.multiply_plain(a2, pt))
+    M, m = ev.multiply(A, B), o.multiply(a2, b2)
+    assert np.array_equal(ev.download(M), m)
+    assert np.array_equal(ev.download(ev.square(A)), o.square(a2))
+    R, r = ev.relinearize(M), o.relinearize(m, relin)
+    assert np.array_equal(ev.download(R), r), "sharded relinearize differs from the oracle"
+    S, s = ev.rescale(R, 30), o.rescale(r)
+    assert S.limbs == l - 1 and np.array_equal(ev.download(S), s), "sharded rescale differs from the oracle"
+    assert np.array_equal(ev.download(ev.rescale(M, 30)), o.rescale(m))
+    for steps in (1, -3, N // 2 - 1):
+        elt = ev.galois_elt_from_step(steps)
+        gk = _rand(rng, primes, N, (l, 2), k)
+        ev.upload_galois_key(elt, gk)
+        assert np.array_equal(ev.download(ev.rotate(A, steps)), o.rotate(a2, steps, gk)), f"sharded rotate({steps}) differs"
+        if l > 2:
+            down = ev.mod_switch(A)
+            assert np.array_equal(ev.download(ev.rotate(down, steps)), o.rotate(o.mod_switch(a2), steps, gk))
+    cur, ref = S, s   # down the chain: special-limb owner moves, shards run out of limbs
+    while cur.limbs >= 2:
+        nxt = ev.relinearize(ev.multiply(cur, cur)) if cur.limbs <= 6 else None
+        if nxt is not None:
+            assert np.array_equal(ev.download(nxt), o.relinearize(o.multiply(ref, ref), relin))
+        cur, ref = ev.rescale(cur, 30), o.rescale(ref)
+        assert np.array_equal(ev.download(cur), ref)
+    ev.close()
+
+
+def test_config5_dag_limb_sharded_over_8_bit_exact():
+    """BASELINE config 5: conv + depth-8 squaring chain, N = 2^16, 13 primes, limbs over 8 shards"""
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    from oracle_executor import c_walk
+    from test_gpu_configs import conv_depth8, pad_chain
+    from test_gpu_e2e import _image
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(conv_depth8())
+    pad_chain(params, 13, 65536)
+    pub, sec = generate_keys(params, 21)
+    enc = pub.encrypt(_image(4096), sig)
+    N, primes = pub.poly_modulus_degree, list(pub.primes)
+    ev = ShardedEvaluator.in_process(N, primes, 8)
+    ev.upload_relin_key(pub.relin_key())
+    for elt, key in pub.galois_keys().items():
+        ev.upload_galois_key(elt, key)
+    outs = execute_sharded(ev, compiled, enc, pub._encode)
+    ref, _ = c_walk(pub, compiled, enc, threads=8)
+    for name, v in outs.items():
+        assert np.array_equal(ev.download(v), ref[name]), f"output {name}: limb-sharded execution differs from the oracle walk"
+    ev.close()
+
+
+WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    from eva_amd.dist import Dist
+    from eva_amd.shard import ShardedEvaluator
+    from oracle import pyoracle as po
+    d = Dist(backend="gloo")
+    N, bits = 8192, [60, 40, 60, 60, 60]
+    primes = po.coeff_modulus_create(N, bits)
+    k, l = len(primes), len(primes) - 1
+    ev = ShardedEvaluator.distributed(N, primes, d)
+    rng = np.random.default_rng(7)
+    rand = lambda prefix, nl: np.stack([rng.integers(0, primes[i], size=prefix + (N,), dtype=np.uint64) for i in range(nl)], axis=len(prefix))
+    relin, gk = rand((l, 2), k), rand((l, 2), k)
+    a2, b2 = rand((2,), l), rand((2,), l)
+    ev.upload_relin_key(relin)
+    ev.upload_galois_key(ev.galois_elt_from_step(-7), gk)
+    A, B = ev.upload_ct(a2, 2.0 ** 20), ev.upload_ct(b2, 2.0 ** 20)
+    out = ev.rotate(ev.rescale(ev.relinearize(ev.multiply(A, B)), 30), -7)
+    got = ev.gather(out, d)
+    o = po.Oracle(N, primes)
+    want = o.rotate(o.rescale(o.relinearize(o.multiply(a2, b2), relin)), -7, gk)
+    if d.rank == 0:
+        print("RESULT " + json.dumps({"equal": bool(np.array_equal(got, want)), "world": d.world}))
+    ev.close()
+    d.close()
+""") % (ROOT,)
+
+
+def test_two_ranks_one_shard_each_on_the_gpu(tmp_path):
+    script = tmp_path / "gpu_shard_worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29643", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][len("RESULT "):])
+    assert r == {"equal": True, "world": 2}
