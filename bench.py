@@ -170,6 +170,87 @@ def dag_leg(reps, cpu_threads):
             "bit_exact_vs_oracle": bool(ok)}
 
 
+def limb_sharded(args, dist):
+    """--shard limb: every op-triple is computed by ALL GPUs together, the RNS limbs dealt over them
+    (limb i on shard i mod G; SURVEY.md 8(e) row 3, BASELINE config 5's mode): per key switch one
+    all-gather of the coefficient-form digits and one broadcast, per rescale one broadcast.  Under
+    torchrun every rank is one shard and the exchange steps are RCCL collectives on the library's
+    device buffers; with one process (--gpus 1) --shards G runs G shards on the one GPU with device
+    copies as the exchange (what a 1-GPU box can measure: the cost of the phase structure, not xGMI)."""
+    import numpy as np
+    from eva_amd.hostref import coeff_modulus_create
+    from eva_amd.shard import ShardedEvaluator
+    N, l = 1 << args.logn, args.limbs
+    k = l + 1
+    primes = coeff_modulus_create(N, [60] * k)
+    world = dist.world
+    if world > 1:
+        ev, G = ShardedEvaluator.distributed(N, primes, dist), world
+    else:
+        G = max(1, args.shards)
+        ev = ShardedEvaluator.in_process(N, primes, G)
+    rng = np.random.default_rng(0xE7A)  # the same operands on every rank: each uploads its own limbs
+
+    def rand(prefix, nl):
+        return np.stack([rng.integers(0, primes[i], size=prefix + (N,), dtype=np.uint64) for i in range(nl)], axis=len(prefix))
+    key_host = rand((l, 2), k)
+    ev.upload_relin_key(key_host)
+    n_pairs = min(args.batch, 16)
+    host, pairs = [], []
+    for i in range(n_pairs):
+        a, b = rand((2,), l), rand((2,), l)
+        pairs.append((ev.upload_ct(a, 2.0 ** 40), ev.upload_ct(b, 2.0 ** 40)))
+        if i == 0:
+            host.append((a, b))
+
+    def step():
+        out = None
+        for i in range(args.batch):
+            A, B = pairs[i % n_pairs]
+            out = ev.rescale(ev.relinearize(ev.multiply(A, B)), 60)
+        return out
+
+    def barrier():
+        ev.sync()
+        dist.barrier()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = dist.max_over_ranks(time.perf_counter() - t0)
+    value = args.steps * args.batch / dt
+    first = ev.rescale(ev.relinearize(ev.multiply(*pairs[0])), 60)
+    got = ev.gather(first, dist) if world > 1 else ev.download(first)
+    if dist.rank == 0:
+        from oracle import pyoracle as po  # checker only
+        ok = bool(np.array_equal(got, po.Oracle(N, primes).op_triple(host[0][0], host[0][1], key_host)))
+        if not ok:
+            raise SystemExit("bench.py --shard limb: the sharded result differs from the CPU oracle — number withheld")
+        xbytes = (l * N * 8) * (G - 1) / G + 2 * N * 8 + 2 * N * 8  # per GPU per triple: all-gather receive + two broadcasts
+        line = {"metric": "homomorphic ops/sec (mul+rescale+relin) at N=2^16, L=10; execute() wall-time",
+                "value": round(value, 2), "unit": "op-triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "config": {"workload": f"op-triple multiply+relinearize+rescale, N=2^{args.logn}, L={l}, {args.batch} triples per step, "
+                                       f"each computed by all shards together", "poly_modulus_degree": N, "limbs": l,
+                           "parallelism": f"RNS limbs over {G} shard(s) on {world} GPU(s): limb i on shard i mod G; per key switch "
+                                          "all-gather of the digits + broadcast of the special limb, per rescale one broadcast",
+                           "exchange": "RCCL (torch.distributed nccl) on device buffers" if world > 1 else "device copies between the shards' queues (one GPU)",
+                           "exchange_bytes_per_gpu_per_triple": int(xbytes)},
+                "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "achieved": round(triple_bytes(N, l) * value / max(world, 1) / 1e9, 1),
+                             "frac": round(triple_bytes(N, l) * value / max(world, 1) / 1e9 / HBM_PEAK_GBPS, 4),
+                             "bytes_per_unit": triple_bytes(N, l),
+                             "basis": "SURVEY.md 8(d) algorithmic bytes of one op-triple x op-triples/s, per GPU"},
+                "verified": {"triples_checked": 1, "bit_exact_vs_oracle": ok}, "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    ev.close()
+    dist.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +266,10 @@ def main():
     ap.add_argument("--fused-multiply", action="store_true",
                     help="evah_multiply_relinearize_rescale_many (no size-3 product in HBM; measured 1.5 %% slower at this size: "
                          "the combine pass re-reads both operands) instead of multiply_many + relinearize_rescale_many")
+    ap.add_argument("--shard", choices=["ciphertexts", "limb"], default="ciphertexts",
+                    help="ciphertexts: independent triples per GPU, no collective (default, weak scaling); "
+                         "limb: every triple on all GPUs, RNS limbs dealt over them (strong scaling)")
+    ap.add_argument("--shards", type=int, default=1, help="--shard limb with one process: shards on the one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the execute()-path and DAG legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -205,6 +290,9 @@ def main():
     rank, world, local = dist.rank, dist.world, dist.local_rank
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    if args.shard == "limb":
+        return limb_sharded(args, dist)
 
     from eva_amd import backend
     from eva_amd.hostref import coeff_modulus_create

@@ -38,6 +38,8 @@ _SIGS = {
     "evah_galois_elt_from_step": [_vp, C.c_int32, C.POINTER(C.c_uint32)],
     "evah_ct_upload": [_vp, C.c_uint32, C.c_uint32, C.c_double, _u64p, _vpp],
     "evah_ct_write": [_vp, _vp, _u64p],
+    "evah_ct_copy": [_vp, _vp, _vpp],
+    "evah_pt_copy": [_vp, _vp, _vpp],
     "evah_pt_write": [_vp, _vp, _u64p],
     "evah_capture_begin": [_vp, _vpp, C.c_uint32],
     "evah_capture_end": [_vp, _vpp, C.c_uint32, _vpp],
@@ -377,6 +379,15 @@ class Context:
         h = C.c_void_p()
         _chk(_lib.evah_shard_rescale_finish(self.h, a.h, int(l), r.h, int(divisor_bits), C.byref(h)))
         return Ciphertext(self, h)
+
+    def copy_here(self, value):
+        """a copy of a Ciphertext / Plaintext of another context (another GPU: peer copy), owned by this one"""
+        h = C.c_void_p()
+        if isinstance(value, Ciphertext):
+            _chk(_lib.evah_ct_copy(self.h, value.h, C.byref(h)))
+            return Ciphertext(self, h)
+        _chk(_lib.evah_pt_copy(self.h, value.h, C.byref(h)))
+        return Plaintext(self, h)
 
     # ---- plumbing
     def set_stream(self, stream_ptr):

@@ -415,6 +415,31 @@ int evah_ct_unstack(evah_ctx *c, const evah_ct *ct, uint32_t b, evah_ct **out) {
   API_END
 }
 
+// a copy of `src` owned by `c` — another device (peer copy over xGMI) or another queue of the same
+// device; ordered after the producer of src, asynchronous on c's stream
+int evah_ct_copy(evah_ctx *c, const evah_ct *src, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  acquire(c, src->buf);
+  evah_ct *o = ct_new(c, src->size, src->limbs, src->scale, src->batch);
+  const size_t row = sizeof(u64) * (size_t)src->limbs * c->N, polys = (size_t)src->size * src->batch;
+  if (src->ps == (size_t)src->limbs * c->N)
+    HIPCHK(hipMemcpyAsync(o->d, src->d, row * polys, hipMemcpyDefault, c->stream));
+  else // a mod-switched view: gather its rows
+    HIPCHK(hipMemcpy2DAsync(o->d, row, src->d, sizeof(u64) * src->ps, row, polys, hipMemcpyDefault, c->stream));
+  *out = o;
+  API_END
+}
+int evah_pt_copy(evah_ctx *c, const evah_pt *src, evah_pt **out) {
+  API_BEGIN
+  use(c);
+  acquire(c, src->buf);
+  evah_pt *o = pt_new(c, src->limbs, src->scale);
+  HIPCHK(hipMemcpyAsync(o->d, src->d, sizeof(u64) * (size_t)src->limbs * c->N, hipMemcpyDefault, c->stream));
+  *out = o;
+  API_END
+}
+
 int evah_ct_write(evah_ctx *c, evah_ct *ct, const uint64_t *data) {
   API_BEGIN
   use(c);

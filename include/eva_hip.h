@@ -97,6 +97,11 @@ int evah_ct_stack(evah_ctx *ctx, const evah_ct *const *cts, uint32_t n, evah_ct 
 /* instance b of a batched handle as a single-ciphertext view (shares the buffer; free separately) */
 int evah_ct_unstack(evah_ctx *ctx, const evah_ct *ct, uint32_t b, evah_ct **out);
 
+/* a copy of a value owned by another context: another GPU (peer copy over xGMI — the P2P step at the
+ * join of independent sub-DAGs) or another issue queue; asynchronous, ordered
+ * after the producer of src on its own queue */
+int evah_ct_copy(evah_ctx *dst_ctx, const evah_ct *src, evah_ct **out);
+int evah_pt_copy(evah_ctx *dst_ctx, const evah_pt *src, evah_pt **out);
 /* overwrite an existing handle's residues (same shape) — refills the input slots of a graph */
 int evah_ct_write(evah_ctx *ctx, evah_ct *ct, const uint64_t *data);
 int evah_pt_write(evah_ctx *ctx, evah_pt *pt, const uint64_t *data);
