@@ -87,6 +87,9 @@ _SIGS = {
     "evah_profile_get": [_vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
     "evah_timer_start": [_vp],
     "evah_timer_stop": [_vp, C.POINTER(C.c_float)],
+    "evah_client_key_upload": [_vp, C.c_int, _u64p],
+    "evah_encrypt": [_vp, _vp, C.POINTER(C.c_int8), _vpp],
+    "evah_decrypt_decode": [_vp, _vp, C.c_uint32, C.POINTER(C.c_double)],
     # limb-sharded execution
     "evah_ctx_set_shard": [_vp, C.c_uint32, C.c_uint32],
     "evah_ctx_shard_info": [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
@@ -379,6 +382,27 @@ class Context:
         h = C.c_void_p()
         _chk(_lib.evah_shard_rescale_finish(self.h, a.h, int(l), r.h, int(divisor_bits), C.byref(h)))
         return Ciphertext(self, h)
+
+    # ---- client side on the device (encrypt / decrypt + decode)
+    def upload_public_key(self, pk):
+        pk = np.ascontiguousarray(pk, dtype=np.uint64)
+        _chk(_lib.evah_client_key_upload(self.h, 2, _p(pk)))
+
+    def upload_secret_key(self, sk_ntt):
+        sk = np.ascontiguousarray(sk_ntt, dtype=np.uint64)
+        _chk(_lib.evah_client_key_upload(self.h, 3, _p(sk)))
+
+    def encrypt(self, pt, small):
+        """pt: Plaintext (NTT form); small: int8 [3][N] = (u, e0, e1)"""
+        small = np.ascontiguousarray(small, dtype=np.int8)
+        h = C.c_void_p()
+        _chk(_lib.evah_encrypt(self.h, pt.h, small.ctypes.data_as(C.POINTER(C.c_int8)), C.byref(h)))
+        return Ciphertext(self, h)
+
+    def decrypt_decode(self, ct, n_out):
+        out = np.empty(n_out, dtype=np.float64)
+        _chk(_lib.evah_decrypt_decode(self.h, ct.h, int(n_out), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
 
     def copy_here(self, value):
         """a copy of a Ciphertext / Plaintext of another context (another GPU: peer copy), owned by this one"""

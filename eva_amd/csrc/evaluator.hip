@@ -1345,3 +1345,4 @@ int evah_test_ntt(evah_ctx *c, uint32_t prime_idx, int inverse, uint64_t *host) 
 } // extern "C"
 
 #include "shard.hip.h"
+#include "client.hip.h"

@@ -157,6 +157,8 @@ struct SharedDev {
   int device = 0;
   void *d_tables = nullptr;
   KeyDev relin;
+  KeyDev pk, sk; // client side (client.hip.h): public key [2][k][N], secret key in NTT form [k][N]
+  double2 *dec_roots = nullptr; // CKKS decoder: zeta^br(j) (forward special FFT, heap order)
   std::map<uint32_t, KeyDev> galois;
   std::map<uint32_t, uint32_t *> perms;
   double2 *enc_roots = nullptr;     // CKKS encoder: inverse-FFT roots in the order the stages consume them
@@ -167,6 +169,9 @@ struct SharedDev {
     if (enc_roots) (void)hipFree(enc_roots);
     if (enc_slot_map) (void)hipFree(enc_slot_map);
     if (relin.d) (void)hipFree(relin.d);
+    if (pk.d) (void)hipFree(pk.d);
+    if (sk.d) (void)hipFree(sk.d);
+    if (dec_roots) (void)hipFree(dec_roots);
     for (auto &kv : galois) (void)hipFree(kv.second.d);
     for (auto &kv : perms) (void)hipFree(kv.second);
     if (d_tables) (void)hipFree(d_tables);

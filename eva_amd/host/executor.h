@@ -711,6 +711,14 @@ public:
         std::vector<double> vec(slots);
         for (size_t r = 0; r < slots / v.size(); r++) std::copy(v.begin(), v.end(), vec.begin() + r * v.size());
         host->encode_coeff(vec.data(), pt.scale, pt.limbs, pt.data.data());
+        if (info.input_type == Type::Cipher && client_on_device()) {
+          // device path: the per-limb transforms, the public-key products and the mod-down run on the
+          // GPU (evah_encrypt); the host keeps the FP64 encoder and the sampling (same sampler calls,
+          // in the same order, as evahost::encrypt — so both paths give the same ciphertext for the
+          // same random stream)
+          out.values[kv.first] = encrypt_on_device(pt, rng);
+          continue;
+        }
         for (uint32_t i = 0; i < pt.limbs; i++) host->ntt(i, pt.data.data() + (size_t)i * host->N);
         if (info.input_type == Type::Cipher) out.values[kv.first] = evahost::encrypt(*host, pk, pt, rng);
         else out.values[kv.first] = std::move(pt);
@@ -1039,6 +1047,49 @@ private:
     for (int i = 0; i + 1 < want; i++) q.push_back(forks[i]->h);
     return q;
   }
+  // EVA_DEVICE_CLIENT=0 keeps encrypt on the host; without a HIP device the host path is the only one
+  // (encrypt, unlike execute(), is client-side work the reference also does on the CPU)
+  bool client_on_device() {
+    if (client_device < 0) {
+      const char *e = std::getenv("EVA_DEVICE_CLIENT");
+      int n = 0;
+      client_device = (!e || std::atoi(e) != 0) && evah_device_count(&n) == 0 && n > 0 ? 1 : 0;
+    }
+    return client_device == 1;
+  }
+  int client_device = -1;
+  bool pk_uploaded = false;
+  HostCipher encrypt_on_device(const HostPlain &coeff_pt, SecureRng &rng) {
+    ensure_device();
+    if (!pk_uploaded) {
+      chk(evah_client_key_upload(dev->h, EVAH_KEY_PUBLIC, (const uint64_t *)pk.data.data()));
+      pk_uploaded = true;
+    }
+    const uint32_t N = host->N;
+    std::vector<int8_t> u, e0, e1, small((size_t)3 * N);
+    host->sample_ternary(rng, u);
+    host->sample_error(rng, e0);
+    host->sample_error(rng, e1);
+    std::copy(u.begin(), u.end(), small.begin());
+    std::copy(e0.begin(), e0.end(), small.begin() + N);
+    std::copy(e1.begin(), e1.end(), small.begin() + 2 * (size_t)N);
+    evah_pt *p = nullptr;
+    chk(evah_pt_upload_coeff(dev->h, coeff_pt.limbs, coeff_pt.scale, (const uint64_t *)coeff_pt.data.data(), &p));
+    evah_ct *c = nullptr;
+    int rc = evah_encrypt(dev->h, p, small.data(), &c);
+    evah_pt_free(dev->h, p);
+    chk(rc);
+    HostCipher out;
+    out.size = 2;
+    out.limbs = coeff_pt.limbs;
+    out.scale = coeff_pt.scale;
+    out.data.resize((size_t)2 * out.limbs * N);
+    rc = evah_ct_download(dev->h, c, (uint64_t *)out.data.data());
+    evah_ct_free(dev->h, c);
+    chk(rc);
+    return out;
+  }
+
   void ensure_device() {
     if (dev) return;
     dev = std::make_shared<DeviceCtx>(host->N, host->primes, device);
@@ -1052,12 +1103,41 @@ class HipSecret {
 public:
   std::shared_ptr<HostContext> host;
   SecretKey sk;
+  int device = 0;
+  // decrypt + decode on the GPU when one is present (EVA_DEVICE_CLIENT=0: host); the secret key is
+  // uploaded once, in NTT form, to a context of its own
+  bool on_device() {
+    if (state < 0) {
+      const char *e = std::getenv("EVA_DEVICE_CLIENT");
+      int n = 0;
+      state = (!e || std::atoi(e) != 0) && evah_device_count(&n) == 0 && n > 0 ? 1 : 0;
+      if (state == 1) {
+        dev = std::make_shared<DeviceCtx>(host->N, host->primes, device);
+        chk(evah_client_key_upload(dev->h, EVAH_KEY_SECRET, (const uint64_t *)sk.s_ntt.data()));
+      }
+    }
+    return state == 1;
+  }
+  int state = -1;
+  std::shared_ptr<DeviceCtx> dev;
   // SEALSecret::decrypt (seal.cpp:124-146)
   Valuation decrypt(const HipValuation &enc, const CKKSSignature &sig) {
     Valuation out;
     for (auto &kv : enc.values) {
       std::vector<double> v;
       if (auto *c = std::get_if<HostCipher>(&kv.second)) {
+        if (on_device()) { // dot product with s, inverse transforms, recomposition and the special FFT on the GPU
+          if (c->size < 1 || c->size > 3 || c->limbs < 1 || c->limbs > host->k - 1 || c->data.size() != (size_t)c->size * c->limbs * host->N)
+            throw std::runtime_error("output " + kv.first + ": ciphertext shape does not match its data or the encryption parameters");
+          evah_ct *h = nullptr;
+          chk(evah_ct_upload(dev->h, c->size, c->limbs, c->scale, (const uint64_t *)c->data.data(), &h));
+          v.resize((size_t)sig.vec_size);
+          int rc = evah_decrypt_decode(dev->h, h, (uint32_t)sig.vec_size, v.data());
+          evah_ct_free(dev->h, h);
+          chk(rc);
+          out[kv.first] = std::move(v);
+          continue;
+        }
         auto m = decrypt_to_coeff(*host, sk, *c);
         host->decode_coeff(m.data(), c->limbs, c->scale, v);
       } else if (auto *p = std::get_if<HostPlain>(&kv.second)) {

@@ -62,6 +62,8 @@ int evah_ctx_mem_info(evah_ctx *ctx, size_t *in_use, size_t *cached);
  * SEAL KSwitchKeys layout).  galois_elt is ignored for the relinearization key. */
 #define EVAH_KEY_RELIN 0
 #define EVAH_KEY_GALOIS 1
+#define EVAH_KEY_PUBLIC 2 /* evah_client_key_upload */
+#define EVAH_KEY_SECRET 3
 int evah_key_upload(evah_ctx *ctx, int kind, uint32_t galois_elt, uint32_t n_digits,
                     const uint64_t *data);
 /* Galois element used by evah_rotate for `steps` (SEAL GaloisTool::get_elt_from_step). */
@@ -196,6 +198,18 @@ int evah_relinearize_many(evah_ctx *ctx, const evah_ct *const *cts, uint32_t n, 
 int evah_rescale(evah_ctx *ctx, const evah_ct *a, uint32_t divisor_bits, evah_ct **out);
 /* evaluator.mod_switch_to_next (seal_executor.h:206) */
 int evah_mod_switch(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
+
+/* ---- the neighbours of execute() on the device --------------------------
+ * SEALPublic::encrypt (seal.cpp:24-102: encoder.encode + encryptor.encrypt) and SEALSecret::decrypt
+ * (seal.cpp:124-146: decryptor.decrypt + encoder.decode).  Randomness is the caller's (a host CSPRNG):
+ * `small` holds the ternary u and the two error polynomials as int8 [3][N].  Keys: the public key
+ * [2][k][N] and the secret key in NTT form [k][N], both uploaded with evah_client_key_upload. */
+int evah_client_key_upload(evah_ctx *ctx, int kind /* EVAH_KEY_PUBLIC | EVAH_KEY_SECRET */, const uint64_t *data);
+/* (pk0 u + e0, pk1 u + e1) one level above pt, divided-and-rounded by the extra prime, + pt on c0 */
+int evah_encrypt(evah_ctx *ctx, const evah_pt *pt, const int8_t *small, evah_ct **out);
+/* m = c0 + c1 s (+ c2 s^2) -> inverse transform -> exact recomposition -> / scale -> special FFT:
+ * the first n_out slot values */
+int evah_decrypt_decode(evah_ctx *ctx, const evah_ct *ct, uint32_t n_out, double *out);
 
 /* ---- whole-DAG submit: a topologically sorted flat op list over a value table.
  * One call replaces the per-node loop ProgramTraversal::forwardPass + SEALExecutor::operator()
