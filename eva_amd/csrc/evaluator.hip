@@ -315,8 +315,8 @@ template <> struct OpClass<OpPlain> { static constexpr int fwd_a = KC_NTT_A, fwd
 template <> struct OpClass<OpMulIntt> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
 template <> struct OpClass<OpKsDigit> { static constexpr int fwd_a = KC_KSDIGIT_A, fwd_b = KC_KSDIGIT_B; };
 template <> struct OpClass<OpModDown> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
-template <> struct OpClass<OpRR> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
-template <> struct OpClass<OpRRLast> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
+template <bool M> struct OpClass<OpRRT<M>> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
+template <bool M> struct OpClass<OpRRLastT<M>> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 
 template <int P, int LR, bool STRIDED, bool INVERSE, class Op>
 static void launch_pass(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
@@ -385,18 +385,17 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   const uint32_t n_tiles = c->N / tile;
   // the one-wave workgroup (the default) is compiled with its own launch bound: the register
   // allocator is not held to the 256-thread budget
-  static const MulTab no_mul{};
-  auto go = [&](auto kernel, const MulTab &mt) {
+  auto go = [&](auto kernel, const auto &mt) {
     hipLaunchKernelGGL(kernel, dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev, target, kb.target_bs, scratch,
                        kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n, kb.targets, mt, kb.istep,
                        kb.nout ? kb.nout : l + 1);
   };
   if ((tile >> LR) <= 64) {
     if (kb.mul) go(ks_inner_kernel<P, LR, 64, true>, *kb.mul);
-    else go(ks_inner_kernel<P, LR, 64, false>, no_mul);
+    else go(ks_inner_kernel<P, LR, 64, false>, NoMul{});
   } else {
     if (kb.mul) go(ks_inner_kernel<P, LR, NTT_THREADS, true>, *kb.mul);
-    else go(ks_inner_kernel<P, LR, NTT_THREADS, false>, no_mul);
+    else go(ks_inner_kernel<P, LR, NTT_THREADS, false>, NoMul{});
   }
   HIPCHK(hipGetLastError());
 }
@@ -883,12 +882,17 @@ static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n
   Scratch r(c, (size_t)n * 2 * N), t(c, (size_t)n * 2 * N);
   OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
   ntt_inverse<OpPlain>(c, spp, 2 * n);
-  OpRRLast::Params lp{nullptr, 0, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, a_last};
-  if (mul) { lp.use_mul = true; lp.mul = *mul; }
-  ntt_inverse<OpRRLast>(c, lp, 2 * n);
-  OpRR::Params rp{r.d, N, t.d, N, nullptr, 0, prod.d, pps, out_d, ops, sp, last, l - 1, a_polys};
-  if (mul) { rp.use_mul = true; rp.mul = *mul; }
-  ntt_forward<OpRR>(c, rp, 2 * n * (l - 1));
+  if (mul) {
+    OpRRLastMul::Params lp{nullptr, 0, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, a_last, *mul};
+    ntt_inverse<OpRRLastMul>(c, lp, 2 * n);
+    OpRRMul::Params rp{r.d, N, t.d, N, nullptr, 0, prod.d, pps, out_d, ops, sp, last, l - 1, a_polys, *mul};
+    ntt_forward<OpRRMul>(c, rp, 2 * n * (l - 1));
+  } else {
+    OpRRLast::Params lp{nullptr, 0, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, a_last};
+    ntt_inverse<OpRRLast>(c, lp, 2 * n);
+    OpRR::Params rp{r.d, N, t.d, N, nullptr, 0, prod.d, pps, out_d, ops, sp, last, l - 1, a_polys};
+    ntt_forward<OpRR>(c, rp, 2 * n * (l - 1));
+  }
 }
 
 // multiply (size 2 x size 2) -> relinearize -> rescale_to_next for n (<= 64) independent pairs at one

@@ -307,11 +307,14 @@ __device__ __forceinline__ u64 product_poly(const MulSrc &m, uint32_t K, size_t 
   return barrett128(s, pm);
 }
 
+struct NoMul {}; // placeholder for the operand table in the variants that read a stored product
+
 template <int P, int LR, int MAXT, bool MUL>
 __global__ void __launch_bounds__(MAXT)
 ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
                 size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, uint32_t i0,
-                int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets, MulTab mul, uint32_t istep, uint32_t nout) {
+                int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets, std::conditional_t<MUL, MulTab, NoMul> mul, uint32_t istep,
+                uint32_t nout) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   // grid.x carries (tile, instance): instances of one tile are placed 8 block ids apart, i.e. on
   // the same XCD (blocks are dealt round-robin over the 8 XCDs) and close in dispatch order, so
@@ -365,7 +368,8 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   // Software pipeline over the digits: the key words of digit J are requested before its
   // transform starts and the coefficients of digit J+1 as soon as those of J sit in LDS, so both
   // streams are in flight during the register rounds instead of being waited for at their use.
-  const MulSrc msrc = MUL ? mul_src(mul, cx.N, inst) : MulSrc{nullptr, nullptr, 0, 0};
+  MulSrc msrc{nullptr, nullptr, 0, 0};
+  if constexpr (MUL) msrc = mul_src(mul, cx.N, inst);
   auto load_digits = [&](uint32_t J, ulonglong2 *d) {
     if (MUL && I == J) { // block-uniform
 #pragma unroll
@@ -653,7 +657,7 @@ struct OpModDown {
 //   t_K = INTT_last(a[K][last] + prod[K][last]*P^-1) - u_K,last*P^-1 + floor(q_last/2).
 
 // inverse transform producing t_K; job = K, prime = last data prime
-struct OpRRLast {
+template <bool MUL> struct OpRRLastT {
   struct Params {
     const u64 *a;     // a[0][last]
     size_t a_ps;
@@ -665,8 +669,7 @@ struct OpRRLast {
     size_t t_ps;
     uint32_t last, sp;
     PtrTab a_tab; // used when a == nullptr: a_tab.p[job] = poly K of instance b at limb `last` (job = 2b+K)
-    bool use_mul = false; // a[K] = d_K of product b = job / 2 (fused multiply): evaluated on load
-    MulTab mul{};
+    std::conditional_t<MUL, MulTab, NoMul> mul{}; // MUL: a[K] = d_K of product b = job / 2 (fused multiply), evaluated on load
   };
   struct Job {
     uint32_t prime;
@@ -675,7 +678,6 @@ struct OpRRLast {
     u64 halfP;
     ulonglong2 pinv;
     bool lazy;
-    bool use_mul;
     MulSrc mul;
     uint32_t K;
     size_t off;
@@ -684,11 +686,10 @@ struct OpRRLast {
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t job, uint32_t,
                                                Job &j) {
     j.prime = p.last;
-    j.use_mul = p.use_mul;
-    j.mul = p.use_mul ? mul_src(p.mul, cx.N, job >> 1) : MulSrc{nullptr, nullptr, 0, 0};
+    if constexpr (MUL) j.mul = mul_src(p.mul, cx.N, job >> 1);
     j.K = job & 1u;
     j.off = (size_t)p.last * cx.N;
-    j.a = p.use_mul ? nullptr : (p.a ? p.a + job * p.a_ps : p.a_tab.p[job]);
+    j.a = MUL ? nullptr : (p.a ? p.a + job * p.a_ps : p.a_tab.p[job]);
     j.prod = p.prod + job * p.prod_ps;
     j.r = p.r + job * p.r_ps;
     j.dst = p.t + job * p.t_ps;
@@ -699,7 +700,7 @@ struct OpRRLast {
   }
   template <bool LZ>
   static __device__ __forceinline__ u64 load(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n) {
-    const u64 av = j.use_mul ? product_poly(j.mul, j.K, j.off + n, pm) : j.a[n];
+    const u64 av = MUL ? product_poly(j.mul, j.K, j.off + n, pm) : j.a[n];
     return addmod(av, mul_shoup(j.prod[n], j.pinv.x, j.pinv.y, pm.q), pm.q);
   }
   static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 x) {
@@ -710,7 +711,7 @@ struct OpRRLast {
 };
 
 // forward transform of u*P^-1 + v with the combined epilogue; job -> (K = job / jl, i = job % jl)
-struct OpRR {
+template <bool MUL> struct OpRRT {
   struct Params {
     const u64 *r;
     size_t r_ps;
@@ -724,8 +725,7 @@ struct OpRR {
     size_t dst_ps;
     uint32_t sp, last, jl;
     PtrTab a_tab; // used when a == nullptr: a_tab.p[K] = poly K (limb 0), K = 2b + {0,1}
-    bool use_mul = false; // a[K] = d_(K&1) of product b = K / 2 (fused multiply): evaluated in the epilogue
-    MulTab mul{};
+    std::conditional_t<MUL, MulTab, NoMul> mul{}; // MUL: a[K] = d_(K&1) of product b = K / 2 (fused multiply), evaluated in the epilogue
   };
   struct Job {
     uint32_t prime;
@@ -734,7 +734,6 @@ struct OpRR {
     u64 halfP, halfL;
     ulonglong2 pinv, linv;
     bool lazy;
-    bool use_mul;
     MulSrc mul;
     uint32_t K;
     size_t off;
@@ -745,11 +744,10 @@ struct OpRR {
     j.prime = i;
     j.r = p.r + K * p.r_ps;
     j.t = p.t + K * p.t_ps;
-    j.use_mul = p.use_mul;
-    j.mul = p.use_mul ? mul_src(p.mul, cx.N, K >> 1) : MulSrc{nullptr, nullptr, 0, 0};
+    if constexpr (MUL) j.mul = mul_src(p.mul, cx.N, K >> 1);
     j.K = K & 1u;
     j.off = (size_t)i * cx.N;
-    j.a = p.use_mul ? nullptr : (p.a ? p.a + K * p.a_ps : p.a_tab.p[K]) + (size_t)i * cx.N;
+    j.a = MUL ? nullptr : (p.a ? p.a + K * p.a_ps : p.a_tab.p[K]) + (size_t)i * cx.N;
     j.prod = p.prod + K * p.prod_ps + (size_t)i * cx.N;
     j.dst = p.dst + K * p.dst_ps + (size_t)i * cx.N;
     j.halfP = cx.halfmod[p.sp * cx.k + i];
@@ -770,10 +768,15 @@ struct OpRR {
   }
   static __device__ __forceinline__ void store_fwd(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n, u64 W) {
     W += (W >= pm.q8 ? pm.nq8 : 0);                                                  // [0,16q) -> [0,8q)
-    const u64 av = j.use_mul ? product_poly(j.mul, j.K, j.off + n, pm) : j.a[n];
+    const u64 av = MUL ? product_poly(j.mul, j.K, j.off + n, pm) : j.a[n];
     const u64 x = av + mul_tw_lazy5(j.prod[n], j.pinv.x, j.pinv.y, pm.nq) + pm.q8 - W; // < 14q < 2^64
     j.dst[n] = mul_shoup(x, j.linv.x, j.linv.y, pm.q);                               // exact for any 64-bit operand
   }
 };
+
+using OpRRLast = OpRRLastT<false>;
+using OpRRLastMul = OpRRLastT<true>;
+using OpRR = OpRRT<false>;
+using OpRRMul = OpRRT<true>;
 
 } // namespace evah
