@@ -424,6 +424,47 @@ template <class Op> static void ntt_inverse(evah_ctx *c, const typename Op::Para
   launch_pass_p<true, true, Op>(c, a, prm, jobs);
 }
 
+// ---- latency-bound launches: inverse strided pass + forward strided pass as one launch (ntt_inv_fwd_kernel)
+static bool fuse_small_launch(evah_ctx *c, uint32_t fwd_jobs) {
+  const uint32_t tile = (uint32_t)NTT_THREADS << 3;
+  if (!c->fuse_small_blocks || c->N < tile) return false; // partial tiles (N = 1024) keep the two-launch form
+  return (uint64_t)fwd_jobs * (c->N / tile) <= c->fuse_small_blocks;
+}
+template <int P, class Op> static void launch_inv_fwd_p(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  ProfScope ps(c, OpClass<Op>::fwd_a);
+  constexpr int LR = 3;
+  const uint32_t tile = (uint32_t)NTT_THREADS << LR, n_tiles = c->N / tile;
+  const int logC = (int)ilog2(tile) - P;
+  const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) + 2 * ((size_t)1 << P) * sizeof(ulonglong2);
+  dim3 grid = Op::grid(prm, jobs);
+  grid.x *= n_tiles;
+  hipLaunchKernelGGL((ntt_inv_fwd_kernel<P, LR, Op>), grid, dim3(NTT_THREADS), lds, c->stream, c->dev, prm, (int)ilog2(n_tiles));
+  HIPCHK(hipGetLastError());
+}
+template <class Op> static void launch_inv_fwd(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  switch ((c->logN + 1) / 2) {
+  case 6: launch_inv_fwd_p<6, Op>(c, prm, jobs); break;
+  case 7: launch_inv_fwd_p<7, Op>(c, prm, jobs); break;
+  case 8: launch_inv_fwd_p<8, Op>(c, prm, jobs); break;
+  case 9: launch_inv_fwd_p<9, Op>(c, prm, jobs); break;
+  default: throw std::runtime_error("unsupported poly_modulus_degree for the fused inverse/forward pass");
+  }
+}
+// inverse transform of the source limb(s) (InvOp jobs) followed by the forward transforms of Op:
+// four launches, or three when the forward launch is too small to fill the chip
+template <class InvOp, class Op>
+static void inverse_then_forward(evah_ctx *c, const typename InvOp::Params &ip, uint32_t inv_jobs, const typename Op::Params &fp,
+                                 uint32_t fwd_jobs) {
+  if (fuse_small_launch(c, fwd_jobs)) {
+    launch_pass_p<false, true, InvOp>(c, c->logN / 2, ip, inv_jobs); // contiguous inverse pass: lazy intermediate in ip.dst
+    launch_inv_fwd<Op>(c, fp, fwd_jobs);
+    launch_pass_p<false, false, Op>(c, c->logN / 2, fp, fwd_jobs);
+  } else {
+    ntt_inverse<InvOp>(c, ip, inv_jobs);
+    ntt_forward<Op>(c, fp, fwd_jobs);
+  }
+}
+
 // SEAL Evaluator::switch_key_inplace, device version.
 //   out[K] = (add && K < add_polys ? add[K] : 0) + keyswitch(target)[K],  K in {0,1}
 // steps 1-2 of switch_key for a batch of n (target, key) pairs in one set of launches:
@@ -448,15 +489,27 @@ static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size
   Scratch t(c, (size_t)n * l * N);        // coefficient-form digits
   Scratch sc(c, n * kb.scratch_bs);       // converted digits, NTT form per output limb
   // 1. digits to coefficient form (job -> (b, J))
+  OpKsDigit::Params dp{t.d, sc.d, l, (size_t)l * N, kb.scratch_bs, 0, l + 1};
+  // a small key switch is latency-bound: the digits' strided inverse pass and the first pass of the
+  // digit conversion then run as one launch
+  const bool small = c->fuse_mac && std::max(1, c->ks_groups) == 1 && fuse_small_launch(c, n * (l + 1) * l);
   if (mul) { // the target is the product's d2, formed on load
     OpMulIntt::Params ip{*mul, t.d, (size_t)l * N, l};
-    ntt_inverse<OpMulIntt>(c, ip, n * l);
+    if (small) launch_pass_p<false, true, OpMulIntt>(c, c->logN / 2, ip, n * l);
+    else ntt_inverse<OpMulIntt>(c, ip, n * l);
   } else {
     OpPlain::Params ip{target, t.d, target_bs, (size_t)l * N, l, 0, 0, {}};
     if (target_tab) ip.src_tab = *target_tab;
-    ntt_inverse<OpPlain>(c, ip, n * l);
+    if (small) launch_pass_p<false, true, OpPlain>(c, c->logN / 2, ip, n * l);
+    else ntt_inverse<OpPlain>(c, ip, n * l);
   }
-  OpKsDigit::Params dp{t.d, sc.d, l, (size_t)l * N, kb.scratch_bs, 0, l + 1};
+  if (small) {
+    dp.i0 = kb.i0 = 0;
+    dp.ni = kb.ni = l + 1;
+    launch_inv_fwd<OpKsDigit>(c, dp, n * (l + 1) * l);
+    launch_ks_inner(c, c->logN / 2, target, sc.d, kb, prod_d, l);
+    return;
+  }
   if (c->fuse_mac) { // 128-bit accumulation of lazy (<16q) products, folded every 16 digits
     // Output limbs are processed in slices so that a slice's converted digits (ni * l * N words)
     // are still in L2 / Infinity Cache when the fused second pass consumes them.
@@ -494,10 +547,9 @@ static void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev 
   // 3. mod-down by the special prime: INTT(special limb) + P/2, then per-limb NTT + combine
   Scratch r(c, 2 * N);
   OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
-  ntt_inverse<OpPlain>(c, sp, 2);
-  OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, add, add_ps, add_polys, out, out_ps,
+    OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, add, add_ps, add_polys, out, out_ps,
                        c->k - 1, l};
-  ntt_forward<OpModDown>(c, mp, 2 * l);
+  inverse_then_forward<OpPlain, OpModDown>(c, sp, 2, mp, 2 * l);
 }
 
 } // namespace evah
@@ -788,10 +840,9 @@ int evah_relinearize(evah_ctx *c, const evah_ct *a, evah_ct **out) {
         switch_key_products(c, l, a0 + 2 * a->ps, 3 * a->ps, keys.data(), n, prod.d);
         Scratch r(c, (size_t)n * 2 * N);
         OpPlain::Params sp{prod.d + (size_t)l * N, r.d, pps, N, 1, c->k - 1, 1, {}};
-        ntt_inverse<OpPlain>(c, sp, 2 * n);
         OpModDown::Params mp{r.d, N, prod.d, pps, a0, a->ps, 2, o->d + (size_t)b0 * 2 * o->ps, o->ps, c->k - 1, l};
         mp.add_bs = 3 * a->ps;
-        ntt_forward<OpModDown>(c, mp, 2 * n * l);
+        inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * n, mp, 2 * n * l);
       }
     }
   } catch (...) {
@@ -1081,10 +1132,9 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
         Scratch r(c, (size_t)np * 2 * N);
         // INTT of the special limbs, job = r*2 + K
         OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
-        ntt_inverse<OpPlain>(c, sp, 2 * np);
-        // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
+                // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
         OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, perm.d, pps, ~0u, ob->d, pps, c->k - 1, l};
-        ntt_forward<OpModDown>(c, mp, 2 * np * l);
+        inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * np, mp, 2 * np * l);
       } catch (...) {
         ob->refs = 1;
         buf_unref(c, ob);
@@ -1149,9 +1199,8 @@ int evah_rotate_pairs(evah_ctx *c, const evah_ct *const *cts, const int32_t *ste
     switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), n, prod.d);
     Scratch r(c, (size_t)n * 2 * N);
     OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
-    ntt_inverse<OpPlain>(c, sp, 2 * n);
-    OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, perm.d, pps, ~0u, ob->d, pps, c->k - 1, l};
-    ntt_forward<OpModDown>(c, mp, 2 * n * l);
+        OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, perm.d, pps, ~0u, ob->d, pps, c->k - 1, l};
+    inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * n, mp, 2 * n * l);
   } catch (...) {
     buf_unref(c, ob);
     throw;
@@ -1194,10 +1243,9 @@ int evah_rescale_many(evah_ctx *c, const evah_ct *const *cts, uint32_t n, uint32
   try {
     Scratch r(c, (size_t)polys * N);
     OpPlain::Params ip{nullptr, r.d, 0, N, 1, l - 1, 1, last};
-    ntt_inverse<OpPlain>(c, ip, polys);
-    OpModDown::Params mp{r.d, N, nullptr, 0, nullptr, 0, 0, ob->d, ops, l - 1, l - 1};
+        OpModDown::Params mp{r.d, N, nullptr, 0, nullptr, 0, 0, ob->d, ops, l - 1, l - 1};
     mp.c_tab = all;
-    ntt_forward<OpModDown>(c, mp, polys * (l - 1));
+    inverse_then_forward<OpPlain, OpModDown>(c, ip, polys, mp, polys * (l - 1));
   } catch (...) {
     buf_unref(c, ob);
     throw;
@@ -1242,11 +1290,10 @@ int evah_relinearize_many(evah_ctx *c, const evah_ct *const *cts, uint32_t n, ev
     switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2);
     Scratch r(c, (size_t)n * 2 * N);
     OpPlain::Params sp{prod.d + (size_t)l * N, r.d, pps, N, 1, c->k - 1, 1, {}};
-    ntt_inverse<OpPlain>(c, sp, 2 * n);
-    OpModDown::Params mp{r.d, N, prod.d, pps, nullptr, 0, 0, ob->d, ops, c->k - 1, l};
+        OpModDown::Params mp{r.d, N, prod.d, pps, nullptr, 0, 0, ob->d, ops, c->k - 1, l};
     mp.use_add_tab = true;
     mp.add_tab = c01;
-    ntt_forward<OpModDown>(c, mp, 2 * n * l);
+    inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * n, mp, 2 * n * l);
   } catch (...) {
     buf_unref(c, ob);
     throw;
@@ -1311,9 +1358,8 @@ int evah_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bits, evah_ct *
   evah_ct *o = ct_new(c, a->size, l - 1, a->scale / std::pow(2.0, (double)divisor_bits), a->batch);
   Scratch r(c, (size_t)polys * N);
   OpPlain::Params ip{a->d + (size_t)(l - 1) * N, r.d, a->ps, N, 1, l - 1, 1, {}};
-  ntt_inverse<OpPlain>(c, ip, polys);
-  OpModDown::Params mp{r.d, N, a->d, a->ps, nullptr, 0, 0, o->d, o->ps, l - 1, l - 1};
-  ntt_forward<OpModDown>(c, mp, polys * (l - 1));
+    OpModDown::Params mp{r.d, N, a->d, a->ps, nullptr, 0, 0, o->d, o->ps, l - 1, l - 1};
+  inverse_then_forward<OpPlain, OpModDown>(c, ip, polys, mp, polys * (l - 1));
   *out = o;
   API_END
 }

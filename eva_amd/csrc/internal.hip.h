@@ -195,6 +195,10 @@ struct evah_ctx {
   // evah_execute: run Mul -> Relinearize -> Rescale chains as one evah_multiply_relinearize_rescale_many
   // (EVAH_FUSE_MUL=0/1; default: only where launches, not bytes, bound the chain — see DESIGN.md §4)
   bool fuse_mul = false;
+  // launches of at most this many workgroups are treated as latency-bound: an inverse transform
+  // followed by forward transforms of the result then runs its two strided passes as ONE launch
+  // (ntt_inv_fwd_kernel).  EVAH_FUSE_SMALL=0 disables, =n sets the threshold.
+  uint32_t fuse_small_blocks = 1024;
   int ks_groups = 1;    // output-limb slices per key-switch (EVAH_KS_GROUPS)
   int ks_threads = 64;  // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS): one wave = one
                         // 2^P-point sub-transform per workgroup measured best (barriers are intra-wave)

@@ -258,6 +258,67 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC_rt, int log_tiles) 
   }
 }
 
+// Inverse strided pass + forward strided pass in one launch, for the latency-bound (small) launches:
+// a mod-down / rescale / digit conversion starts from the inverse transform of ONE source limb and
+// continues with forward transforms of that polynomial under other primes.  The second (strided)
+// pass of the inverse transform and the first (strided) pass of the forward transforms work on the
+// same column tiles, so a workgroup finishes the inverse transform of its tile (from the
+// intermediate the contiguous inverse pass left in Op::pre_src), applies the op's conversion in LDS
+// and goes straight on with the forward stages under its own prime: one launch and one HBM round
+// trip fewer per operation.  The inverse tile is recomputed by every job that shares the source
+// limb, so the host uses this form only while the launch is far from filling the chip
+// (fuse_small_launch in evaluator.hip); results are the same canonical residues either way.
+template <int P, int LR, class Op>
+__global__ void __launch_bounds__(NTT_THREADS)
+ntt_inv_fwd_kernel(DevCtx cx, typename Op::Params prm, int log_tiles) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  constexpr int NTT_R = 1 << LR;
+  constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
+  const uint32_t tile_idx = blockIdx.x & ((1u << log_tiles) - 1u);
+  typename Op::Job jb;
+  if (!Op::setup(cx, prm, blockIdx.x >> log_tiles, blockIdx.y, blockIdx.z, jb)) return; // block-uniform
+  const uint32_t pa = Op::pre_prime(prm, jb);
+  const DevPrime pmA = cx.primes[pa], pm = cx.primes[jb.prime];
+  const ulonglong2 *twA = cx.tw_inv + (size_t)pa * cx.N, *tw = cx.tw_fwd + (size_t)jb.prime * cx.N;
+  constexpr int logC = 8 + LR - P, C = 1 << logC, T = NTT_THREADS;
+  const uint32_t stride_log = cx.logN - P;
+  constexpr int ES = 1 << (P - LR);
+  constexpr bool LINEAR = (ES % 16 == 0);
+  const int c = threadIdx.x & (C - 1), e0 = threadIdx.x >> logC;
+  const uint32_t n0 = (tile_idx << logC) + ((uint32_t)e0 << stride_log) + c, nstep = (uint32_t)(T >> logC) << stride_log;
+  const int l0 = c * SP + lds_pad(e0);
+  auto lds_at = [&](int it) -> int {
+    if constexpr (LINEAR) return l0 + it * lds_pad(ES);
+    const int idx = threadIdx.x + it * T;
+    return (idx & (C - 1)) * SP + lds_pad(idx >> logC);
+  };
+  const u64 *src = Op::pre_src(jb);
+#pragma unroll
+  for (int it = 0; it < NTT_R; it++) lds[lds_at(it)] = src[n0 + it * nstep];
+  ulonglong2 *twlA = reinterpret_cast<ulonglong2 *>(lds + ((C * SP + 1) & ~1)), *twl = twlA + S;
+  for (int idx = threadIdx.x; idx < S; idx += T) { twlA[idx] = twA[idx]; twl[idx] = tw[idx]; }
+  __syncthreads();
+  const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
+  RoundSeq<P, LR, 0, true, true, false>::run(lds + sub * SP, tid, 0, 0, twlA, pmA); // canonical mod q_a (N^-1 folded in)
+  __syncthreads();
+  auto convert = [&](auto lazy_tag) {
+    constexpr bool LZ = decltype(lazy_tag)::value;
+#pragma unroll
+    for (int it = 0; it < NTT_R; it++) {
+      u64 v = lds[lds_at(it)];
+      if (Op::pre_addhalf) v = addmod(v, pmA.q >> 1, pmA.q);
+      lds[lds_at(it)] = Op::template conv<LZ>(jb, pm, v);
+    }
+  };
+  if (jb.lazy) convert(std::true_type{});
+  else convert(std::false_type{});
+  __syncthreads();
+  RoundSeq<P, LR, 0, false, true, false>::run(lds + sub * SP, tid, 0, 0, twl, pm);
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NTT_R; it++) jb.dst[n0 + it * nstep] = lds[lds_at(it)]; // lazy intermediate of the forward transform
+}
+
 // Key-switch inner product fused with the second (contiguous) pass of the digit NTTs
 // (SURVEY.md A.6 step 2).  One workgroup owns output limb I = blockIdx.y and one tile of
 // coefficient positions; it walks the digits J, finishing NTT_kappa(t_J) for its tile in LDS
@@ -555,7 +616,7 @@ struct OpKsDigit {
                                       // buffer is shard-major); t_split == 1: row J
   };
   struct Job {
-    uint32_t prime;
+    uint32_t prime, digit;
     const u64 *src;
     u64 *dst;
     bool lazy;
@@ -566,6 +627,7 @@ struct OpKsDigit {
                                                uint32_t b, Job &j) {
     const uint32_t I = p.i0 + iy * p.istep;
     if (I == J) return false;
+    j.digit = J;
     j.prime = (I == p.l) ? cx.k - 1 : I;
     // t_J < q_J: when q_J <= 8 q_kappa the digit is already a valid lazy input (< 12 q_kappa)
     j.lazy = cx.primes[J].q <= cx.primes[j.prime].q8;
@@ -577,7 +639,14 @@ struct OpKsDigit {
   }
   template <bool LZ>
   static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
-    return LZ ? j.src[n] : barrett64(j.src[n], pm.q, pm.brt);
+    return conv<LZ>(j, pm, j.src[n]);
+  }
+  // hooks of ntt_inv_fwd_kernel: the source is digit J's contiguous-inverse-pass intermediate
+  static constexpr bool pre_addhalf = false;
+  static __device__ __forceinline__ uint32_t pre_prime(const Params &, const Job &j) { return j.digit; }
+  static __device__ __forceinline__ const u64 *pre_src(const Job &j) { return j.src; }
+  template <bool LZ> static __device__ __forceinline__ u64 conv(const Job &, const DevPrime &pm, u64 v) {
+    return LZ ? v : barrett64(v, pm.q, pm.brt);
   }
   static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &j, const DevPrime &pm,
                                                    uint32_t n, u64 v) {
@@ -636,8 +705,15 @@ struct OpModDown {
   }
   template <bool LZ>
   static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
-    if (LZ) return j.src[n] + (pm.q - j.halfm);
-    return submod(barrett64(j.src[n], pm.q, pm.brt), j.halfm, pm.q);
+    return conv<LZ>(j, pm, j.src[n]);
+  }
+  // hooks of ntt_inv_fwd_kernel: r holds the contiguous-inverse-pass intermediate of limb a
+  static constexpr bool pre_addhalf = true;
+  static __device__ __forceinline__ uint32_t pre_prime(const Params &p, const Job &) { return p.a; }
+  static __device__ __forceinline__ const u64 *pre_src(const Job &j) { return j.src; }
+  template <bool LZ> static __device__ __forceinline__ u64 conv(const Job &j, const DevPrime &pm, u64 v) {
+    if (LZ) return v + (pm.q - j.halfm);
+    return submod(barrett64(v, pm.q, pm.brt), j.halfm, pm.q);
   }
   static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &j, const DevPrime &pm,
                                                    uint32_t n, u64 U) {

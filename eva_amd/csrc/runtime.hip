@@ -62,6 +62,7 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     if (const char *e = std::getenv("EVAH_KS_GROUPS")) c->ks_groups = std::max(1, std::atoi(e));
     c->fuse_mul = N <= 8192;
     if (const char *e = std::getenv("EVAH_FUSE_MUL")) c->fuse_mul = std::atoi(e) != 0;
+    if (const char *e = std::getenv("EVAH_FUSE_SMALL")) c->fuse_small_blocks = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {
       int t = std::atoi(e);
       if (t == 64 || t == 128 || t == 256) c->ks_threads = t;
@@ -160,6 +161,7 @@ int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
     c->dev = parent->dev;
     c->fuse_mac = parent->fuse_mac;
     c->fuse_mul = parent->fuse_mul;
+    c->fuse_small_blocks = parent->fuse_small_blocks;
     c->ks_threads = parent->ks_threads;
     c->ks_groups = parent->ks_groups;
     HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
