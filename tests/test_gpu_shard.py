@@ -132,3 +132,55 @@ def test_two_ranks_one_shard_each_on_the_gpu(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][len("RESULT "):])
     assert r == {"equal": True, "world": 2}
+
+
+RCCL_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as td
+    from eva_amd.dist import Dist
+    from eva_amd.shard import ShardedEvaluator, DistExchange
+    from oracle import pyoracle as po
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29645")
+    torch.cuda.set_device(0)
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    d = Dist(backend="nccl")
+    N, bits = 8192, [60, 40, 60, 60]
+    primes = po.coeff_modulus_create(N, bits)
+    k, l = len(primes), len(primes) - 1
+    ev = ShardedEvaluator.distributed(N, primes, d)
+    assert isinstance(ev.x, DistExchange) and ev.x.device_collectives
+    # the library's exchange buffer as a torch tensor: same memory, no copy
+    buf = ev.shards[0].buffer(1024)
+    t = torch.as_tensor(buf, device="cuda")
+    t.fill_(7)
+    torch.cuda.synchronize()
+    view_ok = bool((buf.download() == 7).all()) and t.data_ptr() == buf.ptr
+    rng = np.random.default_rng(11)
+    rand = lambda prefix, nl: np.stack([rng.integers(0, primes[i], size=prefix + (N,), dtype=np.uint64) for i in range(nl)], axis=len(prefix))
+    relin, gk = rand((l, 2), k), rand((l, 2), k)
+    a2, b2 = rand((2,), l), rand((2,), l)
+    ev.upload_relin_key(relin)
+    ev.upload_galois_key(ev.galois_elt_from_step(3), gk)
+    A, B = ev.upload_ct(a2, 2.0 ** 20), ev.upload_ct(b2, 2.0 ** 20)
+    out = ev.rotate(ev.rescale(ev.relinearize(ev.multiply(A, B)), 30), 3)   # all-gather + broadcasts through RCCL
+    got = ev.download(out)
+    o = po.Oracle(N, primes)
+    want = o.rotate(o.rescale(o.relinearize(o.multiply(a2, b2), relin)), 3, gk)
+    print("RESULT " + json.dumps({"equal": bool(np.array_equal(got, want)), "view": view_ok}))
+    ev.close()
+    td.destroy_process_group()
+""") % (ROOT,)
+
+
+def test_rccl_exchange_on_library_buffers_single_rank(tmp_path):
+    """the RCCL deployment's code path (torch.distributed "nccl" collectives in place on the library's
+    device buffers, kernels and collectives on one stream) with a one-rank group — what a single-GPU
+    box can execute of it"""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][len("RESULT "):])
+    assert r == {"equal": True, "view": True}
