@@ -105,9 +105,25 @@ PYBIND11_MODULE(_eva, m) {
 
   m.def("evaluate", &evaluate, py::arg("program"), py::arg("inputs"), "Evaluate the program without homomorphic encryption (reference semantics)");
   // serialization (wrapper.cpp:110-116)
-  m.def("save", [](const Program &o, const std::string &path) { save_to_file(Kind::Program, o, path); }, py::arg("obj"), py::arg("path"));
-  m.def("save", [](const CKKSParameters &o, const std::string &path) { save_to_file(Kind::Parameters, o, path); }, py::arg("obj"), py::arg("path"));
-  m.def("save", [](const CKKSSignature &o, const std::string &path) { save_to_file(Kind::Signature, o, path); }, py::arg("obj"), py::arg("path"));
+  // Program / CKKSParameters / CKKSSignature: the reference's protobuf wire format by default (files
+  // interchange with microsoft/EVA); format="native" = this repo's container
+  auto want_wire = [](const std::string &format) {
+    if (format == "eva") return true;
+    if (format == "native") return false;
+    throw std::invalid_argument("format must be 'eva' or 'native'");
+  };
+  m.def("save", [want_wire](const Program &o, const std::string &path, const std::string &format) {
+    if (want_wire(format)) save_wire_to_file("Program", wire::encode(o), path);
+    else save_to_file(Kind::Program, o, path);
+  }, py::arg("obj"), py::arg("path"), py::arg("format") = "eva");
+  m.def("save", [want_wire](const CKKSParameters &o, const std::string &path, const std::string &format) {
+    if (want_wire(format)) save_wire_to_file("CKKSParameters", wire::encode(o), path);
+    else save_to_file(Kind::Parameters, o, path);
+  }, py::arg("obj"), py::arg("path"), py::arg("format") = "eva");
+  m.def("save", [want_wire](const CKKSSignature &o, const std::string &path, const std::string &format) {
+    if (want_wire(format)) save_wire_to_file("CKKSSignature", wire::encode(o), path);
+    else save_to_file(Kind::Signature, o, path);
+  }, py::arg("obj"), py::arg("path"), py::arg("format") = "eva");
   m.def("save", [](const HipValuation &o, const std::string &path) { save_to_file(Kind::Valuation, o, path); }, py::arg("obj"), py::arg("path"));
   m.def("save", [](const HipPublic &o, const std::string &path) { save_to_file(Kind::Public, o, path); }, py::arg("obj"), py::arg("path"));
   m.def("save", [](const HipSecret &o, const std::string &path) { save_to_file(Kind::Secret, o, path); }, py::arg("obj"), py::arg("path"));

@@ -272,12 +272,35 @@ template <class T> void save_to_file(Kind kind, const T &obj, const std::string 
   f.write(w.buf.data(), (std::streamsize)w.buf.size());
 }
 
+} // namespace evahost
+#include "wire.h"
+namespace evahost {
+
+// Program / CKKSParameters / CKKSSignature in the reference's own wire format (protobuf KnownType
+// envelope, wire.h): what eva::save writes and eva::load reads.  The default for these three kinds.
+inline void save_wire_to_file(const std::string &type, const std::string &payload, const std::string &path) {
+  std::ofstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("Could not open file " + path);
+  const std::string buf = wire::envelope(type, payload);
+  f.write(buf.data(), (std::streamsize)buf.size());
+}
+
 using KnownType = std::variant<std::unique_ptr<Program>, CKKSParameters, CKKSSignature, HipValuation, std::shared_ptr<HipPublic>, std::shared_ptr<HipSecret>>;
 inline KnownType load_from_file(const std::string &path) {
   std::ifstream f(path, std::ios::binary);
   if (!f) throw std::runtime_error("Could not open file " + path);
   std::vector<char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
   Reader r(buf);
+  uint32_t magic = 0;
+  if (buf.size() >= 4) std::memcpy(&magic, buf.data(), 4);
+  if (magic != FORMAT_MAGIC) { // not this repo's container: the reference's protobuf envelope
+    auto [type, payload] = wire::open_envelope(std::string(buf.begin(), buf.end()));
+    if (type == "Program") return wire::decode_program(wire::In(payload));
+    if (type == "CKKSParameters") return wire::decode_parameters(wire::In(payload));
+    if (type == "CKKSSignature") return wire::decode_signature(wire::In(payload));
+    throw std::runtime_error("Unknown inner message type eva.msg." + type +
+                             " (SEAL-object messages of the reference are not readable here: seal.proto wraps SEAL's binary format)");
+  }
   if (r.pod<uint32_t>() != FORMAT_MAGIC) throw std::runtime_error("Could not parse message: not an eva_amd file");
   if (r.pod<uint32_t>() != FORMAT_VERSION) throw std::runtime_error("Serialization format version is not compatible");
   switch ((Kind)r.pod<uint32_t>()) {

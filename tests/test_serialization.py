@@ -142,7 +142,7 @@ def test_malformed_files_and_values_are_rejected(tmp_path):
     with prog:
         Output('y', Input('x') + Input('z'))
     path = str(tmp_path / "p.eva")
-    save(prog, path)
+    save(prog, path, format="native")
     raw = bytearray(open(path, "rb").read())
     # find the Add term's record: op code 11 followed by operand count 2 -> make it 1
     needle = struct.pack("<iI", 11, 2)
