@@ -4,8 +4,8 @@ C4 (Sobel N=2^14) and C5 (3x3 convolution + depth-8 squaring chain, N=2^16, 13 p
 usage: dag_bench.py [reps] [--cpu]
 
 The GPU legs use only the product.  --cpu adds the reported CPU baseline of each DAG — the same role
-as bench.py's cpu_baseline leg — by walking the compiled DAG over the CPU oracle through the test
-helpers (tests/evatest.py, tests/oracle_executor.py); nothing of it is on the measured GPU path."""
+as bench.py's cpu_baseline leg — by walking the compiled DAG in C over the CPU oracle (oracle/eva_oracle_dag.c through
+tests/oracle_executor.c_walk); nothing of it is on the measured GPU path."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -41,12 +41,17 @@ def run(name, prog, N, inputs=None, pad_primes=0):
     mse = valuation_mse(sec.decrypt(out, sig), evaluate(compiled, inputs))
     line = f"{name}: N={N} primes={list(params.prime_bits)} terms={sum(ops.values())} {ops}\n  GPU execute(): min {min(ts)*1e3:.2f} ms  median {sorted(ts)[len(ts)//2]*1e3:.2f} ms   MSE {mse:.2e}  [upload {tm[0]:.2f} | host enqueue {tm[1]:.2f} | drain+download {tm[2]:.2f} ms]"
     if not no_cpu:
-        from evatest import oracle_execute
-        t0 = time.perf_counter(); oracle_execute(pub, compiled, enc); tc = time.perf_counter() - t0
-        line += f"\n  CPU oracle walk (1 core): {tc*1e3:.1f} ms   -> GPU speed-up {tc/min(ts):.1f}x"
+        # the compiled DAG walked in C over the oracle (oracle/eva_oracle_dag.c): serial forwardPass and the
+        # dependency-counting traversal on pthreads — lowering / encoding excluded, as key and plaintext
+        # preparation is for the GPU figure
+        from oracle_executor import c_walk
+        import numpy as np
+        ref, tc = c_walk(pub, compiled, enc, threads=1)
+        same = all(np.array_equal(out.get(n)[4], ref[n]) for n in ref)
+        line += f"\n  CPU walk in C over the oracle (1 core): {tc*1e3:.1f} ms   -> GPU speed-up {tc/min(ts):.1f}x   outputs bit-identical: {same}"
         nthr = min(os.cpu_count() or 1, 64)
-        t0 = time.perf_counter(); oracle_execute(pub, compiled, enc, threads=nthr); tp = time.perf_counter() - t0
-        line += f"\n  CPU oracle walk, node-parallel on {nthr} threads: {tp*1e3:.1f} ms   -> GPU speed-up {tp/min(ts):.1f}x"
+        _, tp = c_walk(pub, compiled, enc, threads=nthr)
+        line += f"\n  CPU walk in C, dependency-counting on {nthr} threads: {tp*1e3:.1f} ms   -> GPU speed-up {tp/min(ts):.1f}x"
     print(line, flush=True)
 
 from eva import EvaProgram, Input, Output
