@@ -12,17 +12,17 @@ switch_key_inplace behind relinearize / rotate_vector (/root/reference/eva/seal/
 :181/:188) and rescale_to_next (:213).
 
 Two deployments of the same code:
-  * one process, all G shards (`ShardedEvaluator(backend_factory, G)`): the shards are G contexts —
+  * one process, all G shards (`ShardedEvaluator.in_process(N, primes, G)`): the shards are G contexts —
     on G devices with peer access, or on one device — and the exchange steps are device / peer
     copies (LocalExchange).  This is how the path is validated on a single MI355X.
-  * one process per GPU (`ShardedEvaluator(..., dist=Dist(...))`): every rank owns shard `rank`; the
+  * one process per GPU (`ShardedEvaluator.distributed(N, primes, Dist(...))`): every rank owns shard `rank`; the
     exchange steps are torch.distributed collectives directly on the library's device buffers
     (backend "nccl" = RCCL over xGMI: all_gather_into_tensor, broadcast) or staged through host
     memory (backend "gloo": two ranks can then share one GPU, or run the CPU backend of the tests).
 
-The shard backend is any object with the methods of ShardBackend below; the product's is HipShard
-(libeva_hip.so through eva_amd.backend).  tests/ plugs in a CPU backend over the oracle to check the
-partition / exchange / reassembly logic under gloo without a GPU.
+The shard backend is any object with the methods of HipShard below (the product's: libeva_hip.so
+through eva_amd.backend).  tests/ plugs in a CPU backend over the oracle (tests/shard_cpu_backend.py)
+to check the partition / exchange / reassembly logic, in one process and under gloo, without a GPU.
 """
 import numpy as np
 
