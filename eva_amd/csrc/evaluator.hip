@@ -14,7 +14,8 @@ namespace evah {
   const uint32_t p = blockIdx.z, i = blockIdx.y;                                                 \
   const size_t off = (size_t)i * cx.N + 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);    \
   const DevPrime pm = cx.primes[cx.prime_of(i)];                                                 \
-  (void)p;
+  (void)p;                                                                                        \
+  (void)pm;
 
 __device__ __forceinline__ ulonglong2 ld2(const u64 *p) { return *reinterpret_cast<const ulonglong2 *>(p); }
 __device__ __forceinline__ void st2(u64 *p, ulonglong2 v) { *reinterpret_cast<ulonglong2 *>(p) = v; }
