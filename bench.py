@@ -423,6 +423,24 @@ def main():
             roofline["by_class_us"] = {c: round(v[1] * 1e3 / max(v[0], 1), 2) for c, v in prof.items() if v[0]}
             roofline["by_class_share"] = {c: round(v[1] / kern_total_ms, 3) for c, v in prof.items() if v[0]}
 
+        # secondary limiter: 32-bit integer-multiply / VALU issue.  The instruction count per
+        # op-triple comes from the committed SQ-counter pass of this same command
+        # (profiles/bench_valu_issue.json); the share of the measured time the VALUs spent issuing is
+        # that count's issue time over this run's time per triple.
+        vpath = os.path.join(ROOT, "profiles", "bench_valu_issue.json")
+        if os.path.exists(vpath) and (args.logn, l) == (16, 10):
+            try:
+                vj = json.load(open(vpath))
+                us_per_triple = 1e6 * world / value
+                roofline["secondary"] = {
+                    "bound": "valu integer issue", "valu_wave_instructions_per_triple": vj["valu_wave_instructions_per_triple"],
+                    "valu_issuing_us_per_triple": vj["valu_issuing_us_per_triple"], "us_per_triple": round(us_per_triple, 2),
+                    "frac": round(vj["valu_issuing_us_per_triple"] / us_per_triple, 3),
+                    "note": "9 integer multiplies + 8 other VALU instructions per butterfly at ~4.5-5.6 SIMD-cycles each: "
+                            "the path is issue-bound before it is HBM-bound (DESIGN.md section 4)"}
+            except Exception:
+                pass
+
         legs = {}
         if world == 1 and not args.no_legs:
             try:
