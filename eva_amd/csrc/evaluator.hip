@@ -361,6 +361,13 @@ static void launch_pass_lr(evah_ctx *c, int P, const typename Op::Params &prm, u
 // vs 16: +10 %, profiles/r01_tuning_notes.md); the fused key-switch kernel uses 4.
 template <bool STRIDED, bool INVERSE, class Op>
 static void launch_pass_p(evah_ctx *c, int P, const typename Op::Params &prm, uint32_t jobs) {
+  // a launch that cannot fill the chip is bound by ONE wave's instruction stream (a thread's 8
+  // coefficients are ~600 integer instructions per pass): with 4 coefficients per thread the same
+  // tile work is spread over twice the workgroups and the critical path of a workgroup shrinks
+  if (c->small_lr == 2 && (uint64_t)jobs * (c->N >> 11) <= c->small_lr_blocks && c->N >= 2048) {
+    launch_pass_lr<2, STRIDED, INVERSE, Op>(c, P, prm, jobs);
+    return;
+  }
   launch_pass_lr<3, STRIDED, INVERSE, Op>(c, P, prm, jobs);
 }
 
@@ -431,9 +438,8 @@ static bool fuse_small_launch(evah_ctx *c, uint32_t fwd_jobs) {
   if (!c->fuse_small_blocks || c->N < tile) return false; // partial tiles (N = 1024) keep the two-launch form
   return (uint64_t)fwd_jobs * (c->N / tile) <= c->fuse_small_blocks;
 }
-template <int P, class Op> static void launch_inv_fwd_p(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+template <int P, class Op, int LR> static void launch_inv_fwd_plr(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
   ProfScope ps(c, OpClass<Op>::fwd_a);
-  constexpr int LR = 3;
   const uint32_t tile = (uint32_t)NTT_THREADS << LR, n_tiles = c->N / tile;
   const int logC = (int)ilog2(tile) - P;
   const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) + 2 * ((size_t)1 << P) * sizeof(ulonglong2);
@@ -441,6 +447,10 @@ template <int P, class Op> static void launch_inv_fwd_p(evah_ctx *c, const typen
   grid.x *= n_tiles;
   hipLaunchKernelGGL((ntt_inv_fwd_kernel<P, LR, Op>), grid, dim3(NTT_THREADS), lds, c->stream, c->dev, prm, (int)ilog2(n_tiles));
   HIPCHK(hipGetLastError());
+}
+template <int P, class Op> static void launch_inv_fwd_p(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  if (c->small_lr == 2) launch_inv_fwd_plr<P, Op, 2>(c, prm, jobs);
+  else launch_inv_fwd_plr<P, Op, 3>(c, prm, jobs);
 }
 template <class Op> static void launch_inv_fwd(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
   switch ((c->logN + 1) / 2) {

@@ -198,7 +198,9 @@ struct evah_ctx {
   // launches of at most this many workgroups are treated as latency-bound: an inverse transform
   // followed by forward transforms of the result then runs its two strided passes as ONE launch
   // (ntt_inv_fwd_kernel).  EVAH_FUSE_SMALL=0 disables, =n sets the threshold.
-  uint32_t fuse_small_blocks = 1024;
+  uint32_t fuse_small_blocks = 8192;
+  int small_lr = 2; // log2 coefficients per thread of the NTT passes in latency-bound launches (EVAH_SMALL_LR = 2 | 3)
+  uint32_t small_lr_blocks = 4096; // ... = launches of at most this many 2048-coefficient tiles (EVAH_SMALL_LR_BLOCKS)
   int ks_groups = 1;    // output-limb slices per key-switch (EVAH_KS_GROUPS)
   int ks_threads = 64;  // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS): one wave = one
                         // 2^P-point sub-transform per workgroup measured best (barriers are intra-wave)

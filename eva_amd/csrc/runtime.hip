@@ -62,6 +62,8 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     if (const char *e = std::getenv("EVAH_KS_GROUPS")) c->ks_groups = std::max(1, std::atoi(e));
     c->fuse_mul = N <= 8192;
     if (const char *e = std::getenv("EVAH_FUSE_MUL")) c->fuse_mul = std::atoi(e) != 0;
+    if (const char *e = std::getenv("EVAH_SMALL_LR")) c->small_lr = std::atoi(e) == 3 ? 3 : 2;
+    if (const char *e = std::getenv("EVAH_SMALL_LR_BLOCKS")) c->small_lr_blocks = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("EVAH_FUSE_SMALL")) c->fuse_small_blocks = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {
       int t = std::atoi(e);
@@ -162,6 +164,8 @@ int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
     c->fuse_mac = parent->fuse_mac;
     c->fuse_mul = parent->fuse_mul;
     c->fuse_small_blocks = parent->fuse_small_blocks;
+    c->small_lr = parent->small_lr;
+    c->small_lr_blocks = parent->small_lr_blocks;
     c->ks_threads = parent->ks_threads;
     c->ks_groups = parent->ks_groups;
     HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
