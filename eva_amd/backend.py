@@ -74,6 +74,8 @@ _SIGS = {
     "evah_ct_upload_batch": [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, _u64p, _vpp],
     "evah_ct_upload_instances": [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(_u64p), _vpp],
     "evah_ct_download_instances": [_vp, _vp, C.POINTER(_u64p)],
+    "evah_ct_upload_instances_async": [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(_u64p), _vpp],
+    "evah_ct_download_instances_async": [_vp, _vp, C.POINTER(_u64p)],
     "evah_ct_batch": [_vp, C.POINTER(C.c_uint32)],
     "evah_ct_stack": [_vp, _vpp, C.c_uint32, _vpp],
     "evah_ct_unstack": [_vp, _vp, C.c_uint32, _vpp],

@@ -43,7 +43,12 @@ struct DevCtx {
   // "limb i of every poly lives on GPU i mod G") has (s, G): its values hold
   // only the limbs i = s, s + G, ... and every per-limb kernel works on them unchanged.
   uint32_t p0, pstep;
+  // Guarded launches (hoisted rotations' exact fallback, evaluator.hip): when set, a kernel does
+  // nothing unless the counter it points to exceeds guard_min.  Null for every ordinary launch.
+  const uint32_t *guard;
+  uint32_t guard_min;
   __host__ __device__ uint32_t prime_of(uint32_t limb) const { return p0 + limb * pstep; }
+  __device__ __forceinline__ bool skipped() const { return guard && *guard <= guard_min; }
 };
 
 __device__ __forceinline__ u128_t mul128(u64 a, u64 b) {

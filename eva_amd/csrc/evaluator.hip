@@ -181,16 +181,18 @@ struct PermTables {
   const uint32_t *perm[KS_BATCH_MAX];
 };
 __global__ void __launch_bounds__(256)
-k_galois_perm_many(DevCtx cx, const u64 *a, size_t a_ps, PermTables pt, u64 *out, size_t o_ps, uint32_t B) {
-  // z = 2 * (j * B + b) + K: rotation j of instance b, polynomial K
-  const uint32_t z = blockIdx.z, r = z >> 1, p = z & 1, i = blockIdx.y;
+k_galois_perm_many(DevCtx cx, const u64 *a, size_t a_ps, PermTables pt, u64 *out, size_t o_ps, uint32_t B, uint32_t polys) {
+  // polys == 2: z = 2 * (j * B + b) + K, rotation j of instance b, polynomial K; polys == 1: z = j * B + b
+  // and only c0 is permuted (the hoisted form never needs the permuted c1); output slot 2 * (j * B + b) + K
+  if (cx.skipped()) return;
+  const uint32_t z = blockIdx.z, r = polys == 2 ? z >> 1 : z, p = polys == 2 ? z & 1 : 0, i = blockIdx.y;
   const uint32_t n = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
   const uint2 pi = *reinterpret_cast<const uint2 *>(pt.perm[r / B] + n);
   const u64 *src = a + ((size_t)(r % B) * 2 + p) * a_ps + (size_t)i * cx.N;
   ulonglong2 v;
   v.x = src[pi.x];
   v.y = src[pi.y];
-  st2(out + z * o_ps + (size_t)i * cx.N + n, v);
+  st2(out + (size_t)(2 * r + p) * o_ps + (size_t)i * cx.N + n, v);
 }
 
 // ---- CKKS encoder on the device (SEAL 3.6 CKKSEncoder::encode_internal, reached from
@@ -285,6 +287,7 @@ __global__ void __launch_bounds__(256) k_fill_limbs(DevCtx cx, LimbVals vals, u6
 // reduction at the end.  grid = (N/512, l+1).
 __global__ void __launch_bounds__(256)
 k_ks_mac(DevCtx cx, const u64 *target, const u64 *scratch, const u64 *key, u64 *prod, uint32_t l) {
+  if (cx.skipped()) return;
   const uint32_t I = blockIdx.y;
   const uint32_t kap = (I == l) ? cx.k - 1 : I;
   const size_t n = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
@@ -308,6 +311,118 @@ k_ks_mac(DevCtx cx, const u64 *target, const u64 *scratch, const u64 *key, u64 *
   r1.y = barrett128(a1y, pm);
   st2(prod + (size_t)I * N + n, r0);
   st2(prod + ((size_t)(l + 1) + I) * N + n, r1);
+}
+
+// ---- Hoisted rotations: n rotations of ONE ciphertext share the digit decomposition of c1.
+// SEAL rotates first and decomposes sigma(c1) (Evaluator::rotate_internal -> apply_galois_ntt ->
+// switch_key_inplace; seal_executor.h:181/:188): digit J of the rotated polynomial is
+// sigma(t_J) with the sign flips taken modulo q_J, i.e. as an integer polynomial
+//     t'_J = sigma_Z(t_J) + q_J * s,   s[k'] = 1 where sigma flips the sign at k' and t_J[k] != 0
+// (sigma_Z = the automorphism with integer negation).  NTT_I is linear and commutes with sigma
+// as the NTT-domain index permutation, so under every output prime q_I
+//     NTT_I(t'_J) = perm(NTT_I(t_J)) + (q_J mod q_I) * NTT_I(s)
+// and the key inner product of the rotated ciphertext is
+//     sum_J perm(D[I][J]) * key[J][K][I]  +  NTT_I(s) * sum_J (q_J mod q_I) * key[J][K][I]
+// with D = the transformed digits of the UNROTATED c1 (computed once) and a second term that is a
+// constant of (Galois element, level): the same residues SEAL gets, 1/n of the transforms.
+// The identity needs t_J[k] != 0 at the flipped positions: where t_J[k] = 0 the true digit is 0, not
+// q_J, so the sum above is too large by (q_J mod q_I) * NTT_I(X^k') * key[J][K][I].  Zero coefficients
+// are rare (N / q_J per limb: ~2^-44 at 60 bits, but 6 % of the ciphertexts for N = 2^16 and one of
+// EVA's 20-bit primes), so the inverse transform records them and k_hoist_fix subtracts their terms
+// one by one (NTT_I(X^k')[n] = psi_I^((2 brv(n) + 1) k')).  More than HOIST_ZERO_CAP zeros (a
+// transparent ciphertext) make the guarded, unhoisted launch set recompute the outputs instead.
+struct HoistTab {
+  const uint32_t *perm[KS_BATCH_MAX]; // per rotation of the launch
+  const u64 *key[KS_BATCH_MAX];
+  const u64 *corr[KS_BATCH_MAX];      // [2][l+1][N]
+  uint32_t elt[KS_BATCH_MAX];
+};
+// corr[K][I][n] = sign[kap][n] * sum_J (q_J mod q_kap) * key[J][K][kap][n]   (kap = prime of row I)
+__global__ void __launch_bounds__(256)
+k_hoist_corr(DevCtx cx, const u64 *sign, const u64 *key, u64 *corr, uint32_t l) {
+  const uint32_t I = blockIdx.y, K = blockIdx.z, kap = (I == l) ? cx.k - 1 : I;
+  const size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const DevPrime pm = cx.primes[kap];
+  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
+  u64 acc = 0;
+  for (uint32_t J = 0; J < l; J++) {
+    const u64 qj = cx.primes[J].q % pm.q; // 0 when J == I
+    acc = addmod(acc, mulmod(qj, key[J * key_digit + ((size_t)K * cx.k + kap) * N + n], pm), pm.q);
+  }
+  corr[((size_t)K * (l + 1) + I) * N + n] = mulmod(sign[(size_t)kap * N + n], acc, pm);
+}
+// prod[z][K][I][n] = sum_J D_b[I][J][perm_j[n]] * key_j[J][K][I][n] + corr_j[K][I][n],  z = j * B + b.
+// D_b[I][J] is row (I * l + J) of instance b's converted digits, or limb J of the instance's own c1
+// when I == J (SEAL's shortcut: the NTT-form limb is used as is).  grid = (N/512, l+1, pairs).
+__global__ void __launch_bounds__(256)
+k_hoist_mac(DevCtx cx, const u64 *c1, size_t c1_bs, const u64 *digits, size_t dg_bs, HoistTab tab, u64 *prod,
+            size_t prod_bs, uint32_t l, uint32_t B) {
+  const uint32_t I = blockIdx.y, kap = (I == l) ? cx.k - 1 : I;
+  const uint32_t z = blockIdx.z, j = z / B, b = z - j * B;
+  const size_t n = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
+  const DevPrime pm = cx.primes[kap];
+  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
+  const uint2 pi = *reinterpret_cast<const uint2 *>(tab.perm[j] + n);
+  const u64 *key = tab.key[j] + (size_t)kap * N + n;
+  const u64 *dg = digits + b * dg_bs + (size_t)I * l * N, *own = c1 + b * c1_bs;
+  u128_t a0x = {0, 0}, a0y = {0, 0}, a1x = {0, 0}, a1y = {0, 0};
+  // operands are canonical (< q < 2^60): 256 products fit the 128-bit accumulators, l <= k - 1 < 64
+  for (uint32_t J = 0; J < l; J++) {
+    const u64 *op = (I == J) ? own + (size_t)J * N : dg + (size_t)J * N;
+    const u64 ox = op[pi.x], oy = op[pi.y];
+    const ulonglong2 k0 = ld2(key + J * key_digit), k1 = ld2(key + J * key_digit + (size_t)cx.k * N);
+    acc128(a0x, ox, k0.x);
+    acc128(a0y, oy, k0.y);
+    acc128(a1x, ox, k1.x);
+    acc128(a1y, oy, k1.y);
+  }
+  const u64 *cr = tab.corr[j] + (size_t)I * N + n;
+  const ulonglong2 c0 = ld2(cr), c1c = ld2(cr + (size_t)(l + 1) * N);
+  ulonglong2 r0, r1;
+  r0.x = addmod(barrett128(a0x, pm), c0.x, pm.q);
+  r0.y = addmod(barrett128(a0y, pm), c0.y, pm.q);
+  r1.x = addmod(barrett128(a1x, pm), c1c.x, pm.q);
+  r1.y = addmod(barrett128(a1y, pm), c1c.y, pm.q);
+  u64 *pr = prod + z * prod_bs + (size_t)I * N + n;
+  st2(pr, r0);
+  st2(pr + (size_t)(l + 1) * N, r1);
+}
+
+// zeros[0] (low word) = number of zero digit coefficients seen, zeros[1 + e] = (instance << 48 | J << 32 | k).
+// Same grid as k_hoist_mac with one coefficient per thread; every test below is block-uniform.
+__global__ void __launch_bounds__(256)
+k_hoist_fix(DevCtx cx, const u64 *zeros, HoistTab tab, u64 *prod, size_t prod_bs, uint32_t l, uint32_t B) {
+  const uint32_t count = *reinterpret_cast<const uint32_t *>(zeros);
+  if (count == 0 || count > HOIST_ZERO_CAP) return;
+  const uint32_t I = blockIdx.y, kap = (I == l) ? cx.k - 1 : I;
+  const uint32_t z = blockIdx.z, j = z / B, b = z - j * B;
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  const DevPrime pm = cx.primes[kap];
+  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
+  const uint32_t en = 2u * (__brev(n) >> (32 - cx.logN)) + 1u; // slot n holds the evaluation at psi^en
+  const ulonglong2 *tw = cx.tw_fwd + (size_t)kap * N;
+  const u64 *key = tab.key[j] + (size_t)kap * N + n;
+  u64 acc0 = 0, acc1 = 0;
+  bool any = false;
+  for (uint32_t e = 0; e < count; e++) {
+    const u64 ent = zeros[1 + e];
+    const uint32_t J = (uint32_t)(ent >> 32) & 0xffffu, k = (uint32_t)ent;
+    if ((uint32_t)(ent >> 48) != b || J >= l || J == kap) continue; // q_J mod q_J = 0
+    const u64 raw = (u64)k * tab.elt[j];
+    if (!((raw >> cx.logN) & 1)) continue; // the automorphism does not flip this coefficient
+    const uint32_t kp = (uint32_t)raw & (uint32_t)(N - 1);
+    const uint32_t m = (uint32_t)(((u64)en * kp) & (2 * N - 1));
+    u64 w = tw[__brev(m & (uint32_t)(N - 1)) >> (32 - cx.logN)].x; // psi^(m mod N)
+    if (m >= N) w = negmod(w, pm.q);
+    const u64 t = mulmod(cx.primes[J].q % pm.q, w, pm);
+    acc0 = addmod(acc0, mulmod(t, key[J * key_digit], pm), pm.q);
+    acc1 = addmod(acc1, mulmod(t, key[J * key_digit + (size_t)cx.k * N], pm), pm.q);
+    any = true;
+  }
+  if (!any) return;
+  u64 *pr = prod + z * prod_bs + (size_t)I * N + n;
+  pr[0] = submod(pr[0], acc0, pm.q);
+  pr[(size_t)(l + 1) * N] = submod(pr[(size_t)(l + 1) * N], acc1, pm.q);
 }
 
 // ---- NTT launch plumbing
@@ -561,6 +676,13 @@ static void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev 
     OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, add, add_ps, add_polys, out, out_ps,
                        c->k - 1, l};
   inverse_then_forward<OpPlain, OpModDown>(c, sp, 2, mp, 2 * l);
+}
+
+bool hoist_wanted(const evah_ctx *c, uint32_t l, uint32_t n, uint32_t B) {
+  // hoisting pays when the digit transforms it saves are throughput, not latency (the exact fallback
+  // costs a set of empty launches); limb-sharded contexts go through the shard phases instead
+  return c->hoist && n >= 2 && c->dev.pstep == 1 && c->N >= 2048 &&
+         (uint64_t)n * B * l * (l + 1) * (c->N >> 11) >= c->hoist_min_tiles;
 }
 
 } // namespace evah
@@ -1093,9 +1215,55 @@ static const uint32_t *perm_table(evah_ctx *c, uint32_t elt) {
   return d;
 }
 
+// Hoisted rotations, tables (first use of a Galois element / level: not capturable, like perm_table).
+// sign[k][N]: NTT under every prime of the 0/1 polynomial marking the coefficients whose sign the
+// automorphism flips (SEAL GaloisTool::apply_galois: index_raw = i * elt, bit logN of it set).
+static const u64 *hoist_sign(evah_ctx *c, uint32_t elt) {
+  auto it = c->sh->hoist_sign.find(elt);
+  if (it != c->sh->hoist_sign.end()) return it->second;
+  if (c->capturing) throw std::logic_error("first hoisted use of a Galois element cannot be captured into a graph");
+  const size_t N = c->N;
+  std::vector<u64> s(N * c->k, 0);
+  for (uint32_t i = 0; i < N; i++) {
+    const u64 raw = (u64)i * elt;
+    if ((raw >> c->logN) & 1) s[raw & (N - 1)] = 1;
+  }
+  for (uint32_t p = 1; p < c->k; p++) std::copy_n(s.begin(), N, s.begin() + (size_t)p * N);
+  u64 *d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(u64) * N * c->k));
+  try {
+    HIPCHK(hipMemcpyAsync(d, s.data(), sizeof(u64) * N * c->k, hipMemcpyHostToDevice, c->stream));
+    OpPlain::Params p{d, d, 0, 0, c->k, 0, 0, {}};
+    ntt_forward<OpPlain>(c, p, c->k);
+    HIPCHK(hipStreamSynchronize(c->stream)); // `s` goes out of scope; other queues may use the table next
+  } catch (...) {
+    (void)hipFree(d);
+    throw;
+  }
+  c->sh->hoist_sign.emplace(elt, d);
+  return d;
+}
+static const u64 *hoist_corr(evah_ctx *c, uint32_t elt, uint32_t l, const KeyDev &key) {
+  auto it = c->sh->hoist_corr.find({elt, l});
+  if (it != c->sh->hoist_corr.end()) return it->second;
+  if (c->capturing) throw std::logic_error("first hoisted use of a Galois element cannot be captured into a graph");
+  const u64 *sign = hoist_sign(c, elt);
+  u64 *d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(u64) * 2 * (l + 1) * c->N));
+  hipLaunchKernelGGL(k_hoist_corr, dim3(c->N / 256, l + 1, 2), dim3(256), 0, c->stream, c->dev, sign, key.d, d, l);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    HIPCHK(e);
+  }
+  c->sh->hoist_corr.emplace(std::make_pair(elt, l), d);
+  return d;
+}
+
 // Several rotations of ONE ciphertext (the convolution pattern: image << i*w+j for a 3x3
 // window) issued as one set of wide launches: same results as n evah_rotate calls, 1/n of the
-// kernel launches, each launch n times wider.
+// kernel launches, each launch n times wider.  Large launch sets are hoisted (see k_hoist_mac).
 int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32_t n, evah_ct **outs) {
   API_BEGIN
   use(c);
@@ -1106,51 +1274,63 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
   const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
   std::vector<const KeyDev *> step_key(n);
   std::vector<const uint32_t *> step_perm(n);
+  std::vector<uint32_t> step_elt(n);
   for (uint32_t r = 0; r < n; r++) {
     if (steps[r] == 0) throw std::invalid_argument("rotate_many: zero steps are copies, not key switches");
     uint32_t elt = 0;
     if (evah_galois_elt_from_step(c, steps[r], &elt)) throw std::invalid_argument(g_err);
     auto kit = c->sh->galois.find(elt);
     if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
+    if (kit->second.n_digits < l) throw std::runtime_error("key switching key has too few digits");
     step_key[r] = &kit->second;
     step_perm[r] = perm_table(c, elt);
+    step_elt[r] = elt;
   }
+  const bool hoisted = hoist_wanted(c, l, n, B);
+  std::vector<const u64 *> step_corr(n, nullptr);
+  if (hoisted)
+    for (uint32_t r = 0; r < n; r++) step_corr[r] = hoist_corr(c, step_elt[r], l, *step_key[r]);
   // (rotation j, instance b) pairs go out KS_BATCH_MAX at a time: m rotations x B instances per
   // launch set; pair index r = j * B + b, so rotation j's B outputs are one batched handle.
   const uint32_t m_max = std::max<uint32_t>(1, KS_BATCH_MAX / B);
+  // mod-down of a chunk's products into its output buffer (step 3 of switch_key), c0' = perm[2r] added
+  auto mod_down = [&](uint32_t np, u64 *prod_d, const u64 *perm_d, u64 *out_d) {
+    Scratch r(c, (size_t)np * 2 * N);
+    // INTT of the special limbs, job = r*2 + K
+    OpPlain::Params sp{prod_d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
+    // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
+    OpModDown::Params mp{r.d, N, prod_d, (size_t)(l + 1) * N, perm_d, pps, ~0u, out_d, pps, c->k - 1, l};
+    inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * np, mp, 2 * np * l);
+  };
+  auto perm_launch = [&](const PermTables &pt, uint32_t np, u64 *perm_d, uint32_t polys) {
+    ProfScope ps(c, KC_EW);
+    hipLaunchKernelGGL(k_galois_perm_many, dim3(c->N / 512, l, polys * np), dim3(256), 0, c->stream, c->dev, a->d, a->ps, pt,
+                       perm_d, pps, B, polys);
+    HIPCHK(hipGetLastError());
+  };
+  // the unhoisted launch set of one chunk (every launch honours c->dev.guard)
+  auto plain_chunk = [&](uint32_t j0, uint32_t m, u64 *out_d) {
+    const uint32_t np = m * B;
+    PermTables pt{};
+    std::vector<const KeyDev *> keys(np);
+    for (uint32_t j = 0; j < m; j++) {
+      pt.perm[j] = step_perm[j0 + j];
+      for (uint32_t b = 0; b < B; b++) keys[j * B + b] = step_key[j0 + j];
+    }
+    Scratch perm(c, (size_t)np * 2 * pps); // [r][c0 permuted | c1 permuted = key-switch target]
+    perm_launch(pt, np, perm.d, 2);
+    Scratch prod(c, np * prod_bs);
+    switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), np, prod.d);
+    mod_down(np, prod.d, perm.d, out_d);
+  };
   std::vector<evah_ct *> made;
+  std::vector<Buffer *> chunk_buf;
   try {
     for (uint32_t j0 = 0; j0 < n; j0 += m_max) {
       const uint32_t m = std::min(m_max, n - j0), np = m * B;
-      PermTables pt{};
-      std::vector<const KeyDev *> keys(np);
-      for (uint32_t j = 0; j < m; j++) {
-        pt.perm[j] = step_perm[j0 + j];
-        for (uint32_t b = 0; b < B; b++) keys[j * B + b] = step_key[j0 + j];
-      }
       Buffer *ob = buf_new(c, (size_t)np * 2 * pps); // one buffer for the chunk; the m handles are views into it
       ob->refs = 0;
-      try {
-        Scratch perm(c, (size_t)np * 2 * pps); // [r][c0 permuted | c1 permuted = key-switch target]
-        {
-          ProfScope ps(c, KC_EW);
-          hipLaunchKernelGGL(k_galois_perm_many, dim3(c->N / 512, l, 2 * np), dim3(256), 0, c->stream, c->dev, a->d, a->ps, pt,
-                             perm.d, pps, B);
-        }
-        HIPCHK(hipGetLastError());
-        Scratch prod(c, np * prod_bs);
-        switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), np, prod.d);
-        Scratch r(c, (size_t)np * 2 * N);
-        // INTT of the special limbs, job = r*2 + K
-        OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
-                // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
-        OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, perm.d, pps, ~0u, ob->d, pps, c->k - 1, l};
-        inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * np, mp, 2 * np * l);
-      } catch (...) {
-        ob->refs = 1;
-        buf_unref(c, ob);
-        throw;
-      }
+      chunk_buf.push_back(ob);
       for (uint32_t j = 0; j < m; j++) {
         evah_ct *t = new evah_ct;
         t->buf = ob;
@@ -1164,8 +1344,65 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
         made.push_back(t);
       }
     }
+    if (!hoisted) {
+      for (uint32_t j0 = 0, ci = 0; j0 < n; j0 += m_max, ci++) plain_chunk(j0, std::min(m_max, n - j0), chunk_buf[ci]->d);
+    } else {
+      Scratch flag(c, 1 + HOIST_ZERO_CAP); // [0]: zero-coefficient count, then the recorded positions
+      HIPCHK(hipMemsetAsync(flag.d, 0, sizeof(u64), c->stream));
+      const size_t dg_bs = (size_t)(l + 1) * l * N;
+      {
+        // digits of the unrotated c1 of every instance, once: coefficient form (zeros flagged), then
+        // the full transforms under every output prime
+        Scratch t(c, (size_t)B * l * N), dg(c, B * dg_bs);
+        OpPlain::Params ip{a->d + a->ps, t.d, 2 * a->ps, (size_t)l * N, l, 0, 0, {}};
+        ip.zero_list = flag.d;
+        ntt_inverse<OpPlain>(c, ip, B * l);
+        OpKsDigit::Params dp{t.d, dg.d, l, (size_t)l * N, dg_bs, 0, l + 1};
+        ntt_forward<OpKsDigit>(c, dp, B * (l + 1) * l);
+        for (uint32_t j0 = 0, ci = 0; j0 < n; j0 += m_max, ci++) {
+          const uint32_t m = std::min(m_max, n - j0), np = m * B;
+          PermTables pt{};
+          HoistTab ht{};
+          for (uint32_t j = 0; j < m; j++) {
+            pt.perm[j] = ht.perm[j] = step_perm[j0 + j];
+            ht.key[j] = step_key[j0 + j]->d;
+            ht.corr[j] = step_corr[j0 + j];
+            ht.elt[j] = step_elt[j0 + j];
+          }
+          Scratch perm(c, (size_t)np * 2 * pps); // only the c0 slots (even polys) are filled and read
+          perm_launch(pt, np, perm.d, 1);
+          Scratch prod(c, np * prod_bs);
+          {
+            ProfScope ps(c, KC_KSMAC);
+            hipLaunchKernelGGL(k_hoist_mac, dim3(c->N / 512, l + 1, np), dim3(256), 0, c->stream, c->dev, a->d + a->ps, 2 * a->ps,
+                               dg.d, dg_bs, ht, prod.d, prod_bs, l, B);
+            HIPCHK(hipGetLastError());
+            // the terms of recorded zero coefficients (returns at once when there are none)
+            hipLaunchKernelGGL(k_hoist_fix, dim3(c->N / 256, l + 1, np), dim3(256), 0, c->stream, c->dev, flag.d, ht, prod.d, prod_bs, l, B);
+            HIPCHK(hipGetLastError());
+          }
+          mod_down(np, prod.d, perm.d, chunk_buf[ci]->d);
+        }
+      }
+      // exact fallback: the same outputs through the unhoisted launches, each a no-op unless there
+      // were more zero digit coefficients than k_hoist_fix handles
+      struct GuardScope {
+        evah_ctx *c;
+        GuardScope(evah_ctx *c_, const uint32_t *g) : c(c_) { c->dev.guard = g; c->dev.guard_min = HOIST_ZERO_CAP; }
+        ~GuardScope() { c->dev.guard = nullptr; }
+      } gs(c, reinterpret_cast<const uint32_t *>(flag.d));
+      for (uint32_t j0 = 0, ci = 0; j0 < n; j0 += m_max, ci++) plain_chunk(j0, std::min(m_max, n - j0), chunk_buf[ci]->d);
+      if (!c->capturing && std::getenv("EVAH_HOIST_DEBUG")) { // diagnostics: did this call take the fallback?
+        uint32_t f = 0;
+        HIPCHK(hipMemcpyAsync(&f, flag.d, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::fprintf(stderr, "evah_rotate_many: hoisted %u rotations x %u instances, l = %u, zero coefficients = %u\n", n, B, l, f);
+      }
+    }
   } catch (...) {
     for (evah_ct *t : made) evah_ct_free(c, t);
+    if (made.empty())
+      for (Buffer *b : chunk_buf) { b->refs = 1; buf_unref(c, b); }
     throw;
   }
   for (uint32_t r = 0; r < n; r++) outs[r] = made[r];

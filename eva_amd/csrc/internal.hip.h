@@ -161,6 +161,10 @@ struct SharedDev {
   double2 *dec_roots = nullptr; // CKKS decoder: zeta^br(j) (forward special FFT, heap order)
   std::map<uint32_t, KeyDev> galois;
   std::map<uint32_t, uint32_t *> perms;
+  // hoisted rotations (evaluator.hip): NTT of the sign pattern of a Galois element under every prime
+  // ([k][N]) and, per (element, level), the constant it contributes to the key inner product ([2][l+1][N])
+  std::map<uint32_t, u64 *> hoist_sign;
+  std::map<std::pair<uint32_t, uint32_t>, u64 *> hoist_corr;
   double2 *enc_roots = nullptr;     // CKKS encoder: inverse-FFT roots in the order the stages consume them
   double enc_last_root[2] = {0, 0}; // the single root of the last stage (scaled by fix on the host per call)
   uint32_t *enc_slot_map = nullptr; // slot i (and its conjugate, at slots + i) -> FFT input index
@@ -174,6 +178,8 @@ struct SharedDev {
     if (dec_roots) (void)hipFree(dec_roots);
     for (auto &kv : galois) (void)hipFree(kv.second.d);
     for (auto &kv : perms) (void)hipFree(kv.second);
+    for (auto &kv : hoist_sign) (void)hipFree(kv.second);
+    for (auto &kv : hoist_corr) (void)hipFree(kv.second);
     if (d_tables) (void)hipFree(d_tables);
   }
 };
@@ -201,6 +207,11 @@ struct evah_ctx {
   uint32_t fuse_small_blocks = 8192;
   int small_lr = 2; // log2 coefficients per thread of the NTT passes in latency-bound launches (EVAH_SMALL_LR = 2 | 3)
   uint32_t small_lr_blocks = 4096; // ... = launches of at most this many 2048-coefficient tiles (EVAH_SMALL_LR_BLOCKS)
+  // several rotations of one ciphertext: decompose once and permute the transformed digits (hoisting),
+  // when the launch set is at least this many 2048-coefficient tiles of digit transforms.
+  // EVAH_HOIST=0 disables, EVAH_HOIST_MIN_TILES=n sets the threshold.
+  bool hoist = true;
+  uint32_t hoist_min_tiles = 8192;
   int ks_groups = 1;    // output-limb slices per key-switch (EVAH_KS_GROUPS)
   int ks_threads = 64;  // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS): one wave = one
                         // 2^P-point sub-transform per workgroup measured best (barriers are intra-wave)
@@ -335,6 +346,10 @@ inline evah_pt *pt_new(evah_ctx *c, uint32_t limbs, double scale) {
   t->scale = scale;
   return t;
 }
+
+// evaluator.hip: would evah_rotate_many hoist n rotations of one l-limb ciphertext of B instances?
+// (the scheduler groups sibling rotations for it only when it does)
+bool hoist_wanted(const evah_ctx *c, uint32_t l, uint32_t n, uint32_t B);
 
 struct Scratch { // pool-backed temporary, returned on scope exit (stream-ordered reuse)
   evah_ctx *c;

@@ -32,6 +32,7 @@
 namespace evah {
 
 constexpr int NTT_THREADS = 256; // threads per workgroup (max); tile = NTT_THREADS << LR coefficients
+constexpr uint32_t HOIST_ZERO_CAP = 64; // zero digit coefficients a hoisted rotation set corrects individually
 
 // LR = log2(coefficients per thread): 4 -> 16 coefficients / up to 4 stages per LDS round trip,
 // 3 -> 8 coefficients / 3 stages (half the registers, twice the waves in flight)
@@ -177,6 +178,7 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC_rt, int log_tiles) 
   constexpr int NTT_R = 1 << LR;
   constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
   constexpr bool FIRST = (STRIDED != INVERSE);
+  if (cx.skipped()) return;
   const uint32_t tile_idx = blockIdx.x & ((1u << log_tiles) - 1u);
   typename Op::Job jb;
   if (!Op::setup(cx, prm, blockIdx.x >> log_tiles, blockIdx.y, blockIdx.z, jb)) return; // block-uniform
@@ -274,6 +276,7 @@ ntt_inv_fwd_kernel(DevCtx cx, typename Op::Params prm, int log_tiles) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   constexpr int NTT_R = 1 << LR;
   constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
+  if (cx.skipped()) return;
   const uint32_t tile_idx = blockIdx.x & ((1u << log_tiles) - 1u);
   typename Op::Job jb;
   if (!Op::setup(cx, prm, blockIdx.x >> log_tiles, blockIdx.y, blockIdx.z, jb)) return; // block-uniform
@@ -377,6 +380,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
                 int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets, std::conditional_t<MUL, MulTab, NoMul> mul, uint32_t istep,
                 uint32_t nout) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  if (cx.skipped()) return;
   // grid.x carries (tile, instance): instances of one tile are placed 8 block ids apart, i.e. on
   // the same XCD (blocks are dealt round-robin over the 8 XCDs) and close in dispatch order, so
   // instances that share a key find its tile in that XCD's L2.  Speed only, never correctness.
@@ -532,6 +536,9 @@ struct OpPlain {
     int addhalf;
     PtrTab src_tab; // used when src == nullptr: polynomial pp starts at src_tab.p[pp]
     uint32_t pstep = 1; // limb i is modulo primes[prime0 + i * pstep] (limb-sharded values: the shard count)
+    // inverse transforms of hoisted rotations: coefficients that come out 0 are counted in the low
+    // word of zero_list[0] and the first HOIST_ZERO_CAP of them recorded as (poly << 48 | limb << 32 | index)
+    u64 *zero_list = nullptr;
   };
   struct Job {
     uint32_t prime;
@@ -539,6 +546,8 @@ struct OpPlain {
     u64 *dst;
     int addhalf;
     bool lazy;
+    u64 *zero_list;
+    uint32_t pp;
   };
   // jobs = polys * jl: grid.y = limb i, grid.z = poly
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
@@ -549,6 +558,8 @@ struct OpPlain {
     j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
     j.addhalf = p.addhalf;
     j.lazy = false;
+    j.zero_list = p.zero_list;
+    j.pp = pp;
     return true;
   }
   template <bool LZ>
@@ -557,6 +568,10 @@ struct OpPlain {
   }
   static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm,
                                                uint32_t n, u64 v) {
+    if (j.zero_list && v == 0) {
+      const uint32_t at = atomicAdd(reinterpret_cast<uint32_t *>(j.zero_list), 1u);
+      if (at < HOIST_ZERO_CAP) j.zero_list[1 + at] = ((u64)j.pp << 48) | ((u64)j.prime << 32) | n;
+    }
     if (j.addhalf) v = addmod(v, pm.q >> 1, pm.q);
     j.dst[n] = v;
   }

@@ -65,6 +65,8 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     if (const char *e = std::getenv("EVAH_SMALL_LR")) c->small_lr = std::atoi(e) == 3 ? 3 : 2;
     if (const char *e = std::getenv("EVAH_SMALL_LR_BLOCKS")) c->small_lr_blocks = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("EVAH_FUSE_SMALL")) c->fuse_small_blocks = (uint32_t)std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("EVAH_HOIST")) c->hoist = std::atoi(e) != 0;
+    if (const char *e = std::getenv("EVAH_HOIST_MIN_TILES")) c->hoist_min_tiles = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {
       int t = std::atoi(e);
       if (t == 64 || t == 128 || t == 256) c->ks_threads = t;
@@ -166,6 +168,8 @@ int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
     c->fuse_small_blocks = parent->fuse_small_blocks;
     c->small_lr = parent->small_lr;
     c->small_lr_blocks = parent->small_lr_blocks;
+    c->hoist = parent->hoist;
+    c->hoist_min_tiles = parent->hoist_min_tiles;
     c->ks_threads = parent->ks_threads;
     c->ks_groups = parent->ks_groups;
     HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
@@ -306,9 +310,9 @@ void evah_host_free(void *p) {
 // Host <-> device copies of the instances of a batched handle, back to back on the context's
 // stream.  (Measured on MI355X: splitting them over 4 host threads with a copy stream each is
 // slower — 5.1 k vs 6.9 k Sobel DAGs/s — the pageable staging path of the runtime serialises.)
-static void io_copy(evah_ctx *c, uint32_t n, const std::function<hipError_t(uint32_t, hipStream_t)> &copy_one) {
+static void io_copy(evah_ctx *c, uint32_t n, const std::function<hipError_t(uint32_t, hipStream_t)> &copy_one, bool wait = true) {
   for (uint32_t b = 0; b < n; b++) HIPCHK(copy_one(b, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (wait) HIPCHK(hipStreamSynchronize(c->stream));
 }
 
 int evah_ct_upload(evah_ctx *c, uint32_t size, uint32_t limbs, double scale, const uint64_t *data, evah_ct **out) {
@@ -343,11 +347,10 @@ int evah_ct_upload_batch(evah_ctx *c, uint32_t batch, uint32_t size, uint32_t li
 }
 
 // the same from `batch` separate host arrays (each [size][limbs][N]): no host-side concatenation
-int evah_ct_upload_instances(evah_ctx *c, uint32_t batch, uint32_t size, uint32_t limbs, double scale,
-                             const uint64_t *const *data, evah_ct **out) {
-  API_BEGIN
+static void ct_upload_instances(evah_ctx *c, uint32_t batch, uint32_t size, uint32_t limbs, double scale,
+                                const uint64_t *const *data, evah_ct **out, bool wait) {
   use(c);
-  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  if (c->capturing) throw std::logic_error("host transfers cannot be captured into a graph");
   if (batch < 1 || batch > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("batch must be 1..64");
   if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
   if (limbs < 1 || limbs > c->k - 1) throw std::invalid_argument("invalid limb count for this context");
@@ -356,20 +359,33 @@ int evah_ct_upload_instances(evah_ctx *c, uint32_t batch, uint32_t size, uint32_
   try {
     io_copy(c, batch, [&](uint32_t b, hipStream_t st) {
       return hipMemcpyAsync(t->d + each * b, data[b], sizeof(u64) * each, hipMemcpyHostToDevice, st);
-    });
+    }, wait);
   } catch (...) {
     evah_ct_free(c, t);
     throw;
   }
   *out = t;
+}
+int evah_ct_upload_instances(evah_ctx *c, uint32_t batch, uint32_t size, uint32_t limbs, double scale,
+                             const uint64_t *const *data, evah_ct **out) {
+  API_BEGIN
+  ct_upload_instances(c, batch, size, limbs, scale, data, out, true);
+  API_END
+}
+// stream-ordered form: the copies are enqueued on the context's queue and the call returns; the
+// host arrays must stay untouched until evah_ctx_sync(ctx) (pinned memory from evah_host_alloc
+// makes the copies overlap other queues' kernels; pageable memory is staged by the runtime)
+int evah_ct_upload_instances_async(evah_ctx *c, uint32_t batch, uint32_t size, uint32_t limbs, double scale,
+                                   const uint64_t *const *data, evah_ct **out) {
+  API_BEGIN
+  ct_upload_instances(c, batch, size, limbs, scale, data, out, false);
   API_END
 }
 
 // instance b of a batched handle -> out[b] ([size][limbs][N] each), all instances in one call
-int evah_ct_download_instances(evah_ctx *c, const evah_ct *ct, uint64_t *const *out) {
-  API_BEGIN
+static void ct_download_instances(evah_ctx *c, const evah_ct *ct, uint64_t *const *out, bool wait) {
   use(c);
-  if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
+  if (c->capturing) throw std::logic_error("host transfers cannot be captured into a graph");
   acquire(c, ct->buf);
   const size_t row = sizeof(u64) * (size_t)ct->limbs * c->N;
   const bool dense = ct->ps == (size_t)ct->limbs * c->N; // not a mod-switched view: one linear copy per instance
@@ -377,7 +393,18 @@ int evah_ct_download_instances(evah_ctx *c, const evah_ct *ct, uint64_t *const *
     const u64 *src = ct->d + (size_t)b * ct->size * ct->ps;
     if (dense) return hipMemcpyAsync(out[b], src, row * ct->size, hipMemcpyDeviceToHost, st);
     return hipMemcpy2DAsync(out[b], row, src, sizeof(u64) * ct->ps, row, ct->size, hipMemcpyDeviceToHost, st);
-  });
+  }, wait);
+}
+int evah_ct_download_instances(evah_ctx *c, const evah_ct *ct, uint64_t *const *out) {
+  API_BEGIN
+  ct_download_instances(c, ct, out, true);
+  API_END
+}
+// stream-ordered form: out[b] holds the data after evah_ctx_sync(ctx); the handle may be freed right
+// after this call (the pool recycles in queue order)
+int evah_ct_download_instances_async(evah_ctx *c, const evah_ct *ct, uint64_t *const *out) {
+  API_BEGIN
+  ct_download_instances(c, ct, out, false);
   API_END
 }
 

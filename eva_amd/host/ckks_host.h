@@ -493,6 +493,12 @@ template <class T> struct HostAlloc {
     if (*reinterpret_cast<uint64_t *>(base) == 0x50494e4eull) evah_host_free(base);
     else ::operator delete(base);
   }
+  // resize() leaves new words uninitialised (every user overwrites them: downloads, encrypt): a
+  // value-initialising resize of a 256-instance output batch would memset 134 MB on the host
+  template <class U, class... A> void construct(U *p, A &&...a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+    else ::new ((void *)p) U(std::forward<A>(a)...);
+  }
   template <class U> bool operator==(const HostAlloc<U> &) const { return true; }
   template <class U> bool operator!=(const HostAlloc<U> &) const { return false; }
 };

@@ -191,7 +191,9 @@ public:
   // input becomes one batched device handle ([B][size][limbs][N]); from there each node is a
   // single backend call that covers all B instances.  Plaintext / raw inputs are shared by the
   // batch, so they have to be identical across the instances.
-  void set_inputs_batch(const std::vector<const HipValuation *> &batch) {
+  // async: the uploads are only enqueued (evah_ct_upload_instances_async); the caller keeps the
+  // valuations alive and synchronises the queue before touching them
+  void set_inputs_batch(const std::vector<const HipValuation *> &batch, bool async = false) {
     const uint32_t B = (uint32_t)batch.size();
     for (auto &kv : batch[0]->values) {
       TermId t = program.input(kv.first);
@@ -208,7 +210,7 @@ public:
           ptrs[b] = (const uint64_t *)c.data.data();
         }
         evah_ct *h = nullptr;
-        chk(evah_ct_upload_instances(ctx, B, c0->size, c0->limbs, c0->scale, ptrs.data(), &h));
+        chk((async ? evah_ct_upload_instances_async : evah_ct_upload_instances)(ctx, B, c0->size, c0->limbs, c0->scale, ptrs.data(), &h));
         objects[t] = std::make_shared<CtHandle>(ctx, h);
       } else if (auto *p = std::get_if<HostPlain>(&kv.second)) {
         check_shape(kv.first, *p);
@@ -231,8 +233,9 @@ public:
       }
     }
   }
-  // outputs of a batched run, split back into one valuation per instance
-  void get_outputs_batch(std::vector<HipValuation> &outs) {
+  // outputs of a batched run, split back into one valuation per instance (outs[0..n)).  async: the
+  // downloads are only enqueued; the words are valid after the queue is synchronised
+  void get_outputs_batch(HipValuation *outs, size_t n_outs, bool async = false) {
     for (auto &kv : program.outputs()) {
       auto &o = objects[kv.second];
       if (auto *c = std::get_if<std::shared_ptr<CtHandle>>(&o)) {
@@ -240,7 +243,7 @@ public:
         uint32_t B = 1;
         chk(evah_ct_info((*c)->h, &hc.size, &hc.limbs, &hc.scale));
         chk(evah_ct_batch((*c)->h, &B));
-        if (B != outs.size()) throw std::runtime_error("Output " + kv.first + " does not depend on an encrypted input of the batch");
+        if (B != n_outs) throw std::runtime_error("Output " + kv.first + " does not depend on an encrypted input of the batch");
         const size_t each = (size_t)hc.size * hc.limbs * host.N;
         std::vector<uint64_t *> ptrs(B);
         for (uint32_t b = 0; b < B; b++) {
@@ -249,16 +252,16 @@ public:
           outs[b].values[kv.first] = std::move(one);
           ptrs[b] = (uint64_t *)std::get<HostCipher>(outs[b].values[kv.first]).data.data();
         }
-        chk(evah_ct_download_instances(ctx, (*c)->h, ptrs.data()));
+        chk((async ? evah_ct_download_instances_async : evah_ct_download_instances)(ctx, (*c)->h, ptrs.data()));
       } else {
         if (auto *p = std::get_if<std::shared_ptr<PtHandle>>(&o)) {
           HostPlain hp;
           chk(evah_pt_info((*p)->h, &hp.limbs, &hp.scale));
           hp.data.resize((size_t)hp.limbs * host.N);
           chk(evah_pt_download(ctx, (*p)->h, (uint64_t *)hp.data.data()));
-          for (auto &ov : outs) ov.values[kv.first] = hp;
+          for (size_t b = 0; b < n_outs; b++) outs[b].values[kv.first] = hp;
         } else if (auto *r = std::get_if<std::vector<double>>(&o)) {
-          for (auto &ov : outs) ov.values[kv.first] = *r;
+          for (size_t b = 0; b < n_outs; b++) outs[b].values[kv.first] = *r;
         } else {
           throw std::runtime_error("Output " + kv.first + " was not computed");
         }
@@ -798,47 +801,51 @@ public:
   std::vector<HipValuation> execute_batch(Program &program, const std::vector<const HipValuation *> &inputs) {
     ensure_device();
     if (batch_chunk < 1 || batch_chunk > 64) throw std::runtime_error("batch_chunk must be 1..64");
-    std::vector<HipValuation> all;
-    all.reserve(inputs.size());
-    // groups alternate between two issue queues and are pipelined by one: while the device works
-    // on group g the host uploads and enqueues group g+1, and only then drains g's outputs
+    std::vector<HipValuation> all(inputs.size());
+    // Groups alternate between two issue queues and nothing waits in between: each group's uploads,
+    // launches and downloads are enqueued in queue order (evah_ct_*_instances_async), so the copies
+    // of one group overlap the kernels of the other and the host never idles the device.  Device
+    // memory stays at two groups' working sets (the pools recycle in queue order); the inputs belong
+    // to the caller and the outputs are allocated up front, so both outlive the final synchronisation.
     if (!batch_fork) batch_fork = std::make_unique<Fork>(dev->h);
     evah_ctx *qs[2] = {dev->h, batch_fork->h};
-    std::unique_ptr<HipExecutor> prev;
-    size_t prev_n = 0;
-    auto drain = [&]() {
-      if (!prev) return;
-      std::vector<HipValuation> outs(prev_n);
-      prev->get_outputs_batch(outs);
-      for (auto &o : outs) all.push_back(std::move(o));
-      prev.reset();
-    };
     // constants (Constant / Encode nodes and raw arithmetic on them) are evaluated once, by the
     // first group, and shared by all groups: their plaintexts stay resident for the whole call
     std::vector<char> done;
     std::vector<HipExecutor::RuntimeValue> consts;
+    auto finish = [&]() {
+      int rc0 = evah_ctx_sync(qs[0]), rc1 = evah_ctx_sync(qs[1]);
+      chk(rc0);
+      chk(rc1);
+    };
     size_t g = 0;
-    for (size_t i0 = 0; i0 < inputs.size(); i0 += batch_chunk, g++) {
-      const size_t n = std::min<size_t>(batch_chunk, inputs.size() - i0);
-      std::vector<const HipValuation *> chunk(inputs.begin() + i0, inputs.begin() + i0 + n);
-      auto ex = std::make_unique<HipExecutor>(program, *host, std::vector<evah_ctx *>{qs[g & 1]});
-      if (g == 0) {
-        done = ex->prepare_constants();
-        consts.resize(program.size());
-        for (TermId t = 0; t < program.size(); t++)
-          if (done[t]) consts[t] = ex->value(t);
-      } else {
-        for (TermId t = 0; t < program.size(); t++)
-          if (done[t]) ex->set_value(t, consts[t]);
+    const bool bounded = std::getenv("EVA_BATCH_BOUNDED") ? std::atoi(std::getenv("EVA_BATCH_BOUNDED")) != 0 : false;
+    try {
+      for (size_t i0 = 0; i0 < inputs.size(); i0 += batch_chunk, g++) {
+        const size_t n = std::min<size_t>(batch_chunk, inputs.size() - i0);
+        std::vector<const HipValuation *> chunk(inputs.begin() + i0, inputs.begin() + i0 + n);
+        if (bounded && g >= 2) chk(evah_ctx_sync(qs[g & 1])); // group g-2 (same queue) has left the device
+        HipExecutor ex(program, *host, std::vector<evah_ctx *>{qs[g & 1]});
+        if (g == 0) {
+          done = ex.prepare_constants();
+          consts.resize(program.size());
+          for (TermId t = 0; t < program.size(); t++)
+            if (done[t]) consts[t] = ex.value(t);
+        } else {
+          for (TermId t = 0; t < program.size(); t++)
+            if (done[t]) ex.set_value(t, consts[t]);
+        }
+        ex.set_inputs_batch(chunk, true);
+        if (library_scheduler) ex.run_library(&done, true);
+        else run_counted(program, ex, &done);
+        ex.get_outputs_batch(all.data() + i0, n, true);
       }
-      ex->set_inputs_batch(chunk);
-      if (library_scheduler) ex->run_library(&done, true);
-      else run_counted(program, *ex, &done);
-      drain();
-      prev = std::move(ex);
-      prev_n = n;
+    } catch (...) {
+      (void)evah_ctx_sync(qs[0]); // copies in flight still target `all` and the caller's inputs
+      (void)evah_ctx_sync(qs[1]);
+      throw;
     }
-    drain();
+    finish();
     return all;
   }
 

@@ -93,6 +93,13 @@ int evah_ct_upload_instances(evah_ctx *ctx, uint32_t batch, uint32_t size, uint3
                              const uint64_t *const *data, evah_ct **out);
 /* every instance of a batched handle into its own host array out[b] ([size][limbs][N] each) */
 int evah_ct_download_instances(evah_ctx *ctx, const evah_ct *ct, uint64_t *const *out);
+/* Stream-ordered forms of the two calls above, for pipelining a loop of SEALPublic::execute calls
+ * (seal.cpp:104-122) over several queues: the copies are enqueued on ctx's queue and the call returns.
+ * Host arrays must stay valid and untouched until evah_ctx_sync(ctx); use evah_host_alloc memory for
+ * copies that overlap other queues' kernels.  The handle passed to the download may be freed right away. */
+int evah_ct_upload_instances_async(evah_ctx *ctx, uint32_t batch, uint32_t size, uint32_t limbs, double scale,
+                                   const uint64_t *const *data, evah_ct **out);
+int evah_ct_download_instances_async(evah_ctx *ctx, const evah_ct *ct, uint64_t *const *out);
 int evah_ct_batch(const evah_ct *ct, uint32_t *batch);
 /* n single ciphertexts (same shape, scale) -> one batched handle; device-side copies */
 int evah_ct_stack(evah_ctx *ctx, const evah_ct *const *cts, uint32_t n, evah_ct **out);
@@ -182,7 +189,11 @@ int evah_multiply_relinearize_rescale_many(evah_ctx *ctx, const evah_ct *const *
 int evah_rotate(evah_ctx *ctx, const evah_ct *a, int32_t steps, evah_ct **out);
 /* n (<= 64) non-zero rotations of the SAME ciphertext — n evaluator.rotate_vector calls
  * (seal_executor.h:181) issued as one set of n-times-wider launches; outs[r] == evah_rotate(a, steps[r]).
- * The host executor groups the sibling rotations of a term (convolution windows) into one call. */
+ * The host executor groups the sibling rotations of a term (convolution windows) into one call.
+ * Throughput-sized sets are hoisted: c1 is decomposed once and every rotation's key inner product is
+ * formed from the permuted digits plus a per-(element, level) constant — the residues are exactly
+ * those of rotating first and decomposing after, at 1/n of the transforms.
+ * EVAH_HOIST=0 disables, EVAH_HOIST_MIN_TILES sets the size from which it is used. */
 int evah_rotate_many(evah_ctx *ctx, const evah_ct *a, const int32_t *steps, uint32_t n, evah_ct **outs);
 /* n (<= 64) rotations of SEVERAL ciphertexts of one level, pair i = (cts[i], steps[i] != 0): the
  * sibling rotations of independent sub-expressions (seal_executor.h:181/188 called once per node)

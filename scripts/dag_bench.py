@@ -1,7 +1,7 @@
 """execute() wall time for the BASELINE DAG configs on one GPU vs the CPU oracle walking the same
 compiled DAG (1 core): C1 README polynomial, C2 Sobel N=2^13, C3 Harris N=2^15, one instance of
 C4 (Sobel N=2^14) and C5 (3x3 convolution + depth-8 squaring chain, N=2^16, 13 primes).
-usage: dag_bench.py [reps] [--cpu]
+usage: dag_bench.py [reps] [--cpu] [--only C1,C5]
 
 The GPU legs use only the product.  --cpu adds the reported CPU baseline of each DAG — the same role
 as bench.py's cpu_baseline leg — by walking the compiled DAG in C over the CPU oracle (oracle/eva_oracle_dag.c through
@@ -18,8 +18,11 @@ from test_gpu_e2e import _harris, _image
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
 no_cpu = "--cpu" not in sys.argv
+only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
 
 def run(name, prog, N, inputs=None, pad_primes=0):
+    if only and name.split()[0] not in only:
+        return
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
     if N:
         params.poly_modulus_degree = N

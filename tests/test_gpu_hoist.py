@@ -1,0 +1,200 @@
+"""Hoisted rotations (several rotations of ONE ciphertext share the digit decomposition of c1;
+eva_amd/csrc/evaluator.hip: k_hoist_mac) against the CPU oracle's rotate-then-switch-key, which
+follows SEAL's Evaluator::rotate_internal (/root/reference/eva/seal/seal_executor.h:181,188).
+The contexts are created with EVAH_HOIST_MIN_TILES=0, so every rotate_many of >= 2 steps takes
+the hoisted path; the zero-coefficient cases exercise the per-coefficient correction (k_hoist_fix)
+and, beyond its capacity, the guarded unhoisted fallback."""
+import os
+
+import numpy as np
+import pytest
+
+from eva_amd import backend
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    (2048, [40, 20, 40, 41]),
+    (4096, [60, 20, 60, 60]),
+    (8192, [60, 30, 60, 60, 60]),
+    (16384, [60, 20, 60, 60, 60, 60]),
+    (32768, [60] * 5),
+    (65536, [60] * 4),
+    (4096, [40] * 19 + [41]),  # l = 19 digits
+]
+STEPS = [1, 2, 64, 65, -3, 129, -64, 1000]
+
+
+class Env:
+    def __init__(self, N, bits, hoist=True):
+        old = {k: os.environ.get(k) for k in ("EVAH_HOIST", "EVAH_HOIST_MIN_TILES")}
+        os.environ["EVAH_HOIST"] = "1" if hoist else "0"
+        os.environ["EVAH_HOIST_MIN_TILES"] = "0"
+        try:
+            self.N = N
+            self.primes = po.coeff_modulus_create(N, bits)
+            self.k = len(self.primes)
+            self.o = po.Oracle(N, self.primes)
+            self.g = backend.Context(N, self.primes)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        self.rng = np.random.default_rng(7 * N + len(bits))
+        self.keys = {}
+
+    def rand(self, size, l):
+        return np.stack([np.stack([self.rng.integers(0, self.primes[i], size=self.N, dtype=np.uint64)
+                                   for i in range(l)]) for _ in range(size)])
+
+    def key_for(self, step):
+        if step not in self.keys:
+            key = np.stack([np.stack([np.stack([self.rng.integers(0, self.primes[i], size=self.N, dtype=np.uint64)
+                                                for i in range(self.k)]) for _ in range(2)])
+                            for _ in range(self.k - 1)])
+            self.g.upload_galois_key(self.g.galois_elt_from_step(step), key)
+            self.keys[step] = key
+        return self.keys[step]
+
+
+_envs = {}
+
+
+def env(cfg):
+    key = (cfg[0], tuple(cfg[1]))
+    if key not in _envs:
+        _envs[key] = Env(*cfg)
+    return _envs[key]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"N{c[0]}_k{len(c[1])}")
+def test_hoisted_rotations_bit_exact(cfg):
+    e = env(cfg)
+    l = e.k - 1
+    a2 = e.rand(2, l)
+    A2 = e.g.upload_ct(a2, 2.0 ** 20)
+    steps = STEPS if e.N >= 4096 else STEPS[:-1]
+    for st in steps:
+        e.key_for(st)
+    outs = e.g.rotate_many(A2, steps)
+    for st, o in zip(steps, outs):
+        assert o.info() == (2, l, 2.0 ** 20)
+        assert np.array_equal(o.download(), e.o.rotate(a2, st, e.keys[st])), f"hoisted rotate step {st}"
+    del outs
+    # one level down through a mod-switched view (different level => different constants), two steps
+    if l > 1:
+        ms = e.g.mod_switch(A2)
+        o = e.g.rotate_many(ms, [65, -3])
+        low = e.o.mod_switch(a2)
+        assert np.array_equal(o[0].download(), e.o.rotate(low, 65, e.keys[65]))
+        assert np.array_equal(o[1].download(), e.o.rotate(low, -3, e.keys[-3]))
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[2], CONFIGS[3]], ids=lambda c: f"N{c[0]}")
+def test_hoisted_rotations_of_a_batched_handle(cfg):
+    """B instances x n rotations: more (rotation, instance) pairs than one launch set holds."""
+    e = env(cfg)
+    l = e.k - 1
+    B = 24
+    inst = [e.rand(2, l) for _ in range(B)]
+    H = e.g.upload_ct_batch(np.stack(inst), 2.0 ** 30)
+    steps = [1, 64, 65, -3, 129]
+    for st in steps:
+        e.key_for(st)
+    outs = e.g.rotate_many(H, steps)
+    for st, o in zip(steps, outs):
+        got = o.download()
+        for b in (0, 7, B - 1):
+            assert np.array_equal(got[b], e.o.rotate(inst[b], st, e.keys[st])), f"step {st} instance {b}"
+
+
+@pytest.mark.parametrize("case", ["transparent", "one_zero_flipped", "one_zero_unflipped", "zero_limb", "several_zeros"])
+def test_zero_digit_coefficients_stay_exact(case):
+    """The hoisting identity needs non-zero digit coefficients at the sign-flipped positions; zero
+    coefficients must still give SEAL's bits: a few through the per-coefficient correction, many
+    (transparent ciphertext, a zero limb) through the guarded unhoisted launches."""
+    e = env(CONFIGS[2])
+    l = e.k - 1
+    N = e.N
+    a2 = e.rand(2, l)
+    steps = [1, 65, -3]
+    for st in steps:
+        e.key_for(st)
+    if case == "transparent":
+        a2[1] = 0
+    elif case == "zero_limb":
+        a2[1][1] = 0
+    elif case == "several_zeros":
+        for limb, count in ((0, 5), (2, 3), (l - 1, 1)):
+            x = e.rng.integers(1, e.primes[limb], size=N, dtype=np.uint64)
+            x[e.rng.choice(N, size=count, replace=False)] = 0
+            a2[1][limb] = e.o.ntt(limb, x)
+    else:
+        # coefficient form of limb 0 of c1 with exactly one zero, at a position whose image under the
+        # first rotation is (or is not) sign-flipped: index k maps to k*elt mod 2N, flipped iff >= N
+        elt = po.galois_elt_from_step(N, steps[0])
+        want = case == "one_zero_flipped"
+        kpos = next(k for k in range(1, N) if (((k * elt) >> int(np.log2(N))) & 1 == 1) == want)
+        x = e.rng.integers(1, e.primes[0], size=N, dtype=np.uint64)
+        x[kpos] = 0
+        a2[1][0] = e.o.ntt(0, x)
+    A2 = e.g.upload_ct(a2, 2.0 ** 20)
+    outs = e.g.rotate_many(A2, steps)
+    for st, o in zip(steps, outs):
+        assert np.array_equal(o.download(), e.o.rotate(a2, st, e.keys[st])), f"{case}: step {st}"
+
+
+def test_zero_coefficients_in_some_instances_of_a_batched_handle():
+    e = env(CONFIGS[2])
+    l = e.k - 1
+    B = 6
+    inst = [e.rand(2, l) for _ in range(B)]
+    for b, limb, count in ((1, 0, 2), (4, 1, 1), (4, 3, 2)):
+        x = e.rng.integers(1, e.primes[limb], size=e.N, dtype=np.uint64)
+        x[e.rng.choice(e.N, size=count, replace=False)] = 0
+        inst[b][1][limb] = e.o.ntt(limb, x)
+    steps = [1, 2, 65, -3, -64]
+    for st in steps:
+        e.key_for(st)
+    outs = e.g.rotate_many(e.g.upload_ct_batch(np.stack(inst), 2.0 ** 30), steps)
+    for st, o in zip(steps, outs):
+        got = o.download()
+        for b in range(B):
+            assert np.array_equal(got[b], e.o.rotate(inst[b], st, e.keys[st])), f"step {st} instance {b}"
+
+
+def _launch_classes(e, A2, steps):
+    e.g.profile(True)
+    e.g.profile_reset()
+    outs = e.g.rotate_many(A2, steps)
+    e.g.sync()
+    prof = e.g.profile_get()
+    e.g.profile(False)
+    return outs, prof
+
+
+def test_the_hoisted_path_is_the_one_that_runs_and_can_be_disabled():
+    """Launch accounting: hoisted = ONE inverse transform set of c1 and full digit transforms
+    (ksdigit_pass2 launches exist) whatever the number of rotations; disabled = the fused
+    per-rotation key switch (no stand-alone second digit pass)."""
+    cfg = CONFIGS[2]
+    steps = [1, 2, 65]
+    e1 = env(cfg)
+    for st in steps:
+        e1.key_for(st)
+    l = e1.k - 1
+    a2 = e1.rand(2, l)
+    outs, prof = _launch_classes(e1, e1.g.upload_ct(a2, 2.0 ** 20), steps)
+    assert prof["ksdigit_pass2"][0] >= 1, prof
+    for st, o in zip(steps, outs):
+        assert np.array_equal(o.download(), e1.o.rotate(a2, st, e1.keys[st]))
+    e0 = Env(*cfg, hoist=False)
+    for st in steps:
+        e0.key_for(st)
+    outs, prof = _launch_classes(e0, e0.g.upload_ct(a2, 2.0 ** 20), steps)
+    assert prof["ksdigit_pass2"][0] == 0, prof
+    for st, o in zip(steps, outs):
+        assert np.array_equal(o.download(), e0.o.rotate(a2, st, e0.keys[st]))
