@@ -68,6 +68,7 @@ _SIGS = {
     "evah_execute": [_vp, _vp, C.c_uint32, _vp, C.c_uint32],
     "evah_weighted_sum": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_rotate_pairs": [_vp, _vpp, C.POINTER(C.c_int32), C.c_uint32, _vpp],
+    "evah_multiply_plain_many": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_rescale_many": [_vp, _vpp, C.c_uint32, C.c_uint32, _vpp],
     "evah_relinearize_many": [_vp, _vpp, C.c_uint32, _vpp],
     "evah_pt_encode": [_vp, C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_double, _vpp],
@@ -544,6 +545,14 @@ class Context:
         ib = (C.c_void_p * n)(*[ct.h for ct in cts_b])
         outs = (C.c_void_p * n)()
         _chk(_lib.evah_multiply_many(self.h, ia, ib, n, outs))
+        return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n)]
+
+    def multiply_plain_many(self, cts, pts):
+        n = len(cts)
+        ia = (C.c_void_p * n)(*[ct.h for ct in cts])
+        ib = (C.c_void_p * n)(*[pt.h for pt in pts])
+        outs = (C.c_void_p * n)()
+        _chk(_lib.evah_multiply_plain_many(self.h, ia, ib, n, outs))
         return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n)]
 
     # ---- graph capture of a sequence of calls on this context (single queue)

@@ -162,6 +162,21 @@ k_mul_plain(DevCtx cx, const u64 *a, size_t a_ps, const u64 *pt, u64 *out, size_
   st2(out + p * o_ps + off, r);
 }
 
+// K6 batched: n independent multiply_plain of one shape in one launch; grid.z = instance * size + poly
+struct MpTab {
+  const u64 *ct[KS_BATCH_MAX], *pt[KS_BATCH_MAX];
+  uint32_t ct_ps[KS_BATCH_MAX]; // poly strides in units of N coefficients
+};
+__global__ void __launch_bounds__(256)
+k_mul_plain_many(DevCtx cx, MpTab tab, uint32_t size, u64 *out, size_t o_ps) {
+  EW_SETUP
+  const uint32_t inst = p / size, poly = p - inst * size;
+  ulonglong2 x = ld2(tab.ct[inst] + (size_t)poly * tab.ct_ps[inst] * cx.N + off), y = ld2(tab.pt[inst] + off), r;
+  r.x = mulmod(x.x, y.x, pm);
+  r.y = mulmod(x.y, y.y, pm);
+  st2(out + p * o_ps + off, r);
+}
+
 // K8: NTT-domain Galois automorphism out[p][i][n] = in[p][i][perm[n]]
 __global__ void __launch_bounds__(256)
 k_galois_perm(DevCtx cx, const u64 *a, size_t a_ps, const uint32_t *perm, u64 *out, size_t o_ps) {
@@ -494,6 +509,7 @@ struct KsBatch { // one launch worth of key-switches: regular strides, irregular
   PtrTab targets{}; // used when the targets are separate allocations (target == nullptr)
   const MulTab *mul = nullptr; // fused multiply: the target of instance b is d2 = a1 b1 of product b
   uint32_t istep = 1, nout = 0; // output limbs I = i0 + y * istep; nout = rows per polynomial of prod (0: l + 1)
+  u64 *r_out = nullptr; // != nullptr: the special row leaves as the first inverse pass of the mod-down (INVSP)
 };
 template <int P, int LR>
 static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scratch, const KsBatch &kb, u64 *prod, uint32_t l) {
@@ -511,9 +527,13 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   auto go = [&](auto kernel, const auto &mt) {
     hipLaunchKernelGGL(kernel, dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev, target, kb.target_bs, scratch,
                        kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n, kb.targets, mt, kb.istep,
-                       kb.nout ? kb.nout : l + 1);
+                       kb.nout ? kb.nout : l + 1, kb.r_out);
   };
-  if ((tile >> LR) <= 64) {
+  if (kb.r_out && ((tile >> LR) > 64 || kb.istep != 1)) throw std::logic_error("fused special-row inverse pass needs the one-wave key-switch kernel");
+  if (kb.r_out) {
+    if (kb.mul) go(ks_inner_kernel<P, LR, 64, true, true>, *kb.mul);
+    else go(ks_inner_kernel<P, LR, 64, false, true>, NoMul{});
+  } else if ((tile >> LR) <= 64) {
     if (kb.mul) go(ks_inner_kernel<P, LR, 64, true>, *kb.mul);
     else go(ks_inner_kernel<P, LR, 64, false>, NoMul{});
   } else {
@@ -578,11 +598,14 @@ template <class Op> static void launch_inv_fwd(evah_ctx *c, const typename Op::P
 }
 // inverse transform of the source limb(s) (InvOp jobs) followed by the forward transforms of Op:
 // four launches, or three when the forward launch is too small to fill the chip
+// inv_pass1_done: the contiguous inverse pass already left its intermediate in ip.dst (fused into the
+// key-switch kernel); only ever set when fuse_small_launch(c, fwd_jobs) holds
 template <class InvOp, class Op>
 static void inverse_then_forward(evah_ctx *c, const typename InvOp::Params &ip, uint32_t inv_jobs, const typename Op::Params &fp,
-                                 uint32_t fwd_jobs) {
+                                 uint32_t fwd_jobs, bool inv_pass1_done = false) {
+  if (inv_pass1_done && !fuse_small_launch(c, fwd_jobs)) throw std::logic_error("fused inverse pass outside the small-launch form");
   if (fuse_small_launch(c, fwd_jobs)) {
-    launch_pass_p<false, true, InvOp>(c, c->logN / 2, ip, inv_jobs); // contiguous inverse pass: lazy intermediate in ip.dst
+    if (!inv_pass1_done) launch_pass_p<false, true, InvOp>(c, c->logN / 2, ip, inv_jobs); // contiguous inverse pass: lazy intermediate in ip.dst
     launch_inv_fwd<Op>(c, fp, fwd_jobs);
     launch_pass_p<false, false, Op>(c, c->logN / 2, fp, fwd_jobs);
   } else {
@@ -596,8 +619,12 @@ static void inverse_then_forward(evah_ctx *c, const typename InvOp::Params &ip, 
 // steps 1-2 of switch_key for a batch of n (target, key) pairs in one set of launches:
 // prod[b][K][I] (I <= l, slot l = special prime) = sum_J op_b(I,J) * key_b[J][K].
 // target_b = target + b * target_bs; prod_b = prod_d + b * 2 (l+1) N.
-static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t target_bs, const KeyDev *const *keys,
-                                uint32_t n, u64 *prod_d, const PtrTab *target_tab = nullptr, const MulTab *mul = nullptr) {
+// r_small != nullptr: the caller will mod-down through the latency-bound launch form and offers
+// r_small[2 n][N] for the special rows' first inverse pass; returns true when that pass was done
+// here (fused into the key-switch kernel) — the special rows of prod are then NOT written.
+static bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t target_bs, const KeyDev *const *keys,
+                                uint32_t n, u64 *prod_d, const PtrTab *target_tab = nullptr, const MulTab *mul = nullptr,
+                                u64 *r_small = nullptr) {
   const size_t N = c->N;
   if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::runtime_error("key-switch batch out of range");
   KsBatch kb;
@@ -633,8 +660,10 @@ static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size
     dp.i0 = kb.i0 = 0;
     dp.ni = kb.ni = l + 1;
     launch_inv_fwd<OpKsDigit>(c, dp, n * (l + 1) * l);
+    const uint32_t max_tile = (uint32_t)c->ks_threads << 2;
+    if (r_small && c->fuse_special_inv && (std::min<uint32_t>(c->N, max_tile) >> 2) <= 64) kb.r_out = r_small;
     launch_ks_inner(c, c->logN / 2, target, sc.d, kb, prod_d, l);
-    return;
+    return kb.r_out != nullptr;
   }
   if (c->fuse_mac) { // 128-bit accumulation of lazy (<16q) products, folded every 16 digits
     // Output limbs are processed in slices so that a slice's converted digits (ni * l * N words)
@@ -662,20 +691,21 @@ static void switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size
       HIPCHK(hipGetLastError());
     }
   }
+  return false;
 }
 
 static void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev &key, const u64 *add,
                        size_t add_ps, uint32_t add_polys, u64 *out, size_t out_ps) {
   const size_t N = c->N;
   Scratch prod(c, (size_t)2 * (l + 1) * N);    // [K][l+1][N]
-  const KeyDev *kp = &key;
-  switch_key_products(c, l, target, 0, &kp, 1, prod.d);
-  // 3. mod-down by the special prime: INTT(special limb) + P/2, then per-limb NTT + combine
   Scratch r(c, 2 * N);
+  const KeyDev *kp = &key;
+  const bool inv1 = switch_key_products(c, l, target, 0, &kp, 1, prod.d, nullptr, nullptr, fuse_small_launch(c, 2 * l) ? r.d : nullptr);
+  // 3. mod-down by the special prime: INTT(special limb) + P/2, then per-limb NTT + combine
   OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
     OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, add, add_ps, add_polys, out, out_ps,
                        c->k - 1, l};
-  inverse_then_forward<OpPlain, OpModDown>(c, sp, 2, mp, 2 * l);
+  inverse_then_forward<OpPlain, OpModDown>(c, sp, 2, mp, 2 * l, inv1);
 }
 
 bool hoist_wanted(const evah_ctx *c, uint32_t l, uint32_t n, uint32_t B) {
@@ -918,6 +948,50 @@ int evah_multiply_plain(evah_ctx *c, const evah_ct *a, const evah_pt *b, evah_ct
   EW_LAUNCH(k_mul_plain, ew_grid(c, a->limbs, a->size * a->batch), dim3(256), 0, c->stream, c->dev, a->d, a->ps, b->d, o->d, o->ps);
   HIPCHK(hipGetLastError());
   *out = o;
+  API_END
+}
+
+// n (<= 64) independent multiply_plain calls of one shape (size, limbs) as one launch
+int evah_multiply_plain_many(evah_ctx *c, const evah_ct *const *cts, const evah_pt *const *pts, uint32_t n, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("multiply_plain_many handles 1..64 products per call");
+  const uint32_t size = cts[0]->size, l = cts[0]->limbs;
+  const size_t N = c->N, ops = (size_t)l * N;
+  MpTab tab{};
+  std::vector<double> scales(n);
+  for (uint32_t i = 0; i < n; i++) {
+    const evah_ct *a = cts[i];
+    const evah_pt *b = pts[i];
+    if (a->batch != 1) throw std::invalid_argument("multiply_plain_many takes single ciphertexts");
+    if (a->size != size || a->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    if (b->limbs != l) throw std::invalid_argument("encrypted and plain parameter mismatch");
+    scales[i] = a->scale * b->scale;
+    check_scale(c, scales[i], l);
+    acquire(c, a->buf);
+    acquire(c, b->buf);
+    tab.ct[i] = a->d;
+    tab.pt[i] = b->d;
+    tab.ct_ps[i] = (uint32_t)(a->ps / N);
+  }
+  Buffer *ob = buf_new(c, (size_t)n * size * ops);
+  EW_LAUNCH(k_mul_plain_many, ew_grid(c, l, n * size), dim3(256), 0, c->stream, c->dev, tab, size, ob->d, ops);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    buf_unref(c, ob);
+    HIPCHK(e);
+  }
+  ob->refs = (int)n;
+  for (uint32_t i = 0; i < n; i++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)i * size * ops;
+    t->size = size;
+    t->limbs = l;
+    t->ps = ops;
+    t->scale = scales[i];
+    outs[i] = t;
+  }
   API_END
 }
 
@@ -1294,13 +1368,12 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
   // launch set; pair index r = j * B + b, so rotation j's B outputs are one batched handle.
   const uint32_t m_max = std::max<uint32_t>(1, KS_BATCH_MAX / B);
   // mod-down of a chunk's products into its output buffer (step 3 of switch_key), c0' = perm[2r] added
-  auto mod_down = [&](uint32_t np, u64 *prod_d, const u64 *perm_d, u64 *out_d) {
-    Scratch r(c, (size_t)np * 2 * N);
+  auto mod_down = [&](uint32_t np, u64 *prod_d, const u64 *perm_d, u64 *out_d, u64 *r_d, bool inv1) {
     // INTT of the special limbs, job = r*2 + K
-    OpPlain::Params sp{prod_d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
+    OpPlain::Params sp{prod_d + (size_t)l * N, r_d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
     // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
-    OpModDown::Params mp{r.d, N, prod_d, (size_t)(l + 1) * N, perm_d, pps, ~0u, out_d, pps, c->k - 1, l};
-    inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * np, mp, 2 * np * l);
+    OpModDown::Params mp{r_d, N, prod_d, (size_t)(l + 1) * N, perm_d, pps, ~0u, out_d, pps, c->k - 1, l};
+    inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * np, mp, 2 * np * l, inv1);
   };
   auto perm_launch = [&](const PermTables &pt, uint32_t np, u64 *perm_d, uint32_t polys) {
     ProfScope ps(c, KC_EW);
@@ -1319,9 +1392,10 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
     }
     Scratch perm(c, (size_t)np * 2 * pps); // [r][c0 permuted | c1 permuted = key-switch target]
     perm_launch(pt, np, perm.d, 2);
-    Scratch prod(c, np * prod_bs);
-    switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), np, prod.d);
-    mod_down(np, prod.d, perm.d, out_d);
+    Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N);
+    const bool inv1 = switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), np, prod.d, nullptr, nullptr,
+                                          fuse_small_launch(c, 2 * np * l) ? r.d : nullptr);
+    mod_down(np, prod.d, perm.d, out_d, r.d, inv1);
   };
   std::vector<evah_ct *> made;
   std::vector<Buffer *> chunk_buf;
@@ -1381,7 +1455,8 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
             hipLaunchKernelGGL(k_hoist_fix, dim3(c->N / 256, l + 1, np), dim3(256), 0, c->stream, c->dev, flag.d, ht, prod.d, prod_bs, l, B);
             HIPCHK(hipGetLastError());
           }
-          mod_down(np, prod.d, perm.d, chunk_buf[ci]->d);
+          Scratch r(c, (size_t)np * 2 * N);
+          mod_down(np, prod.d, perm.d, chunk_buf[ci]->d, r.d, false);
         }
       }
       // exact fallback: the same outputs through the unhoisted launches, each a no-op unless there
@@ -1443,12 +1518,12 @@ int evah_rotate_pairs(evah_ctx *c, const evah_ct *const *cts, const int32_t *ste
       hipLaunchKernelGGL(k_galois_perm_pairs, dim3(c->N / 512, l, 2 * n), dim3(256), 0, c->stream, c->dev, pt, perm.d, pps);
     }
     HIPCHK(hipGetLastError());
-    Scratch prod(c, n * prod_bs);
-    switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), n, prod.d);
-    Scratch r(c, (size_t)n * 2 * N);
+    Scratch prod(c, n * prod_bs), r(c, (size_t)n * 2 * N);
+    const bool inv1 = switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), n, prod.d, nullptr, nullptr,
+                                          fuse_small_launch(c, 2 * n * l) ? r.d : nullptr);
     OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
-        OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, perm.d, pps, ~0u, ob->d, pps, c->k - 1, l};
-    inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * n, mp, 2 * n * l);
+    OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, perm.d, pps, ~0u, ob->d, pps, c->k - 1, l};
+    inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * n, mp, 2 * n * l, inv1);
   } catch (...) {
     buf_unref(c, ob);
     throw;

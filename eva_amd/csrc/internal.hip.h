@@ -212,6 +212,9 @@ struct evah_ctx {
   // EVAH_HOIST=0 disables, EVAH_HOIST_MIN_TILES=n sets the threshold.
   bool hoist = true;
   uint32_t hoist_min_tiles = 8192;
+  // latency-bound key switches: the special row's first inverse pass runs inside the key-switch
+  // kernel (ks_inner_kernel INVSP) instead of as its own launch.  EVAH_FUSE_SPECIAL_INV=0 disables.
+  bool fuse_special_inv = true;
   int ks_groups = 1;    // output-limb slices per key-switch (EVAH_KS_GROUPS)
   int ks_threads = 64;  // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS): one wave = one
                         // 2^P-point sub-transform per workgroup measured best (barriers are intra-wave)

@@ -373,12 +373,16 @@ __device__ __forceinline__ u64 product_poly(const MulSrc &m, uint32_t K, size_t 
 
 struct NoMul {}; // placeholder for the operand table in the variants that read a stored product
 
-template <int P, int LR, int MAXT, bool MUL>
+// INVSP (latency-bound launches): the workgroups of the special-prime row (I == l) go straight on
+// with the contiguous pass of that row's inverse transform — the first step of the mod-down that
+// always follows — on the tile they hold, and store its lazy intermediate to r_out[2 inst + K]
+// instead of the row itself: one launch fewer per key switch, same residues.
+template <int P, int LR, int MAXT, bool MUL, bool INVSP = false>
 __global__ void __launch_bounds__(MAXT)
 ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
                 size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, uint32_t i0,
                 int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets, std::conditional_t<MUL, MulTab, NoMul> mul, uint32_t istep,
-                uint32_t nout) {
+                uint32_t nout, u64 *__restrict__ r_out) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   if (cx.skipped()) return;
   // grid.x carries (tile, instance): instances of one tile are placed 8 block ids apart, i.e. on
@@ -506,6 +510,37 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
         acc0[i] = {barrett128(acc0[i], pm), 0};
         acc1[i] = {barrett128(acc1[i], pm), 0};
       }
+    }
+  }
+  if constexpr (INVSP) {
+    if (I == l) { // block-uniform
+      const ulonglong2 *twi = cx.tw_inv + (size_t)kap * cx.N;
+#pragma unroll
+      for (int K = 0; K < 2; K++) {
+        __syncthreads(); // the tile in LDS has been consumed
+#pragma unroll
+        for (int it = 0; it < NPAIR; it++) {
+          const int idx = 2 * (threadIdx.x + it * T);
+          const int sb = idx >> P, e = idx & (S - 1);
+          lds[sb * SP + lds_pad(e)] = barrett128(K ? acc1[2 * it] : acc0[2 * it], pm);
+          lds[sb * SP + lds_pad(e + 1)] = barrett128(K ? acc1[2 * it + 1] : acc0[2 * it + 1], pm);
+        }
+        __syncthreads();
+        // as ntt_pass_kernel<P, LR, contiguous, inverse>: global twiddle heap of the row's prime
+        RoundSeq<P, LR, 0, true, false, true>::run(lds + sub * SP, tid, sub0 + sub, pre, twi, pm);
+        __syncthreads();
+        u64 *r = r_out + ((size_t)2 * inst + K) * N + gbase;
+#pragma unroll
+        for (int it = 0; it < NPAIR; it++) {
+          const int idx = 2 * (threadIdx.x + it * T);
+          const int sb = idx >> P, e = idx & (S - 1);
+          ulonglong2 v;
+          v.x = lds[sb * SP + lds_pad(e)];
+          v.y = lds[sb * SP + lds_pad(e + 1)];
+          *reinterpret_cast<ulonglong2 *>(r + idx) = v; // lazy intermediate of the inverse transform
+        }
+      }
+      return;
     }
   }
   u64 *p0 = prod + (size_t)Irow * N + gbase, *p1 = prod + ((size_t)nout + Irow) * N + gbase;

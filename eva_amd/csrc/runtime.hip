@@ -66,6 +66,7 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     if (const char *e = std::getenv("EVAH_SMALL_LR_BLOCKS")) c->small_lr_blocks = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("EVAH_FUSE_SMALL")) c->fuse_small_blocks = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("EVAH_HOIST")) c->hoist = std::atoi(e) != 0;
+    if (const char *e = std::getenv("EVAH_FUSE_SPECIAL_INV")) c->fuse_special_inv = std::atoi(e) != 0;
     if (const char *e = std::getenv("EVAH_HOIST_MIN_TILES")) c->hoist_min_tiles = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {
       int t = std::atoi(e);
@@ -169,6 +170,7 @@ int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
     c->small_lr = parent->small_lr;
     c->small_lr_blocks = parent->small_lr_blocks;
     c->hoist = parent->hoist;
+    c->fuse_special_inv = parent->fuse_special_inv;
     c->hoist_min_tiles = parent->hoist_min_tiles;
     c->ks_threads = parent->ks_threads;
     c->ks_groups = parent->ks_groups;

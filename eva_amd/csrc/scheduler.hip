@@ -137,6 +137,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
 
   for (auto &lvl : buckets) {
     std::map<uint32_t, std::vector<uint32_t>> rots, relins, muls, batched_rots;
+    std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> mulps; // ct x pt products by (size, limbs)
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<uint32_t>> rescales;
     std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> fused, fused3;
     // ---- one op through the ordinary entry points (seal_executor.h:114-215)
@@ -230,11 +231,12 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
           shape(o.src0, size, limbs, scale);
           relins[limbs].push_back(i);
         }
-      } else if (o.op == 13 && o.src0 != o.src1 && is_ct(o.src0) && is_ct(o.src1)) {
+      } else if (o.op == 13 && is_ct(o.src0) && is_ct(o.src1) &&
+                 (o.src0 != o.src1 || (!batched && ct_of(o.src0)->size == 2))) { // a square is the product (a, a): same residues
         // Mul read only by a Relinearize that is read only by a Rescale (the commonest CKKS
         // pattern): nothing is computed here, the three run as one fused call at the Rescale
         evah_ct *x = ct_of(o.src0), *y = ct_of(o.src1);
-        const bool chain = c->fuse_mac && c->fuse_mul && feeds_only(o.dst, 20) && feeds_only(ops[only_reader[o.dst]].dst, 22);
+        const bool chain = o.src0 != o.src1 && c->fuse_mac && c->fuse_mul && feeds_only(o.dst, 20) && feeds_only(ops[only_reader[o.dst]].dst, 22);
         if (chain && x->size == 2 && y->size == 2 && x->limbs == y->limbs && x->limbs >= 2 && x->batch == 1 && y->batch == 1) {
           check_scale(c, x->scale * y->scale, x->limbs);
           st.prods[o.dst] = {alias_ct(x), alias_ct(y)};
@@ -253,6 +255,13 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         ls.cts.push_back(alias_ct(x));
         ls.pts.push_back(alias_pt(w));
         st.sums[o.dst] = std::move(ls);
+      } else if (o.op == 13 && !batched &&
+                 ((is_plain_ct(o.src0) && slot(o.src1).kind == EVAH_VAL_PT) || (is_plain_ct(o.src1) && slot(o.src0).kind == EVAH_VAL_PT))) {
+        // independent ciphertext x plaintext products of one shape at this level: one launch
+        const uint32_t a = is_plain_ct(o.src0) ? o.src0 : o.src1, b = a == o.src0 ? o.src1 : o.src0;
+        evah_ct *x = static_cast<evah_ct *>(tab[a].h);
+        if (static_cast<evah_pt *>(tab[b].h)->limbs != x->limbs) { single(o); continue; } // multiply_plain reports the mismatch
+        mulps[{x->size, x->limbs}].push_back(i);
       } else if (o.op == 11 && is_ct(o.src0) && is_ct(o.src1) && !st.relins.count(o.src0) && !st.relins.count(o.src1) &&
                  (st.sums.count(o.src0) || st.sums.count(o.src1) || feeds_only(o.dst, 11))) {
         uint32_t s0, l0, s1, l1;
@@ -388,6 +397,20 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         std::vector<evah_ct *> outs(n, nullptr);
         for (uint32_t j = 0; j < n; j++) in[j] = ct_of(ops[is[j]].src0);
         chk(evah_relinearize_many(c, in.data(), n, outs.data()));
+        store(is, n, outs);
+      });
+    for (auto &kv : mulps)
+      each_chunk(kv.second, KS_BATCH_MAX, [&](const uint32_t *is, uint32_t n) {
+        std::vector<const evah_ct *> ia(n);
+        std::vector<const evah_pt *> ib(n);
+        std::vector<evah_ct *> outs(n, nullptr);
+        for (uint32_t j = 0; j < n; j++) {
+          const evah_op &o = ops[is[j]];
+          const uint32_t a = is_plain_ct(o.src0) ? o.src0 : o.src1, b = a == o.src0 ? o.src1 : o.src0;
+          ia[j] = static_cast<evah_ct *>(tab[a].h);
+          ib[j] = static_cast<evah_pt *>(tab[b].h);
+        }
+        chk(evah_multiply_plain_many(c, ia.data(), ib.data(), n, outs.data()));
         store(is, n, outs);
       });
     for (auto &kv : muls)

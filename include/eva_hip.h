@@ -163,6 +163,9 @@ int evah_weighted_sum(evah_ctx *ctx, const evah_ct *const *cts, const evah_pt *c
 int evah_square(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
 /* evaluator.multiply_plain (seal_executor.h:168) */
 int evah_multiply_plain(evah_ctx *ctx, const evah_ct *a, const evah_pt *b, evah_ct **out);
+/* n (<= 64) independent multiply_plain calls (seal_executor.h:168) on single ciphertexts of one shape
+ * as one launch; outs[i] == evah_multiply_plain(cts[i], pts[i]) */
+int evah_multiply_plain_many(evah_ctx *ctx, const evah_ct *const *cts, const evah_pt *const *pts, uint32_t n, evah_ct **outs);
 /* evaluator.relinearize, size 3 -> 2 (seal_executor.h:200); needs the relin key */
 int evah_relinearize(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
 /* evaluator.relinearize immediately followed by evaluator.rescale_to_next (+ scale fix-up) on the

@@ -468,3 +468,37 @@ def test_more_than_16_limbs():
     # and one level down, where l = 17 still exceeds 16
     ms = e.g.mod_switch(A3)
     assert np.array_equal(e.g.relinearize(ms).download(), e.o.relinearize(e.o.mod_switch(a3), key))
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[3], CONFIGS[5]], ids=lambda c: f"N{c[0]}")
+def test_multiply_plain_many_and_squares_as_products(cfg):
+    """evah_multiply_plain_many == the multiply_plain calls it stands for (sizes 2 and 3, one a
+    mod-switched view); a square issued as the product (a, a) through evah_multiply_many has the
+    residues of evaluator.square (seal_executor.h:162)."""
+    e = env(cfg)
+    l = e.k - 1
+    for size in (2, 3):
+        cts = [e.rand(size, l) for _ in range(5)]
+        pts = [e.rand(1, l)[0] for _ in range(5)]
+        hc = [e.g.upload_ct(x, 2.0 ** 20) for x in cts]
+        hp = [e.g.upload_pt(p, 2.0 ** 10) for p in pts]
+        outs = e.g.multiply_plain_many(hc, hp)
+        for x, p, o in zip(cts, pts, outs):
+            assert o.info() == (size, l, 2.0 ** 30)
+            assert np.array_equal(o.download(), e.o.multiply_plain(x, p))
+    if l > 1:
+        big = e.rand(2, l)
+        view = e.g.mod_switch(e.g.upload_ct(big, 2.0 ** 20))
+        other = e.rand(2, l - 1)
+        ptl = [e.rand(1, l - 1)[0] for _ in range(2)]
+        outs = e.g.multiply_plain_many([view, e.g.upload_ct(other, 2.0 ** 20)], [e.g.upload_pt(p, 2.0 ** 10) for p in ptl])
+        assert np.array_equal(outs[0].download(), e.o.multiply_plain(e.o.mod_switch(big), ptl[0]))
+        assert np.array_equal(outs[1].download(), e.o.multiply_plain(other, ptl[1]))
+        with pytest.raises(backend.EvaHipError, match="mismatch"):
+            e.g.multiply_plain_many([view], [e.g.upload_pt(e.rand(1, l)[0], 2.0 ** 10)])
+    a, b = e.rand(2, l), e.rand(2, l)
+    A, B = e.g.upload_ct(a, 2.0 ** 20), e.g.upload_ct(b, 2.0 ** 20)
+    outs = e.g.multiply_many([A, A, B], [A, B, B])
+    assert np.array_equal(outs[0].download(), e.o.square(a))
+    assert np.array_equal(outs[1].download(), e.o.multiply(a, b))
+    assert np.array_equal(outs[2].download(), e.o.square(b))
