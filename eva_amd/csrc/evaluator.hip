@@ -190,26 +190,6 @@ k_galois_perm(DevCtx cx, const u64 *a, size_t a_ps, const uint32_t *perm, u64 *o
   st2(out + p * o_ps + off, r);
 }
 
-// K8 for a batch of sibling rotations of one ciphertext: out[r][p][i][n] = in[p][i][perm_r[n]];
-// grid.z = r * 2 + p
-struct PermTables {
-  const uint32_t *perm[KS_BATCH_MAX];
-};
-__global__ void __launch_bounds__(256)
-k_galois_perm_many(DevCtx cx, const u64 *a, size_t a_ps, PermTables pt, u64 *out, size_t o_ps, uint32_t B, uint32_t polys) {
-  // polys == 2: z = 2 * (j * B + b) + K, rotation j of instance b, polynomial K; polys == 1: z = j * B + b
-  // and only c0 is permuted (the hoisted form never needs the permuted c1); output slot 2 * (j * B + b) + K
-  if (cx.skipped()) return;
-  const uint32_t z = blockIdx.z, r = polys == 2 ? z >> 1 : z, p = polys == 2 ? z & 1 : 0, i = blockIdx.y;
-  const uint32_t n = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
-  const uint2 pi = *reinterpret_cast<const uint2 *>(pt.perm[r / B] + n);
-  const u64 *src = a + ((size_t)(r % B) * 2 + p) * a_ps + (size_t)i * cx.N;
-  ulonglong2 v;
-  v.x = src[pi.x];
-  v.y = src[pi.y];
-  st2(out + (size_t)(2 * r + p) * o_ps + (size_t)i * cx.N + n, v);
-}
-
 // ---- CKKS encoder on the device (SEAL 3.6 CKKSEncoder::encode_internal, reached from
 // seal_executor.h:242): values -> conjugate-symmetric slot vector -> inverse special FFT in FP64
 // (Gentleman-Sande, one launch per stage, roots in the order the stages consume them) with the
@@ -274,15 +254,18 @@ struct PermPairs {
   uint32_t src_ps[KS_BATCH_MAX]; // poly strides in units of N coefficients
 };
 __global__ void __launch_bounds__(256)
-k_galois_perm_pairs(DevCtx cx, PermPairs pt, u64 *out, size_t o_ps) {
-  const uint32_t z = blockIdx.z, r = z >> 1, p = z & 1, i = blockIdx.y;
+k_galois_perm_pairs(DevCtx cx, PermPairs pt, u64 *out, size_t o_ps, uint32_t polys) {
+  // polys == 2: z = 2 r + K, polynomial K of pair r; polys == 1: z = r and only c0 is permuted (the
+  // hoisted form never needs the permuted c1).  Output slot 2 r + K either way.
+  if (cx.skipped()) return;
+  const uint32_t z = blockIdx.z, r = polys == 2 ? z >> 1 : z, p = polys == 2 ? z & 1 : 0, i = blockIdx.y;
   const uint32_t n = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
   const uint2 pi = *reinterpret_cast<const uint2 *>(pt.perm[r] + n);
   const u64 *src = pt.src[r] + ((size_t)p * pt.src_ps[r] + i) * cx.N;
   ulonglong2 v;
   v.x = src[pi.x];
   v.y = src[pi.y];
-  st2(out + z * o_ps + (size_t)i * cx.N + n, v);
+  st2(out + (size_t)(2 * r + p) * o_ps + (size_t)i * cx.N + n, v);
 }
 
 // per-limb constant fill (uniform-constant plaintexts); the per-limb values travel as a
@@ -346,11 +329,13 @@ k_ks_mac(DevCtx cx, const u64 *target, const u64 *scratch, const u64 *key, u64 *
 // EVA's 20-bit primes), so the inverse transform records them and k_hoist_fix subtracts their terms
 // one by one (NTT_I(X^k')[n] = psi_I^((2 brv(n) + 1) k')).  More than HOIST_ZERO_CAP zeros (a
 // transparent ciphertext) make the guarded, unhoisted launch set recompute the outputs instead.
-struct HoistTab {
-  const uint32_t *perm[KS_BATCH_MAX]; // per rotation of the launch
+struct HoistTab { // per (source, rotation) pair of the launch
+  const uint32_t *perm[KS_BATCH_MAX];
   const u64 *key[KS_BATCH_MAX];
-  const u64 *corr[KS_BATCH_MAX];      // [2][l+1][N]
+  const u64 *corr[KS_BATCH_MAX]; // [2][l+1][N]
+  const u64 *c1[KS_BATCH_MAX];   // the source's own c1 (NTT form): the digit used as is where I == J
   uint32_t elt[KS_BATCH_MAX];
+  uint8_t src[KS_BATCH_MAX];     // index of the source among the set's transformed digits
 };
 // corr[K][I][n] = sign[kap][n] * sum_J (q_J mod q_kap) * key[J][K][kap][n]   (kap = prime of row I)
 __global__ void __launch_bounds__(256)
@@ -366,20 +351,19 @@ k_hoist_corr(DevCtx cx, const u64 *sign, const u64 *key, u64 *corr, uint32_t l) 
   }
   corr[((size_t)K * (l + 1) + I) * N + n] = mulmod(sign[(size_t)kap * N + n], acc, pm);
 }
-// prod[z][K][I][n] = sum_J D_b[I][J][perm_j[n]] * key_j[J][K][I][n] + corr_j[K][I][n],  z = j * B + b.
-// D_b[I][J] is row (I * l + J) of instance b's converted digits, or limb J of the instance's own c1
+// prod[z][K][I][n] = sum_J D_s[I][J][perm_z[n]] * key_z[J][K][I][n] + corr_z[K][I][n] for pair z with source s.
+// D_s[I][J] is row (I * l + J) of source s's converted digits, or limb J of the source's own c1
 // when I == J (SEAL's shortcut: the NTT-form limb is used as is).  grid = (N/512, l+1, pairs).
 __global__ void __launch_bounds__(256)
-k_hoist_mac(DevCtx cx, const u64 *c1, size_t c1_bs, const u64 *digits, size_t dg_bs, HoistTab tab, u64 *prod,
-            size_t prod_bs, uint32_t l, uint32_t B) {
+k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistTab tab, u64 *prod, size_t prod_bs, uint32_t l) {
   const uint32_t I = blockIdx.y, kap = (I == l) ? cx.k - 1 : I;
-  const uint32_t z = blockIdx.z, j = z / B, b = z - j * B;
+  const uint32_t z = blockIdx.z;
   const size_t n = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
   const DevPrime pm = cx.primes[kap];
   const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
-  const uint2 pi = *reinterpret_cast<const uint2 *>(tab.perm[j] + n);
-  const u64 *key = tab.key[j] + (size_t)kap * N + n;
-  const u64 *dg = digits + b * dg_bs + (size_t)I * l * N, *own = c1 + b * c1_bs;
+  const uint2 pi = *reinterpret_cast<const uint2 *>(tab.perm[z] + n);
+  const u64 *key = tab.key[z] + (size_t)kap * N + n;
+  const u64 *dg = digits + tab.src[z] * dg_bs + (size_t)I * l * N, *own = tab.c1[z];
   u128_t a0x = {0, 0}, a0y = {0, 0}, a1x = {0, 0}, a1y = {0, 0};
   // operands are canonical (< q < 2^60): 256 products fit the 128-bit accumulators, l <= k - 1 < 64
   for (uint32_t J = 0; J < l; J++) {
@@ -391,7 +375,7 @@ k_hoist_mac(DevCtx cx, const u64 *c1, size_t c1_bs, const u64 *digits, size_t dg
     acc128(a1x, ox, k1.x);
     acc128(a1y, oy, k1.y);
   }
-  const u64 *cr = tab.corr[j] + (size_t)I * N + n;
+  const u64 *cr = tab.corr[z] + (size_t)I * N + n;
   const ulonglong2 c0 = ld2(cr), c1c = ld2(cr + (size_t)(l + 1) * N);
   ulonglong2 r0, r1;
   r0.x = addmod(barrett128(a0x, pm), c0.x, pm.q);
@@ -403,27 +387,27 @@ k_hoist_mac(DevCtx cx, const u64 *c1, size_t c1_bs, const u64 *digits, size_t dg
   st2(pr + (size_t)(l + 1) * N, r1);
 }
 
-// zeros[0] (low word) = number of zero digit coefficients seen, zeros[1 + e] = (instance << 48 | J << 32 | k).
+// zeros[0] (low word) = number of zero digit coefficients seen, zeros[1 + e] = (source << 48 | J << 32 | k).
 // Same grid as k_hoist_mac with one coefficient per thread; every test below is block-uniform.
 __global__ void __launch_bounds__(256)
-k_hoist_fix(DevCtx cx, const u64 *zeros, HoistTab tab, u64 *prod, size_t prod_bs, uint32_t l, uint32_t B) {
+k_hoist_fix(DevCtx cx, const u64 *zeros, HoistTab tab, u64 *prod, size_t prod_bs, uint32_t l) {
   const uint32_t count = *reinterpret_cast<const uint32_t *>(zeros);
   if (count == 0 || count > HOIST_ZERO_CAP) return;
   const uint32_t I = blockIdx.y, kap = (I == l) ? cx.k - 1 : I;
-  const uint32_t z = blockIdx.z, j = z / B, b = z - j * B;
+  const uint32_t z = blockIdx.z, b = tab.src[z];
   const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
   const DevPrime pm = cx.primes[kap];
   const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
   const uint32_t en = 2u * (__brev(n) >> (32 - cx.logN)) + 1u; // slot n holds the evaluation at psi^en
   const ulonglong2 *tw = cx.tw_fwd + (size_t)kap * N;
-  const u64 *key = tab.key[j] + (size_t)kap * N + n;
+  const u64 *key = tab.key[z] + (size_t)kap * N + n;
   u64 acc0 = 0, acc1 = 0;
   bool any = false;
   for (uint32_t e = 0; e < count; e++) {
     const u64 ent = zeros[1 + e];
     const uint32_t J = (uint32_t)(ent >> 32) & 0xffffu, k = (uint32_t)ent;
     if ((uint32_t)(ent >> 48) != b || J >= l || J == kap) continue; // q_J mod q_J = 0
-    const u64 raw = (u64)k * tab.elt[j];
+    const u64 raw = (u64)k * tab.elt[z];
     if (!((raw >> cx.logN) & 1)) continue; // the automorphism does not flip this coefficient
     const uint32_t kp = (uint32_t)raw & (uint32_t)(N - 1);
     const uint32_t m = (uint32_t)(((u64)en * kp) & (2 * N - 1));
@@ -442,7 +426,7 @@ k_hoist_fix(DevCtx cx, const u64 *zeros, HoistTab tab, u64 *prod, size_t prod_bs
 
 // ---- NTT launch plumbing
 template <class Op> struct OpClass;
-template <> struct OpClass<OpPlain> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
+template <bool Z> struct OpClass<OpPlainT<Z>> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
 template <> struct OpClass<OpMulIntt> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
 template <> struct OpClass<OpKsDigit> { static constexpr int fwd_a = KC_KSDIGIT_A, fwd_b = KC_KSDIGIT_B; };
 template <> struct OpClass<OpModDown> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
@@ -1335,6 +1319,133 @@ static const u64 *hoist_corr(evah_ctx *c, uint32_t elt, uint32_t l, const KeyDev
   return d;
 }
 
+// ---- rotation sets.  A set is a list of (source ciphertext, Galois element) pairs at one level,
+// issued KS_BATCH_MAX pairs at a time; pair r of a chunk writes out_d[r][2][l N].
+struct RotPair {
+  const u64 *src;   // c0 of the source ciphertext; c1 = src + src_ps
+  size_t src_ps;
+  uint32_t src_idx; // index into the set's distinct sources (hoisted digits)
+  uint32_t elt;
+  const KeyDev *key;
+  const uint32_t *perm;
+  const u64 *corr;  // hoisting constant of (elt, l); null when the set is not hoisted
+};
+struct RotChunk {
+  uint32_t first, count; // pairs [first, first + count)
+  u64 *out;
+};
+static RotPair rot_pair(evah_ctx *c, const u64 *src, size_t src_ps, uint32_t src_idx, int32_t step, uint32_t l, const char *who) {
+  if (step == 0) throw std::invalid_argument(std::string(who) + ": zero steps are copies, not key switches");
+  RotPair p{src, src_ps, src_idx, 0, nullptr, nullptr, nullptr};
+  if (evah_galois_elt_from_step(c, step, &p.elt)) throw std::invalid_argument(g_err);
+  auto kit = c->sh->galois.find(p.elt);
+  if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
+  if (kit->second.n_digits < l) throw std::runtime_error("key switching key has too few digits");
+  p.key = &kit->second;
+  p.perm = perm_table(c, p.elt);
+  return p;
+}
+static void rot_perm_launch(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t np, u64 *perm_d, uint32_t polys) {
+  PermPairs pt{};
+  for (uint32_t r = 0; r < np; r++) {
+    pt.perm[r] = pr[r].perm;
+    pt.src[r] = pr[r].src;
+    pt.src_ps[r] = (uint32_t)(pr[r].src_ps / c->N);
+  }
+  ProfScope ps(c, KC_EW);
+  hipLaunchKernelGGL(k_galois_perm_pairs, dim3(c->N / 512, l, polys * np), dim3(256), 0, c->stream, c->dev, pt, perm_d, (size_t)l * c->N,
+                     polys);
+  HIPCHK(hipGetLastError());
+}
+// mod-down of a chunk's products (step 3 of switch_key); c0' = perm_d[2r] is added to the even polys
+static void rot_mod_down(evah_ctx *c, uint32_t l, uint32_t np, u64 *prod_d, const u64 *perm_d, u64 *out_d, u64 *r_d, bool inv1) {
+  const size_t N = c->N, pps = (size_t)l * N;
+  // INTT of the special limbs, job = r*2 + K
+  OpPlain::Params sp{prod_d + (size_t)l * N, r_d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
+  // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
+  OpModDown::Params mp{r_d, N, prod_d, (size_t)(l + 1) * N, perm_d, pps, ~0u, out_d, pps, c->k - 1, l};
+  inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * np, mp, 2 * np * l, inv1);
+}
+// SEAL's order — rotate, then decompose the rotated c1 (every launch honours c->dev.guard)
+static void rot_chunk_plain(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t np, u64 *out_d) {
+  const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
+  std::vector<const KeyDev *> keys(np);
+  for (uint32_t r = 0; r < np; r++) keys[r] = pr[r].key;
+  Scratch perm(c, (size_t)np * 2 * pps); // [r][c0 permuted | c1 permuted = key-switch target]
+  rot_perm_launch(c, l, pr, np, perm.d, 2);
+  Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N);
+  const bool inv1 = switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), np, prod.d, nullptr, nullptr,
+                                        fuse_small_launch(c, 2 * np * l) ? r.d : nullptr);
+  rot_mod_down(c, l, np, prod.d, perm.d, out_d, r.d, inv1);
+}
+// The whole set.  hoisted: the digits of every distinct source are transformed once and each pair's
+// key inner product is formed from them (k_hoist_mac / k_hoist_fix), then the unhoisted launches
+// follow under the device-side guard.  srcs[i] = c0 of distinct source i (poly stride src_ps[i]).
+static void rotation_set(evah_ctx *c, uint32_t l, const std::vector<RotPair> &pairs, const std::vector<RotChunk> &chunks,
+                         const std::vector<const u64 *> &srcs, const std::vector<size_t> &src_ps, bool hoisted) {
+  const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
+  if (!hoisted) {
+    for (const RotChunk &ch : chunks) rot_chunk_plain(c, l, pairs.data() + ch.first, ch.count, ch.out);
+    return;
+  }
+  const uint32_t n_src = (uint32_t)srcs.size();
+  if (n_src > (uint32_t)KS_BATCH_MAX) throw std::logic_error("hoisted rotation set with too many sources");
+  Scratch flag(c, 1 + HOIST_ZERO_CAP); // [0]: zero-coefficient count, then the recorded positions
+  HIPCHK(hipMemsetAsync(flag.d, 0, sizeof(u64), c->stream));
+  const size_t dg_bs = (size_t)(l + 1) * l * N;
+  {
+    // digits of the unrotated c1 of every source, once: coefficient form (zeros recorded), then the
+    // full transforms under every output prime
+    Scratch t(c, (size_t)n_src * l * N), dg(c, n_src * dg_bs);
+    PtrTab c1{};
+    for (uint32_t i = 0; i < n_src; i++) c1.p[i] = srcs[i] + src_ps[i];
+    OpPlainZ::Params ip{nullptr, t.d, 0, (size_t)l * N, l, 0, 0, c1};
+    ip.zero_list = flag.d;
+    ntt_inverse<OpPlainZ>(c, ip, n_src * l);
+    OpKsDigit::Params dp{t.d, dg.d, l, (size_t)l * N, dg_bs, 0, l + 1};
+    ntt_forward<OpKsDigit>(c, dp, n_src * (l + 1) * l);
+    for (const RotChunk &ch : chunks) {
+      const RotPair *pr = pairs.data() + ch.first;
+      const uint32_t np = ch.count;
+      HoistTab ht{};
+      for (uint32_t r = 0; r < np; r++) {
+        ht.perm[r] = pr[r].perm;
+        ht.key[r] = pr[r].key->d;
+        ht.corr[r] = pr[r].corr;
+        ht.elt[r] = pr[r].elt;
+        ht.c1[r] = pr[r].src + pr[r].src_ps;
+        ht.src[r] = (uint8_t)pr[r].src_idx;
+      }
+      Scratch perm(c, (size_t)np * 2 * pps); // only the c0 slots (even polys) are filled and read
+      rot_perm_launch(c, l, pr, np, perm.d, 1);
+      Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N);
+      {
+        ProfScope ps(c, KC_KSMAC);
+        hipLaunchKernelGGL(k_hoist_mac, dim3(c->N / 512, l + 1, np), dim3(256), 0, c->stream, c->dev, dg.d, dg_bs, ht, prod.d, prod_bs, l);
+        HIPCHK(hipGetLastError());
+        // the terms of recorded zero coefficients (returns at once when there are none)
+        hipLaunchKernelGGL(k_hoist_fix, dim3(c->N / 256, l + 1, np), dim3(256), 0, c->stream, c->dev, flag.d, ht, prod.d, prod_bs, l);
+        HIPCHK(hipGetLastError());
+      }
+      rot_mod_down(c, l, np, prod.d, perm.d, ch.out, r.d, false);
+    }
+  }
+  // exact fallback: the same outputs through the unhoisted launches, each a no-op unless there
+  // were more zero digit coefficients than k_hoist_fix handles
+  struct GuardScope {
+    evah_ctx *c;
+    GuardScope(evah_ctx *c_, const uint32_t *g) : c(c_) { c->dev.guard = g; c->dev.guard_min = HOIST_ZERO_CAP; }
+    ~GuardScope() { c->dev.guard = nullptr; }
+  } gs(c, reinterpret_cast<const uint32_t *>(flag.d));
+  for (const RotChunk &ch : chunks) rot_chunk_plain(c, l, pairs.data() + ch.first, ch.count, ch.out);
+  if (!c->capturing && std::getenv("EVAH_HOIST_DEBUG")) { // diagnostics: how many zero coefficients did this set see?
+    uint32_t f = 0;
+    HIPCHK(hipMemcpyAsync(&f, flag.d, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::fprintf(stderr, "rotation set: hoisted %zu rotations of %u sources, l = %u, zero coefficients = %u\n", pairs.size(), n_src, l, f);
+  }
+}
+
 // Several rotations of ONE ciphertext (the convolution pattern: image << i*w+j for a 3x3
 // window) issued as one set of wide launches: same results as n evah_rotate calls, 1/n of the
 // kernel launches, each launch n times wider.  Large launch sets are hoisted (see k_hoist_mac).
@@ -1345,66 +1456,35 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
   if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
   if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("rotate_many handles 1..64 rotations per call");
   const uint32_t l = a->limbs, B = a->batch;
-  const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
-  std::vector<const KeyDev *> step_key(n);
-  std::vector<const uint32_t *> step_perm(n);
-  std::vector<uint32_t> step_elt(n);
-  for (uint32_t r = 0; r < n; r++) {
-    if (steps[r] == 0) throw std::invalid_argument("rotate_many: zero steps are copies, not key switches");
-    uint32_t elt = 0;
-    if (evah_galois_elt_from_step(c, steps[r], &elt)) throw std::invalid_argument(g_err);
-    auto kit = c->sh->galois.find(elt);
-    if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
-    if (kit->second.n_digits < l) throw std::runtime_error("key switching key has too few digits");
-    step_key[r] = &kit->second;
-    step_perm[r] = perm_table(c, elt);
-    step_elt[r] = elt;
-  }
+  const size_t pps = (size_t)l * c->N;
   const bool hoisted = hoist_wanted(c, l, n, B);
-  std::vector<const u64 *> step_corr(n, nullptr);
-  if (hoisted)
-    for (uint32_t r = 0; r < n; r++) step_corr[r] = hoist_corr(c, step_elt[r], l, *step_key[r]);
   // (rotation j, instance b) pairs go out KS_BATCH_MAX at a time: m rotations x B instances per
   // launch set; pair index r = j * B + b, so rotation j's B outputs are one batched handle.
-  const uint32_t m_max = std::max<uint32_t>(1, KS_BATCH_MAX / B);
-  // mod-down of a chunk's products into its output buffer (step 3 of switch_key), c0' = perm[2r] added
-  auto mod_down = [&](uint32_t np, u64 *prod_d, const u64 *perm_d, u64 *out_d, u64 *r_d, bool inv1) {
-    // INTT of the special limbs, job = r*2 + K
-    OpPlain::Params sp{prod_d + (size_t)l * N, r_d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
-    // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
-    OpModDown::Params mp{r_d, N, prod_d, (size_t)(l + 1) * N, perm_d, pps, ~0u, out_d, pps, c->k - 1, l};
-    inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * np, mp, 2 * np * l, inv1);
-  };
-  auto perm_launch = [&](const PermTables &pt, uint32_t np, u64 *perm_d, uint32_t polys) {
-    ProfScope ps(c, KC_EW);
-    hipLaunchKernelGGL(k_galois_perm_many, dim3(c->N / 512, l, polys * np), dim3(256), 0, c->stream, c->dev, a->d, a->ps, pt,
-                       perm_d, pps, B, polys);
-    HIPCHK(hipGetLastError());
-  };
-  // the unhoisted launch set of one chunk (every launch honours c->dev.guard)
-  auto plain_chunk = [&](uint32_t j0, uint32_t m, u64 *out_d) {
-    const uint32_t np = m * B;
-    PermTables pt{};
-    std::vector<const KeyDev *> keys(np);
-    for (uint32_t j = 0; j < m; j++) {
-      pt.perm[j] = step_perm[j0 + j];
-      for (uint32_t b = 0; b < B; b++) keys[j * B + b] = step_key[j0 + j];
+  std::vector<RotPair> pairs;
+  pairs.reserve((size_t)n * B);
+  for (uint32_t j = 0; j < n; j++) {
+    RotPair p = rot_pair(c, a->d, a->ps, 0, steps[j], l, "rotate_many");
+    if (hoisted) p.corr = hoist_corr(c, p.elt, l, *p.key);
+    for (uint32_t b = 0; b < B; b++) {
+      p.src = a->d + (size_t)b * 2 * a->ps;
+      p.src_idx = b;
+      pairs.push_back(p);
     }
-    Scratch perm(c, (size_t)np * 2 * pps); // [r][c0 permuted | c1 permuted = key-switch target]
-    perm_launch(pt, np, perm.d, 2);
-    Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N);
-    const bool inv1 = switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), np, prod.d, nullptr, nullptr,
-                                          fuse_small_launch(c, 2 * np * l) ? r.d : nullptr);
-    mod_down(np, prod.d, perm.d, out_d, r.d, inv1);
-  };
+  }
+  std::vector<const u64 *> srcs(B);
+  std::vector<size_t> src_ps(B, a->ps);
+  for (uint32_t b = 0; b < B; b++) srcs[b] = a->d + (size_t)b * 2 * a->ps;
+  const uint32_t m_max = std::max<uint32_t>(1, KS_BATCH_MAX / B);
   std::vector<evah_ct *> made;
   std::vector<Buffer *> chunk_buf;
+  std::vector<RotChunk> chunks;
   try {
     for (uint32_t j0 = 0; j0 < n; j0 += m_max) {
       const uint32_t m = std::min(m_max, n - j0), np = m * B;
       Buffer *ob = buf_new(c, (size_t)np * 2 * pps); // one buffer for the chunk; the m handles are views into it
       ob->refs = 0;
       chunk_buf.push_back(ob);
+      chunks.push_back({j0 * B, np, ob->d});
       for (uint32_t j = 0; j < m; j++) {
         evah_ct *t = new evah_ct;
         t->buf = ob;
@@ -1418,62 +1498,7 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
         made.push_back(t);
       }
     }
-    if (!hoisted) {
-      for (uint32_t j0 = 0, ci = 0; j0 < n; j0 += m_max, ci++) plain_chunk(j0, std::min(m_max, n - j0), chunk_buf[ci]->d);
-    } else {
-      Scratch flag(c, 1 + HOIST_ZERO_CAP); // [0]: zero-coefficient count, then the recorded positions
-      HIPCHK(hipMemsetAsync(flag.d, 0, sizeof(u64), c->stream));
-      const size_t dg_bs = (size_t)(l + 1) * l * N;
-      {
-        // digits of the unrotated c1 of every instance, once: coefficient form (zeros flagged), then
-        // the full transforms under every output prime
-        Scratch t(c, (size_t)B * l * N), dg(c, B * dg_bs);
-        OpPlain::Params ip{a->d + a->ps, t.d, 2 * a->ps, (size_t)l * N, l, 0, 0, {}};
-        ip.zero_list = flag.d;
-        ntt_inverse<OpPlain>(c, ip, B * l);
-        OpKsDigit::Params dp{t.d, dg.d, l, (size_t)l * N, dg_bs, 0, l + 1};
-        ntt_forward<OpKsDigit>(c, dp, B * (l + 1) * l);
-        for (uint32_t j0 = 0, ci = 0; j0 < n; j0 += m_max, ci++) {
-          const uint32_t m = std::min(m_max, n - j0), np = m * B;
-          PermTables pt{};
-          HoistTab ht{};
-          for (uint32_t j = 0; j < m; j++) {
-            pt.perm[j] = ht.perm[j] = step_perm[j0 + j];
-            ht.key[j] = step_key[j0 + j]->d;
-            ht.corr[j] = step_corr[j0 + j];
-            ht.elt[j] = step_elt[j0 + j];
-          }
-          Scratch perm(c, (size_t)np * 2 * pps); // only the c0 slots (even polys) are filled and read
-          perm_launch(pt, np, perm.d, 1);
-          Scratch prod(c, np * prod_bs);
-          {
-            ProfScope ps(c, KC_KSMAC);
-            hipLaunchKernelGGL(k_hoist_mac, dim3(c->N / 512, l + 1, np), dim3(256), 0, c->stream, c->dev, a->d + a->ps, 2 * a->ps,
-                               dg.d, dg_bs, ht, prod.d, prod_bs, l, B);
-            HIPCHK(hipGetLastError());
-            // the terms of recorded zero coefficients (returns at once when there are none)
-            hipLaunchKernelGGL(k_hoist_fix, dim3(c->N / 256, l + 1, np), dim3(256), 0, c->stream, c->dev, flag.d, ht, prod.d, prod_bs, l, B);
-            HIPCHK(hipGetLastError());
-          }
-          Scratch r(c, (size_t)np * 2 * N);
-          mod_down(np, prod.d, perm.d, chunk_buf[ci]->d, r.d, false);
-        }
-      }
-      // exact fallback: the same outputs through the unhoisted launches, each a no-op unless there
-      // were more zero digit coefficients than k_hoist_fix handles
-      struct GuardScope {
-        evah_ctx *c;
-        GuardScope(evah_ctx *c_, const uint32_t *g) : c(c_) { c->dev.guard = g; c->dev.guard_min = HOIST_ZERO_CAP; }
-        ~GuardScope() { c->dev.guard = nullptr; }
-      } gs(c, reinterpret_cast<const uint32_t *>(flag.d));
-      for (uint32_t j0 = 0, ci = 0; j0 < n; j0 += m_max, ci++) plain_chunk(j0, std::min(m_max, n - j0), chunk_buf[ci]->d);
-      if (!c->capturing && std::getenv("EVAH_HOIST_DEBUG")) { // diagnostics: did this call take the fallback?
-        uint32_t f = 0;
-        HIPCHK(hipMemcpyAsync(&f, flag.d, sizeof(f), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        std::fprintf(stderr, "evah_rotate_many: hoisted %u rotations x %u instances, l = %u, zero coefficients = %u\n", n, B, l, f);
-      }
-    }
+    rotation_set(c, l, pairs, chunks, srcs, src_ps, hoisted);
   } catch (...) {
     for (evah_ct *t : made) evah_ct_free(c, t);
     if (made.empty())
@@ -1485,45 +1510,38 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
 }
 
 // n (<= 64) independent (ciphertext, step) rotations at one level as one launch set: the sibling
-// rotations of SEVERAL ciphertexts (independent convolutions of one program level)
+// rotations of SEVERAL ciphertexts (independent convolutions of one program level).  Sources that
+// appear more than once share their digit decomposition when the set is large enough to hoist.
 int evah_rotate_pairs(evah_ctx *c, const evah_ct *const *cts, const int32_t *steps, uint32_t n, evah_ct **outs) {
   API_BEGIN
   use(c);
   if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("rotate_pairs handles 1..64 rotations per call");
   const uint32_t l = cts[0]->limbs;
-  const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
-  PermPairs pt{};
-  std::vector<const KeyDev *> keys(n);
+  const size_t pps = (size_t)l * c->N;
+  std::vector<RotPair> pairs;
+  std::vector<const u64 *> srcs;
+  std::vector<size_t> src_ps;
   for (uint32_t r = 0; r < n; r++) {
     const evah_ct *a = cts[r];
     if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
     if (a->batch != 1) throw std::invalid_argument("rotate_pairs takes single ciphertexts");
     if (a->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
-    if (steps[r] == 0) throw std::invalid_argument("rotate_pairs: zero steps are copies, not key switches");
     acquire(c, a->buf);
-    uint32_t elt = 0;
-    if (evah_galois_elt_from_step(c, steps[r], &elt)) throw std::invalid_argument(g_err);
-    auto kit = c->sh->galois.find(elt);
-    if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
-    keys[r] = &kit->second;
-    pt.perm[r] = perm_table(c, elt);
-    pt.src[r] = a->d;
-    pt.src_ps[r] = (uint32_t)(a->ps / N);
+    uint32_t si = 0;
+    while (si < srcs.size() && !(srcs[si] == a->d && src_ps[si] == a->ps)) si++;
+    if (si == srcs.size()) {
+      srcs.push_back(a->d);
+      src_ps.push_back(a->ps);
+    }
+    pairs.push_back(rot_pair(c, a->d, a->ps, si, steps[r], l, "rotate_pairs"));
   }
+  // worth hoisting when sources repeat and the digit transforms of the set are throughput-sized
+  const bool hoisted = srcs.size() < n && hoist_wanted(c, l, n, 1);
+  if (hoisted)
+    for (RotPair &p : pairs) p.corr = hoist_corr(c, p.elt, l, *p.key);
   Buffer *ob = buf_new(c, (size_t)n * 2 * pps);
   try {
-    Scratch perm(c, (size_t)n * 2 * pps);
-    {
-      ProfScope ps(c, KC_EW);
-      hipLaunchKernelGGL(k_galois_perm_pairs, dim3(c->N / 512, l, 2 * n), dim3(256), 0, c->stream, c->dev, pt, perm.d, pps);
-    }
-    HIPCHK(hipGetLastError());
-    Scratch prod(c, n * prod_bs), r(c, (size_t)n * 2 * N);
-    const bool inv1 = switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), n, prod.d, nullptr, nullptr,
-                                          fuse_small_launch(c, 2 * n * l) ? r.d : nullptr);
-    OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
-    OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, perm.d, pps, ~0u, ob->d, pps, c->k - 1, l};
-    inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * n, mp, 2 * n * l, inv1);
+    rotation_set(c, l, pairs, {RotChunk{0, n, ob->d}}, srcs, src_ps, hoisted);
   } catch (...) {
     buf_unref(c, ob);
     throw;

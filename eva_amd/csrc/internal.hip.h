@@ -206,12 +206,12 @@ struct evah_ctx {
   // (ntt_inv_fwd_kernel).  EVAH_FUSE_SMALL=0 disables, =n sets the threshold.
   uint32_t fuse_small_blocks = 8192;
   int small_lr = 2; // log2 coefficients per thread of the NTT passes in latency-bound launches (EVAH_SMALL_LR = 2 | 3)
-  uint32_t small_lr_blocks = 4096; // ... = launches of at most this many 2048-coefficient tiles (EVAH_SMALL_LR_BLOCKS)
+  uint32_t small_lr_blocks = 1024; // ... = launches of at most this many 2048-coefficient tiles (EVAH_SMALL_LR_BLOCKS)
   // several rotations of one ciphertext: decompose once and permute the transformed digits (hoisting),
   // when the launch set is at least this many 2048-coefficient tiles of digit transforms.
   // EVAH_HOIST=0 disables, EVAH_HOIST_MIN_TILES=n sets the threshold.
   bool hoist = true;
-  uint32_t hoist_min_tiles = 8192;
+  uint32_t hoist_min_tiles = 2048;
   // latency-bound key switches: the special row's first inverse pass runs inside the key-switch
   // kernel (ks_inner_kernel INVSP) instead of as its own launch.  EVAH_FUSE_SPECIAL_INV=0 disables.
   bool fuse_special_inv = true;

@@ -562,7 +562,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
 // Plain batched transform over limbs.  job -> (poly p = job / jl, limb i = job % jl),
 // prime = prime0 + i.  addhalf: x <- x + floor(q/2) mod q on store (rounding offset of
 // rescale / key-switch mod-down).
-struct OpPlain {
+template <bool ZEROS> struct OpPlainT { // ZEROS: the inverse transform also records zero coefficients
   struct Params {
     const u64 *src;
     u64 *dst;
@@ -603,9 +603,11 @@ struct OpPlain {
   }
   static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm,
                                                uint32_t n, u64 v) {
-    if (j.zero_list && v == 0) {
-      const uint32_t at = atomicAdd(reinterpret_cast<uint32_t *>(j.zero_list), 1u);
-      if (at < HOIST_ZERO_CAP) j.zero_list[1 + at] = ((u64)j.pp << 48) | ((u64)j.prime << 32) | n;
+    if constexpr (ZEROS) {
+      if (v == 0) {
+        const uint32_t at = atomicAdd(reinterpret_cast<uint32_t *>(j.zero_list), 1u);
+        if (at < HOIST_ZERO_CAP) j.zero_list[1 + at] = ((u64)j.pp << 48) | ((u64)j.prime << 32) | n;
+      }
     }
     if (j.addhalf) v = addmod(v, pm.q >> 1, pm.q);
     j.dst[n] = v;
@@ -615,6 +617,9 @@ struct OpPlain {
     store(cx, j, pm, n, barrett64(v, pm.q, pm.brt));
   }
 };
+
+using OpPlain = OpPlainT<false>;
+using OpPlainZ = OpPlainT<true>;
 
 // Inverse transform of d2 = a1 b1 of a batch of products (the key-switch target of a fused
 // multiply -> relinearize): job -> (instance b = job / jl, limb i = job % jl); the product is

@@ -262,6 +262,15 @@ int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digit
     auto it = c->sh->galois.find(galois_elt);
     if (it != c->sh->galois.end()) (void)hipFree(it->second.d);
     c->sh->galois[galois_elt] = kd;
+    // the hoisting constants of this element were derived from the key it replaces
+    for (auto hc = c->sh->hoist_corr.begin(); hc != c->sh->hoist_corr.end();) {
+      if (hc->first.first == galois_elt) {
+        (void)hipFree(hc->second);
+        hc = c->sh->hoist_corr.erase(hc);
+      } else {
+        ++hc;
+      }
+    }
   } else {
     (void)hipFree(kd.d);
     throw std::invalid_argument("unknown key kind");

@@ -306,29 +306,9 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         store(is, n, outs);
       });
     for (auto &kv : rots) {
-      // sibling rotations of one ciphertext go out together when evah_rotate_many would hoist them
-      // (one digit decomposition for all of them); everything else of the level is one launch set
-      std::map<uint32_t, std::vector<uint32_t>> by_src;
-      for (uint32_t i : kv.second) by_src[ops[i].src0].push_back(i);
-      std::vector<uint32_t> rest;
-      for (uint32_t i : kv.second) {
-        auto &sib = by_src[ops[i].src0];
-        if (sib.empty()) continue; // already issued with its siblings
-        if (!hoist_wanted(c, kv.first, (uint32_t)std::min<size_t>(sib.size(), KS_BATCH_MAX), 1)) {
-          rest.push_back(i);
-          continue;
-        }
-        const uint32_t src = ops[i].src0;
-        each_chunk(sib, KS_BATCH_MAX, [&](const uint32_t *is, uint32_t n) {
-          std::vector<int32_t> steps(n);
-          std::vector<evah_ct *> outs(n, nullptr);
-          for (uint32_t j = 0; j < n; j++) steps[j] = ops[is[j]].op == 14 ? ops[is[j]].imm : -ops[is[j]].imm;
-          chk(evah_rotate_many(c, ct_of(src), steps.data(), n, outs.data()));
-          store(is, n, outs);
-        });
-        sib.clear();
-      }
-      if (rest.empty()) continue;
+      // one launch set per level; evah_rotate_pairs shares the digit decomposition of sources that
+      // occur more than once (sibling rotations of a convolution) when the set is large enough
+      std::vector<uint32_t> &rest = kv.second;
       each_chunk(rest, KS_BATCH_MAX, [&](const uint32_t *is, uint32_t n) {
         std::vector<const evah_ct *> in(n);
         std::vector<int32_t> steps(n);

@@ -166,6 +166,40 @@ def test_zero_coefficients_in_some_instances_of_a_batched_handle():
             assert np.array_equal(got[b], e.o.rotate(inst[b], st, e.keys[st])), f"step {st} instance {b}"
 
 
+@pytest.mark.parametrize("cfg", [CONFIGS[2], CONFIGS[4]], ids=lambda c: f"N{c[0]}")
+def test_rotation_set_with_several_sources_shares_each_sources_digits(cfg):
+    """evah_rotate_pairs: three convolutions' worth of sibling rotations plus a lone rotation in one
+    set (what a level of Harris looks like); one source carries zero digit coefficients."""
+    e = env(cfg)
+    l = e.k - 1
+    srcs = [e.rand(2, l) for _ in range(4)]
+    x = e.rng.integers(1, e.primes[1], size=e.N, dtype=np.uint64)
+    x[e.rng.choice(e.N, size=3, replace=False)] = 0
+    srcs[1][1][1] = e.o.ntt(1, x)
+    hs = [e.g.upload_ct(a, 2.0 ** 20) for a in srcs]
+    plan = [(0, 1), (1, 1), (2, 1), (0, 65), (1, 65), (2, 65), (0, -3), (1, -64), (2, 129), (3, 2), (1, 2)]
+    for _, st in plan:
+        e.key_for(st)
+    outs = e.g.rotate_pairs([hs[i] for i, _ in plan], [st for _, st in plan])
+    for (i, st), o in zip(plan, outs):
+        assert np.array_equal(o.download(), e.o.rotate(srcs[i], st, e.keys[st])), f"source {i} step {st}"
+
+
+def test_replacing_a_galois_key_invalidates_the_hoisting_constants():
+    e = Env(*CONFIGS[1])
+    l = e.k - 1
+    a2 = e.rand(2, l)
+    A2 = e.g.upload_ct(a2, 2.0 ** 20)
+    steps = [1, 65]
+    for round_ in range(2):
+        e.keys.clear()  # fresh random keys for the same Galois elements
+        for st in steps:
+            e.key_for(st)
+        outs = e.g.rotate_many(A2, steps)
+        for st, o in zip(steps, outs):
+            assert np.array_equal(o.download(), e.o.rotate(a2, st, e.keys[st])), f"round {round_} step {st}"
+
+
 def _launch_classes(e, A2, steps):
     e.g.profile(True)
     e.g.profile_reset()
