@@ -764,7 +764,7 @@ private:
     }
     forward_pass(p, TypeDeducer{p, types});
     {
-      ModSwitcher ms{p, types, scales, {}};
+      ModSwitcher ms{p, types, scales, TermTable<uint32_t>(0), {}};
       backward_pass(p, ms);
       ms.finish();
     }
