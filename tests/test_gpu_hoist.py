@@ -22,6 +22,7 @@ CONFIGS = [
     (32768, [60] * 5),
     (65536, [60] * 4),
     (4096, [40] * 19 + [41]),  # l = 19 digits
+    (4096, [50, 60]),  # l = 1: one digit, data limb + special prime only
 ]
 STEPS = [1, 2, 64, 65, -3, 129, -64, 1000]
 
