@@ -324,6 +324,38 @@ def test_execute_batch_equals_execute_per_instance():
         pub.execute_batch(compiled, encs)
 
 
+def test_execute_batch_called_repeatedly_with_fresh_inputs_and_a_partial_last_group():
+    """Repeated execute_batch calls of one program (resident constants, recycled pools, both issue
+    queues, a partial last group): every instance equals execute() on it."""
+    import numpy as np
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    sob = _sobel(32, 32, 1024)
+    sob.set_input_scales(25)
+    sob.set_output_ranges(10)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(sob)
+    pub, sec = generate_keys(params, 9)
+    pub.batch_chunk = 4
+
+    def batch(seed, n):
+        return [pub.encrypt({'image': [((31 * i + 7 * u + seed) % 256) / 255.0 for i in range(1024)]}, sig) for u in range(n)]
+
+    pub.execute_batch(compiled, batch(0, 9))
+    encs = batch(100, 19)                         # 4 full groups + 3 instances
+    for round_ in range(2):
+        outs = pub.execute_batch(compiled, encs)
+        assert len(outs) == 19
+        pub.use_graphs = False
+        for u in (0, 3, 4, 7, 8, 12, 15, 16, 18):
+            one = pub.execute(compiled, encs[u])
+            for name in one.names():
+                g, r = outs[u].get(name), one.get(name)
+                assert g[:4] == r[:4]
+                assert np.array_equal(g[4], r[4]), f"round {round_}, instance {u}, {name}: batched instance differs from execute()"
+        pub.use_graphs = True
+        encs = batch(200 + round_, 19)
+
+
 def test_product_of_several_constants_with_a_ciphertext():
     """see tests/test_host_e2e_cpu.py: a Rescale lands on an unencrypted constant product"""
     from test_host_e2e_cpu import _constant_chain_program
