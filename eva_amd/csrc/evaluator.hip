@@ -555,6 +555,7 @@ template <class Op> static void ntt_inverse(evah_ctx *c, const typename Op::Para
 static bool fuse_small_launch(evah_ctx *c, uint32_t fwd_jobs) {
   const uint32_t tile = (uint32_t)NTT_THREADS << 3;
   if (!c->fuse_small_blocks || c->N < tile) return false; // partial tiles (N = 1024) keep the two-launch form
+  if (c->dev.guard) return true; // a guarded (normally skipped) launch set: the fewest launches, whatever the size
   return (uint64_t)fwd_jobs * (c->N / tile) <= c->fuse_small_blocks;
 }
 template <int P, class Op, int LR> static void launch_inv_fwd_plr(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {

@@ -1,4 +1,4 @@
-"""Run one DAG config repeatedly (graph replay) for rocprofv3 --kernel-trace: dag_profile.py sobel|harris|deep [reps]"""
+"""Run one DAG config repeatedly (graph replay) for rocprofv3 --kernel-trace: dag_profile.py sobel|harris|harris8|deep [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,7 +10,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "sobel"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 if which == "sobel":
     prog = _sobel(64, 64, 4096); prog.set_input_scales(25); prog.set_output_ranges(10); N = 8192
-elif which == "harris":
+elif which in ("harris", "harris8"):
     prog = _harris(); N = 32768
 else:  # BASELINE config 5: 3x3 convolution + depth-8 squaring chain, N = 2^16, 13 primes
     from eva import EvaProgram, Input, Output
@@ -28,6 +28,9 @@ else:  # BASELINE config 5: 3x3 convolution + depth-8 squaring chain, N = 2^16, 
     prog.set_input_scales(30); prog.set_output_ranges(20); N = 65536
 compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
 params.poly_modulus_degree = N
+if which == "harris8":  # the bench's DAG leg: chain padded to L = 8 data limbs
+    pb = list(params.prime_bits)
+    params.prime_bits = pb[:1] + [60] * (9 - len(pb)) + pb[1:]
 if which == "deep" and len(params.prime_bits) < 13:
     pb = list(params.prime_bits)
     params.prime_bits = pb[:1] + [60] * (13 - len(pb)) + pb[1:]
