@@ -200,7 +200,8 @@ int evah_rotate(evah_ctx *ctx, const evah_ct *a, int32_t steps, evah_ct **out);
 int evah_rotate_many(evah_ctx *ctx, const evah_ct *a, const int32_t *steps, uint32_t n, evah_ct **outs);
 /* n (<= 64) rotations of SEVERAL ciphertexts of one level, pair i = (cts[i], steps[i] != 0): the
  * sibling rotations of independent sub-expressions (seal_executor.h:181/188 called once per node)
- * as one launch set; outs[i] == evah_rotate(cts[i], steps[i]) bit for bit */
+ * as one launch set; outs[i] == evah_rotate(cts[i], steps[i]) bit for bit.  A ciphertext that occurs
+ * in several pairs is decomposed once for all of them when the set is large enough (hoisting, as above). */
 int evah_rotate_pairs(evah_ctx *ctx, const evah_ct *const *cts, const int32_t *steps, uint32_t n, evah_ct **outs);
 /* n independent evaluator.rescale_to_next calls (seal_executor.h:213) of one size and level,
  * n * size <= 128, as one launch set */
