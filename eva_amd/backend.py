@@ -39,6 +39,9 @@ _SIGS = {
     "evah_ct_upload": [_vp, C.c_uint32, C.c_uint32, C.c_double, _u64p, _vpp],
     "evah_ct_write": [_vp, _vp, _u64p],
     "evah_ct_copy": [_vp, _vp, _vpp],
+    "evah_ct_assign": [_vp, _vp, _vp],
+    "evah_ctx_wait": [_vp, _vp],
+    "evah_ctx_transfer_stats": [_vp, _u64p],
     "evah_pt_copy": [_vp, _vp, _vpp],
     "evah_pt_write": [_vp, _vp, _u64p],
     "evah_capture_begin": [_vp, _vpp, C.c_uint32],
@@ -222,6 +225,10 @@ class Ciphertext:
         """overwrite the device words of this handle (same shape): refill of a captured graph's input"""
         data = np.ascontiguousarray(data, dtype=np.uint64)
         _chk(_lib.evah_ct_write(self.ctx.h, self.h, _p(data)))
+
+    def assign(self, src, queue=None):
+        """refill this handle from another one of the same shape, device to device (evah_ct_assign)"""
+        _chk(_lib.evah_ct_assign((queue or self.ctx).h, self.h, src.h))
 
     def unstack(self, b):
         h = C.c_void_p()
@@ -422,6 +429,16 @@ class Context:
 
     def sync(self):
         _chk(_lib.evah_ctx_sync(self.h))
+
+    def wait_for(self, other):
+        """this queue waits (on the device) for everything enqueued so far on `other`"""
+        _chk(_lib.evah_ctx_wait(self.h, other.h))
+
+    def transfer_stats(self):
+        """(h2d value transfers, d2h value transfers, h2d bytes, d2h bytes) of this device state"""
+        out = (C.c_uint64 * 4)()
+        _chk(_lib.evah_ctx_transfer_stats(self.h, out))
+        return tuple(int(x) for x in out)
 
     def mem_info(self):
         a, b = C.c_size_t(), C.c_size_t()

@@ -113,7 +113,10 @@ int evah_client_key_upload(evah_ctx *c, int kind, const uint64_t *data) {
   HIPCHK(hipMalloc(&kd.d, kd.bytes));
   HIPCHK(hipMemcpy(kd.d, data, kd.bytes, hipMemcpyHostToDevice));
   KeyDev &slot = kind == EVAH_KEY_PUBLIC ? c->sh->pk : c->sh->sk;
-  if (slot.d) (void)hipFree(slot.d);
+  if (slot.d) {
+    if (kind == EVAH_KEY_SECRET) (void)hipMemset(slot.d, 0, slot.bytes); // no key material in freed HBM
+    (void)hipFree(slot.d);
+  }
   slot = kd;
   API_END
 }

@@ -168,13 +168,14 @@ struct SharedDev {
   double2 *enc_roots = nullptr;     // CKKS encoder: inverse-FFT roots in the order the stages consume them
   double enc_last_root[2] = {0, 0}; // the single root of the last stage (scaled by fix on the host per call)
   uint32_t *enc_slot_map = nullptr; // slot i (and its conjugate, at slots + i) -> FFT input index
+  uint64_t xfer[4] = {0, 0, 0, 0};  // value transfers: h2d calls, d2h calls, h2d bytes, d2h bytes (evah_ctx_transfer_stats)
   ~SharedDev() {
     (void)hipSetDevice(device);
     if (enc_roots) (void)hipFree(enc_roots);
     if (enc_slot_map) (void)hipFree(enc_slot_map);
     if (relin.d) (void)hipFree(relin.d);
     if (pk.d) (void)hipFree(pk.d);
-    if (sk.d) (void)hipFree(sk.d);
+    if (sk.d) { (void)hipMemset(sk.d, 0, sk.bytes); (void)hipFree(sk.d); } // key material does not stay behind in freed HBM
     if (dec_roots) (void)hipFree(dec_roots);
     for (auto &kv : galois) (void)hipFree(kv.second.d);
     for (auto &kv : perms) (void)hipFree(kv.second);
@@ -229,6 +230,8 @@ struct evah_ctx {
 namespace evah {
 
 inline void use(evah_ctx *c) { HIPCHK(hipSetDevice(c->device)); }
+inline void count_h2d(evah_ctx *c, size_t bytes) { c->sh->xfer[0]++; c->sh->xfer[2] += bytes; }
+inline void count_d2h(evah_ctx *c, size_t bytes) { c->sh->xfer[1]++; c->sh->xfer[3] += bytes; }
 
 inline hipEvent_t prof_event(evah_ctx *c) {
   if (!c->prof_free.empty()) {

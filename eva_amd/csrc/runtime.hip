@@ -115,6 +115,26 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
       d.q8 = 8 * q;
       d.nq5 = 0ull - 5 * q;
       d.nq8 = 0ull - 8 * q;
+      { // top-bit lazy reductions (devmath.hip.h); EVAH_FAST_REDUCE=0 keeps the compare-and-select forms
+        const uint32_t b = (uint32_t)bitlen64(q);
+        const bool allow = !std::getenv("EVAH_FAST_REDUCE") || std::atoi(std::getenv("EVAH_FAST_REDUCE")) != 0;
+        d.fs = d.fmask = d.fc = d.is = d.imask = d.ic = d.fast = d.pad_ = 0;
+        if (allow && b + 3 >= 33 && b + 3 <= 63) {
+          const uint32_t s = b + 3;
+          const u64 c = (u64)((((u128)1) << s) % q);
+          // 2^s = 8q + c exactly (q just below a power of two, as CoeffModulus::Create's primes are): the
+          // transform's outputs then stay below 16q + 2c, which the fused epilogues (ntt.hip.h) rely on
+          if (c < ((u64)1 << 32) && (((u128)1) << s) == 8 * (u128)q + c) { d.fs = s - 32; d.fmask = (uint32_t)(((u64)1 << (s - 32)) - 1); d.fc = (uint32_t)c; d.fast |= 1u; }
+        }
+        if (allow && b + 2 >= 33) {
+          const uint32_t s = b + 2;
+          const u64 c = (u64)((((u128)1) << s) % q);
+          // the reduced sum (< 2^s + 2c) has to stay below the 5q the difference path adds
+          if (c < ((u64)1 << 32) && (((u128)1) << s) + 2 * (u128)c <= 5 * (u128)q) {
+            d.is = s - 32; d.imask = (uint32_t)(((u64)1 << (s - 32)) - 1); d.ic = (uint32_t)c; d.fast |= 2u;
+          }
+        }
+      }
       for (uint32_t a = 0; a < k; a++) {
         const u64 qa = c->primes[a];
         if (a == i) {
@@ -335,6 +355,7 @@ int evah_ct_upload(evah_ctx *c, uint32_t size, uint32_t limbs, double scale, con
   evah_ct *t = ct_new(c, size, limbs, scale);
   HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)size * limbs * c->N, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  count_h2d(c, sizeof(u64) * (size_t)size * limbs * c->N);
   t->buf->ready_everywhere = true;
   *out = t;
   API_END
@@ -352,6 +373,7 @@ int evah_ct_upload_batch(evah_ctx *c, uint32_t batch, uint32_t size, uint32_t li
   evah_ct *t = ct_new(c, size, limbs, scale, batch);
   HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)batch * size * limbs * c->N, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  count_h2d(c, sizeof(u64) * (size_t)batch * size * limbs * c->N);
   t->buf->ready_everywhere = true;
   *out = t;
   API_END
@@ -375,6 +397,7 @@ static void ct_upload_instances(evah_ctx *c, uint32_t batch, uint32_t size, uint
     evah_ct_free(c, t);
     throw;
   }
+  count_h2d(c, sizeof(u64) * each * batch);
   *out = t;
 }
 int evah_ct_upload_instances(evah_ctx *c, uint32_t batch, uint32_t size, uint32_t limbs, double scale,
@@ -405,6 +428,7 @@ static void ct_download_instances(evah_ctx *c, const evah_ct *ct, uint64_t *cons
     if (dense) return hipMemcpyAsync(out[b], src, row * ct->size, hipMemcpyDeviceToHost, st);
     return hipMemcpy2DAsync(out[b], row, src, sizeof(u64) * ct->ps, row, ct->size, hipMemcpyDeviceToHost, st);
   }, wait);
+  count_d2h(c, row * ct->size * ct->batch);
 }
 int evah_ct_download_instances(evah_ctx *c, const evah_ct *ct, uint64_t *const *out) {
   API_BEGIN
@@ -484,6 +508,39 @@ int evah_pt_copy(evah_ctx *c, const evah_pt *src, evah_pt **out) {
   API_END
 }
 
+// refill of an existing handle from another handle of the same shape, device to device
+int evah_ct_assign(evah_ctx *c, evah_ct *dst, const evah_ct *src) {
+  API_BEGIN
+  use(c);
+  if (c->capturing) throw std::logic_error("evah_ct_assign cannot be captured into a graph");
+  if (dst->size != src->size || dst->limbs != src->limbs || dst->batch != src->batch)
+    throw std::invalid_argument("evah_ct_assign: shapes differ");
+  if (dst->ps != (size_t)dst->limbs * c->N) throw std::invalid_argument("cannot write into a mod-switched view");
+  acquire(c, dst->buf);
+  acquire(c, src->buf);
+  const size_t row = sizeof(u64) * (size_t)src->limbs * c->N, polys = (size_t)src->size * src->batch;
+  if (src->ps == (size_t)src->limbs * c->N)
+    HIPCHK(hipMemcpyAsync(dst->d, src->d, row * polys, hipMemcpyDefault, c->stream));
+  else
+    HIPCHK(hipMemcpy2DAsync(dst->d, row, src->d, sizeof(u64) * src->ps, row, polys, hipMemcpyDefault, c->stream));
+  dst->scale = src->scale;
+  API_END
+}
+
+int evah_ctx_wait(evah_ctx *waiter, evah_ctx *signaller) {
+  API_BEGIN
+  use(waiter);
+  if (waiter->capturing || signaller->capturing) throw std::logic_error("evah_ctx_wait cannot be captured into a graph");
+  stream_wait(waiter, signaller);
+  API_END
+}
+
+int evah_ctx_transfer_stats(evah_ctx *c, uint64_t out[4]) {
+  API_BEGIN
+  for (int i = 0; i < 4; i++) out[i] = c->sh->xfer[i];
+  API_END
+}
+
 int evah_ct_write(evah_ctx *c, evah_ct *ct, const uint64_t *data) {
   API_BEGIN
   use(c);
@@ -493,6 +550,7 @@ int evah_ct_write(evah_ctx *c, evah_ct *ct, const uint64_t *data) {
   HIPCHK(hipMemcpyAsync(ct->d, data, sizeof(u64) * (size_t)ct->batch * ct->size * ct->limbs * c->N, hipMemcpyHostToDevice,
                         c->stream));
   HIPCHK(hipStreamSynchronize(c->stream)); // pageable source: the caller may reuse it after return
+  count_h2d(c, sizeof(u64) * (size_t)ct->batch * ct->size * ct->limbs * c->N);
   API_END
 }
 
@@ -503,6 +561,7 @@ int evah_pt_write(evah_ctx *c, evah_pt *pt, const uint64_t *data) {
   acquire(c, pt->buf);
   HIPCHK(hipMemcpyAsync(pt->d, data, sizeof(u64) * (size_t)pt->limbs * c->N, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  count_h2d(c, sizeof(u64) * (size_t)pt->limbs * c->N);
   API_END
 }
 
@@ -585,6 +644,7 @@ int evah_ct_download(evah_ctx *c, const evah_ct *ct, uint64_t *out) {
     HIPCHK(hipMemcpy2DAsync(out, row, ct->d, sizeof(u64) * ct->ps, row, (size_t)ct->size * ct->batch, hipMemcpyDeviceToHost,
                             c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  count_d2h(c, row * ct->size * ct->batch);
   API_END
 }
 
@@ -602,6 +662,7 @@ int evah_pt_upload(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *da
   evah_pt *t = pt_new(c, limbs, scale);
   HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)limbs * c->N, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  count_h2d(c, sizeof(u64) * (size_t)limbs * c->N);
   t->buf->ready_everywhere = true;
   *out = t;
   API_END
@@ -621,6 +682,7 @@ int evah_pt_download(evah_ctx *c, const evah_pt *pt, uint64_t *out) {
   acquire(c, pt->buf);
   HIPCHK(hipMemcpyAsync(out, pt->d, sizeof(u64) * (size_t)pt->limbs * c->N, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  count_d2h(c, sizeof(u64) * (size_t)pt->limbs * c->N);
   API_END
 }
 

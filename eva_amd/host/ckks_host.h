@@ -503,10 +503,17 @@ template <class T> struct HostAlloc {
   template <class U> bool operator!=(const HostAlloc<U> &) const { return false; }
 };
 using CipherWords = std::vector<u64, HostAlloc<u64>>;
+// A ciphertext value of a valuation.  It may live on the host (data), on the device (dev: a handle
+// of a device context, executor.h) or both: SURVEY.md 8(b) keeps the reference's SEALValuation
+// opaque so that it "may hold device handles", and encrypt -> execute -> decrypt then never moves a
+// ciphertext over PCIe.  The host words are filled on demand (words(): a download) — by get(),
+// save(), a context on another device, or the host-only code paths.
+struct DeviceResident;
 struct HostCipher {
   uint32_t size = 0, limbs = 0;
   double scale = 1.0;
-  CipherWords data; // [size][limbs][N]
+  mutable CipherWords data; // [size][limbs][N]; empty while the value lives only on the device
+  std::shared_ptr<DeviceResident> dev;
 };
 struct HostPlain {
   uint32_t limbs = 0;

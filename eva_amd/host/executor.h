@@ -129,6 +129,47 @@ struct PtHandle {
   ~PtHandle() { reset(); }
 };
 
+// ---- device contexts (seal.h:45-97 keeps a SEALContext per key set; here: tables + keys in HBM)
+struct DeviceCtx {
+  evah_ctx *h = nullptr;
+  DeviceCtx(uint32_t N, const std::vector<u64> &primes, int device) {
+    chk(evah_ctx_create(N, (uint32_t)primes.size(), (const uint64_t *)primes.data(), device, &h));
+  }
+  ~DeviceCtx() { evah_ctx_destroy(h); }
+  DeviceCtx(const DeviceCtx &) = delete;
+  DeviceCtx &operator=(const DeviceCtx &) = delete;
+};
+// A second issue queue of a device context (evah_ctx_fork).  It keeps its parent alive, so a value
+// that was produced through it can outlive the HipPublic that created the queue.
+struct Fork {
+  std::shared_ptr<DeviceCtx> parent;
+  evah_ctx *h = nullptr;
+  explicit Fork(std::shared_ptr<DeviceCtx> p) : parent(std::move(p)) { chk(evah_ctx_fork(parent->h, &h)); }
+  ~Fork() { evah_ctx_destroy(h); }
+  Fork(const Fork &) = delete;
+  Fork &operator=(const Fork &) = delete;
+};
+// The device half of a ciphertext value (ckks_host.h HostCipher::dev): a handle of `root`'s device
+// state.  seal_executor.h:264-277 / :420-435 copy values in and out of the executor; a resident value
+// is passed by handle instead — no copy, no PCIe.
+struct DeviceResident {
+  std::shared_ptr<DeviceCtx> root; // tables and keys the handle belongs to
+  std::shared_ptr<Fork> queue;     // the issue queue whose pool holds the buffer (null: the root's own)
+  std::shared_ptr<CtHandle> h;
+  uint32_t N = 0;                  // poly_modulus_degree: words per limb
+  evah_ctx *ctx() const { return queue ? queue->h : root->h; }
+};
+// host words of a ciphertext value, downloaded on first use (waits for the value to be computed)
+inline const CipherWords &words(const HostCipher &c) {
+  if (c.data.empty() && c.dev) {
+    CipherWords w((size_t)c.size * c.limbs * c.dev->N);
+    chk(evah_ct_download(c.dev->ctx(), c.dev->h->h, (uint64_t *)w.data()));
+    c.data = std::move(w);
+  }
+  return c.data;
+}
+inline bool resident_only(const HostCipher &c) { return c.data.empty() && c.dev; }
+
 // Per-term dispatcher: Term -> one libeva_hip call (SEALExecutor::operator(), :279-404)
 class HipExecutor {
 public:
@@ -148,16 +189,25 @@ public:
   // are its forks.  Independent DAG nodes are spread over them (the GPU counterpart of the
   // reference's Galois worker threads, multicore_program_traversal.h:55-78); ordering between
   // queues is enforced inside libeva_hip.so per buffer.
-  HipExecutor(Program &g, const HostContext &hc, std::vector<evah_ctx *> qs)
-      : program(g), host(hc), queues(std::move(qs)), ctx(queues.at(0)), objects(g.size()), queue_of(g.size(), 0) {
+  // root: the device state the queues belong to — a resident input of the same state is used by handle
+  HipExecutor(Program &g, const HostContext &hc, std::vector<evah_ctx *> qs, const DeviceCtx *root_ = nullptr)
+      : program(g), host(hc), queues(std::move(qs)), ctx(queues.at(0)), objects(g.size()), queue_of(g.size(), 0), root(root_) {
     if (program.vec_size() > host.N / 2) throw std::runtime_error("Vector size cannot be larger than slot count");
   }
 
   // values may come from files or from Python (_set_cipher): before any upload the declared shape
   // has to agree with the data length and the context, or the copy would read past the host buffer
   void check_shape(const std::string &name, const HostCipher &c) const {
-    if (c.size < 1 || c.size > 3 || c.limbs < 1 || c.limbs > host.k - 1 || c.data.size() != (size_t)c.size * c.limbs * host.N)
+    if (c.size < 1 || c.size > 3 || c.limbs < 1 || c.limbs > host.k - 1 ||
+        (!resident_only(c) && c.data.size() != (size_t)c.size * c.limbs * host.N))
       throw std::runtime_error("input " + name + ": ciphertext shape does not match its data or the encryption parameters");
+  }
+  // a value resident on this executor's device state: its handle, else null
+  std::shared_ptr<CtHandle> resident_handle(const HostCipher &c) const {
+    if (!c.dev || !root || c.dev->root.get() != root) return nullptr;
+    uint32_t s = 0, l = 0;
+    if (evah_ct_info(c.dev->h->h, &s, &l, nullptr) || s != c.size || l != c.limbs) return nullptr;
+    return c.dev->h;
   }
   void check_shape(const std::string &name, const HostPlain &p) const {
     if (p.limbs < 1 || p.limbs > host.k - 1 || p.data.size() != (size_t)p.limbs * host.N)
@@ -170,8 +220,14 @@ public:
       TermId t = program.input(kv.first);
       if (auto *c = std::get_if<HostCipher>(&kv.second)) {
         check_shape(kv.first, *c);
+        if (auto rh = resident_handle(*c)) { // already in HBM: passed by handle (ordering per buffer is the library's)
+          objects[t] = std::move(rh);
+          resident_inputs.push_back(c->dev);
+          continue;
+        }
+        const CipherWords &w = words(*c); // a value of another device state comes through the host
         evah_ct *h = nullptr;
-        chk(evah_ct_upload(ctx, c->size, c->limbs, c->scale, (const uint64_t *)c->data.data(), &h));
+        chk(evah_ct_upload(ctx, c->size, c->limbs, c->scale, (const uint64_t *)w.data(), &h));
         objects[t] = std::make_shared<CtHandle>(ctx, h);
       } else if (auto *p = std::get_if<HostPlain>(&kv.second)) {
         check_shape(kv.first, *p);
@@ -207,7 +263,7 @@ public:
           check_shape(kv.first, c);
           if (c.size != c0->size || c.limbs != c0->limbs || c.scale != c0->scale)
             throw std::runtime_error("execute_batch: input " + kv.first + " differs in shape or scale across the batch");
-          ptrs[b] = (const uint64_t *)c.data.data();
+          ptrs[b] = (const uint64_t *)words(c).data(); // the batched handle is assembled from host words
         }
         evah_ct *h = nullptr;
         chk((async ? evah_ct_upload_instances_async : evah_ct_upload_instances)(ctx, B, c0->size, c0->limbs, c0->scale, ptrs.data(), &h));
@@ -489,13 +545,23 @@ public:
       }
   }
 
-  // seal_executor.h:420-435 — outputs are downloaded into host values
-  void get_outputs(HipValuation &out) {
+  // seal_executor.h:420-435 — outputs are downloaded into host values, or (res != null) handed over
+  // as handles: `res` is the template (root, queue) of the resident value, the handle is filled in
+  void get_outputs(HipValuation &out, const DeviceResident *res = nullptr) {
     for (auto &kv : program.outputs()) {
       auto &o = objects[kv.second];
       if (auto *c = std::get_if<std::shared_ptr<CtHandle>>(&o)) {
         HostCipher hc;
         chk(evah_ct_info((*c)->h, &hc.size, &hc.limbs, &hc.scale));
+        if (res) {
+          // an output that IS an input (Output(Input)) keeps the queue it came with
+          bool passed_through = false;
+          for (auto &in : resident_inputs)
+            if (in->h == *c) { hc.dev = in; passed_through = true; break; }
+          if (!passed_through) hc.dev = std::make_shared<DeviceResident>(DeviceResident{res->root, res->queue, *c, host.N});
+          out.values[kv.first] = std::move(hc);
+          continue;
+        }
         hc.data.resize((size_t)hc.size * hc.limbs * host.N);
         chk(evah_ct_download(ctx, (*c)->h, (uint64_t *)hc.data.data()));
         out.values[kv.first] = std::move(hc);
@@ -523,6 +589,8 @@ private:
   uint32_t next_queue = 0;
   std::vector<double> scratch;
   std::vector<std::pair<TermId, TermId>> deferred_free; // (lazy relin term, its source)
+  const DeviceCtx *root = nullptr;
+  std::vector<std::shared_ptr<DeviceResident>> resident_inputs;
   bool batch_rotations = std::getenv("EVA_BATCH_ROTATIONS") ? std::atoi(std::getenv("EVA_BATCH_ROTATIONS")) != 0 : true;
   bool fuse_relin_rescale = std::getenv("EVA_FUSE_RELIN_RESCALE") ? std::atoi(std::getenv("EVA_FUSE_RELIN_RESCALE")) != 0 : true;
   bool device_encode = std::getenv("EVA_DEVICE_ENCODE") ? std::atoi(std::getenv("EVA_DEVICE_ENCODE")) != 0 : true;
@@ -667,14 +735,11 @@ template <class Exec> void run_counted(Program &p, Exec &ex, const std::vector<c
 }
 
 // ---- contexts (seal.h:45-97)
-struct DeviceCtx {
-  evah_ctx *h = nullptr;
-  DeviceCtx(uint32_t N, const std::vector<u64> &primes, int device) {
-    chk(evah_ctx_create(N, (uint32_t)primes.size(), (const uint64_t *)primes.data(), device, &h));
-  }
-  ~DeviceCtx() { evah_ctx_destroy(h); }
-  DeviceCtx(const DeviceCtx &) = delete;
-  DeviceCtx &operator=(const DeviceCtx &) = delete;
+// The device state generate_keys() hands to BOTH halves of a key pair: a valuation produced by the
+// public context can then be decrypted by the secret context without leaving the device.  Contexts
+// loaded from files get a holder of their own.
+struct DeviceHolder {
+  std::shared_ptr<DeviceCtx> dev;
 };
 
 class HipPublic {
@@ -686,6 +751,16 @@ public:
   int device = 0;
   bool free_eagerly = true;
   std::array<double, 3> last_timing{0, 0, 0}; // ms: input upload, DAG enqueue (host), drain + output download
+  // Valuations stay on the device (the valuation "may hold device handles"): encrypt()
+  // leaves its ciphertexts in HBM, execute() takes and returns handles and does NOT wait for the GPU,
+  // decrypt() reads handles; host words appear when somebody asks for them (get(), save(), a context on
+  // another device).  EVA_RESIDENT=0 restores host valuations (every call copies in and out and waits).
+  bool resident = std::getenv("EVA_RESIDENT") ? std::atoi(std::getenv("EVA_RESIDENT")) != 0 : true;
+  // Device-resident inputs above this many bytes are walked eagerly instead of replaying the captured
+  // graph: a replay would first copy them into the graph's fixed input slots (and its outputs out
+  // again), and launches of that size gain nothing from a graph.
+  size_t graph_copy_limit = (size_t)32 << 20;
+  std::shared_ptr<DeviceHolder> holder = std::make_shared<DeviceHolder>();
   // HIP streams independent DAG nodes are spread over (EVA_NUM_STREAMS).  Default 1: at these
   // kernel sizes a single in-order queue keeps the GPU as busy as the host can feed it; more
   // queues are correct (ordering is enforced per buffer inside libeva_hip.so) and pay off when
@@ -710,6 +785,13 @@ public:
         HostPlain pt;
         pt.limbs = host->k - 1 - (uint32_t)info.level;
         pt.scale = std::pow(2.0, (double)info.scale);
+        if (info.input_type == Type::Cipher && client_on_device() && device_encodable(v, pt.scale, pt.limbs)) {
+          // encoder and encryptor both on the GPU (evah_pt_encode -> evah_encrypt): the plaintext never
+          // exists on the host.  Same plaintext as the host encoder bit for bit (tests/test_encode_parity.py)
+          // and the same sampler calls in the same order, hence the same ciphertext as every other path
+          out.values[kv.first] = encrypt_on_device(nullptr, &v, pt.scale, pt.limbs, rng);
+          continue;
+        }
         pt.data.resize((size_t)pt.limbs * host->N);
         std::vector<double> vec(slots);
         for (size_t r = 0; r < slots / v.size(); r++) std::copy(v.begin(), v.end(), vec.begin() + r * v.size());
@@ -719,7 +801,7 @@ public:
           // GPU (evah_encrypt); the host keeps the FP64 encoder and the sampling (same sampler calls,
           // in the same order, as evahost::encrypt — so both paths give the same ciphertext for the
           // same random stream)
-          out.values[kv.first] = encrypt_on_device(pt, rng);
+          out.values[kv.first] = encrypt_on_device(&pt, nullptr, pt.scale, pt.limbs, rng);
           continue;
         }
         for (uint32_t i = 0; i < pt.limbs; i++) host->ntt(i, pt.data.data() + (size_t)i * host->N);
@@ -739,7 +821,7 @@ public:
   bool use_graphs = true; // EVA_GRAPH=0 disables
   HipValuation execute(Program &program, const HipValuation &inputs) {
     ensure_device();
-    if (graphs_enabled() && graphable(program, inputs)) {
+    if (graphs_enabled() && graphable(program, inputs) && resident_bytes(inputs) <= graph_copy_limit) {
       auto it = plans.find(&program);
       if (it == plans.end() && !no_graph.count(&program)) {
         seen[&program]++;
@@ -763,7 +845,18 @@ public:
     }
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
-    HipExecutor ex(program, *host, queue_handles());
+    // Resident outputs: nothing below waits for the GPU, so consecutive calls queue up behind each
+    // other.  Calls alternate between two issue queues; a call with host inputs blocks only in its own
+    // uploads, which therefore overlap the previous call's kernels on the other queue (the
+    // double-buffering of setInputs, seal_executor.h:264-277, against compute).
+    std::shared_ptr<Fork> rq;
+    std::vector<evah_ctx *> qh = queue_handles();
+    if (resident && library_scheduler && num_queues <= 1 && qh.size() == 1) {
+      if (!exec_q[0]) { exec_q[0] = std::make_shared<Fork>(dev); exec_q[1] = std::make_shared<Fork>(dev); }
+      rq = exec_q[exec_turn++ & 1];
+      qh = {rq->h};
+    }
+    HipExecutor ex(program, *host, qh, dev.get());
     // constants (Constant / Encode nodes and arithmetic on them) are evaluated by the first walk
     // of a program and stay resident: later walks only look them up
     ConstCache &cc = const_cache[&program];
@@ -784,11 +877,31 @@ public:
     else run_counted(program, ex, &cc.done);
     auto t2 = clk::now();
     HipValuation out;
-    ex.get_outputs(out);
+    if (resident) {
+      const DeviceResident where{dev, rq, nullptr, host->N};
+      ex.get_outputs(out, &where);
+    } else {
+      ex.get_outputs(out);
+    }
     auto t3 = clk::now();
     last_timing = {std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
                    std::chrono::duration<double, std::milli>(t3 - t2).count()};
     return out;
+  }
+
+  // wait until everything execute() / encrypt() have enqueued on this context's queues is done
+  void synchronize() {
+    if (!dev) return;
+    chk(evah_ctx_sync(dev->h));
+    for (auto &f : forks) chk(evah_ctx_sync(f->h));
+    for (auto &f : exec_q) if (f) chk(evah_ctx_sync(f->h));
+    for (auto &kv : plans) for (auto &f : kv.second->queues) chk(evah_ctx_sync(f->h));
+  }
+  // (h2d value transfers, d2h value transfers, h2d bytes, d2h bytes) of this context's device state
+  std::array<uint64_t, 4> transfer_stats() {
+    std::array<uint64_t, 4> st{0, 0, 0, 0};
+    if (dev) chk(evah_ctx_transfer_stats(dev->h, st.data()));
+    return st;
   }
 
   // A batch of independent executions of one program (BASELINE config 4): instances are grouped
@@ -807,7 +920,7 @@ public:
     // of one group overlap the kernels of the other and the host never idles the device.  Device
     // memory stays at two groups' working sets (the pools recycle in queue order); the inputs belong
     // to the caller and the outputs are allocated up front, so both outlive the final synchronisation.
-    if (!batch_fork) batch_fork = std::make_unique<Fork>(dev->h);
+    if (!batch_fork) batch_fork = std::make_shared<Fork>(dev);
     evah_ctx *qs[2] = {dev->h, batch_fork->h};
     // constants (Constant / Encode nodes and raw arithmetic on them) are evaluated once, by the
     // first group, and shared by all groups: their plaintexts stay resident for the whole call
@@ -825,7 +938,7 @@ public:
         const size_t n = std::min<size_t>(batch_chunk, inputs.size() - i0);
         std::vector<const HipValuation *> chunk(inputs.begin() + i0, inputs.begin() + i0 + n);
         if (bounded && g >= 2) chk(evah_ctx_sync(qs[g & 1])); // group g-2 (same queue) has left the device
-        HipExecutor ex(program, *host, std::vector<evah_ctx *>{qs[g & 1]});
+        HipExecutor ex(program, *host, std::vector<evah_ctx *>{qs[g & 1]}, dev.get());
         if (g == 0) {
           done = ex.prepare_constants();
           consts.resize(program.size());
@@ -858,22 +971,27 @@ public:
     const_cache.clear();
     plans.clear();
     batch_fork.reset();
-    forks.clear(); // queues go before the root context
+    exec_q[0].reset();
+    exec_q[1].reset();
+    forks.clear(); // queues go before the root context (each fork also holds it)
     dev.reset();
   }
   void drop_graphs() { plans.clear(); seen.clear(); no_graph.clear(); const_cache.clear(); }
 
 private:
-  std::shared_ptr<DeviceCtx> dev;
-  struct Fork {
-    evah_ctx *h = nullptr;
-    explicit Fork(evah_ctx *parent) { chk(evah_ctx_fork(parent, &h)); }
-    ~Fork() { evah_ctx_destroy(h); }
-    Fork(const Fork &) = delete;
-    Fork &operator=(const Fork &) = delete;
-  };
-  std::vector<std::unique_ptr<Fork>> forks;
-  std::unique_ptr<Fork> batch_fork; // second issue queue of execute_batch
+  std::shared_ptr<DeviceCtx> dev; // == holder->dev once a device is in use
+  std::vector<std::shared_ptr<Fork>> forks;
+  std::shared_ptr<Fork> batch_fork; // second issue queue of execute_batch
+  std::shared_ptr<Fork> exec_q[2];  // the two issue queues resident execute() calls alternate between
+  unsigned exec_turn = 0;
+  // bytes of the inputs that are resident on this context's device (and nowhere on the host)
+  size_t resident_bytes(const HipValuation &inputs) const {
+    size_t b = 0;
+    for (auto &kv : inputs.values)
+      if (auto *c = std::get_if<HostCipher>(&kv.second))
+        if (c->dev && c->dev->root == dev) b += sizeof(u64) * (size_t)c->size * c->limbs * host->N;
+    return b;
+  }
 
   // A captured execute(): its own queues (pools are exclusive to the graph), persistent input
   // slots and constant plaintexts, the outputs' handles, the instantiated hipGraph.
@@ -891,12 +1009,13 @@ private:
   struct GraphPlan {
     size_t program_size = 0;
     uint64_t hash = 0;
-    std::vector<std::unique_ptr<Fork>> queues;
+    std::vector<std::shared_ptr<Fork>> queues;
     std::unordered_map<std::string, std::shared_ptr<CtHandle>> in_ct;
     std::unordered_map<std::string, std::shared_ptr<PtHandle>> in_pt;
     std::vector<HipExecutor::RuntimeValue> persistent; // constants
     std::unordered_map<std::string, HipExecutor::RuntimeValue> outputs;
     evah_graph *graph = nullptr;
+    bool outputs_copied = false; // device copies of the last replay's outputs were enqueued on the root queue
     ~GraphPlan() {
       outputs.clear();
       persistent.clear();
@@ -955,7 +1074,7 @@ private:
     // the ROCm 7.2 runtime (recursion blow-up in hipStreamEndCapture on reconvergent DAGs); a
     // linear graph replays with ~10 us of host time.
     const int want = 1;
-    for (int i = 0; i < want; i++) plan->queues.push_back(std::make_unique<Fork>(dev->h));
+    for (int i = 0; i < want; i++) plan->queues.push_back(std::make_shared<Fork>(dev));
     std::vector<evah_ctx *> q;
     for (auto &f : plan->queues) q.push_back(f->h);
     evah_ctx *q0 = q[0];
@@ -966,7 +1085,8 @@ private:
       if (auto *c = std::get_if<HostCipher>(&kv.second)) {
         ex.check_shape(kv.first, *c);
         evah_ct *h = nullptr;
-        chk(evah_ct_upload(q0, c->size, c->limbs, c->scale, (const uint64_t *)c->data.data(), &h));
+        if (c->dev && c->dev->root == dev) chk(evah_ct_copy(q0, c->dev->h->h, &h)); // the slot is the graph's own buffer
+        else chk(evah_ct_upload(q0, c->size, c->limbs, c->scale, (const uint64_t *)words(*c).data(), &h));
         auto sp = std::make_shared<CtHandle>(q0, h);
         plan->in_ct[kv.first] = sp;
         ex.set_value(t, sp);
@@ -1005,11 +1125,20 @@ private:
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
     evah_ctx *q0 = plan.queues[0]->h;
+    // the previous replay's outputs may still be being copied out on the root queue (below): the
+    // graph's kernels are not tracked per buffer, so the replay is ordered after those copies here
+    if (plan.outputs_copied) chk(evah_ctx_wait(q0, dev->h));
+    plan.outputs_copied = false;
     for (auto &kv : inputs.values) {
       // matches() compared the declared shapes with the slots; the data length must agree as well
       if (auto *c = std::get_if<HostCipher>(&kv.second)) {
-        if (c->data.size() != (size_t)c->size * c->limbs * host->N) throw std::runtime_error("input " + kv.first + ": ciphertext shape does not match its data");
-        chk(evah_ct_write(q0, plan.in_ct.at(kv.first)->h, (const uint64_t *)c->data.data()));
+        if (c->dev && c->dev->root == dev) { // resident: refill the slot device to device
+          chk(evah_ct_assign(q0, plan.in_ct.at(kv.first)->h, c->dev->h->h));
+          continue;
+        }
+        const CipherWords &w = words(*c);
+        if (w.size() != (size_t)c->size * c->limbs * host->N) throw std::runtime_error("input " + kv.first + ": ciphertext shape does not match its data");
+        chk(evah_ct_write(q0, plan.in_ct.at(kv.first)->h, (const uint64_t *)w.data()));
       } else {
         auto &pl = std::get<HostPlain>(kv.second);
         if (pl.data.size() != (size_t)pl.limbs * host->N) throw std::runtime_error("input " + kv.first + ": plaintext shape does not match its data");
@@ -1024,6 +1153,14 @@ private:
       if (auto *c = std::get_if<std::shared_ptr<CtHandle>>(&kv.second)) {
         HostCipher hc;
         chk(evah_ct_info((*c)->h, &hc.size, &hc.limbs, &hc.scale));
+        if (resident) { // the graph owns its output buffers: hand out a device copy (root queue, ordered after the replay)
+          evah_ct *copy = nullptr;
+          chk(evah_ct_copy(dev->h, (*c)->h, &copy));
+          hc.dev = std::make_shared<DeviceResident>(DeviceResident{dev, nullptr, std::make_shared<CtHandle>(dev->h, copy), host->N});
+          plan.outputs_copied = true;
+          out.values[kv.first] = std::move(hc);
+          continue;
+        }
         hc.data.resize((size_t)hc.size * hc.limbs * host->N);
         chk(evah_ct_download(q0, (*c)->h, (uint64_t *)hc.data.data()));
         out.values[kv.first] = std::move(hc);
@@ -1049,7 +1186,7 @@ private:
     int want = num_queues;
     if (const char *e = std::getenv("EVA_NUM_STREAMS")) want = std::atoi(e);
     if (want < 1) want = 1;
-    while ((int)forks.size() + 1 < want) forks.push_back(std::make_unique<Fork>(dev->h));
+    while ((int)forks.size() + 1 < want) forks.push_back(std::make_shared<Fork>(dev));
     std::vector<evah_ctx *> q{dev->h};
     for (int i = 0; i + 1 < want; i++) q.push_back(forks[i]->h);
     return q;
@@ -1066,7 +1203,22 @@ private:
   }
   int client_device = -1;
   bool pk_uploaded = false;
-  HostCipher encrypt_on_device(const HostPlain &coeff_pt, SecureRng &rng) {
+  // same bound as HipExecutor::device_encodable: every rounded coefficient below 2^62 and inside the modulus
+  bool device_encodable(const std::vector<double> &in, double scale, uint32_t limbs) const {
+    const size_t slots = host->N / 2;
+    if (std::getenv("EVA_DEVICE_ENCODE") && !std::atoi(std::getenv("EVA_DEVICE_ENCODE"))) return false;
+    if (in.empty() || in.size() > slots || slots % in.size()) return false;
+    double sum = 0;
+    for (double x : in) {
+      if (!std::isfinite(x)) return false;
+      sum += std::fabs(x);
+    }
+    const double bound = 2.0 * sum * (double)(slots / in.size()) * scale / (double)host->N;
+    const int bits = (int)std::ceil(std::log2(std::max(bound, 1.0))) + 1;
+    return bits < 62 && bits < host->total_bits[limbs];
+  }
+  // coeff_pt: the host encoder's coefficient-form plaintext, or (null) values: the slot values for the device encoder
+  HostCipher encrypt_on_device(const HostPlain *coeff_pt, const std::vector<double> *values, double scale, uint32_t limbs, SecureRng &rng) {
     ensure_device();
     if (!pk_uploaded) {
       chk(evah_client_key_upload(dev->h, EVAH_KEY_PUBLIC, (const uint64_t *)pk.data.data()));
@@ -1081,25 +1233,30 @@ private:
     std::copy(e0.begin(), e0.end(), small.begin() + N);
     std::copy(e1.begin(), e1.end(), small.begin() + 2 * (size_t)N);
     evah_pt *p = nullptr;
-    chk(evah_pt_upload_coeff(dev->h, coeff_pt.limbs, coeff_pt.scale, (const uint64_t *)coeff_pt.data.data(), &p));
+    if (coeff_pt) chk(evah_pt_upload_coeff(dev->h, limbs, scale, (const uint64_t *)coeff_pt->data.data(), &p));
+    else chk(evah_pt_encode(dev->h, values->data(), (uint32_t)values->size(), limbs, scale, &p));
     evah_ct *c = nullptr;
     int rc = evah_encrypt(dev->h, p, small.data(), &c);
     evah_pt_free(dev->h, p);
     chk(rc);
     HostCipher out;
     out.size = 2;
-    out.limbs = coeff_pt.limbs;
-    out.scale = coeff_pt.scale;
+    out.limbs = limbs;
+    out.scale = scale;
+    auto handle = std::make_shared<CtHandle>(dev->h, c);
+    if (resident) { // stays in HBM; host words on demand
+      out.dev = std::make_shared<DeviceResident>(DeviceResident{dev, nullptr, handle, host->N});
+      return out;
+    }
     out.data.resize((size_t)2 * out.limbs * N);
-    rc = evah_ct_download(dev->h, c, (uint64_t *)out.data.data());
-    evah_ct_free(dev->h, c);
-    chk(rc);
+    chk(evah_ct_download(dev->h, c, (uint64_t *)out.data.data()));
     return out;
   }
 
   void ensure_device() {
     if (dev) return;
-    dev = std::make_shared<DeviceCtx>(host->N, host->primes, device);
+    if (!holder->dev) holder->dev = std::make_shared<DeviceCtx>(host->N, host->primes, device);
+    dev = holder->dev; // may have been created by the secret half of the key pair (decrypt first)
     chk(evah_key_upload(dev->h, EVAH_KEY_RELIN, 0, relin.n_digits, (const uint64_t *)relin.data.data()));
     for (auto &kv : galois)
       chk(evah_key_upload(dev->h, EVAH_KEY_GALOIS, kv.first, kv.second.n_digits, (const uint64_t *)kv.second.data.data()));
@@ -1119,13 +1276,17 @@ public:
       int n = 0;
       state = (!e || std::atoi(e) != 0) && evah_device_count(&n) == 0 && n > 0 ? 1 : 0;
       if (state == 1) {
-        dev = std::make_shared<DeviceCtx>(host->N, host->primes, device);
+        // the device state of the key pair (generate_keys shares one holder between both halves), so
+        // that the public context's resident results are read in place
+        if (!holder->dev) holder->dev = std::make_shared<DeviceCtx>(host->N, host->primes, device);
+        dev = holder->dev;
         chk(evah_client_key_upload(dev->h, EVAH_KEY_SECRET, (const uint64_t *)sk.s_ntt.data()));
       }
     }
     return state == 1;
   }
   int state = -1;
+  std::shared_ptr<DeviceHolder> holder = std::make_shared<DeviceHolder>();
   std::shared_ptr<DeviceCtx> dev;
   // SEALSecret::decrypt (seal.cpp:124-146)
   Valuation decrypt(const HipValuation &enc, const CKKSSignature &sig) {
@@ -1134,17 +1295,23 @@ public:
       std::vector<double> v;
       if (auto *c = std::get_if<HostCipher>(&kv.second)) {
         if (on_device()) { // dot product with s, inverse transforms, recomposition and the special FFT on the GPU
-          if (c->size < 1 || c->size > 3 || c->limbs < 1 || c->limbs > host->k - 1 || c->data.size() != (size_t)c->size * c->limbs * host->N)
+          if (c->size < 1 || c->size > 3 || c->limbs < 1 || c->limbs > host->k - 1 ||
+              (!resident_only(*c) && c->data.size() != (size_t)c->size * c->limbs * host->N))
             throw std::runtime_error("output " + kv.first + ": ciphertext shape does not match its data or the encryption parameters");
-          evah_ct *h = nullptr;
-          chk(evah_ct_upload(dev->h, c->size, c->limbs, c->scale, (const uint64_t *)c->data.data(), &h));
           v.resize((size_t)sig.vec_size);
-          int rc = evah_decrypt_decode(dev->h, h, (uint32_t)sig.vec_size, v.data());
-          evah_ct_free(dev->h, h);
-          chk(rc);
+          if (c->dev && c->dev->root == dev) { // resident on this key pair's device state: read in place
+            chk(evah_decrypt_decode(dev->h, c->dev->h->h, (uint32_t)sig.vec_size, v.data()));
+          } else {
+            evah_ct *h = nullptr;
+            chk(evah_ct_upload(dev->h, c->size, c->limbs, c->scale, (const uint64_t *)words(*c).data(), &h));
+            int rc = evah_decrypt_decode(dev->h, h, (uint32_t)sig.vec_size, v.data());
+            evah_ct_free(dev->h, h);
+            chk(rc);
+          }
           out[kv.first] = std::move(v);
           continue;
         }
+        (void)words(*c);
         auto m = decrypt_to_coeff(*host, sk, *c);
         host->decode_coeff(m.data(), c->limbs, c->scale, v);
       } else if (auto *p = std::get_if<HostPlain>(&kv.second)) {
@@ -1172,6 +1339,7 @@ generate_keys(const CKKSParameters &params, uint64_t seed = 0) {
   KeyGenerator kg(*host, seed); // seed == 0: keyed from the OS; otherwise the reproducible test hook
   auto pub = std::make_shared<HipPublic>();
   auto sec = std::make_shared<HipSecret>();
+  sec->holder = pub->holder; // one device state for the pair: results stay resident from encrypt to decrypt
   pub->host = host;
   pub->pk = kg.public_key();
   pub->relin = kg.relin_key();

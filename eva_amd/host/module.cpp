@@ -189,13 +189,33 @@ PYBIND11_MODULE(_eva, m) {
       })
       .def("_set_raw", [](HipValuation &v, const std::string &name, std::vector<double> data) { v.values[name] = std::move(data); })
       .def("names", [](const HipValuation &v) { std::vector<std::string> n; for (auto &kv : v.values) n.push_back(kv.first); return n; })
+      .def("is_resident", [](const HipValuation &v, const std::string &name) {
+        auto it = v.values.find(name);
+        if (it == v.values.end()) throw std::out_of_range("No value named " + name);
+        auto *c = std::get_if<HostCipher>(&it->second);
+        return c && c->dev != nullptr;
+      }, py::arg("name"), "True while the ciphertext lives in HBM (a handle of the device context that produced it)")
+      .def("on_host", [](const HipValuation &v, const std::string &name) {
+        auto it = v.values.find(name);
+        if (it == v.values.end()) throw std::out_of_range("No value named " + name);
+        auto *c = std::get_if<HostCipher>(&it->second);
+        return !c || !c->data.empty();
+      }, py::arg("name"), "True when host words of the value exist (always, for plaintexts and raw vectors)")
+      .def("to_host", [](HipValuation &v, bool drop_device) {
+        for (auto &kv : v.values)
+          if (auto *c = std::get_if<HostCipher>(&kv.second)) {
+            (void)words(*c);
+            if (drop_device) c->dev.reset();
+          }
+      }, py::arg("drop_device") = false, "Download every device-resident ciphertext (waits for it); drop_device releases the HBM copies")
       // (kind, size, limbs, scale, data) — raw residues for the bit-exact parity tests
       .def("get", [](const HipValuation &v, const std::string &name) -> py::object {
         auto it = v.values.find(name);
         if (it == v.values.end()) throw std::out_of_range("No value named " + name);
         if (auto *c = std::get_if<HostCipher>(&it->second)) {
-          py::ssize_t n = (py::ssize_t)(c->data.size() / ((size_t)c->size * c->limbs));
-          return py::make_tuple("cipher", c->size, c->limbs, c->scale, to_numpy(c->data, {(py::ssize_t)c->size, (py::ssize_t)c->limbs, n}));
+          const CipherWords &w = words(*c); // a device-resident value is downloaded (and kept) here
+          py::ssize_t n = (py::ssize_t)(w.size() / ((size_t)c->size * c->limbs));
+          return py::make_tuple("cipher", c->size, c->limbs, c->scale, to_numpy(w, {(py::ssize_t)c->size, (py::ssize_t)c->limbs, n}));
         }
         if (auto *p = std::get_if<HostPlain>(&it->second)) {
           py::ssize_t n = (py::ssize_t)(p->data.size() / p->limbs);
@@ -216,6 +236,15 @@ PYBIND11_MODULE(_eva, m) {
       .def_readwrite("free_eagerly", &HipPublic::free_eagerly)
       .def_readwrite("use_graphs", &HipPublic::use_graphs, "replay repeated executions of one program from a captured hipGraph")
       .def("drop_graphs", &HipPublic::drop_graphs)
+      .def_readwrite("resident", &HipPublic::resident, "keep valuations in HBM: encrypt/execute return device handles and execute does not wait for the GPU (EVA_RESIDENT=0: host valuations)")
+      .def_readwrite("graph_copy_limit", &HipPublic::graph_copy_limit, "device-resident inputs above this many bytes are walked eagerly instead of copied into a captured graph's slots")
+      .def("synchronize", &HipPublic::synchronize, "wait for everything this context has enqueued")
+      .def("transfer_stats", [](HipPublic &p) {
+        auto st = p.transfer_stats();
+        py::dict d;
+        d["h2d_values"] = st[0]; d["d2h_values"] = st[1]; d["h2d_bytes"] = st[2]; d["d2h_bytes"] = st[3];
+        return d;
+      }, "ciphertext / plaintext transfers across the host boundary since the device context was created")
       .def_readonly("last_timing", &HipPublic::last_timing, "ms of the last execute(): (input upload, DAG enqueue on the host, drain + output download)")
       .def_readwrite("num_queues", &HipPublic::num_queues, "HIP streams independent DAG nodes are spread over")
       .def_property_readonly("poly_modulus_degree", [](const HipPublic &p) { return p.host->N; })

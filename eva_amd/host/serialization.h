@@ -174,7 +174,10 @@ inline void write(Writer &w, const HipValuation &v) {
   w.pod<uint64_t>(v.values.size());
   for (auto &kv : v.values) {
     w.str(kv.first);
-    if (auto *c = std::get_if<HostCipher>(&kv.second)) { w.pod<uint32_t>(1); w.pod(c->size); w.pod(c->limbs); w.pod(c->scale); w.vec(c->data); }
+    if (auto *c = std::get_if<HostCipher>(&kv.second)) {
+      w.pod<uint32_t>(1); w.pod(c->size); w.pod(c->limbs); w.pod(c->scale);
+      w.vec(words(*c)); // a device-resident value is downloaded for the file
+    }
     else if (auto *p = std::get_if<HostPlain>(&kv.second)) { w.pod<uint32_t>(2); w.pod(p->limbs); w.pod(p->scale); w.vec(p->data); }
     else { w.pod<uint32_t>(3); w.vec(std::get<std::vector<double>>(kv.second)); }
   }

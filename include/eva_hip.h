@@ -114,6 +114,18 @@ int evah_pt_copy(evah_ctx *dst_ctx, const evah_pt *src, evah_pt **out);
 /* overwrite an existing handle's residues (same shape) — refills the input slots of a graph */
 int evah_ct_write(evah_ctx *ctx, evah_ct *ct, const uint64_t *data);
 int evah_pt_write(evah_ctx *ctx, evah_pt *pt, const uint64_t *data);
+/* device-to-device refill of an existing handle from another one of the same shape (the input slot of a
+ * captured execute() from a device-resident valuation entry: seal_executor.h:264-277 copies inputs in,
+ * here without leaving the device); asynchronous on ctx's queue, ordered after the producer of src */
+int evah_ct_assign(evah_ctx *ctx, evah_ct *dst, const evah_ct *src);
+/* `waiter`'s queue waits for everything enqueued so far on `signaller`'s queue (both of one device
+ * state); no host synchronisation.  Orders work the per-buffer tracking cannot see (graph replays). */
+int evah_ctx_wait(evah_ctx *waiter, evah_ctx *signaller);
+/* values that crossed the host boundary through this context and its forks since creation:
+ * out[0] = host->device value transfers (ct / pt upload, write), out[1] = device->host (download),
+ * out[2], out[3] = their bytes.  The valuation of the reference "may hold device handles"
+ * (SURVEY.md 8(b)); tests assert that encrypt -> execute -> decrypt moves no ciphertext across. */
+int evah_ctx_transfer_stats(evah_ctx *ctx, uint64_t out[4]);
 int evah_ct_info(const evah_ct *ct, uint32_t *size, uint32_t *limbs, double *scale);
 int evah_ct_download(evah_ctx *ctx, const evah_ct *ct, uint64_t *out /* [size][limbs][N] */);
 void evah_ct_free(evah_ctx *ctx, evah_ct *ct);
