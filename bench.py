@@ -83,13 +83,33 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def pad_chain(params, n_primes, N):
+    """force N and pad prime_bits with 60-bit primes (after the output prime) up to n_primes."""
+    params.poly_modulus_degree = N
+    pb = list(params.prime_bits)
+    if len(pb) < n_primes:
+        params.prime_bits = pb[:1] + [60] * (n_primes - len(pb)) + pb[1:]
+
+
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
 def execute_leg(N, l, n_products, reps):
     """The op-triples as a compiled program through public_ctx.execute(): z_i = x_i * y_i with eager
-    relinearization, so every product is Mul -> Relinearize -> Rescale on l limbs."""
+    relinearization, so every product is Mul -> Relinearize -> Rescale on l limbs.  Three ways of
+    holding the valuations (the valuation "may hold device handles"):
+      resident        inputs left in HBM by encrypt(), outputs left in HBM for decrypt(): execute() is
+                      an asynchronous enqueue; timed as `reps` calls + one synchronize
+      pipelined_host  host inputs (pinned), resident outputs: each call blocks in its own uploads, which
+                      overlap the previous call's kernels on the other issue queue
+      host_roundtrip  host valuations in and out (EVA_RESIDENT=0 behaviour): upload, run, download, per call"""
     import numpy as np
     from eva import EvaProgram, Input, Output
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
+    from eva_amd.roofline import dag_bytes, roofline as rl
     prog = EvaProgram('op_triples', vec_size=1024)
     with prog:
         for i in range(n_products):
@@ -105,30 +125,58 @@ def execute_leg(N, l, n_products, reps):
     for i in range(n_products):
         inputs[f'x{i}'] = list(rng.uniform(-1, 1, 1024))
         inputs[f'y{i}'] = list(rng.uniform(-1, 1, 1024))
-    enc = pub.encrypt(inputs, sig)
-    out = pub.execute(compiled, enc)            # eager walk (device context, key upload, pool)
-    out = pub.execute(compiled, enc)            # graph capture
-    ts, parts = [], []
-    for _ in range(reps):
+    enc = pub.encrypt(inputs, sig)              # resident: the ciphertexts stay in HBM
+    nbytes, _ = dag_bytes(compiled, sig, N, l + 1)
+
+    def timed(valuation, n):
+        for _ in range(2):                      # device context / key upload / pools; queue pair warm
+            out = pub.execute(compiled, valuation)
+        pub.synchronize()
         t0 = time.perf_counter()
-        out = pub.execute(compiled, enc)
-        ts.append(time.perf_counter() - t0)
-        parts.append(list(pub.last_timing))
-    ts.sort()
-    med = ts[len(ts) // 2]
-    # check product 0 against the oracle's op-triple on the same encrypted inputs and key
+        for _ in range(n):
+            out = pub.execute(compiled, valuation)
+        pub.synchronize()
+        return (time.perf_counter() - t0) / n, out
+
+    st0 = pub.transfer_stats()
+    t_res, out = timed(enc, reps)
+    st1 = pub.transfer_stats()
+    moved = {k: st1[k] - st0[k] for k in ("ct_uploads", "ct_downloads")}
+    # check the first and the last product against the oracle's op-triple on the same encrypted inputs and key
     from oracle import pyoracle as po  # checker only
     o = po.Oracle(N, list(pub.primes))
-    want = o.op_triple(enc.get('x0')[4], enc.get('y0')[4], pub.relin_key())
-    ok = bool(np.array_equal(out.get('z0')[4], want))
-    from eva import Op
+    ok = True
+    for i in (0, n_products - 1):
+        want = o.op_triple(enc.get(f'x{i}')[4], enc.get(f'y{i}')[4], pub.relin_key())
+        ok = ok and bool(np.array_equal(out.get(f'z{i}')[4], want))
+    enc.to_host(True)                           # host words only from here on (pinned pages)
+    t_pipe, out2 = timed(enc, max(3, reps // 2))
+    ok = ok and bool(np.array_equal(out2.get('z0')[4], out.get('z0')[4]))
+    pub.resident = False
+    ts, parts = [], []
+    for _ in range(max(3, reps // 2) + 2):
+        t0 = time.perf_counter()
+        out3 = pub.execute(compiled, enc)
+        ts.append(time.perf_counter() - t0)
+        parts.append(list(pub.last_timing))
+    ts, parts = ts[2:], parts[2:]
+    t_host = _median(ts)
+    ok = ok and bool(np.array_equal(out3.get('z0')[4], out.get('z0')[4]))
     kinds = [str(d["op"]).split(".")[-1] for d in compiled._dump()]
-    pm = [sorted(p[j] for p in parts)[len(parts) // 2] for j in range(3)]
+    pm = [_median([p[j] for p in parts]) for j in range(3)]
+    in_mb = 2 * n_products * 2 * l * N * 8 / 1e6
     return {"program": f"{n_products} independent products z_i = x_i * y_i (Mul -> Relinearize -> Rescale), N=2^{N.bit_length() - 1}, L={l}",
-            "ms_per_execute": round(med * 1e3, 3), "triples_per_s": round(n_products / med, 1),
-            "includes": "input upload (PCIe), hipGraph replay, output download (PCIe)",
-            "ms_upload_enqueue_drain": [round(x, 3) for x in pm],
             "ops": {kk: kinds.count(kk) for kk in ("Mul", "Relinearize", "Rescale")},
+            "triples_per_s": round(n_products / t_res, 1), "ms_per_execute": round(t_res * 1e3, 3),
+            "valuations": "device-resident (encrypt -> execute -> decrypt by handle; no PCIe, execute() does not wait for the GPU)",
+            "ciphertexts_moved_over_pcie": moved,
+            "roofline": rl(nbytes, t_res),
+            "pipelined_host_inputs": {"triples_per_s": round(n_products / t_pipe, 1), "ms_per_execute": round(t_pipe * 1e3, 3),
+                                      "input_mb_per_execute": round(in_mb, 1), "pcie_gb_per_s": round(in_mb / 1e3 / t_pipe, 1),
+                                      "note": "PCIe-bound: 21 MB of operands per triple; uploads overlap the previous call's kernels"},
+            "host_roundtrip": {"triples_per_s": round(n_products / t_host, 1), "ms_per_execute": round(t_host * 1e3, 3),
+                               "ms_upload_enqueue_drain": [round(x, 3) for x in pm],
+                               "includes": "input upload (PCIe), run, output download (PCIe), synchronous"},
             "bit_exact_vs_oracle": ok}
 
 
@@ -138,32 +186,47 @@ def dag_leg(reps, cpu_threads):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
+    from eva_amd.roofline import dag_bytes, roofline as rl
     from test_gpu_e2e import _harris, _image
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
-    params.poly_modulus_degree = 32768
-    pb = list(params.prime_bits)
-    params.prime_bits = pb[:1] + [60] * (9 - len(pb)) + pb[1:]
+    pad_chain(params, 9, 32768)
     pub, sec = generate_keys(params, 1)
+    nbytes, by = dag_bytes(compiled, sig, 32768, 9)
     enc = pub.encrypt(_image(4096), sig)
-    out = pub.execute(compiled, enc)
-    out = pub.execute(compiled, enc)
+    # resident valuations: enqueue + synchronize per call (the latency of one execute())
+    for _ in range(3):
+        out = pub.execute(compiled, enc)
+    pub.synchronize()
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
         out = pub.execute(compiled, enc)
+        pub.synchronize()
         ts.append(time.perf_counter() - t0)
-    ts.sort()
-    gpu_ms = ts[len(ts) // 2] * 1e3
+    res_ms = _median(ts) * 1e3
+    # host valuations: upload + replay + download, as the reference's execute() hands values over
+    enc.to_host(True)
+    pub.resident = False
+    for _ in range(3):
+        out_h = pub.execute(compiled, enc)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out_h = pub.execute(compiled, enc)
+        ts.append(time.perf_counter() - t0)
+    gpu_ms = _median(ts) * 1e3
     # CPU: the same compiled DAG walked in C over the oracle (checker / reported baseline only)
     from oracle_executor import c_walk
     ref, t1 = c_walk(pub, compiled, enc, threads=1)
-    ok = all(np.array_equal(out.get(name)[4], ref[name]) for name in ref)
+    ok = all(np.array_equal(out_h.get(name)[4], ref[name]) and np.array_equal(out.get(name)[4], ref[name]) for name in ref)
     _, tn = c_walk(pub, compiled, enc, threads=cpu_threads)
     kinds = [str(d["op"]).split(".")[-1] for d in compiled._dump()]
     return {"workload": "Harris corner detector (examples/image_processing.py), 64x64 image, N=2^15, L=8 data limbs",
             "terms": len(kinds), "rotations": kinds.count("RotateLeftConst") + kinds.count("RotateRightConst"),
             "relinearize": kinds.count("Relinearize"), "rescale": kinds.count("Rescale"),
-            "gpu_execute_ms": round(gpu_ms, 3), "gpu_includes": "input upload, hipGraph replay, output download",
+            "gpu_execute_ms": round(gpu_ms, 3), "gpu_includes": "input upload, hipGraph replay, output download (host valuations)",
+            "gpu_execute_resident_ms": round(res_ms, 3),
+            "roofline": rl(nbytes, gpu_ms * 1e-3), "roofline_resident": rl(nbytes, res_ms * 1e-3),
             "cpu_walk_ms": {"1": round(t1 * 1e3, 1), str(cpu_threads): round(tn * 1e3, 1)},
             "cpu_walk": "oracle/eva_oracle_dag.c: serial forwardPass / dependency-counting traversal on pthreads",
             "speedup_vs_cpu": {"1": round(t1 * 1e3 / gpu_ms, 1), str(cpu_threads): round(tn * 1e3 / gpu_ms, 1)},
@@ -171,35 +234,40 @@ def dag_leg(reps, cpu_threads):
 
 
 def dag_batch_leg(batch, reps):
-    """BASELINE config 4: a batch of independent Sobel DAGs at N = 2^14 through execute_batch
-    (uploads and downloads included); two instances are checked against the C walk of the oracle."""
+    """BASELINE config 4: a batch of independent Sobel DAGs at N = 2^14, L = 5 through
+    execute_batch (uploads and downloads included); two instances are checked against the C walk of the oracle."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
+    from eva_amd.roofline import dag_bytes, roofline as rl
     from test_compiler import _sobel
     prog = _sobel(64, 64, 4096)
     prog.set_input_scales(25)
     prog.set_output_ranges(10)
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
-    params.poly_modulus_degree = 16384
+    pad_chain(params, 6, 16384)
     pub, sec = generate_keys(params, 1)
+    pub.resident = False  # execute_batch assembles batched handles from host words and returns host words
+    nbytes, _ = dag_bytes(compiled, sig, 16384, len(params.prime_bits))
     encs = [pub.encrypt({'image': [((37 * i + u) % 256) / 255.0 for i in range(4096)]}, sig) for u in range(8)]
     inputs = [encs[i % len(encs)] for i in range(batch)]
     pub.execute_batch(compiled, inputs[:32])  # warm-up: tables, constants, pools
-    best, outs = None, None
+    ts, outs = [], None
     for _ in range(reps):
         t0 = time.perf_counter()
         outs = pub.execute_batch(compiled, inputs)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+        ts.append(time.perf_counter() - t0)
+    med = _median(ts)
     from oracle_executor import c_walk
     ok = True
     for i in (1, batch - 3):
         ref, _ = c_walk(pub, compiled, inputs[i], threads=1)
         ok = ok and all(np.array_equal(outs[i].get(name)[4], ref[name]) for name in ref)
     return {"workload": f"{batch} independent Sobel DAGs (examples/image_processing.py), 64x64 images, N=2^14, primes={list(params.prime_bits)}",
-            "dags_per_s": round(batch / best, 1), "ms_total": round(best * 1e3, 2), "instances_per_device_handle": 32,
+            "dags_per_s": round(batch / med, 1), "ms_total": round(med * 1e3, 2), "best_dags_per_s": round(batch / min(ts), 1),
+            "timing": f"median of {reps} calls", "instances_per_device_handle": 32,
+            "roofline": rl(nbytes * batch, med),
             "includes": "input uploads, one DAG walk per 32 instances, output downloads", "bit_exact_vs_oracle": bool(ok)}
 
 
@@ -477,7 +545,7 @@ def main():
         legs = {}
         if world == 1 and not args.no_legs:
             try:
-                legs["execute_path"] = execute_leg(N, l, 8, 15)
+                legs["execute_path"] = execute_leg(N, l, 32, 12)
             except Exception as e:  # noqa: BLE001 — a leg must not cost the headline line
                 legs["execute_path"] = {"error": repr(e)}
             try:
@@ -485,7 +553,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 legs["dag"] = {"error": repr(e)}
             try:
-                legs["dag_batch"] = dag_batch_leg(256, 4)
+                legs["dag_batch"] = dag_batch_leg(256, 5)
             except Exception as e:  # noqa: BLE001
                 legs["dag_batch"] = {"error": repr(e)}
 

@@ -435,8 +435,8 @@ class Context:
         _chk(_lib.evah_ctx_wait(self.h, other.h))
 
     def transfer_stats(self):
-        """(h2d value transfers, d2h value transfers, h2d bytes, d2h bytes) of this device state"""
-        out = (C.c_uint64 * 4)()
+        """(ct uploads, ct downloads, pt uploads, pt downloads, bytes up, bytes down) of this device state"""
+        out = (C.c_uint64 * 6)()
         _chk(_lib.evah_ctx_transfer_stats(self.h, out))
         return tuple(int(x) for x in out)
 

@@ -6,10 +6,12 @@
 // travel as int8 arrays (3 N bytes per encryption); everything of size N log N or l N runs here.
 //   encrypt  : c = (pk0 u + e0, pk1 u + e1) at l+1 limbs, divided-and-rounded by the extra prime
 //              (same rule as rescale A.5), plus the plaintext on c0
-//   decrypt  : m = c0 + c1 s (+ c2 s^2) per limb, inverse transform, exact mixed-radix (Garner)
-//              recomposition with the sign taken against Q/2, scaled to double, forward special FFT
-//              (CKKSEncoder::decode), slot values out.  FP64; results agree with the host decoder
-//              to rounding (decode is not a bit-level contract: the reference checks MSE, tests/common.py:34)
+//   decrypt  : m = c0 + c1 s (+ c2 s^2) per limb, inverse transform, exact recomposition to base-2^64
+//              words (mixed-radix digits first), the words to one double in SEAL 3.6's order with
+//              1/scale folded in and the sign taken against (Q+1)/2, forward special FFT
+//              (CKKSEncoder::decode_internal), slot values out.  FP64 with SEAL's operation order and no
+//              FMA contraction: the doubles are those of the oracle's evo_decode and of the host
+//              decoder, bit for bit (tests/test_decode_parity.py)
 
 namespace evah {
 
@@ -48,10 +50,9 @@ k_decrypt_dot(DevCtx cx, const u64 *ct, size_t ps, uint32_t size, const u64 *sk,
   m[off] = acc;
 }
 // Garner tables of a level: inv_prefix[i] = (q_0..q_{i-1})^-1 mod q_i, pre_mod[i][t] = q_0..q_{t-1} mod q_i,
-// half[i] = mixed-radix digit i of floor(Q/2), scaled[i] = (q_0..q_{i-1}) / scale as double
+// prefix[i][w] = word w of q_0..q_{i-1} (base 2^64, l words), qwords[w] / half[w] = word w of Q / of floor(Q/2)
 struct CrtTab {
-  const u64 *inv_prefix, *pre_mod, *half;
-  const double *scaled;
+  const u64 *inv_prefix, *pre_mod, *prefix, *qwords, *half;
 };
 __device__ __forceinline__ void garner(const DevCtx &cx, const CrtTab &t, uint32_t l, const u64 *r, u64 *v) {
   for (uint32_t i = 0; i < l; i++) {
@@ -62,33 +63,64 @@ __device__ __forceinline__ void garner(const DevCtx &cx, const CrtTab &t, uint32
     v[i] = i ? mulmod(submod(r[i], a, pm.q), t.inv_prefix[i], pm) : r[0];
   }
 }
+// SEAL 3.6 CKKSEncoder::decode_internal between the inverse NTTs and the FFT: the composed coefficient
+// x in [0, Q) as l base-2^64 words (here from the mixed-radix digits: x = sum_i v_i q_0..q_{i-1}, exact),
+// then ONE double from the words, least significant first, with inv_scale folded into the running power
+// of 2^64; x >= (Q + 1) / 2 is negative and accumulates the signed per-word differences against Q's
+// words.  Same operations in the same order as the oracle's evo_decode and the host decoder: same doubles.
 __global__ void __launch_bounds__(256)
-k_crt_to_double(DevCtx cx, CrtTab t, uint32_t l, const u64 *coeff, double2 *out) {
+k_crt_to_double(DevCtx cx, CrtTab t, uint32_t l, const u64 *coeff, double inv_scale, double2 *out) {
+#pragma clang fp contract(off)
   const size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  u64 r[62], v[62];
+  u64 r[62], v[62], x[63];
   for (uint32_t i = 0; i < l; i++) r[i] = coeff[(size_t)i * cx.N + n];
   garner(cx, t, l, r, v);
-  bool neg = false; // x > floor(Q/2), compared digit by digit from the most significant
-  for (int i = (int)l - 1; i >= 0; i--)
-    if (v[i] != t.half[i]) { neg = v[i] > t.half[i]; break; }
-  if (neg) { // magnitude = Q - x: residues of -x, recomposed
-    for (uint32_t i = 0; i < l; i++) r[i] = negmod(r[i], cx.primes[i].q);
-    garner(cx, t, l, r, v);
+  for (uint32_t w = 0; w <= l; w++) x[w] = 0;
+  for (uint32_t i = 0; i < l; i++) { // x += v_i * prefix_i (prefix_i has at most i words; the sum stays below Q)
+    u64 carry = 0;
+    const u64 *pf = t.prefix + (size_t)i * l;
+    for (uint32_t w = 0; w < l; w++) {
+      u128_t p = mul128(pf[w], v[i]);
+      const u64 lo = p.lo + carry;
+      u64 hi = p.hi + (lo < carry);
+      const u64 sum = x[w] + lo;
+      hi += (sum < lo);
+      x[w] = sum;
+      carry = hi;
+    }
   }
-  double d = 0;
-  for (uint32_t i = 0; i < l; i++)
-    if (v[i]) d += (double)v[i] * t.scaled[i];
-  out[n] = make_double2(neg ? -d : d, 0.0);
+  bool negative = false; // x > floor(Q/2), compared from the most significant word
+  for (int w = (int)l - 1; w >= 0; w--)
+    if (x[w] != t.half[w]) { negative = x[w] > t.half[w]; break; }
+  const double two_pow_64 = 18446744073709551616.0;
+  double acc = 0.0, scaled = inv_scale;
+  for (uint32_t w = 0; w < l; w++, scaled *= two_pow_64) {
+    const u64 xw = x[w], qw = t.qwords[w];
+    if (!negative) {
+      acc += xw ? (double)xw * scaled : 0.0;
+    } else if (xw > qw) {
+      const u64 diff = xw - qw;
+      acc += diff ? (double)diff * scaled : 0.0;
+    } else {
+      const u64 diff = qw - xw;
+      acc -= diff ? (double)diff * scaled : 0.0;
+    }
+  }
+  out[n] = make_double2(acc, 0.0);
 }
 // forward special FFT stage (Cooley-Tukey): group g of `groups` uses roots[groups + g]
+// (DWTHandler::transform_to_rev of SEAL 3.6: x = u + v r, y = u - v r; the complex product as four rounded
+// multiplies, a rounded difference and a rounded sum — no FMA contraction, as in the encoder)
 __global__ void __launch_bounds__(256)
 k_dec_fft_stage(double2 *c, const double2 *roots, uint32_t groups, uint32_t log_gap, uint32_t half_n) {
+#pragma clang fp contract(off)
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= half_n) return;
   const uint32_t gap = 1u << log_gap, g = idx >> log_gap, j = idx & (gap - 1);
   const uint32_t a = 2 * g * gap + j, b = a + gap;
   const double2 w = roots[groups + g], u = c[a], y = c[b];
-  const double tx = y.x * w.x - y.y * w.y, ty = y.x * w.y + y.y * w.x;
+  const double ac = y.x * w.x, bd = y.y * w.y, ad = y.x * w.y, bc = y.y * w.x;
+  const double tx = ac - bd, ty = ad + bc;
   c[a] = make_double2(u.x + tx, u.y + ty);
   c[b] = make_double2(u.x - tx, u.y - ty);
 }
@@ -166,6 +198,7 @@ int evah_decrypt_decode(evah_ctx *c, const evah_ct *ct, uint32_t n_out, double *
   const uint32_t l = ct->limbs, N = c->N, slots = N >> 1;
   if (n_out < 1 || n_out > slots) throw std::invalid_argument("slot count out of range");
   if (l > 61) throw std::invalid_argument("too many limbs");
+  check_scale(c, ct->scale, l); // decode_internal: "scale out of bounds"
   enc_tables(c);
   if (!c->sh->dec_roots) { // forward roots zeta^br(j) (hostmath.h), once per context family
     const CkksRoots cr = ckks_roots(N);
@@ -174,11 +207,12 @@ int evah_decrypt_decode(evah_ctx *c, const evah_ct *ct, uint32_t n_out, double *
     HIPCHK(hipMalloc(&c->sh->dec_roots, sizeof(double2) * N));
     HIPCHK(hipMemcpy(c->sh->dec_roots, roots.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
   }
-  // Garner tables of this level and scale
-  std::vector<u64> tab((size_t)l * l + 2 * l);
-  std::vector<double> scaled(l);
+  // Garner tables of this level: [inv_prefix l][pre_mod l*l][prefix l*l][Q l][floor(Q/2) l]
+  std::vector<u64> tab((size_t)2 * l * l + 3 * l, 0);
   {
-    u64 *inv_prefix = tab.data(), *pre_mod = inv_prefix + l, *half = pre_mod + (size_t)l * l;
+    u64 *inv_prefix = tab.data(), *pre_mod = inv_prefix + l, *prefix = pre_mod + (size_t)l * l,
+        *qwords = prefix + (size_t)l * l, *half = qwords + l;
+    std::vector<u64> w{1}; // q_0..q_{i-1}, little-endian words
     for (uint32_t i = 0; i < l; i++) {
       const u64 qi = c->primes[i];
       u64 acc = 1 % qi;
@@ -187,38 +221,32 @@ int evah_decrypt_decode(evah_ctx *c, const evah_ct *ct, uint32_t n_out, double *
         acc = mulmod(acc, c->primes[j] % qi, qi);
       }
       inv_prefix[i] = invmod(acc, qi);
-    }
-    // mixed-radix digits of floor(Q/2): divide Q = prod q_i (little-endian words) by 2, then peel the digits
-    std::vector<u64> w{1};
-    for (uint32_t i = 0; i < l; i++) {
+      for (size_t t = 0; t < w.size() && t < l; t++) prefix[(size_t)i * l + t] = w[t];
       u64 carry = 0;
-      for (auto &x : w) { u128 t = (u128)x * c->primes[i] + carry; x = (u64)t; carry = (u64)(t >> 64); }
+      for (auto &x : w) { u128 t = (u128)x * qi + carry; x = (u64)t; carry = (u64)(t >> 64); }
       if (carry) w.push_back(carry);
     }
-    for (size_t i = 0; i < w.size(); i++) w[i] = (w[i] >> 1) | (i + 1 < w.size() ? w[i + 1] << 63 : 0);
-    for (uint32_t i = 0; i < l; i++) { // digit i = w mod q_i ; w /= q_i
-      u128 rem = 0;
-      for (size_t j = w.size(); j-- > 0;) { u128 cur = (rem << 64) | w[j]; w[j] = (u64)(cur / c->primes[i]); rem = cur % c->primes[i]; }
-      half[i] = (u64)rem;
-    }
-    double s = 1.0 / ct->scale;
-    for (uint32_t i = 0; i < l; i++) { scaled[i] = s; s *= (double)c->primes[i]; }
+    for (size_t t = 0; t < w.size() && t < l; t++) qwords[t] = w[t];
+    for (size_t t = 0; t < w.size() && t < l; t++) half[t] = (w[t] >> 1) | (t + 1 < w.size() ? w[t + 1] << 63 : 0);
   }
-  Scratch m(c, (size_t)l * N), tabd(c, tab.size()), scd(c, l), cbuf(c, 2 * (size_t)N), outd(c, n_out);
+  Scratch m(c, (size_t)l * N), tabd(c, tab.size()), cbuf(c, 2 * (size_t)N), outd(c, n_out);
   HIPCHK(hipMemcpyAsync(tabd.d, tab.data(), sizeof(u64) * tab.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(scd.d, scaled.data(), sizeof(double) * l, hipMemcpyHostToDevice, c->stream));
   EW_LAUNCH(k_decrypt_dot, dim3(N / 256, l), dim3(256), 0, c->stream, c->dev, ct->d, ct->ps, ct->size, c->sh->sk.d, m.d);
   OpPlain::Params ip{m.d, m.d, 0, 0, l, 0, 0, {}};
   ntt_inverse<OpPlain>(c, ip, l);
-  CrtTab t{tabd.d, tabd.d + l, tabd.d + l + (size_t)l * l, reinterpret_cast<const double *>(scd.d)};
+  CrtTab t{tabd.d, tabd.d + l, tabd.d + l + (size_t)l * l, tabd.d + l + (size_t)2 * l * l, tabd.d + 2 * l + (size_t)2 * l * l};
   double2 *cd = reinterpret_cast<double2 *>(cbuf.d);
-  EW_LAUNCH(k_crt_to_double, dim3(N / 256), dim3(256), 0, c->stream, c->dev, t, l, m.d, cd);
+  EW_LAUNCH(k_crt_to_double, dim3(N / 256), dim3(256), 0, c->stream, c->dev, t, l, m.d, 1.0 / ct->scale, cd);
+  // the decrypted message and its FP image do not stay behind in pool memory the next call reuses
+  HIPCHK(hipMemsetAsync(m.d, 0, sizeof(u64) * (size_t)l * N, c->stream));
   for (uint32_t groups = 1, lg = c->logN - 1; groups < N; groups <<= 1, lg--)
     hipLaunchKernelGGL(k_dec_fft_stage, dim3((slots + 255) / 256), dim3(256), 0, c->stream, cd, c->sh->dec_roots, groups, lg, slots);
   hipLaunchKernelGGL(k_dec_gather, dim3((n_out + 255) / 256), dim3(256), 0, c->stream, cd, c->sh->enc_slot_map, n_out,
                      reinterpret_cast<double *>(outd.d));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, outd.d, sizeof(double) * n_out, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemsetAsync(cbuf.d, 0, sizeof(double2) * (size_t)N, c->stream));
+  HIPCHK(hipMemsetAsync(outd.d, 0, sizeof(double) * n_out, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   API_END
 }

@@ -28,16 +28,6 @@ struct DevPrime {
   u64 q5;       // 5q, the inverse lazy-butterfly threshold
   u64 q4, q8;   // 4q (forward difference offset), 8q (forward reduction threshold)
   u64 nq5, nq8; // 2^64 - 5q, 2^64 - 8q: conditional subtraction as select + one 64-bit add (data, as nq)
-  // Lazy reductions read off the top bits (ntt.hip.h, bfly_fwd / bfly_inv): with 2^s the power of two
-  // in (8q, 16q] (forward, s = bits(q) + 3) resp. (4q, 8q] (inverse, s = bits(q) + 2),
-  //     x mod-ish q  =  (x mod 2^s) + (x >> s) * (2^s mod q)
-  // is a shift, a mask of the high word and one v_mad_u64_u32 instead of compare + two selects + a
-  // 64-bit add.  Usable when s >= 33 and 2^s mod q fits 32 bits — true for every prime
-  // CoeffModulus::Create returns at 31..60 bits (q = 2^b - delta, delta < 2^26); `fast` bit 0 / 1 says
-  // whether the forward / inverse butterflies of this prime may use it (block-uniform branch).
-  uint32_t fs, fmask, fc; // forward: s - 32, 2^(s-32) - 1, 2^s mod q
-  uint32_t is, imask, ic; // inverse
-  uint32_t fast, pad_;
 };
 
 // Device-side view of a context (passed by value to kernels).

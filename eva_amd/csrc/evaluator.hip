@@ -714,7 +714,7 @@ int evah_pt_upload_coeff(evah_ctx *c, uint32_t limbs, double scale, const uint64
   OpPlain::Params p{t->d, t->d, 0, 0, limbs, 0, 0, {}};
   ntt_forward<OpPlain>(c, p, limbs);
   HIPCHK(hipStreamSynchronize(c->stream)); // the pageable host buffer may go away after return
-  count_h2d(c, sizeof(u64) * (size_t)limbs * c->N);
+  count_h2d(c, sizeof(u64) * (size_t)limbs * c->N, true);
   t->buf->ready_everywhere = true;
   *out = t;
   API_END

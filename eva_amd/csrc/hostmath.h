@@ -38,11 +38,6 @@ inline uint32_t bitrev(uint32_t x, uint32_t bits) {
   for (uint32_t i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
   return r;
 }
-inline int bitlen64(u64 x) {
-  int b = 0;
-  while (x) { b++; x >>= 1; }
-  return b;
-}
 inline uint32_t ilog2(uint32_t n) {
   uint32_t l = 0;
   while ((1u << l) < n) l++;

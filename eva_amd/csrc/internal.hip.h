@@ -168,7 +168,7 @@ struct SharedDev {
   double2 *enc_roots = nullptr;     // CKKS encoder: inverse-FFT roots in the order the stages consume them
   double enc_last_root[2] = {0, 0}; // the single root of the last stage (scaled by fix on the host per call)
   uint32_t *enc_slot_map = nullptr; // slot i (and its conjugate, at slots + i) -> FFT input index
-  uint64_t xfer[4] = {0, 0, 0, 0};  // value transfers: h2d calls, d2h calls, h2d bytes, d2h bytes (evah_ctx_transfer_stats)
+  uint64_t xfer[6] = {0, 0, 0, 0, 0, 0}; // evah_ctx_transfer_stats: ct up / down, pt up / down, bytes up / down
   ~SharedDev() {
     (void)hipSetDevice(device);
     if (enc_roots) (void)hipFree(enc_roots);
@@ -230,8 +230,8 @@ struct evah_ctx {
 namespace evah {
 
 inline void use(evah_ctx *c) { HIPCHK(hipSetDevice(c->device)); }
-inline void count_h2d(evah_ctx *c, size_t bytes) { c->sh->xfer[0]++; c->sh->xfer[2] += bytes; }
-inline void count_d2h(evah_ctx *c, size_t bytes) { c->sh->xfer[1]++; c->sh->xfer[3] += bytes; }
+inline void count_h2d(evah_ctx *c, size_t bytes, bool plain = false) { c->sh->xfer[plain ? 2 : 0]++; c->sh->xfer[4] += bytes; }
+inline void count_d2h(evah_ctx *c, size_t bytes, bool plain = false) { c->sh->xfer[plain ? 3 : 1]++; c->sh->xfer[5] += bytes; }
 
 inline hipEvent_t prof_event(evah_ctx *c) {
   if (!c->prof_free.empty()) {

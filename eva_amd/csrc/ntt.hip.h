@@ -73,31 +73,17 @@ __device__ __forceinline__ u64 mul_tw_lazy5_add(u64 x, u64 w, u64 ws, u64 nq, u6
 //   plain stage  : X < 12q            -> outputs < 16q
 // (Y only feeds the multiply, which accepts any 64-bit value.)  X' = x + t comes out of the mad
 // chain; Y' = x + 4q - t = (2x + 4q) - X' (mod 2^64; the true value is < 16q).
-// FAST (DevPrime::fast, block-uniform): the reduction is read off the top bits of X.  With 2^s the
-// power of two in (8q, 16q] and c = 2^s mod q, x = (X mod 2^s) + (X >> s) c is congruent to X and
-// below 2^s + c for X < 2^(s+1); two stages add < 8q <= 2^s - c, so X < 2^(s+1) <= 2^64 is kept
-// (the compare-and-select form keeps X < 16q; 2^(s+1) <= 2^64 needs q < 2^60 like it).
-struct FastRed {
-  uint32_t sh, mask, c;
-};
-__device__ __forceinline__ u64 top_bits_reduce(u64 X, const FastRed &f) {
-  const uint32_t hi = (uint32_t)(X >> 32);
-  return (((u64)(hi & f.mask) << 32) | (uint32_t)X) + (u64)(hi >> f.sh) * f.c; // and, shift, one v_mad_u64_u32
-}
-template <bool REDUCE, bool FAST>
-__device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q4, u64 q8, u64 nq8, const FastRed &f) {
-  u64 x = X;
-  if constexpr (REDUCE) x = FAST ? top_bits_reduce(X, f) : X + (X >= q8 ? nq8 : 0);
+template <bool REDUCE>
+__device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q4, u64 q8, u64 nq8) {
+  u64 x = REDUCE ? X + (X >= q8 ? nq8 : 0) : X;
   X = mul_tw_lazy5_add(Y, w.x, w.y, nq, x);
   Y = ((x << 1) + q4) - X;
 }
-// inverse Gentleman-Sande butterfly, X,Y in [0,5q) -> [0,5q).  FAST: 2^s in (4q, 8q], the sum
-// (< 10q < 2^(s+2)) comes back below 2^s + 2c <= 5q (checked when the tables are built).
-template <bool FAST>
-__device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q5, u64 nq5, const FastRed &f) {
+// inverse Gentleman-Sande butterfly, X,Y in [0,5q) -> [0,5q)
+__device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q5, u64 nq5) {
   u64 s = X + Y;
   u64 d = X + q5 - Y;
-  X = FAST ? top_bits_reduce(s, f) : s + (s >= q5 ? nq5 : 0);
+  X = s + (s >= q5 ? nq5 : 0);
   Y = mul_tw_lazy5(d, w.x, w.y, nq);
 }
 
@@ -105,7 +91,7 @@ __device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u
 // RED_EVEN: forward passes reduce on even (true) or odd (false) local stage indices — the first
 // (strided) pass starts from canonical input and reduces on odd stages, so it always exits < 16q;
 // the second pass therefore reduces on even stages.
-template <int P, int LR, int RB, int LO, bool INVERSE, bool STRIDED, bool RED_EVEN, bool FAST>
+template <int P, int LR, int RB, int LO, bool INVERSE, bool STRIDED, bool RED_EVEN>
 __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
                                           const ulonglong2 *__restrict__ tw, const DevPrime &pm) {
   constexpr int NTT_R = 1 << LR;
@@ -113,7 +99,6 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
   constexpr int S0 = P - LO - RB; // local stages above this round
   const u64 q = pm.q, nq = pm.nq, q5 = pm.q5, q4 = pm.q4, q8 = pm.q8, nq5 = pm.nq5, nq8 = pm.nq8;
   (void)q4; (void)q8; (void)q5; (void)nq5; (void)nq8;
-  const FastRed fr = INVERSE ? FastRed{pm.is, pm.imask, pm.ic} : FastRed{pm.fs, pm.fmask, pm.fc};
   u64 x[NTT_R];
 #pragma unroll
   for (int g = 0; g < G; g++) {
@@ -136,8 +121,8 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
           if (u & half) continue;
           const int v = u >> (RB - s);
           const ulonglong2 w = tw[((size_t)node << s) + v];
-          if ((((S0 + s) & 1) == 0) == RED_EVEN) bfly_fwd<true, FAST>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8, fr);
-          else bfly_fwd<false, FAST>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8, fr);
+          if ((((S0 + s) & 1) == 0) == RED_EVEN) bfly_fwd<true>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8);
+          else bfly_fwd<false>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8);
         }
       }
     } else {
@@ -157,7 +142,7 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
           } else {
             const int v = u >> (RB - s);
             const ulonglong2 w = tw[((size_t)node << s) + v];
-            bfly_inv<FAST>(X, Y, w, nq, q5, nq5, fr);
+            bfly_inv(X, Y, w, nq, q5, nq5);
           }
         }
       }
@@ -167,23 +152,17 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
   }
 }
 
-template <int P, int LR, int I, bool INVERSE, bool STRIDED, bool RED_EVEN, bool FAST = false> struct RoundSeq {
+template <int P, int LR, int I, bool INVERSE, bool STRIDED, bool RED_EVEN> struct RoundSeq {
   // forward: rounds 0..NR-1 (top bits first); inverse: NR-1..0 (low bits first)
-  static __device__ __forceinline__ void run_as(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
-                                                const ulonglong2 *tw, const DevPrime &pm) {
-    using RS = Rounds<P, LR>;
-    constexpr int idx = INVERSE ? (RS::NR - 1 - I) : I;
-    ntt_round<P, LR, RS::bits(idx), RS::lo(idx), INVERSE, STRIDED, RED_EVEN, FAST>(sub_lds, tid, h, pre, tw, pm);
-    if constexpr (I + 1 < RS::NR) {
-      __syncthreads();
-      RoundSeq<P, LR, I + 1, INVERSE, STRIDED, RED_EVEN, FAST>::run_as(sub_lds, tid, h, pre, tw, pm);
-    }
-  }
-  // entry point: picks the reduction form the prime allows (one block-uniform branch per pass)
   static __device__ __forceinline__ void run(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
                                              const ulonglong2 *tw, const DevPrime &pm) {
-    if (pm.fast & (INVERSE ? 2u : 1u)) RoundSeq<P, LR, I, INVERSE, STRIDED, RED_EVEN, true>::run_as(sub_lds, tid, h, pre, tw, pm);
-    else RoundSeq<P, LR, I, INVERSE, STRIDED, RED_EVEN, false>::run_as(sub_lds, tid, h, pre, tw, pm);
+    using RS = Rounds<P, LR>;
+    constexpr int idx = INVERSE ? (RS::NR - 1 - I) : I;
+    ntt_round<P, LR, RS::bits(idx), RS::lo(idx), INVERSE, STRIDED, RED_EVEN>(sub_lds, tid, h, pre, tw, pm);
+    if constexpr (I + 1 < RS::NR) {
+      __syncthreads();
+      RoundSeq<P, LR, I + 1, INVERSE, STRIDED, RED_EVEN>::run(sub_lds, tid, h, pre, tw, pm);
+    }
   }
 };
 
@@ -793,10 +772,8 @@ struct OpModDown {
   }
   static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &j, const DevPrime &pm,
                                                    uint32_t n, u64 U) {
-    // the transform leaves [0, 16q) (compare-and-select reductions) or [0, 16q + 2c), c = 2^s mod q < q
-    // (top-bit reductions): after one conditional subtraction U < 8q + 2c < 10q
-    U += (U >= pm.q8 ? pm.nq8 : 0);
-    u64 v = mul_shoup(j.c[n] + (pm.q8 + 2 * pm.q) - U, j.inv.x, j.inv.y, pm.q); // in (0, 11q); exact for any 64-bit operand
+    U += (U >= pm.q8 ? pm.nq8 : 0);                       // [0,16q) -> [0,8q)
+    u64 v = mul_shoup(j.c[n] + pm.q8 - U, j.inv.x, j.inv.y, pm.q); // exact for any 64-bit operand
     if (j.add) v = addmod(j.add[n], v, pm.q);
     j.dst[n] = v;
   }
@@ -921,9 +898,9 @@ template <bool MUL> struct OpRRT {
     return addmod(mul_shoup(u, j.pinv.x, j.pinv.y, pm.q), v, pm.q);
   }
   static __device__ __forceinline__ void store_fwd(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n, u64 W) {
-    W += (W >= pm.q8 ? pm.nq8 : 0);                                                  // [0,16q + 2c) -> [0,8q + 2c), see OpModDown
+    W += (W >= pm.q8 ? pm.nq8 : 0);                                                  // [0,16q) -> [0,8q)
     const u64 av = MUL ? product_poly(j.mul, j.K, j.off + n, pm) : j.a[n];
-    const u64 x = av + mul_tw_lazy5(j.prod[n], j.pinv.x, j.pinv.y, pm.nq) + (pm.q8 + 2 * pm.q) - W; // in (0, 15q), 15q < 2^64
+    const u64 x = av + mul_tw_lazy5(j.prod[n], j.pinv.x, j.pinv.y, pm.nq) + pm.q8 - W; // < 14q < 2^64
     j.dst[n] = mul_shoup(x, j.linv.x, j.linv.y, pm.q);                               // exact for any 64-bit operand
   }
 };

@@ -115,26 +115,6 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
       d.q8 = 8 * q;
       d.nq5 = 0ull - 5 * q;
       d.nq8 = 0ull - 8 * q;
-      { // top-bit lazy reductions (devmath.hip.h); EVAH_FAST_REDUCE=0 keeps the compare-and-select forms
-        const uint32_t b = (uint32_t)bitlen64(q);
-        const bool allow = !std::getenv("EVAH_FAST_REDUCE") || std::atoi(std::getenv("EVAH_FAST_REDUCE")) != 0;
-        d.fs = d.fmask = d.fc = d.is = d.imask = d.ic = d.fast = d.pad_ = 0;
-        if (allow && b + 3 >= 33 && b + 3 <= 63) {
-          const uint32_t s = b + 3;
-          const u64 c = (u64)((((u128)1) << s) % q);
-          // 2^s = 8q + c exactly (q just below a power of two, as CoeffModulus::Create's primes are): the
-          // transform's outputs then stay below 16q + 2c, which the fused epilogues (ntt.hip.h) rely on
-          if (c < ((u64)1 << 32) && (((u128)1) << s) == 8 * (u128)q + c) { d.fs = s - 32; d.fmask = (uint32_t)(((u64)1 << (s - 32)) - 1); d.fc = (uint32_t)c; d.fast |= 1u; }
-        }
-        if (allow && b + 2 >= 33) {
-          const uint32_t s = b + 2;
-          const u64 c = (u64)((((u128)1) << s) % q);
-          // the reduced sum (< 2^s + 2c) has to stay below the 5q the difference path adds
-          if (c < ((u64)1 << 32) && (((u128)1) << s) + 2 * (u128)c <= 5 * (u128)q) {
-            d.is = s - 32; d.imask = (uint32_t)(((u64)1 << (s - 32)) - 1); d.ic = (uint32_t)c; d.fast |= 2u;
-          }
-        }
-      }
       for (uint32_t a = 0; a < k; a++) {
         const u64 qa = c->primes[a];
         if (a == i) {
@@ -535,9 +515,9 @@ int evah_ctx_wait(evah_ctx *waiter, evah_ctx *signaller) {
   API_END
 }
 
-int evah_ctx_transfer_stats(evah_ctx *c, uint64_t out[4]) {
+int evah_ctx_transfer_stats(evah_ctx *c, uint64_t out[6]) {
   API_BEGIN
-  for (int i = 0; i < 4; i++) out[i] = c->sh->xfer[i];
+  for (int i = 0; i < 6; i++) out[i] = c->sh->xfer[i];
   API_END
 }
 
@@ -561,7 +541,7 @@ int evah_pt_write(evah_ctx *c, evah_pt *pt, const uint64_t *data) {
   acquire(c, pt->buf);
   HIPCHK(hipMemcpyAsync(pt->d, data, sizeof(u64) * (size_t)pt->limbs * c->N, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  count_h2d(c, sizeof(u64) * (size_t)pt->limbs * c->N);
+  count_h2d(c, sizeof(u64) * (size_t)pt->limbs * c->N, true);
   API_END
 }
 
@@ -662,7 +642,7 @@ int evah_pt_upload(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *da
   evah_pt *t = pt_new(c, limbs, scale);
   HIPCHK(hipMemcpyAsync(t->d, data, sizeof(u64) * (size_t)limbs * c->N, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  count_h2d(c, sizeof(u64) * (size_t)limbs * c->N);
+  count_h2d(c, sizeof(u64) * (size_t)limbs * c->N, true);
   t->buf->ready_everywhere = true;
   *out = t;
   API_END
@@ -682,7 +662,7 @@ int evah_pt_download(evah_ctx *c, const evah_pt *pt, uint64_t *out) {
   acquire(c, pt->buf);
   HIPCHK(hipMemcpyAsync(out, pt->d, sizeof(u64) * (size_t)pt->limbs * c->N, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  count_d2h(c, sizeof(u64) * (size_t)pt->limbs * c->N);
+  count_d2h(c, sizeof(u64) * (size_t)pt->limbs * c->N, true);
   API_END
 }
 

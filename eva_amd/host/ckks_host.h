@@ -238,7 +238,7 @@ public:
       inv_prefix[i] = evah::invmod(acc, primes[i]);
     }
     std::vector<u64> v(limbs), x;
-    const double inv_scale = 1.0 / scale;
+    const double inv_scale = 1.0 / scale, two_pow_64 = std::pow(2.0, 64);
     for (uint32_t j = 0; j < N; j++) {
       for (uint32_t i = 0; i < limbs; i++) {
         u64 qi = primes[i], acc = 0;
@@ -249,10 +249,25 @@ public:
       x.assign(Q.size() + 1, 0);
       for (uint32_t i = 0; i < limbs; i++) add_mul(x, prefix[i], v[i]);
       x.resize(Q.size());
-      double d;
-      if (cmp(x, halfQ) > 0) d = -to_double(sub(Q, x));
-      else d = to_double(x);
-      c[j] = d * inv_scale;
+      // SEAL 3.6 CKKSEncoder::decode_internal: the base-2^64 words of the composed coefficient go into
+      // ONE double, least significant first, with 1/scale folded into the running power of 2^64; a
+      // coefficient above Q/2 is negative and is accumulated as signed per-word differences against the
+      // words of Q.  `limbs` words per coefficient (SEAL's coeff_modulus_size), high ones zero.
+      const bool negative = cmp(x, halfQ) > 0; // x >= upper_half_threshold = (Q + 1) / 2
+      double acc = 0.0, scaled = inv_scale;
+      for (uint32_t w = 0; w < limbs; w++, scaled *= two_pow_64) {
+        const u64 xw = w < x.size() ? x[w] : 0, qw = w < Q.size() ? Q[w] : 0;
+        if (!negative) {
+          acc += xw ? (double)xw * scaled : 0.0;
+        } else if (xw > qw) {
+          const u64 diff = xw - qw;
+          acc += diff ? (double)diff * scaled : 0.0;
+        } else {
+          const u64 diff = qw - xw;
+          acc -= diff ? (double)diff * scaled : 0.0;
+        }
+      }
+      c[j] = acc;
     }
     // forward special FFT (Cooley-Tukey, zeta^br(m+g))
     for (uint32_t mm = 1, gap = N >> 1; mm < N; mm <<= 1, gap >>= 1)

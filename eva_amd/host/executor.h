@@ -897,9 +897,9 @@ public:
     for (auto &f : exec_q) if (f) chk(evah_ctx_sync(f->h));
     for (auto &kv : plans) for (auto &f : kv.second->queues) chk(evah_ctx_sync(f->h));
   }
-  // (h2d value transfers, d2h value transfers, h2d bytes, d2h bytes) of this context's device state
-  std::array<uint64_t, 4> transfer_stats() {
-    std::array<uint64_t, 4> st{0, 0, 0, 0};
+  // ciphertexts up / down, plaintexts up / down, bytes up / down across the host boundary (evah_ctx_transfer_stats)
+  std::array<uint64_t, 6> transfer_stats() {
+    std::array<uint64_t, 6> st{0, 0, 0, 0, 0, 0};
     if (dev) chk(evah_ctx_transfer_stats(dev->h, st.data()));
     return st;
   }
@@ -1147,6 +1147,9 @@ private:
     }
     auto t1 = clk::now();
     chk(evah_graph_launch(q0, plan.graph));
+    // the copies below run on the root queue: the library orders a queue behind the producer of a buffer
+    // only once per buffer (values are immutable), but a replay rewrites the graph's output buffers
+    if (resident) chk(evah_ctx_wait(dev->h, q0));
     auto t2 = clk::now();
     HipValuation out;
     for (auto &kv : plan.outputs) {

@@ -242,7 +242,8 @@ PYBIND11_MODULE(_eva, m) {
       .def("transfer_stats", [](HipPublic &p) {
         auto st = p.transfer_stats();
         py::dict d;
-        d["h2d_values"] = st[0]; d["d2h_values"] = st[1]; d["h2d_bytes"] = st[2]; d["d2h_bytes"] = st[3];
+        d["ct_uploads"] = st[0]; d["ct_downloads"] = st[1]; d["pt_uploads"] = st[2]; d["pt_downloads"] = st[3];
+        d["h2d_bytes"] = st[4]; d["d2h_bytes"] = st[5];
         return d;
       }, "ciphertext / plaintext transfers across the host boundary since the device context was created")
       .def_readonly("last_timing", &HipPublic::last_timing, "ms of the last execute(): (input upload, DAG enqueue on the host, drain + output download)")
@@ -274,5 +275,7 @@ PYBIND11_MODULE(_eva, m) {
         return d;
       });
   py::class_<HipSecret, std::shared_ptr<HipSecret>>(mseal, "SEALSecret", "Secret context: decryption. Holds the secret key.")
-      .def("decrypt", &HipSecret::decrypt, py::arg("enc_outputs"), py::arg("signature"));
+      .def("decrypt", &HipSecret::decrypt, py::arg("enc_outputs"), py::arg("signature"))
+      // test hook (as relin_key() on the public side): the secret key under every key prime, NTT form [k][N]
+      .def("_secret_key_ntt", [](const HipSecret &s) { return to_numpy(s.sk.s_ntt, {(py::ssize_t)s.host->k, (py::ssize_t)s.host->N}); });
 }

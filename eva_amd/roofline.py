@@ -1,0 +1,128 @@
+"""Algorithmic HBM bytes of a compiled program: every input word of an op read
+once, every output word written once, key words read once; transforms inside an op count as zero.
+With P = l * N * 8 bytes per polynomial at l limbs:
+
+    add / sub (sizes sa, sb)      (sa + sb + max(sa, sb)) P      (6P for 2 + 2)
+    add_plain / sub_plain (s)     (s + 1 + s) P
+    negate (s)                    2 s P
+    multiply_plain (s)            (2 s + 1) P
+    multiply 2 x 2                7 P           square 5 P
+    relinearize                   5 P + 2 l (l + 1) N 8
+    rotate (step != 0)            4 P + 2 l (l + 1) N 8
+    rescale (s)                   s P + s (l - 1) N 8
+    mod_switch (s)                2 s (l - 1) N 8   (the library returns a view: the bytes the reference copies)
+
+`dag_bytes` walks the compiler's output the way the executor does — shapes (size, limbs) are
+propagated from the signature's input levels — and returns the total plus a per-op breakdown.  It is
+what bench.py divides by the measured execute() time to get `roofline.achieved` for the DAG legs
+(reference walk: /root/reference/eva/seal/seal_executor.h:279-404)."""
+from . import Op
+
+
+def op_bytes(kind, N, l, sa=2, sb=2):
+    P = l * N * 8
+    key = 2 * l * (l + 1) * N * 8
+    if kind in ("add", "sub"):
+        return (sa + sb + max(sa, sb)) * P
+    if kind in ("add_plain", "sub_plain"):
+        return (2 * sa + 1) * P
+    if kind == "negate":
+        return 2 * sa * P
+    if kind == "multiply_plain":
+        return (2 * sa + 1) * P
+    if kind == "multiply":
+        return 7 * P
+    if kind == "square":
+        return 5 * P
+    if kind == "relinearize":
+        return 5 * P + key
+    if kind == "rotate":
+        return 4 * P + key
+    if kind == "rescale":
+        return sa * P + sa * (l - 1) * N * 8
+    if kind == "mod_switch":
+        return 2 * sa * (l - 1) * N * 8
+    raise ValueError(kind)
+
+
+def dag_bytes(compiled, signature, N, n_primes):
+    """-> (total algorithmic bytes of one execute(), {op kind: (count, bytes)})"""
+    k = n_primes
+    shape = {}   # term -> ("ct", size, limbs) | ("pt", limbs) | ("raw",)
+    by = {}
+    total = 0
+
+    def note(kind, b):
+        nonlocal total
+        c, s = by.get(kind, (0, 0))
+        by[kind] = (c + 1, s + b)
+        total += b
+
+    in_ids = {t.index: name for name, t in compiled.inputs.items()}
+    for d in compiled._dump():
+        t, op, a = d["id"], d["op"], d["operands"]
+        if op == Op.Input:
+            info = signature.inputs[in_ids[t]]
+            kind = str(info.input_type).split(".")[-1]
+            limbs = k - 1 - info.level
+            shape[t] = ("ct", 2, limbs) if kind == "Cipher" else ("pt", limbs) if kind == "Plain" else ("raw",)
+            continue
+        if op == Op.Constant:
+            shape[t] = ("raw",)
+            continue
+        if op == Op.Encode:
+            shape[t] = ("pt", k - 1 - d["encode_level"])
+            continue
+        x = [shape[i] for i in a]
+        cts = [s for s in x if s[0] == "ct"]
+        if not cts:  # arithmetic on unencrypted values / their outputs: host work, no HBM traffic
+            shape[t] = x[0] if op == Op.Output else ("raw",)
+            continue
+        if op == Op.Output:
+            shape[t] = x[0]
+            continue
+        c0 = cts[0]
+        l = c0[2]
+        if op in (Op.Add, Op.Sub):
+            name = "add" if op == Op.Add else "sub"
+            if len(cts) == 2:
+                note(name, op_bytes(name, N, l, cts[0][1], cts[1][1]))
+                shape[t] = ("ct", max(cts[0][1], cts[1][1]), l)
+            else:
+                note(name + "_plain", op_bytes(name + "_plain", N, l, c0[1]))
+                shape[t] = c0
+        elif op == Op.Mul:
+            if len(cts) == 2:
+                same = a[0] == a[1]
+                note("square" if same else "multiply", op_bytes("square" if same else "multiply", N, l))
+                shape[t] = ("ct", 3, l)
+            else:
+                note("multiply_plain", op_bytes("multiply_plain", N, l, c0[1]))
+                shape[t] = c0
+        elif op == Op.Negate:
+            note("negate", op_bytes("negate", N, l, c0[1]))
+            shape[t] = c0
+        elif op in (Op.RotateLeftConst, Op.RotateRightConst):
+            if d.get("rotation", 0):
+                note("rotate", op_bytes("rotate", N, l))
+            shape[t] = c0
+        elif op == Op.Relinearize:
+            note("relinearize", op_bytes("relinearize", N, l))
+            shape[t] = ("ct", 2, l)
+        elif op == Op.Rescale:
+            note("rescale", op_bytes("rescale", N, l, c0[1]))
+            shape[t] = ("ct", c0[1], l - 1)
+        elif op == Op.ModSwitch:
+            note("mod_switch", op_bytes("mod_switch", N, l, c0[1]))
+            shape[t] = ("ct", c0[1], l - 1)
+        else:
+            raise ValueError(f"unexpected op {op}")
+    return total, by
+
+
+def roofline(total_bytes, seconds, peak_gbps=8000.0):
+    """the `roofline` object of a bench line for one unit of `total_bytes` done in `seconds`"""
+    ach = total_bytes / seconds / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": peak_gbps, "unit": "GB/s",
+            "frac": round(ach / peak_gbps, 4), "bytes_per_unit": int(total_bytes),
+            "basis": "SURVEY.md 8(d) algorithmic bytes summed over the compiled op list (eva_amd/roofline.py) / measured time"}

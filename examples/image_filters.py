@@ -84,8 +84,10 @@ def main():
     encrypted = public_ctx.encrypt(inputs, signature)
     public_ctx.execute(compiled, encrypted)            # first call: eager walk
     public_ctx.execute(compiled, encrypted)            # second: hipGraph capture
+    public_ctx.synchronize()
     t0 = time.perf_counter()
-    result = public_ctx.execute(compiled, encrypted)   # replay
+    result = public_ctx.execute(compiled, encrypted)   # replay; the valuations stay in HBM, the call does not wait
+    public_ctx.synchronize()
     ms = (time.perf_counter() - t0) * 1e3
     outputs = secret_ctx.decrypt(result, signature)
     clear = evaluate(compiled, inputs)

@@ -122,10 +122,11 @@ int evah_ct_assign(evah_ctx *ctx, evah_ct *dst, const evah_ct *src);
  * state); no host synchronisation.  Orders work the per-buffer tracking cannot see (graph replays). */
 int evah_ctx_wait(evah_ctx *waiter, evah_ctx *signaller);
 /* values that crossed the host boundary through this context and its forks since creation:
- * out[0] = host->device value transfers (ct / pt upload, write), out[1] = device->host (download),
- * out[2], out[3] = their bytes.  The valuation of the reference "may hold device handles"
- * (SURVEY.md 8(b)); tests assert that encrypt -> execute -> decrypt moves no ciphertext across. */
-int evah_ctx_transfer_stats(evah_ctx *ctx, uint64_t out[4]);
+ * out[0] / out[1] = ciphertexts uploaded (evah_ct_upload*, evah_ct_write) / downloaded, out[2] / out[3] =
+ * plaintexts uploaded / downloaded, out[4] / out[5] = bytes host->device / device->host of all of them.
+ * The valuation of the reference "may hold device handles" (SURVEY.md 8(b)); tests assert that
+ * encrypt -> execute -> decrypt moves no ciphertext across. */
+int evah_ctx_transfer_stats(evah_ctx *ctx, uint64_t out[6]);
 int evah_ct_info(const evah_ct *ct, uint32_t *size, uint32_t *limbs, double *scale);
 int evah_ct_download(evah_ctx *ctx, const evah_ct *ct, uint64_t *out /* [size][limbs][N] */);
 void evah_ct_free(evah_ctx *ctx, evah_ct *ct);
@@ -234,8 +235,9 @@ int evah_mod_switch(evah_ctx *ctx, const evah_ct *a, evah_ct **out);
 int evah_client_key_upload(evah_ctx *ctx, int kind /* EVAH_KEY_PUBLIC | EVAH_KEY_SECRET */, const uint64_t *data);
 /* (pk0 u + e0, pk1 u + e1) one level above pt, divided-and-rounded by the extra prime, + pt on c0 */
 int evah_encrypt(evah_ctx *ctx, const evah_pt *pt, const int8_t *small, evah_ct **out);
-/* m = c0 + c1 s (+ c2 s^2) -> inverse transform -> exact recomposition -> / scale -> special FFT:
- * the first n_out slot values */
+/* m = c0 + c1 s (+ c2 s^2) -> inverse transform -> exact recomposition -> double (1/scale folded in) ->
+ * special FFT, in the operation order of SEAL 3.6's CKKSEncoder::decode_internal: the first n_out slot
+ * values, the same doubles as the host decoder and the CPU oracle produce */
 int evah_decrypt_decode(evah_ctx *ctx, const evah_ct *ct, uint32_t n_out, double *out);
 
 /* ---- whole-DAG submit: a topologically sorted flat op list over a value table.

@@ -708,6 +708,190 @@ int evo_encode(const evo_ctx *c, uint32_t l, const double *values, double scale,
   return rc;
 }
 
+/* ------------------------------------------------------------------ decrypt + CKKS decoder */
+
+/* SEAL 3.6 Decryptor::decrypt for CKKS (decryptor.cpp: ckks_decrypt -> dot_product_ct_sk_array), the
+ * call at /root/reference/eva/seal/seal.cpp:132-133: pt = c0 + c1 s (+ c2 s^2) per limb, NTT form
+ * in and out, scale unchanged.  Canonical residues, so the evaluation order is free.
+ * ct: [size][l][N], sk_ntt: [k][N] (the secret key under every key prime, NTT form), pt: [l][N]. */
+void evo_decrypt(const evo_ctx *c, uint32_t l, uint32_t size, const uint64_t *ct, const uint64_t *sk_ntt, uint64_t *pt) {
+  const uint32_t N = c->N;
+  for (uint32_t i = 0; i < l; i++) {
+    const evo_mod *m = &c->m[i];
+    const u64 *s = sk_ntt + (size_t)i * N;
+    for (uint32_t j = 0; j < N; j++) {
+      u64 acc = ct[(size_t)i * N + j], sp = s[j];
+      for (uint32_t p = 1; p < size; p++) {
+        acc = addm(acc, mulm(ct[((size_t)p * l + i) * N + j], sp, m), m->q);
+        sp = mulm(sp, s[j], m);
+      }
+      pt[(size_t)i * N + j] = acc;
+    }
+  }
+}
+
+/* little-endian multi-word helpers for the CRT composition (n <= 64 words) */
+static void mp_mul_word(const u64 *a, int n, u64 w, u64 *out /* n + 1 words */) {
+  u64 carry = 0;
+  for (int t = 0; t < n; t++) {
+    u128 p = (u128)a[t] * w + carry;
+    out[t] = (u64)p;
+    carry = (u64)(p >> 64);
+  }
+  out[n] = carry;
+}
+static int mp_cmp(const u64 *a, const u64 *b, int n) {
+  for (int t = n - 1; t >= 0; t--)
+    if (a[t] != b[t]) return a[t] > b[t] ? 1 : -1;
+  return 0;
+}
+static void mp_sub(u64 *a, const u64 *b, int n) { /* a -= b */
+  u64 borrow = 0;
+  for (int t = 0; t < n; t++) {
+    u128 d = (u128)a[t] - b[t] - borrow;
+    a[t] = (u64)d;
+    borrow = (u64)(d >> 64) & 1;
+  }
+}
+static void mp_add(u64 *a, const u64 *b, int n) { /* a += b, carry out dropped by the caller's sizing */
+  u64 carry = 0;
+  for (int t = 0; t < n; t++) {
+    u128 d = (u128)a[t] + b[t] + carry;
+    a[t] = (u64)d;
+    carry = (u64)(d >> 64);
+  }
+}
+
+/* root_powers_ of CKKSEncoder (ckks.cpp): root_powers_[i] = get_root(reverse_bits(i, logn)), i = 1..n-1 */
+static cplx *ckks_root_powers(uint32_t N, uint32_t logN) {
+  size_t degree = (size_t)2 * N;
+  cplx *oct = (cplx *)malloc(sizeof(cplx) * (degree / 8 + 1));
+  for (size_t i = 0; i <= degree / 8; i++) {
+    double theta = 2 * SEAL_PI * (double)i / (double)degree;
+    oct[i] = (cplx){libm_cos(theta), libm_sin(theta)};
+  }
+  cplx *rp = (cplx *)malloc(sizeof(cplx) * N);
+  rp[0] = (cplx){0, 0};
+  for (uint32_t i = 1; i < N; i++) rp[i] = croots_get(oct, degree, (size_t)bitrev(i, logN));
+  free(oct);
+  return rp;
+}
+
+/* SEAL 3.6 CKKSEncoder::decode_internal (ckks.h), the call at /root/reference/eva/seal/seal.cpp:134-135
+ * (`encoder.decode(plain, vec)`), routine by routine:
+ *   - per-limb inverse_ntt_negacyclic_harvey;
+ *   - RNSBase::compose_array: every coefficient as a base-2^64 integer x in [0, Q), l words;
+ *   - the words to ONE double, least significant first, with inv_scale = 1.0 / scale folded into the
+ *     running power of 2^64 (res += (double)word * scaled; scaled *= 2^64), zero words skipped; a
+ *     coefficient >= upper_half_threshold = (Q + 1) / 2 is negative and is accumulated as the signed
+ *     per-word differences against the words of Q (word > Q_j: += (word - Q_j) * scaled, else
+ *     -= (Q_j - word) * scaled) — exactly SEAL's loop, which is NOT a multi-word subtraction;
+ *   - util::DWTHandler::transform_to_rev with root_powers_ (Cooley-Tukey: x = u + v r, y = u - v r,
+ *     roots consumed sequentially), complex product as in the encoder above (no FMA);
+ *   - slot i = real part of res[matrix_reps_index_map_[i]].
+ * pt: [l][N] NTT form; out: N/2 slot values.  returns 0, or -1 for "scale out of bounds". */
+int evo_decode(const evo_ctx *c, uint32_t l, const uint64_t *pt, double scale, double *out) {
+  const uint32_t N = c->N, slots = N >> 1, m2 = 2 * N;
+  uint32_t logN = 0;
+  while ((1u << logN) < N) logN++;
+  if (l < 1 || l > 62) return -1;
+  /* Q and the punctured products Q / q_i (l words each), (Q / q_i)^-1 mod q_i */
+  u64 Q[64] = {1}, tmp[65];
+  int nw = 1;
+  for (uint32_t i = 0; i < l; i++) {
+    mp_mul_word(Q, nw, c->m[i].q, tmp);
+    nw++;
+    memcpy(Q, tmp, sizeof(u64) * nw);
+  }
+  while (nw > 1 && Q[nw - 1] == 0) nw--;
+  int total_bits = (nw - 1) * 64;
+  for (u64 top = Q[nw - 1]; top; top >>= 1) total_bits++;
+  if (!(scale > 0) || (int)log2(scale) >= total_bits) return -1;
+  const int L = (int)l; /* coeff_modulus_size words per composed coefficient, as SEAL lays them out */
+  u64 *punct = (u64 *)calloc((size_t)l * (L + 1), sizeof(u64)), *inv_punct = (u64 *)malloc(sizeof(u64) * l);
+  for (uint32_t i = 0; i < l; i++) {
+    u64 *pp = punct + (size_t)i * (L + 1);
+    pp[0] = 1;
+    int n = 1;
+    for (uint32_t j = 0; j < l; j++) {
+      if (j == i) continue;
+      mp_mul_word(pp, n, c->m[j].q, tmp);
+      n++;
+      memcpy(pp, tmp, sizeof(u64) * (n < L + 1 ? n : L + 1));
+    }
+    u64 r = 0; /* (Q / q_i) mod q_i */
+    for (int t = L - 1; t >= 0; t--) r = (u64)((((u128)r << 64) | pp[t]) % c->m[i].q);
+    inv_punct[i] = evo_invmod(r, c->m[i].q);
+  }
+  u64 Qw[64] = {0}, half[64] = {0}; /* Q and (Q + 1) >> 1 on L words */
+  memcpy(Qw, Q, sizeof(u64) * (size_t)(nw < L ? nw : L));
+  {
+    u64 t1[64];
+    memcpy(t1, Qw, sizeof(t1));
+    u64 one[64] = {1};
+    mp_add(t1, one, L);
+    for (int t = 0; t < L; t++) half[t] = (t1[t] >> 1) | (t + 1 < L ? t1[t + 1] << 63 : 0);
+  }
+  u64 *co = (u64 *)malloc(sizeof(u64) * (size_t)l * N);
+  memcpy(co, pt, sizeof(u64) * (size_t)l * N);
+  for (uint32_t i = 0; i < l; i++) ntt_inv(c, &c->m[i], co + (size_t)i * N);
+  cplx *res = (cplx *)malloc(sizeof(cplx) * N);
+  const double inv_scale = 1.0 / scale, two_pow_64 = pow(2.0, 64);
+  for (uint32_t n = 0; n < N; n++) {
+    u64 x[65] = {0}, term[66];
+    for (uint32_t i = 0; i < l; i++) { /* x = sum_i [r_i (Q/q_i)^-1 mod q_i] (Q/q_i) mod Q */
+      const u64 tp = mulm(co[(size_t)i * N + n], inv_punct[i], &c->m[i]);
+      mp_mul_word(punct + (size_t)i * (L + 1), L, tp, term); /* < Q, fits L words */
+      mp_add(x, term, L + 1);
+      if (x[L] || mp_cmp(x, Qw, L) >= 0) { mp_sub(x, Qw, L); x[L] = 0; } /* add_uint_uint_mod */
+    }
+    double acc = 0.0, scaled = inv_scale;
+    if (mp_cmp(x, half, L) >= 0) {
+      for (int j = 0; j < L; j++, scaled *= two_pow_64) {
+        if (x[j] > Qw[j]) {
+          const u64 diff = x[j] - Qw[j];
+          acc += diff ? (double)diff * scaled : 0.0;
+        } else {
+          const u64 diff = Qw[j] - x[j];
+          acc -= diff ? (double)diff * scaled : 0.0;
+        }
+      }
+    } else {
+      for (int j = 0; j < L; j++, scaled *= two_pow_64) acc += x[j] ? (double)x[j] * scaled : 0.0;
+    }
+    res[n] = (cplx){acc, 0.0};
+  }
+  /* transform_to_rev(res, logn, root_powers_) */
+  cplx *rp = ckks_root_powers(N, logN);
+  const cplx *roots = rp;
+  size_t gap = N >> 1, mm = 1;
+  for (; mm < N; mm <<= 1) { /* the unrolled last stage (gap = 1) of SEAL is the same butterfly */
+    size_t offset = 0;
+    for (size_t i = 0; i < mm; i++) {
+      cplx r = *++roots;
+      cplx *x = res + offset, *y = x + gap;
+      for (size_t j = 0; j < gap; j++) {
+        cplx u = *x, v = c_mul(*y, r);
+        *x++ = c_add(u, v);
+        *y++ = c_sub(u, v);
+      }
+      offset += gap << 1;
+    }
+    gap >>= 1;
+  }
+  u64 pos = 1;
+  for (uint32_t i = 0; i < slots; i++) { /* matrix_reps_index_map_[i], i < slots */
+    out[i] = res[bitrev((uint32_t)((pos - 1) >> 1), logN)].re;
+    pos = (pos * 3) & (m2 - 1);
+  }
+  free(rp);
+  free(res);
+  free(co);
+  free(punct);
+  free(inv_punct);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ bench helper */
 
 void evo_op_triple(const evo_ctx *c, uint32_t l, const uint64_t *a2, const uint64_t *b2,

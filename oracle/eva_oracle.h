@@ -105,6 +105,14 @@ int evo_encode(const evo_ctx *c, uint32_t l, const double *values, double scale,
 /* coefficient form only (before per-limb NTT); signed coefficients as doubles (rounded) */
 void evo_encode_coeffs(uint32_t N, const double *values, double scale, double *coeffs);
 
+/* ---- Decryptor::decrypt + CKKSEncoder::decode restatement (/root/reference/eva/seal/seal.cpp:124-146) ----
+ * decrypt: ct [size][l][N], sk_ntt [k][N] -> plaintext [l][N], NTT form (c0 + c1 s + c2 s^2).
+ * decode : plaintext [l][N] NTT form at `scale` -> the N/2 slot values, SEAL 3.6's FP64 operation order
+ * (CRT composition to base-2^64 words, words to double least significant first with 1/scale folded in,
+ * transform_to_rev).  returns 0, -1 for "scale out of bounds". */
+void evo_decrypt(const evo_ctx *c, uint32_t l, uint32_t size, const uint64_t *ct, const uint64_t *sk_ntt, uint64_t *pt);
+int evo_decode(const evo_ctx *c, uint32_t l, const uint64_t *pt, double scale, double *out);
+
 /* op-triple used by bench.py's cpu_baseline: multiply + relinearize + rescale */
 void evo_op_triple(const evo_ctx *c, uint32_t l, const uint64_t *a2, const uint64_t *b2,
                    const uint64_t *relin_key, uint64_t *out2 /* [2][l-1][N] */);

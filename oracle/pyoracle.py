@@ -67,6 +67,8 @@ def _load():
         "evo_rotate": (None, [vp, C.c_uint32, u64p, C.c_int32, u64p, u64p]),
         "evo_encode": (C.c_int, [vp, C.c_uint32, dblp, C.c_double, u64p]),
         "evo_encode_coeffs": (None, [C.c_uint32, dblp, C.c_double, dblp]),
+        "evo_decrypt": (None, [vp, C.c_uint32, C.c_uint32, u64p, u64p, u64p]),
+        "evo_decode": (C.c_int, [vp, C.c_uint32, u64p, C.c_double, dblp]),
         "evo_op_triple": (None, [vp, C.c_uint32, u64p, u64p, u64p, u64p]),
         "evo_dag_walk": (C.c_int, [vp, C.POINTER(DagOp), C.c_uint32, C.POINTER(DagVal), C.c_uint32, u64p, u32p,
                                    C.POINTER(u64p), C.c_uint32, C.c_int]),
@@ -219,6 +221,23 @@ class Oracle:
         if rc != 0:
             raise ValueError("encoded values are too large")
         return pt
+
+    def decrypt(self, ct, sk_ntt):
+        """Decryptor::decrypt: ct [size][l][N], sk_ntt [k][N] -> plaintext [l][N] (NTT form)"""
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        sk = np.ascontiguousarray(sk_ntt, dtype=np.uint64)
+        pt = np.empty((ct.shape[1], self.N), dtype=np.uint64)
+        lib.evo_decrypt(self._c, ct.shape[1], ct.shape[0], _p(ct), _p(sk), _p(pt))
+        return pt
+
+    def decode(self, pt, scale):
+        """CKKSEncoder::decode: plaintext [l][N] (NTT form) -> the N/2 slot values (SEAL 3.6's FP64 order)"""
+        pt = np.ascontiguousarray(pt, dtype=np.uint64)
+        out = np.empty(self.N // 2, dtype=np.float64)
+        rc = lib.evo_decode(self._c, pt.shape[0], _p(pt), float(scale), out.ctypes.data_as(C.POINTER(C.c_double)))
+        if rc != 0:
+            raise ValueError("scale out of bounds")
+        return out
 
     def dag_walk(self, ops, values, n_vals, relin_key, galois_keys, threads=1):
         """Walks a flat op list [(op, dst, src0, src1, imm)] (the reference's op codes) over the

@@ -41,6 +41,7 @@ for _ in range(args.reps):
             return
         for i, u in enumerate(units):
             pub.execute(compiled, encs[keys[i % len(keys)]])
+        pub.synchronize()
     _, secs = d.timed(body)
     best = secs if best is None else min(best, secs)
 if d.rank == 0:

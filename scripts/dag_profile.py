@@ -38,3 +38,4 @@ pub, sec = generate_keys(params, 1)
 enc = pub.encrypt(_image(4096), sig)
 for _ in range(reps + 2):
     pub.execute(compiled, enc)
+pub.synchronize()

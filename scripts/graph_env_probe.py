@@ -15,8 +15,9 @@ for name, prog, N in (("sobel", None, 8192), ("harris", _harris(), 32768)):
     enc = pub.encrypt(_image(4096), sig)
     for _ in range(3):
         pub.execute(compiled, enc)
+    pub.synchronize()
     ts = []
     for _ in range(15):
-        t0 = time.perf_counter(); pub.execute(compiled, enc); ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); pub.execute(compiled, enc); pub.synchronize(); ts.append(time.perf_counter() - t0)
     ts.sort()
     print(f"{name}: min {ts[0]*1e3:.3f} median {ts[7]*1e3:.3f} ms  timing {['%.3f' % x for x in pub.last_timing]}", flush=True)

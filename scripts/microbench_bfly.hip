@@ -73,11 +73,13 @@ template <int V> __device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, u64 w,
 
 constexpr int ITERS = 512;
 // 8 values per thread, 3 stages per iteration (12 butterflies), like one register round of the passes
-template <int V, bool INV> __global__ void __launch_bounds__(256) k_round(u64 *out, Pm p, u64 w0, u64 ws0, int check) {
+template <int V, bool INV> __global__ void __launch_bounds__(256) k_round(u64 *out, Pm p, const ulonglong2 *tw, int check) {
   u64 x[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) x[i] = (threadIdx.x * 0x9E3779B97F4A7C15ull + i * 0x1234567ull) % p.q;
-  u64 w = w0 + threadIdx.x, ws = ws0 + 3 * threadIdx.x; // per-lane operands (VGPRs), as twiddles from LDS are
+  ulonglong2 t[6]; // per-lane (w, floor(w 2^64 / q)) pairs in VGPRs, as twiddles from LDS are
+#pragma unroll
+  for (int s = 0; s < 6; s++) t[s] = tw[s * 256 + threadIdx.x];
   for (int it = 0; it < ITERS / 2; it++) { // two rounds of three stages: plain / reducing stages alternate
 #pragma unroll
     for (int s = 0; s < 6; s++) {
@@ -85,9 +87,9 @@ template <int V, bool INV> __global__ void __launch_bounds__(256) k_round(u64 *o
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         if (u & half) continue;
-        if (INV) bfly_inv<V>(x[u], x[u + half], w + s, ws + s, p);
-        else if ((s & 1) == 0) bfly_fwd<V, false>(x[u], x[u + half], w + s, ws + s, p);
-        else bfly_fwd<V, true>(x[u], x[u + half], w + s, ws + s, p);
+        if (INV) bfly_inv<V>(x[u], x[u + half], t[s].x, t[s].y, p);
+        else if ((s & 1) == 0) bfly_fwd<V, false>(x[u], x[u + half], t[s].x, t[s].y, p);
+        else bfly_fwd<V, true>(x[u], x[u + half], t[s].x, t[s].y, p);
       }
     }
   }
@@ -125,12 +127,18 @@ int main() {
   p.q = q; p.nq = 0 - q; p.q4 = 4 * q; p.q5 = 5 * q; p.q8 = 8 * q; p.nq5 = 0 - 5 * q; p.nq8 = 0 - 8 * q;
   p.fs = 31; p.fmask = 0x7fffffffu; p.fc = (uint32_t)((1ull << 63) % q);
   p.is = 30; p.imask = 0x3fffffffu; p.ic = (uint32_t)((1ull << 62) % q);
-  const u64 w = 0x123456789abcdefull % q;
-  const u64 ws = (u64)((((unsigned __int128)w) << 64) / q);
+  std::vector<ulonglong2> twh(6 * 256);
+  for (size_t i = 0; i < twh.size(); i++) {
+    const u64 w = (0x123456789abcdefull * (i + 1)) % q;
+    twh[i] = make_ulonglong2(w, (u64)((((unsigned __int128)w) << 64) / q));
+  }
+  ulonglong2 *tw;
+  CHK(hipMalloc(&tw, twh.size() * sizeof(ulonglong2)));
+  CHK(hipMemcpy(tw, twh.data(), twh.size() * sizeof(ulonglong2), hipMemcpyHostToDevice));
   u64 *out; const size_t words = (size_t)8 * 256 * 8;
   CHK(hipMalloc(&out, words * 8));
   std::vector<u64> ref(words), got(words);
-#define LAUNCH(V, INV) [&](int b, int chk) { hipLaunchKernelGGL((k_round<V, INV>), dim3(b), dim3(256), 0, 0, out, p, w, ws, chk); }
+#define LAUNCH(V, INV) [&](int b, int chk) { hipLaunchKernelGGL((k_round<V, INV>), dim3(b), dim3(256), 0, 0, out, p, tw, chk); }
 #define CHECK(V, INV, NAME) { LAUNCH(V, INV)(8, 1); CHK(hipMemcpy(got.data(), out, words * 8, hipMemcpyDeviceToHost)); \
     if (V == 0) ref = got; else if (got != ref) { printf("%s: residues differ from the base variant\n", NAME); return 1; } }
   CHECK(0, false, "fwd base") CHECK(1, false, "fwd bit") CHECK(2, false, "fwd madlo") CHECK(3, false, "fwd bit+madlo")
