@@ -7,6 +7,7 @@ libeva_hip.so), `metric`, `std.numeric`.  `eva_amd.backend` is the raw ctypes vi
 Importing this package does not import torch.
 """
 import numbers
+import operator
 
 from . import _hipruntime  # noqa: F401  (one HIP runtime per process; must precede the native modules)
 from ._eva import *  # noqa: F401,F403  (Program, Term, Op, Type, evaluate, save, load, set_num_threads)
@@ -83,7 +84,13 @@ class Expr:
     def __pow__(self, exponent):
         """x ** n for a positive integer n: a left-leaning chain of n - 1 products (the compiler's
         reduction balancer reshapes it); the reference lowers powers the same way"""
-        if not isinstance(exponent, int) or exponent < 1:
+        try:  # any integral type (int, numpy integers, ...), as the reference accepts; bool is not a count
+            if isinstance(exponent, bool):
+                raise TypeError
+            exponent = operator.index(exponent)
+        except TypeError:
+            raise ValueError(f"only positive integer powers are supported, got {exponent!r}") from None
+        if exponent < 1:
             raise ValueError(f"only positive integer powers are supported, got {exponent!r}")
         power = self
         for _ in range(exponent - 1):

@@ -55,6 +55,39 @@ template <int P> constexpr int lds_sub_stride() { return (1 << P) + ((1 << P) >>
 // with 3 multiplies.  x*w - q~*q is evaluated as x*w + q~*(2^64 - q) so the second product
 // accumulates onto the first (one mad chain, no 64-bit subtract).  Moduli are < 2^60, so every
 // lazy value below stays < 10q < 2^64.
+#ifdef EVAH_MADLO
+// Every partial product through v_mad_u64_u32, the low-word cross terms included: the compiler lowers
+// `hi += lo32(a*b)` to v_mul_lo_u32 + v_add3_u32, and on gfx950 a chain of v_mad_u64_u32 whose upper
+// result word is simply ignored issues faster than that pair (scripts/microbench_bfly.hip: 60.0 against
+// 68.4 SIMD cycles per wave-butterfly).  Inline asm, because the compiler narrows the C form back.
+__device__ __forceinline__ u64 mad64(uint32_t a, uint32_t b, u64 c) {
+  u64 d;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+  return d;
+}
+// a + x*w + t*nq (mod 2^64)
+__device__ __forceinline__ u64 mad_chain(u64 x, u64 w, u64 t, u64 nq, u64 a) {
+  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+  const uint32_t t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32), n0 = (uint32_t)nq, n1 = (uint32_t)(nq >> 32);
+  u64 r = mad64(x0, w0, a);
+  r = mad64(t0, n0, r);
+  u64 h = mad64(x0, w1, r >> 32); // from here on only the low word of h matters: its upper word is never read
+  h = mad64(x1, w0, h);
+  h = mad64(t0, n1, h);
+  h = mad64(t1, n0, h);
+  return (h << 32) | (uint32_t)r;
+}
+__device__ __forceinline__ u64 mul_tw_lazy5(u64 x, u64 w, u64 ws, u64 nq) {
+  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
+  const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
+  return mad_chain(x, w, qt, nq, 0);
+}
+__device__ __forceinline__ u64 mul_tw_lazy5_add(u64 x, u64 w, u64 ws, u64 nq, u64 a) {
+  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
+  const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
+  return mad_chain(x, w, qt, nq, a);
+}
+#else
 __device__ __forceinline__ u64 mul_tw_lazy5(u64 x, u64 w, u64 ws, u64 nq) {
   const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
   const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
@@ -67,6 +100,7 @@ __device__ __forceinline__ u64 mul_tw_lazy5_add(u64 x, u64 w, u64 ws, u64 nq, u6
   const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
   return (a + x * w) + qt * nq;
 }
+#endif
 // forward Cooley-Tukey butterfly.  The twiddle product is in [0,4q), so each stage grows the
 // bound by 4q; moduli are < 2^60 (16q < 2^64), which leaves room to reduce only every other stage:
 //   REDUCE stage : X < 16q -> x < 8q  -> outputs < 12q

@@ -529,11 +529,13 @@ struct HostCipher {
   double scale = 1.0;
   mutable CipherWords data; // [size][limbs][N]; empty while the value lives only on the device
   std::shared_ptr<DeviceResident> dev;
+  mutable bool words_checked = false; // every word < its prime: verified (values from files / Python) or by construction
 };
 struct HostPlain {
   uint32_t limbs = 0;
   double scale = 1.0;
   std::vector<u64> data; // [limbs][N], NTT form
+  mutable bool words_checked = false;
 };
 
 // Public-key encryption of an NTT-form plaintext at `limbs` data limbs (A.10): encrypt zero one

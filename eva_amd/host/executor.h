@@ -165,6 +165,7 @@ inline const CipherWords &words(const HostCipher &c) {
     CipherWords w((size_t)c.size * c.limbs * c.dev->N);
     chk(evah_ct_download(c.dev->ctx(), c.dev->h->h, (uint64_t *)w.data()));
     c.data = std::move(w);
+    c.words_checked = true; // the device's own residues
   }
   return c.data;
 }
@@ -201,6 +202,21 @@ public:
     if (c.size < 1 || c.size > 3 || c.limbs < 1 || c.limbs > host.k - 1 ||
         (!resident_only(c) && c.data.size() != (size_t)c.size * c.limbs * host.N))
       throw std::runtime_error("input " + name + ": ciphertext shape does not match its data or the encryption parameters");
+    if (!c.words_checked && !c.data.empty()) { // once per value: files and Python arrays are untrusted
+      check_words(name, c.data.data(), c.size, c.limbs);
+      c.words_checked = true;
+    }
+  }
+  // the kernels' lazy-reduction bounds assume canonical residues: a word >= its prime would give
+  // silently wrong results, so it is an error at the boundary
+  void check_words(const std::string &name, const u64 *w, uint32_t polys, uint32_t limbs) const {
+    for (uint32_t p = 0; p < polys; p++)
+      for (uint32_t i = 0; i < limbs; i++) {
+        const u64 q = host.primes[i];
+        const u64 *row = w + ((size_t)p * limbs + i) * host.N;
+        for (uint32_t j = 0; j < host.N; j++)
+          if (row[j] >= q) throw std::runtime_error("input " + name + ": a word is not reduced modulo its prime");
+      }
   }
   // a value resident on this executor's device state: its handle, else null
   std::shared_ptr<CtHandle> resident_handle(const HostCipher &c) const {
@@ -212,6 +228,10 @@ public:
   void check_shape(const std::string &name, const HostPlain &p) const {
     if (p.limbs < 1 || p.limbs > host.k - 1 || p.data.size() != (size_t)p.limbs * host.N)
       throw std::runtime_error("input " + name + ": plaintext shape does not match its data or the encryption parameters");
+    if (!p.words_checked) {
+      check_words(name, p.data.data(), 1, p.limbs);
+      p.words_checked = true;
+    }
   }
 
   // seal_executor.h:264-277 (the reference deep-copies; here inputs are uploaded to HBM)
@@ -563,6 +583,7 @@ public:
           continue;
         }
         hc.data.resize((size_t)hc.size * hc.limbs * host.N);
+        hc.words_checked = true;
         chk(evah_ct_download(ctx, (*c)->h, (uint64_t *)hc.data.data()));
         out.values[kv.first] = std::move(hc);
       } else if (auto *p = std::get_if<std::shared_ptr<PtHandle>>(&o)) {
@@ -770,6 +791,7 @@ public:
   // SEALPublic::encrypt (seal.cpp:24-102)
   HipValuation encrypt(const Valuation &inputs, const CKKSSignature &sig) {
     const size_t slots = host->N / 2;
+    if (sig.vec_size <= 0) throw std::runtime_error("Signature vector size must be positive");
     if (slots < (size_t)sig.vec_size) throw std::runtime_error("Vector size cannot be larger than slot count");
     if (slots % sig.vec_size) throw std::runtime_error("Vector size must exactly divide the slot count");
     HipValuation out;
@@ -1165,6 +1187,7 @@ private:
           continue;
         }
         hc.data.resize((size_t)hc.size * hc.limbs * host->N);
+        hc.words_checked = true;
         chk(evah_ct_download(q0, (*c)->h, (uint64_t *)hc.data.data()));
         out.values[kv.first] = std::move(hc);
       } else if (auto *p = std::get_if<std::shared_ptr<PtHandle>>(&kv.second)) {
@@ -1252,6 +1275,7 @@ private:
       return out;
     }
     out.data.resize((size_t)2 * out.limbs * N);
+    out.words_checked = true;
     chk(evah_ct_download(dev->h, c, (uint64_t *)out.data.data()));
     return out;
   }

@@ -122,7 +122,7 @@ inline std::unique_ptr<Program> read_program(Reader &r) {
     x.has_rescale_divisor = flags & 1; x.has_rotation = flags & 2; x.has_type = flags & 4; x.has_range = flags & 8;
     x.has_encode_scale = flags & 16; x.has_encode_level = flags & 32;
     if (flags & 64) x.constant = std::make_shared<ConstantValue>(ConstantValue{r.vec<double>()});
-    if (op == Op::Constant && (!x.constant || x.constant->values.empty() || x.constant->values.size() > vs))
+    if (op == Op::Constant && (!x.constant || x.constant->values.empty() || x.constant->values.size() > vs || vs % x.constant->values.size()))
       throw std::runtime_error("Could not parse message: constant without a valid value");
     if ((op == Op::RotateLeftConst || op == Op::RotateRightConst) && !x.has_rotation)
       throw std::runtime_error("Could not parse message: rotation without a step count");
@@ -151,6 +151,11 @@ inline CKKSParameters read_parameters(Reader &r) {
   auto rot = r.vec<int32_t>();
   p.rotations.insert(rot.begin(), rot.end());
   p.poly_modulus_degree = r.pod<uint32_t>();
+  if (p.poly_modulus_degree == 0 || (p.poly_modulus_degree & (p.poly_modulus_degree - 1)) || p.poly_modulus_degree > (1u << 17))
+    throw std::runtime_error("Could not parse message: poly_modulus_degree must be a power of two up to 131072");
+  if (p.prime_bits.empty() || p.prime_bits.size() > 62) throw std::runtime_error("Could not parse message: invalid prime count");
+  for (uint32_t b : p.prime_bits)
+    if (b < 2 || b > 60) throw std::runtime_error("Could not parse message: prime bit sizes must be 2..60");
   return p;
 }
 inline void write(Writer &w, const CKKSSignature &s) {
@@ -166,8 +171,11 @@ inline CKKSSignature read_signature(Reader &r) {
     std::string name = r.str();
     Type t = (Type)r.pod<int32_t>();
     int sc = r.pod<int32_t>(), lv = r.pod<int32_t>();
+    if ((int)t < 0 || (int)t > 3 || sc < 0 || lv < 0) throw std::runtime_error("Could not parse message: invalid encoding info for input " + name);
     s.inputs.emplace(name, CKKSEncodingInfo{t, sc, lv});
   }
+  if (s.vec_size <= 0 || (s.vec_size & (s.vec_size - 1)))
+    throw std::runtime_error("Could not parse message: signature vector size must be a positive power of two");
   return s;
 }
 inline void write(Writer &w, const HipValuation &v) {
@@ -230,15 +238,28 @@ inline void write(Writer &w, const HipPublic &p) {
   w.pod<uint64_t>(p.galois.size());
   for (auto &kv : p.galois) { w.pod(kv.first); w.pod(kv.second.n_digits); w.vec(kv.second.data); }
 }
+// every word of a key-level object ([...][k][N]) must be a canonical residue of its prime: the kernels'
+// lazy-reduction bounds assume it, so an out-of-range word would give silently wrong results
+template <class Vec> inline void check_residues(const Vec &words, const HostContext &h, const char *what) {
+  const size_t N = h.N, rows = words.size() / N;
+  for (size_t r = 0; r < rows; r++) {
+    const u64 q = h.primes[r % h.k];
+    const u64 *w = words.data() + r * N;
+    for (size_t j = 0; j < N; j++)
+      if (w[j] >= q) throw std::runtime_error(std::string("Could not parse message: ") + what + " holds a word that is not reduced modulo its prime");
+  }
+}
 inline void check_switch_key(const SwitchKey &k, const HostContext &h, const char *what) {
   if (k.n_digits == 0 || k.n_digits > h.k - 1 || k.data.size() != (size_t)k.n_digits * 2 * h.k * h.N)
     throw std::runtime_error(std::string("Could not parse message: ") + what + " has the wrong size for its context");
+  check_residues(k.data, h, what);
 }
 inline std::shared_ptr<HipPublic> read_public(Reader &r) {
   auto p = std::make_shared<HipPublic>();
   p->host = read_ctx(r);
   p->pk.data = r.vec<u64>();
   if (p->pk.data.size() != (size_t)2 * p->host->k * p->host->N) throw std::runtime_error("Could not parse message: public key has the wrong size for its context");
+  check_residues(p->pk.data, *p->host, "public key");
   p->relin.n_digits = r.pod<uint32_t>(); p->relin.data = r.vec<u64>();
   check_switch_key(p->relin, *p->host, "relinearization key");
   uint64_t n = r.pod<uint64_t>();
@@ -263,6 +284,9 @@ inline std::shared_ptr<HipSecret> read_secret(Reader &r) {
   s->sk.s_ntt = r.vec<u64>();
   if (s->sk.s.size() != s->host->N || s->sk.s_ntt.size() != (size_t)s->host->k * s->host->N)
     throw std::runtime_error("Could not parse message: secret key has the wrong size for its context");
+  for (int8_t v : s->sk.s)
+    if (v < -1 || v > 1) throw std::runtime_error("Could not parse message: secret key coefficients must be ternary");
+  check_residues(s->sk.s_ntt, *s->host, "secret key");
   return s;
 }
 

@@ -233,6 +233,12 @@ inline std::unique_ptr<Program> decode_program(In in) {
             else c.skip(cw);
           }
           if (size == 0) throw std::runtime_error("Constant must have non-zero size");
+          // `size` comes from the file: bound it by the program's vector size BEFORE anything is sized by
+          // it (a sparse constant expands to `size` doubles), and hold dense values to the rule the
+          // reference's validateSlots applies — the value count divides `size`, `size` divides vec_size
+          if (size > vec_size || vec_size % size) throw std::runtime_error("Could not parse message: constant does not fit the vector size");
+          if (!values.empty() && sparse.empty() && (values.size() > size || size % values.size()))
+            throw std::runtime_error("Could not parse message: constant value count does not divide its size");
           std::vector<double> dense;
           if (values.empty()) dense.assign(1, 0.0);                 // the zero constant
           else if (sparse.empty()) dense = std::move(values);       // dense, broadcast over `size`
@@ -282,6 +288,11 @@ inline CKKSParameters decode_parameters(In in) {
     else if (f == 3 && wt == 0) p.poly_modulus_degree = (uint32_t)in.varint();
     else in.skip(wt);
   }
+  if (p.poly_modulus_degree == 0 || (p.poly_modulus_degree & (p.poly_modulus_degree - 1)) || p.poly_modulus_degree > (1u << 17))
+    throw std::runtime_error("Could not parse message: poly_modulus_degree must be a power of two up to 131072");
+  if (p.prime_bits.empty() || p.prime_bits.size() > 62) throw std::runtime_error("Could not parse message: invalid prime count");
+  for (uint32_t b : p.prime_bits)
+    if (b < 2 || b > 60) throw std::runtime_error("Could not parse message: prime bit sizes must be 2..60");
   return p;
 }
 inline std::string encode(const CKKSSignature &s) {
@@ -325,9 +336,14 @@ inline CKKSSignature decode_signature(In in) {
           }
         } else e.skip((uint32_t)(et & 7));
       }
+      // a signature is loaded from untrusted files too: the enum and the two counts are range-checked here
+      if ((int)info.input_type < 0 || (int)info.input_type > 3 || info.scale < 0 || info.level < 0)
+        throw std::runtime_error("Could not parse message: invalid encoding info for input " + key);
       s.inputs.emplace(key, info);
     } else in.skip(wt);
   }
+  if (s.vec_size <= 0 || (s.vec_size & (s.vec_size - 1)))
+    throw std::runtime_error("Could not parse message: signature vector size must be a positive power of two");
   return s;
 }
 

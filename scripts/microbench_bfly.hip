@@ -39,12 +39,11 @@ __device__ __forceinline__ u64 mul_add_madlo(u64 x, u64 w, u64 ws, u64 nq, u64 a
   const uint32_t t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32), n0 = (uint32_t)nq, n1 = (uint32_t)(nq >> 32);
   u64 r = mad64(x0, w0, a);
   r = mad64(t0, n0, r);
-  uint32_t hi = (uint32_t)(r >> 32);
-  hi = (uint32_t)mad64(x0, w1, hi);
-  hi = (uint32_t)mad64(x1, w0, hi);
-  hi = (uint32_t)mad64(t0, n1, hi);
-  hi = (uint32_t)mad64(t1, n0, hi);
-  return ((u64)hi << 32) | (uint32_t)r;
+  u64 h = mad64(x0, w1, r >> 32); // only the low word of h matters from here on
+  h = mad64(x1, w0, h);
+  h = mad64(t0, n1, h);
+  h = mad64(t1, n0, h);
+  return (h << 32) | (uint32_t)r;
 }
 
 template <int V, bool REDUCE> __device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, u64 w, u64 ws, const Pm &p) {
