@@ -30,7 +30,7 @@ def _hipcc():
 
 
 HIP_UNITS = ("runtime.hip", "evaluator.hip", "scheduler.hip")
-HIP_HEADERS = ("internal.hip.h", "ntt.hip.h", "devmath.hip.h", "hostmath.h")
+HIP_HEADERS = ("internal.hip.h", "ntt.hip.h", "devmath.hip.h", "hostmath.h", "shard.hip.h", "client.hip.h")
 
 
 def build_hip(force=False, verbose=False):

@@ -28,6 +28,7 @@ struct DevPrime {
   u64 q5;       // 5q, the inverse lazy-butterfly threshold
   u64 q4, q8;   // 4q (forward difference offset), 8q (forward reduction threshold)
   u64 nq5, nq8; // 2^64 - 5q, 2^64 - 8q: conditional subtraction as select + one 64-bit add (data, as nq)
+  u64 c64, c64s; // 2^64 mod q and its Shoup quotient: folds the high word of a 128-bit value (barrett128)
 };
 
 // Device-side view of a context (passed by value to kernels).
@@ -89,19 +90,28 @@ __device__ __forceinline__ u64 barrett64(u64 x, u64 q, u64 brt) {
   return r >= q ? r - q : r;
 }
 
-// (hi:lo) mod q for any 128-bit input, q < 2^62; (r1:r0) = floor(2^128/q)
+// Twiddle product with a cheap quotient estimate.  Shoup's q^ = floor(x*ws / 2^64) needs the
+// full 64x64 high product (4 multiplies + carries); dropping the partial products that only
+// feed carries gives q~ with q^ - 2 <= q~ <= q^, i.e. x*w - q~*q in [0, 4q) for ANY 64-bit x,
+// with 3 multiplies.  x*w - q~*q is evaluated as x*w + q~*(2^64 - q) so the second product
+// accumulates onto the first (one mad chain, no 64-bit subtract).
+__device__ __forceinline__ u64 mul_tw_lazy5(u64 x, u64 w, u64 ws, u64 nq) {
+  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
+  const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
+  return x * w + qt * nq;
+}
+
+// (hi:lo) mod q for any 128-bit input, canonical.  The high word is folded with the constant
+// 2^64 mod q as a lazy Shoup product (< 4q, 11 instructions), the sum with the low word is brought
+// back below 2^64 with the same constant when it carries, and one 64-bit Barrett step finishes:
+// ~40 VALU instructions where the textbook 128-bit Barrett (two 64x64 high products against
+// floor(2^128/q)) compiles to ~95 on gfx950.  Every ciphertext product, weighted sum and key inner
+// product ends in this reduction.
 __device__ __forceinline__ u64 barrett128(u128_t x, const DevPrime &m) {
-  u64 carry = __umul64hi(x.lo, m.r0);
-  u64 t_lo = x.lo * m.r1, t_hi = __umul64hi(x.lo, m.r1);
-  u64 tmp1 = t_lo + carry;
-  u64 tmp3 = t_hi + (tmp1 < carry);
-  u64 s_lo = x.hi * m.r0, s_hi = __umul64hi(x.hi, m.r0);
-  u64 tmp1b = tmp1 + s_lo;
-  carry = s_hi + (tmp1b < tmp1);
-  u64 qhat = x.hi * m.r1 + tmp3 + carry;
-  u64 r = x.lo - qhat * m.q;
-  r = r >= m.q ? r - m.q : r;
-  return r >= m.q ? r - m.q : r;
+  const u64 t = mul_tw_lazy5(x.hi, m.c64, m.c64s, m.nq); // hi * 2^64 mod q, lazy in [0, 4q)
+  u64 v = t + x.lo;
+  v += (v < t) ? m.c64 : 0; // carried: v = t + lo - 2^64 < t < 4q, and 2^64 = c64 (mod q); no second carry
+  return barrett64(v, m.q, m.brt);
 }
 __device__ __forceinline__ u64 mulmod(u64 a, u64 b, const DevPrime &m) {
   return barrett128(mul128(a, b), m);

@@ -205,7 +205,7 @@ struct evah_ctx {
   // launches of at most this many workgroups are treated as latency-bound: an inverse transform
   // followed by forward transforms of the result then runs its two strided passes as ONE launch
   // (ntt_inv_fwd_kernel).  EVAH_FUSE_SMALL=0 disables, =n sets the threshold.
-  uint32_t fuse_small_blocks = 8192;
+  uint32_t fuse_small_blocks = 2048; // r03 sweep at the BASELINE sizes: Harris L=8 1.18 -> 1.15 ms, 256 Sobel DAGs (l=5) 9.6 k -> 10.3 k/s vs 8192
   int small_lr = 2; // log2 coefficients per thread of the NTT passes in latency-bound launches (EVAH_SMALL_LR = 2 | 3)
   uint32_t small_lr_blocks = 1024; // ... = launches of at most this many 2048-coefficient tiles (EVAH_SMALL_LR_BLOCKS)
   // several rotations of one ciphertext: decompose once and permute the transformed digits (hoisting),

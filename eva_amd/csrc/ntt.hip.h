@@ -49,25 +49,31 @@ template <int P, int LR> struct Rounds {
 __device__ __forceinline__ int lds_pad(int e) { return e + (e >> 4); }
 template <int P> constexpr int lds_sub_stride() { return (1 << P) + ((1 << P) >> 4) + 1; }
 
-// Twiddle product with a cheap quotient estimate.  Shoup's q^ = floor(x*ws / 2^64) needs the
-// full 64x64 high product (4 multiplies + carries); dropping the partial products that only
-// feed carries gives q~ with q^ - 3 <= q~ <= q^, i.e. x*w - q~*q in [0, 5q) for ANY 64-bit x,
-// with 3 multiplies.  x*w - q~*q is evaluated as x*w + q~*(2^64 - q) so the second product
-// accumulates onto the first (one mad chain, no 64-bit subtract).  Moduli are < 2^60, so every
-// lazy value below stays < 10q < 2^64.
-#ifdef EVAH_MADLO
-// Every partial product through v_mad_u64_u32, the low-word cross terms included: the compiler lowers
-// `hi += lo32(a*b)` to v_mul_lo_u32 + v_add3_u32, and on gfx950 a chain of v_mad_u64_u32 whose upper
-// result word is simply ignored issues faster than that pair (scripts/microbench_bfly.hip: 60.0 against
-// 68.4 SIMD cycles per wave-butterfly).  Inline asm, because the compiler narrows the C form back.
+// mul_tw_lazy5 (devmath.hip.h): x*w - q~*q in [0, 4q) for any 64-bit x with a 3-multiply quotient estimate.
+// Moduli are < 2^60, so every lazy value below stays < 16q <= 2^64.
+// a + (x*w - q~*q): the mad chain of mul_tw_lazy5 started from `a` instead of 0 (the first
+// v_mad_u64_u32 has a free 64-bit addend), so the butterfly's sum costs nothing extra
+__device__ __forceinline__ u64 mul_tw_lazy5_add(u64 x, u64 w, u64 ws, u64 nq, u64 a) {
+  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
+  const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
+  return (a + x * w) + qt * nq;
+}
+// The same value with EVERY partial product going through v_mad_u64_u32, the low-word cross terms
+// included: the compiler lowers `hi += lo32(a*b)` to v_mul_lo_u32 + v_add3_u32, and on gfx950 a chain of
+// v_mad_u64_u32 whose upper result word is simply never read issues faster than that pair
+// (scripts/microbench_bfly.hip: 60.0 against 68.4 SIMD cycles per wave-butterfly; in the library: the
+// 8-coefficient strided forward passes -3..-6 %, but +1.5 % in the fused key-switch kernel and +8 % in
+// the combine pass, whose register budgets it tips — profiles/r03_tuning_notes.md).  Inline asm, because
+// the compiler narrows the C form back.  ntt_round selects it per pass.
 __device__ __forceinline__ u64 mad64(uint32_t a, uint32_t b, u64 c) {
   u64 d;
   asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
   return d;
 }
-// a + x*w + t*nq (mod 2^64)
-__device__ __forceinline__ u64 mad_chain(u64 x, u64 w, u64 t, u64 nq, u64 a) {
-  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+__device__ __forceinline__ u64 mul_tw_lazy5_add_mad(u64 x, u64 w, u64 ws, u64 nq, u64 a) {
+  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
+  const u64 t = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
+  const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
   const uint32_t t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32), n0 = (uint32_t)nq, n1 = (uint32_t)(nq >> 32);
   u64 r = mad64(x0, w0, a);
   r = mad64(t0, n0, r);
@@ -77,29 +83,8 @@ __device__ __forceinline__ u64 mad_chain(u64 x, u64 w, u64 t, u64 nq, u64 a) {
   h = mad64(t1, n0, h);
   return (h << 32) | (uint32_t)r;
 }
-__device__ __forceinline__ u64 mul_tw_lazy5(u64 x, u64 w, u64 ws, u64 nq) {
-  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
-  const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
-  return mad_chain(x, w, qt, nq, 0);
-}
-__device__ __forceinline__ u64 mul_tw_lazy5_add(u64 x, u64 w, u64 ws, u64 nq, u64 a) {
-  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
-  const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
-  return mad_chain(x, w, qt, nq, a);
-}
-#else
-__device__ __forceinline__ u64 mul_tw_lazy5(u64 x, u64 w, u64 ws, u64 nq) {
-  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
-  const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
-  return x * w + qt * nq;
-}
-// a + (x*w - q~*q): the same mad chain started from `a` instead of 0 (the first v_mad_u64_u32 has
-// a free 64-bit addend), so the butterfly's sum costs nothing extra
-__device__ __forceinline__ u64 mul_tw_lazy5_add(u64 x, u64 w, u64 ws, u64 nq, u64 a) {
-  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
-  const u64 qt = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
-  return (a + x * w) + qt * nq;
-}
+#ifndef EVAH_MADLO
+#define EVAH_MADLO 1 // 0: the compiler's form everywhere (A/B switch of the build)
 #endif
 // forward Cooley-Tukey butterfly.  The twiddle product is in [0,4q), so each stage grows the
 // bound by 4q; moduli are < 2^60 (16q < 2^64), which leaves room to reduce only every other stage:
@@ -107,10 +92,10 @@ __device__ __forceinline__ u64 mul_tw_lazy5_add(u64 x, u64 w, u64 ws, u64 nq, u6
 //   plain stage  : X < 12q            -> outputs < 16q
 // (Y only feeds the multiply, which accepts any 64-bit value.)  X' = x + t comes out of the mad
 // chain; Y' = x + 4q - t = (2x + 4q) - X' (mod 2^64; the true value is < 16q).
-template <bool REDUCE>
+template <bool REDUCE, bool MAD = false>
 __device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q4, u64 q8, u64 nq8) {
   u64 x = REDUCE ? X + (X >= q8 ? nq8 : 0) : X;
-  X = mul_tw_lazy5_add(Y, w.x, w.y, nq, x);
+  X = MAD ? mul_tw_lazy5_add_mad(Y, w.x, w.y, nq, x) : mul_tw_lazy5_add(Y, w.x, w.y, nq, x);
   Y = ((x << 1) + q4) - X;
 }
 // inverse Gentleman-Sande butterfly, X,Y in [0,5q) -> [0,5q)
@@ -133,6 +118,10 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
   constexpr int S0 = P - LO - RB; // local stages above this round
   const u64 q = pm.q, nq = pm.nq, q5 = pm.q5, q4 = pm.q4, q8 = pm.q8, nq5 = pm.nq5, nq8 = pm.nq8;
   (void)q4; (void)q8; (void)q5; (void)nq5; (void)nq8;
+  // the all-mad twiddle product pays in the 8-coefficient strided forward passes (digit conversion
+  // -4.4 %, mod-down pass 1 -2.5 %); the contiguous passes (combine epilogue: +8 %), the one-wave
+  // key-switch kernel (LR = 2: +1.5 %) and the inverse butterflies keep the compiler's form
+  constexpr bool MAD = EVAH_MADLO && !INVERSE && STRIDED && LR == 3;
   u64 x[NTT_R];
 #pragma unroll
   for (int g = 0; g < G; g++) {
@@ -155,8 +144,8 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
           if (u & half) continue;
           const int v = u >> (RB - s);
           const ulonglong2 w = tw[((size_t)node << s) + v];
-          if ((((S0 + s) & 1) == 0) == RED_EVEN) bfly_fwd<true>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8);
-          else bfly_fwd<false>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8);
+          if ((((S0 + s) & 1) == 0) == RED_EVEN) bfly_fwd<true, MAD>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8);
+          else bfly_fwd<false, MAD>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8);
         }
       }
     } else {

@@ -115,6 +115,8 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
       d.q8 = 8 * q;
       d.nq5 = 0ull - 5 * q;
       d.nq8 = 0ull - 8 * q;
+      d.c64 = (u64)((((u128)1) << 64) % q);
+      d.c64s = shoup(d.c64, q);
       for (uint32_t a = 0; a < k; a++) {
         const u64 qa = c->primes[a];
         if (a == i) {
