@@ -352,6 +352,54 @@ def limb_sharded(args, dist):
     dist.close()
 
 
+def subdag_leg(args, dist):
+    """--shard subdag: ONE execute() of the Harris DAG (N = 2^15, L = 8) with its independent sub-DAGs on all
+    GPUs of the job.  The mode lives inside public_ctx.execute (one process drives the
+    devices, peer copies at the cuts — eva_amd/host/multi_device.h), so rank 0 computes on devices
+    0..world-1 and the other ranks of a torchrun job only take part in the barriers."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    from eva_amd.roofline import dag_bytes, roofline as rl
+    world = dist.world
+    names = [torch.cuda.get_device_name(i) for i in range(torch.cuda.device_count())]
+    line = None
+    if dist.rank == 0:
+        from test_gpu_e2e import _harris, _image
+        compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
+        pad_chain(params, 9, 32768)
+        members = list(range(world)) if world > 1 else [0] * max(2, args.shards)
+        pub, sec = generate_keys(params, 1, devices=members, shard="subdag")
+        nbytes, _ = dag_bytes(compiled, sig, 32768, 9)
+        enc = pub.encrypt(_image(4096), sig)
+        for _ in range(max(2, args.warmup)):
+            out = pub.execute(compiled, enc)
+        pub.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = pub.execute(compiled, enc)
+        pub.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        from oracle_executor import c_walk  # checker only
+        ref, _ = c_walk(pub, compiled, enc, threads=8)
+        ok = all(np.array_equal(out.get(n)[4], ref[n]) for n in ref)
+        if not ok:
+            raise SystemExit("bench.py --shard subdag: the split execution differs from the CPU oracle — number withheld")
+        line = {"metric": "execute() wall-time of one Harris DAG (N=2^15, L=8) split over the GPUs", "value": round(1.0 / dt, 2),
+                "unit": "DAGs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4),
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "config": {"workload": "Harris corner detector, 64x64 image, N=2^15, L=8, independent sub-DAGs per device",
+                           "members": members, "devices": names[:max(world, 1)],
+                           "plan": [list(p) for p in pub.last_subdag_plan], "parallelism": f"sub-DAG split over {len(members)} member(s), peer copies at the cuts, one process"},
+                "roofline": rl(nbytes, dt), "verified": {"bit_exact_vs_oracle": ok}, "cpu_baseline": None}
+    dist.barrier()
+    if line:
+        print(json.dumps(line), flush=True)
+    dist.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,9 +415,10 @@ def main():
     ap.add_argument("--fused-multiply", action="store_true",
                     help="evah_multiply_relinearize_rescale_many (no size-3 product in HBM; measured 1.5 %% slower at this size: "
                          "the combine pass re-reads both operands) instead of multiply_many + relinearize_rescale_many")
-    ap.add_argument("--shard", choices=["ciphertexts", "limb"], default="ciphertexts",
+    ap.add_argument("--shard", choices=["ciphertexts", "limb", "subdag"], default="ciphertexts",
                     help="ciphertexts: independent triples per GPU, no collective (default, weak scaling); "
-                         "limb: every triple on all GPUs, RNS limbs dealt over them (strong scaling)")
+                         "limb: every triple on all GPUs, RNS limbs dealt over them (strong scaling); "
+                         "subdag: one Harris execute() with its independent sub-DAGs on the GPUs")
     ap.add_argument("--shards", type=int, default=1, help="--shard limb with one process: shards on the one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the execute()-path and DAG legs")
@@ -394,6 +443,16 @@ def main():
 
     if args.shard == "limb":
         return limb_sharded(args, dist)
+    if args.shard == "subdag":
+        return subdag_leg(args, dist)
+    # what every rank runs on: the driver's multi-GPU runs show that RCCL saw N ranks on N devices
+    dev_name = torch.cuda.get_device_name(local)
+    rank_devices = [dev_name]
+    if world > 1:
+        import torch.distributed as tdist
+        gathered = [None] * world
+        tdist.all_gather_object(gathered, f"rank {rank}: cuda:{local} {dev_name}")
+        rank_devices = gathered
 
     from eva_amd import backend
     from eva_amd.hostref import coeff_modulus_create
@@ -614,7 +673,9 @@ def main():
                        "streams_per_gpu": len(queues), "triples_per_call": G,
                        "entry_point": "evah_multiply_relinearize_rescale_many" if fused else
                                       "evah_multiply_many + evah_relinearize_rescale_many",
-                       "parallelism": f"independent ciphertexts sharded over {world} GPU(s), no collective"},
+                       "parallelism": f"independent ciphertexts sharded over {world} GPU(s), no collective",
+                       "rccl_ranks": world, "rank_devices": rank_devices,
+                       "collectives": "barrier + max-over-ranks of the wall time (torch.distributed nccl = RCCL); none in the data path"},
             "roofline": roofline, "verified": verified, "cpu_baseline": cpu,
         }
         line.update(legs)

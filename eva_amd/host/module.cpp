@@ -138,7 +138,8 @@ PYBIND11_MODULE(_eva, m) {
   }, py::arg("path"), "Load a previously saved object (same class as was saved)");
 
   m.def("set_num_threads", [](int n) { if (n < 1) throw std::invalid_argument("num_threads must be positive"); g_num_threads = n; }, py::arg("num_threads"),
-        "Kept for API compatibility: node-level parallelism is HIP streams on the GPU, not host threads");
+        "Node-level parallelism of execute(): contexts made by generate_keys() afterwards spread independent DAG nodes over min(n, 8) "
+        "issue queues (HIP streams) — the GPU counterpart of the reference's Galois worker threads; 1 (the default) = one in-order queue");
   struct GaloisGuard {};
   py::class_<GaloisGuard>(m, "_GaloisGuard").def(py::init());
 
@@ -167,7 +168,16 @@ PYBIND11_MODULE(_eva, m) {
 
   // ---- backend
   py::module mseal = m.def_submodule("_seal", "MI355X CKKS execution backend (drop-in for eva._eva._seal)");
-  mseal.def("generate_keys", [](const CKKSParameters &p, uint64_t seed) { return generate_keys(p, seed); }, py::arg("abstract_params"), py::arg("seed") = 0);
+  // devices / shard: several GPUs behind one execute() (eva_amd/host/multi_device.h); the defaults come from
+  // EVA_NUM_GPUS / EVA_DEVICES / EVA_SHARD.  set_num_threads(n) — the reference's size of the parallel
+  // traversal (wrapper.cpp:128-137) — is the number of issue queues independent DAG nodes are spread over.
+  mseal.def("generate_keys", [](const CKKSParameters &p, uint64_t seed, py::object devices, py::object shard) {
+    auto kp = generate_keys(p, seed);
+    if (!devices.is_none()) kp.first->devices = devices.cast<std::vector<int>>();
+    if (!shard.is_none()) kp.first->shard_mode = shard.cast<std::string>();
+    if (g_num_threads > 1) kp.first->num_queues = std::min(g_num_threads, 8);
+    return kp;
+  }, py::arg("abstract_params"), py::arg("seed") = 0, py::arg("devices") = py::none(), py::arg("shard") = py::none());
   py::class_<HipValuation>(mseal, "SEALValuation", "Inputs or outputs of execute(): ciphertexts, plaintexts or raw vectors")
       .def(py::init<>())
       .def("_set_cipher", [](HipValuation &v, const std::string &name, py::array_t<uint64_t, py::array::c_style | py::array::forcecast> data, double scale) {
@@ -236,6 +246,10 @@ PYBIND11_MODULE(_eva, m) {
       .def_readwrite("free_eagerly", &HipPublic::free_eagerly)
       .def_readwrite("use_graphs", &HipPublic::use_graphs, "replay repeated executions of one program from a captured hipGraph")
       .def("drop_graphs", &HipPublic::drop_graphs)
+      .def_readwrite("devices", &HipPublic::devices, "device index per member of the multi-GPU modes (a repeated index = several contexts on one GPU)")
+      .def_readwrite("shard_mode", &HipPublic::shard_mode, "'' (one device) | 'subdag' | 'limb' | 'dag' — how execute() / execute_batch() use `devices`")
+      .def_readonly("last_subdag_plan", &HipPublic::last_subdag_plan, "(member, ops) per piece of the last sub-DAG split: prefix, components..., suffix")
+      .def_readonly("last_exchanged_words", &HipPublic::last_exchanged_words, "uint64 words moved between shards by the last limb-sharded execute()")
       .def_readwrite("resident", &HipPublic::resident, "keep valuations in HBM: encrypt/execute return device handles and execute does not wait for the GPU (EVA_RESIDENT=0: host valuations)")
       .def_readwrite("graph_copy_limit", &HipPublic::graph_copy_limit, "device-resident inputs above this many bytes are walked eagerly instead of copied into a captured graph's slots")
       .def("synchronize", &HipPublic::synchronize, "wait for everything this context has enqueued")

@@ -344,6 +344,19 @@ public:
     return out;
   }
 
+  std::vector<u64> download_plain(const ShardedValue &v) {
+    const size_t N = host.N;
+    std::vector<u64> out((size_t)v.limbs * N), local;
+    for (uint32_t s = 0; s < G; s++) {
+      if (!v.pt[s]) continue;
+      const uint32_t nl = (v.limbs - s + G - 1) / G;
+      local.resize((size_t)nl * N);
+      chk(evah_pt_download(g.ctx[s], v.pt[s]->h, (uint64_t *)local.data()));
+      for (uint32_t j = 0; j < nl; j++) std::memcpy(out.data() + ((size_t)s + (size_t)j * G) * N, local.data() + (size_t)j * N, sizeof(u64) * N);
+    }
+    return out;
+  }
+
   // ---- per-limb operations (no exchange)
   ShardedValue add(const ShardedValue &a, const ShardedValue &b) { same_level(a, b, true); return each2(a, b, std::max(a.size, b.size), a.scale, evah_add); }
   ShardedValue sub(const ShardedValue &a, const ShardedValue &b) { same_level(a, b, true); return each2(a, b, std::max(a.size, b.size), a.scale, evah_sub); }

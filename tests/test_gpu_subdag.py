@@ -1,53 +1,61 @@
-"""Independent sub-DAGs of one program on several devices (eva_amd/subdag.py):
-the Harris corner detector's three convolutions run as three evah_execute submits on three contexts
-(three devices on a multi-GPU node; three contexts of the one GPU here), with evah_ct_copy at the
-cuts — the output ciphertext must equal the oracle's walk of the same DAG and the single-context
-execute(), bit for bit."""
+"""Several GPUs behind ONE public_ctx.execute() (eva_amd/host/multi_device.h): the mode is
+chosen inside execute(), as the reference chooses its parallel traversal inside SEALPublic::execute
+(/root/reference/eva/seal/seal.cpp:105-113).
+
+  sub-DAG split   Harris' three convolutions (/root/reference/examples/image_processing.py:65-100) as
+                  three evah_execute submits on three members, evah_ct_copy at the cuts
+  limb sharding   RNS limbs dealt over the members; all-gather + broadcast per key switch
+  dag             execute_batch deals the groups of a batch over the members
+
+Members are device indices; a repeated index gives several contexts on the one GPU of this box (the
+cross-device branch runs when a second device is visible, see test_two_real_devices).  Every result must
+equal the oracle's walk of the same DAG and the single-device execute(), bit for bit."""
 import numpy as np
 import pytest
 
 from eva import EvaProgram, Input, Output
 from eva.ckks import CKKSCompiler
 from eva.seal import generate_keys
-from eva_amd import subdag
+from eva_amd import backend
 from oracle_executor import c_walk
 from test_gpu_e2e import _harris, _image
 
 pytestmark = pytest.mark.gpu
 
 
-def test_plan_finds_the_three_convolutions_of_harris():
-    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
-    params.poly_modulus_degree = 8192
-    pub, sec = generate_keys(params, 1)
-    enc = pub.encrypt(_image(4096), sig)
-    ops, placed, outs, raw = subdag.lower(compiled, enc, pub._encode)
-    pre, comps, suf = subdag.plan(ops, placed, 3)
-    assert sorted(d for d, _ in comps) == [0, 1, 2] and len({len(c) for _, c in comps}) == 1
-    assert sorted(pre + [i for _, c in comps for i in c] + suf) == list(range(len(ops)))  # a partition of the op list
-    assert subdag.plan(ops, placed, 1) == (list(range(len(ops))), [], [])
+def _same_as(out, ref, single=None):
+    for name in ref:
+        got = out.get(name)
+        assert np.array_equal(got[4], ref[name]), f"{name}: differs from the oracle walk"
+        if single is not None:
+            assert np.array_equal(got[4], single.get(name)[4]) and got[3] == single.get(name)[3]
 
 
-@pytest.mark.parametrize("n_ctx", [2, 3])
-def test_harris_split_over_contexts_bit_exact(n_ctx):
+@pytest.mark.parametrize("members", [[0, 0], [0, 0, 0]], ids=["2", "3"])
+def test_harris_subdag_split_through_execute(members):
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
     params.poly_modulus_degree = 16384
     pub, sec = generate_keys(params, 4)
     enc = pub.encrypt(_image(4096), sig)
-    ex = subdag.SubDagExecutor(pub, [0] * n_ctx)
-    out = ex.execute(compiled, enc)
-    assert len(ex.last_plan["components"]) >= 2
-    ref, _ = c_walk(pub, compiled, enc, threads=4)
     single = pub.execute(compiled, enc)
-    for name, (data, scale) in out.items():
-        assert np.array_equal(data, ref[name]), f"{name}: split execution differs from the oracle walk"
-        assert np.array_equal(data, single.get(name)[4]) and scale == single.get(name)[3]
-    again = ex.execute(compiled, enc)   # a second run reuses the contexts
-    assert all(np.array_equal(again[k][0], out[k][0]) for k in out)
-    ex.close()
+    ref, _ = c_walk(pub, compiled, enc, threads=4)
+    pub.devices, pub.shard_mode = members, "subdag"
+    out = pub.execute(compiled, enc)
+    plan = pub.last_subdag_plan
+    comps = plan[1:-1]
+    assert len(comps) >= 2 and sorted({m for m, _ in comps}) == list(range(len(members)))[:len({m for m, _ in comps})]
+    if len(members) == 3:  # the three convolutions: equal pieces, one per member
+        assert sorted(m for m, _ in comps) == [0, 1, 2] and len({n for _, n in comps}) == 1
+    _same_as(out, ref, single)
+    again = pub.execute(compiled, enc)  # the device group is reused
+    _same_as(again, ref)
+    res = sec.decrypt(again, sig)       # resident outputs live on member 0's device state
+    assert np.isfinite(np.array(res['image'])).all()
+    pub.devices, pub.shard_mode = [], ""
+    _same_as(pub.execute(compiled, enc), ref)
 
 
-def test_program_without_parallel_branches_runs_on_one_context():
+def test_program_without_parallel_branches_stays_on_one_member():
     prog = EvaProgram('chain', vec_size=64)
     with prog:
         x = Input('x')
@@ -55,11 +63,89 @@ def test_program_without_parallel_branches_runs_on_one_context():
     prog.set_input_scales(30)
     prog.set_output_ranges(20)
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
-    pub, sec = generate_keys(params, 2)
+    pub, sec = generate_keys(params, 2, devices=[0, 0], shard="subdag")
     enc = pub.encrypt({'x': [i / 64.0 for i in range(64)]}, sig)
-    ex = subdag.SubDagExecutor(pub, [0, 0])
-    out = ex.execute(compiled, enc)
-    assert ex.last_plan["components"] == []
+    out = pub.execute(compiled, enc)
+    assert [n for _, n in pub.last_subdag_plan[1:-1]] == []  # nothing worth cutting: one piece
     ref, _ = c_walk(pub, compiled, enc)
-    assert np.array_equal(out['y'][0], ref['y'])
-    ex.close()
+    _same_as(out, ref)
+
+
+def _conv_chain(depth):
+    prog = EvaProgram('conv+chain', vec_size=1024)
+    with prog:
+        x = Input('x')
+        acc = None
+        for i in range(3):
+            t = (x << i) * ([0.25 * (i + 1)] * 1024)
+            acc = t if acc is None else acc + t
+        for _ in range(depth):
+            acc = acc * acc
+        Output('y', acc)
+    prog.set_input_scales(30)
+    prog.set_output_ranges(20)
+    return CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+
+
+@pytest.mark.parametrize("G", [2, 3, 4])
+def test_limb_sharded_execute_bit_exact(G):
+    compiled, params, sig = _conv_chain(3)
+    params.poly_modulus_degree = 8192
+    pub, sec = generate_keys(params, 6)
+    rng = np.random.default_rng(G)
+    inputs = {'x': list(rng.uniform(-1, 1, 1024))}
+    enc = pub.encrypt(inputs, sig)
+    single = pub.execute(compiled, enc)
+    ref, _ = c_walk(pub, compiled, enc)
+    pub.devices, pub.shard_mode = [0] * G, "limb"
+    for call in range(2):  # the second call finds the program's plaintexts already dealt over the shards
+        out = pub.execute(compiled, enc)
+        _same_as(out, ref, single)
+    assert pub.last_exchanged_words > 0
+    res = sec.decrypt(out, sig)
+    from eva import evaluate
+    want = evaluate(compiled, inputs)
+    assert np.abs(np.array(res['y']) - np.array(want['y'])).max() < 1e-2
+
+
+def test_dag_mode_deals_a_batch_over_the_members():
+    from test_compiler import _sobel
+    prog = _sobel(64, 64, 4096)
+    prog.set_input_scales(25)
+    prog.set_output_ranges(10)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    params.poly_modulus_degree = 8192
+    pub, sec = generate_keys(params, 3)
+    pub.resident = False
+    encs = [pub.encrypt({'image': [((37 * i + u) % 256) / 255.0 for i in range(4096)]}, sig) for u in range(5)]
+    batch = [encs[i % 5] for i in range(23)]
+    pub.batch_chunk = 4
+    one = pub.execute_batch(compiled, batch)
+    pub.devices, pub.shard_mode = [0, 0, 0], "dag"
+    many = pub.execute_batch(compiled, batch)
+    for a, b in zip(one, many):
+        assert np.array_equal(a.get('image')[4], b.get('image')[4])
+    ref, _ = c_walk(pub, compiled, batch[7])
+    assert np.array_equal(many[7].get('image')[4], ref['image'])
+
+
+@pytest.mark.skipif(backend.device_count() < 2, reason="needs two HIP devices: the cross-device (xGMI peer copy) branch of evah_ct_copy")
+def test_two_real_devices():
+    """sub-DAG split and limb sharding with members on DIFFERENT GPUs: peer copies at the cuts / in the exchanges"""
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
+    params.poly_modulus_degree = 16384
+    pub, sec = generate_keys(params, 4)
+    enc = pub.encrypt(_image(4096), sig)
+    ref, _ = c_walk(pub, compiled, enc, threads=4)
+    pub.devices, pub.shard_mode = [0, 1], "subdag"
+    _same_as(pub.execute(compiled, enc), ref)
+    assert {m for m, _ in pub.last_subdag_plan[1:-1]} == {0, 1}
+    pub.devices, pub.shard_mode = [0, 1], "limb"
+    _same_as(pub.execute(compiled, enc), ref)
+    # the raw C-ABI copy between two device states
+    g0 = backend.Context(pub.poly_modulus_degree, list(pub.primes), device=0)
+    g1 = backend.Context(pub.poly_modulus_degree, list(pub.primes), device=1)
+    data = enc.get('image')[4]
+    a = g0.upload_ct(data, 2.0 ** 30)
+    assert np.array_equal(g1.copy_here(a).download(), data)
+    g1.close(); g0.close()
