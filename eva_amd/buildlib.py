@@ -29,13 +29,13 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm to build the gfx950 backend)")
 
 
-HIP_UNITS = ("runtime.hip", "evaluator.hip", "scheduler.hip")
-HIP_HEADERS = ("internal.hip.h", "ntt.hip.h", "devmath.hip.h", "hostmath.h", "shard.hip.h", "client.hip.h")
+HIP_UNITS = ("runtime.hip", "elementwise.hip", "keyswitch.hip", "rotate.hip", "shard.hip", "client.hip", "scheduler.hip")
+HIP_HEADERS = ("internal.hip.h", "launch.hip.h", "ntt.hip.h", "devmath.hip.h", "hostmath.h")
 
 
 def build_hip(force=False, verbose=False):
-    """The three translation units of libeva_hip.so are compiled concurrently (only evaluator.hip
-    holds device code) and linked into one shared library."""
+    """The translation units of libeva_hip.so are compiled concurrently and linked into one shared
+    library (runtime and scheduler hold no device code)."""
     units = [os.path.join(CSRC, f) for f in HIP_UNITS]
     srcs = units + [os.path.join(CSRC, f) for f in HIP_HEADERS]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "eva_hip.h"))

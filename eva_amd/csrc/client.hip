@@ -1,8 +1,7 @@
-// client.hip.h — the host-side neighbours of execute() on the device:
+// client.hip — the host-side neighbours of execute() on the device:
 // public-key encryption of an encoded plaintext and decryption + decoding of a result, i.e. the
 // arithmetic of SEALPublic::encrypt and SEALSecret::decrypt (/root/reference/eva/seal/seal.cpp:24-102,
-// 124-146: encoder.encode + encryptor.encrypt; decryptor.decrypt + encoder.decode).  Included at the
-// end of evaluator.hip.  Randomness stays on the host (csprng.h): the sampled small polynomials
+// 124-146: encoder.encode + encryptor.encrypt; decryptor.decrypt + encoder.decode).  Randomness stays on the host (csprng.h): the sampled small polynomials
 // travel as int8 arrays (3 N bytes per encryption); everything of size N log N or l N runs here.
 //   encrypt  : c = (pk0 u + e0, pk1 u + e1) at l+1 limbs, divided-and-rounded by the extra prime
 //              (same rule as rescale A.5), plus the plaintext on c0
@@ -12,6 +11,8 @@
 //              (CKKSEncoder::decode_internal), slot values out.  FP64 with SEAL's operation order and no
 //              FMA contraction: the doubles are those of the oracle's evo_decode and of the host
 //              decoder, bit for bit (tests/test_decode_parity.py)
+
+#include "launch.hip.h"
 
 namespace evah {
 

@@ -44,7 +44,7 @@ struct DevCtx {
   // "limb i of every poly lives on GPU i mod G") has (s, G): its values hold
   // only the limbs i = s, s + G, ... and every per-limb kernel works on them unchanged.
   uint32_t p0, pstep;
-  // Guarded launches (hoisted rotations' exact fallback, evaluator.hip): when set, a kernel does
+  // Guarded launches (hoisted rotations' exact fallback, rotate.hip): when set, a kernel does
   // nothing unless the counter it points to exceeds guard_min.  Null for every ordinary launch.
   const uint32_t *guard;
   uint32_t guard_min;

@@ -2,8 +2,14 @@
 // device pool, buffers with cross-queue ordering, handle and context structs, profiling scopes.
 //   runtime.hip    contexts, forks (issue queues), keys, pinned host memory, uploads / downloads,
 //                  graph capture, profiling hooks                       (no kernels)
-//   evaluator.hip  kernels + one C-ABI entry point per SEAL Evaluator call (elementwise, encoder,
-//                  key switching, rescale, rotations, the fused and batched forms)
+//   elementwise.hip  elementwise kernels + entry points (add .. multiply_plain, weighted sums), the device
+//                    CKKS encoder, plaintext uploads, mod_switch
+//   keyswitch.hip    the key-switch core (digit decomposition, fused second pass + key inner product,
+//                    mod-down) and relinearize / rescale with their fused and batched forms
+//   rotate.hip       Galois permutation, rotations, hoisted rotation sets with the guarded fallback
+//   shard.hip        limb-sharded phases (evah_shard_*), exchange buffers
+//   client.hip       encrypt, decrypt + decode
+//   launch.hip.h     launch plumbing of the transform kernels shared by the units above
 //   scheduler.hip  evah_execute: the whole-DAG submit (level scheduler, peepholes)   (no kernels)
 #pragma once
 #include "../../include/eva_hip.h"
@@ -157,11 +163,11 @@ struct SharedDev {
   int device = 0;
   void *d_tables = nullptr;
   KeyDev relin;
-  KeyDev pk, sk; // client side (client.hip.h): public key [2][k][N], secret key in NTT form [k][N]
+  KeyDev pk, sk; // client side (client.hip): public key [2][k][N], secret key in NTT form [k][N]
   double2 *dec_roots = nullptr; // CKKS decoder: zeta^br(j) (forward special FFT, heap order)
   std::map<uint32_t, KeyDev> galois;
   std::map<uint32_t, uint32_t *> perms;
-  // hoisted rotations (evaluator.hip): NTT of the sign pattern of a Galois element under every prime
+  // hoisted rotations (rotate.hip): NTT of the sign pattern of a Galois element under every prime
   // ([k][N]) and, per (element, level), the constant it contributes to the key inner product ([2][l+1][N])
   std::map<uint32_t, u64 *> hoist_sign;
   std::map<std::pair<uint32_t, uint32_t>, u64 *> hoist_corr;
@@ -185,6 +191,63 @@ struct SharedDev {
   }
 };
 
+// Every knob that decides HOW a call is launched (never what it computes: all settings give the same
+// residues).  Defaults are the measured optima on MI355X (profiles/r0*_tuning_notes.md); each can be
+// overridden by the environment variable named beside it, read ONCE in evah_ctx_create — forks copy
+// their parent's values.
+struct Tunables {
+  // EVAH_FUSE_MAC (1): key switch — fuse the key inner product into the digit transforms' second pass
+  // (ks_inner_kernel); 0 = separate digit transforms + k_ks_mac, the unfused reference path
+  bool fuse_mac = true;
+  // EVAH_FUSE_MUL (N <= 8192): evah_execute runs Mul -> Relinearize -> Rescale chains as ONE
+  // evah_multiply_relinearize_rescale_many where launches, not bytes, bound the chain
+  bool fuse_mul = false;
+  // EVAH_FUSE_SMALL (2048): launches of at most this many 2048-coefficient tiles are latency-bound — an
+  // inverse transform followed by forward transforms of the result runs its two strided passes as one
+  // launch (ntt_inv_fwd_kernel); 0 disables.  r03 sweep at the BASELINE sizes: Harris L=8 1.18 -> 1.15 ms,
+  // 256 Sobel DAGs (l=5) 9.6 k -> 10.3 k/s against the r02 value 8192
+  uint32_t fuse_small_blocks = 2048;
+  // EVAH_SMALL_LR (2) / EVAH_SMALL_LR_BLOCKS (1024): log2 coefficients per thread of the transform passes
+  // in launches of at most that many tiles (2 = 4 per thread: twice the workgroups, half a wave's critical path)
+  int small_lr = 2;
+  uint32_t small_lr_blocks = 1024;
+  // EVAH_HOIST (1) / EVAH_HOIST_MIN_TILES (2048): several rotations of one ciphertext decompose it once
+  // (hoisting) when the set is at least this many tiles of digit transforms
+  bool hoist = true;
+  uint32_t hoist_min_tiles = 2048;
+  // EVAH_HOIST_DEBUG (0): print the zero-coefficient count of every hoisted set (synchronises)
+  bool hoist_debug = false;
+  // EVAH_FUSE_SPECIAL_INV (1): latency-bound key switches run the special row's first inverse pass
+  // inside the key-switch kernel (ks_inner_kernel INVSP)
+  bool fuse_special_inv = true;
+  // EVAH_KS_GROUPS (1): output-limb slices per key switch; EVAH_KS_THREADS (64): threads per workgroup of the
+  // fused key-switch kernel — one wave = one 2^P-point sub-transform measured best (barriers are intra-wave)
+  int ks_groups = 1;
+  int ks_threads = 64;
+
+  static Tunables from_env(uint32_t N) {
+    Tunables t;
+    auto flag = [](const char *name, bool &v) { if (const char *e = std::getenv(name)) v = std::atoi(e) != 0; };
+    auto count = [](const char *name, uint32_t &v) { if (const char *e = std::getenv(name)) v = (uint32_t)std::max(0, std::atoi(e)); };
+    t.fuse_mul = N <= 8192;
+    flag("EVAH_FUSE_MAC", t.fuse_mac);
+    flag("EVAH_FUSE_MUL", t.fuse_mul);
+    count("EVAH_FUSE_SMALL", t.fuse_small_blocks);
+    if (const char *e = std::getenv("EVAH_SMALL_LR")) t.small_lr = std::atoi(e) == 3 ? 3 : 2;
+    count("EVAH_SMALL_LR_BLOCKS", t.small_lr_blocks);
+    flag("EVAH_HOIST", t.hoist);
+    count("EVAH_HOIST_MIN_TILES", t.hoist_min_tiles);
+    flag("EVAH_HOIST_DEBUG", t.hoist_debug);
+    flag("EVAH_FUSE_SPECIAL_INV", t.fuse_special_inv);
+    if (const char *e = std::getenv("EVAH_KS_GROUPS")) t.ks_groups = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("EVAH_KS_THREADS")) {
+      const int n = std::atoi(e);
+      if (n == 64 || n == 128 || n == 256) t.ks_threads = n;
+    }
+    return t;
+  }
+};
+
 struct evah_ctx {
   std::shared_ptr<SharedDev> sh;
   int device = 0;
@@ -198,27 +261,7 @@ struct evah_ctx {
   bool capturing = false;              // inside evah_capture_begin/end: no syncs, no profiling events
   std::vector<hipEvent_t> capture_events; // events consumed by the capture in progress
   std::vector<hipEvent_t> sync_events; // recycled events for cross-queue ordering
-  bool fuse_mac = true; // key-switch: fuse the inner product into the digit NTTs' second pass
-  // evah_execute: run Mul -> Relinearize -> Rescale chains as one evah_multiply_relinearize_rescale_many
-  // (EVAH_FUSE_MUL=0/1; default: only where launches, not bytes, bound the chain — see DESIGN.md §4)
-  bool fuse_mul = false;
-  // launches of at most this many workgroups are treated as latency-bound: an inverse transform
-  // followed by forward transforms of the result then runs its two strided passes as ONE launch
-  // (ntt_inv_fwd_kernel).  EVAH_FUSE_SMALL=0 disables, =n sets the threshold.
-  uint32_t fuse_small_blocks = 2048; // r03 sweep at the BASELINE sizes: Harris L=8 1.18 -> 1.15 ms, 256 Sobel DAGs (l=5) 9.6 k -> 10.3 k/s vs 8192
-  int small_lr = 2; // log2 coefficients per thread of the NTT passes in latency-bound launches (EVAH_SMALL_LR = 2 | 3)
-  uint32_t small_lr_blocks = 1024; // ... = launches of at most this many 2048-coefficient tiles (EVAH_SMALL_LR_BLOCKS)
-  // several rotations of one ciphertext: decompose once and permute the transformed digits (hoisting),
-  // when the launch set is at least this many 2048-coefficient tiles of digit transforms.
-  // EVAH_HOIST=0 disables, EVAH_HOIST_MIN_TILES=n sets the threshold.
-  bool hoist = true;
-  uint32_t hoist_min_tiles = 2048;
-  // latency-bound key switches: the special row's first inverse pass runs inside the key-switch
-  // kernel (ks_inner_kernel INVSP) instead of as its own launch.  EVAH_FUSE_SPECIAL_INV=0 disables.
-  bool fuse_special_inv = true;
-  int ks_groups = 1;    // output-limb slices per key-switch (EVAH_KS_GROUPS)
-  int ks_threads = 64;  // threads per workgroup of the fused key-switch kernel (EVAH_KS_THREADS): one wave = one
-                        // 2^P-point sub-transform per workgroup measured best (barriers are intra-wave)
+  Tunables tun; // launch-shape decisions, read from the environment once when the context is created
   // per-launch profile
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
@@ -353,7 +396,7 @@ inline evah_pt *pt_new(evah_ctx *c, uint32_t limbs, double scale) {
   return t;
 }
 
-// evaluator.hip: would evah_rotate_many hoist n rotations of one l-limb ciphertext of B instances?
+// rotate.hip: would evah_rotate_many hoist n rotations of one l-limb ciphertext of B instances?
 // (the scheduler groups sibling rotations for it only when it does)
 bool hoist_wanted(const evah_ctx *c, uint32_t l, uint32_t n, uint32_t B);
 

@@ -1,0 +1,535 @@
+// keyswitch.hip — libeva_hip.so: the key-switch core (SEAL Evaluator::switch_key_inplace, SURVEY.md A.6: digit decomposition, the fused
+// second pass + key inner product, mod-down) and the evaluator calls built on it or on the same transforms:
+// relinearize, rescale_to_next and their fused / batched forms (/root/reference/eva/seal/seal_executor.h:197-215).
+#include "launch.hip.h"
+
+namespace evah {
+
+// K9 inner product: prod[K][I] = sum_J op(I,J) * key[J][K][kappa(I)],
+// op(I,J) = target[J] when I == J, else scratch[I][J].  128-bit lazy accumulation, one Barrett
+// reduction at the end.  grid = (N/512, l+1).
+__global__ void __launch_bounds__(256)
+k_ks_mac(DevCtx cx, const u64 *target, const u64 *scratch, const u64 *key, u64 *prod, uint32_t l) {
+  if (cx.skipped()) return;
+  const uint32_t I = blockIdx.y;
+  const uint32_t kap = (I == l) ? cx.k - 1 : I;
+  const size_t n = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
+  const DevPrime pm = cx.primes[kap];
+  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
+  u128_t a0x = {0, 0}, a0y = {0, 0}, a1x = {0, 0}, a1y = {0, 0};
+  for (uint32_t J = 0; J < l; J++) {
+    const u64 *op = (I == J) ? target + (size_t)J * N : scratch + ((size_t)I * l + J) * N;
+    const ulonglong2 o = ld2(op + n);
+    const u64 *kp = key + J * key_digit + (size_t)kap * N + n;
+    const ulonglong2 k0 = ld2(kp), k1 = ld2(kp + (size_t)cx.k * N);
+    acc128(a0x, o.x, k0.x);
+    acc128(a0y, o.y, k0.y);
+    acc128(a1x, o.x, k1.x);
+    acc128(a1y, o.y, k1.y);
+  }
+  ulonglong2 r0, r1;
+  r0.x = barrett128(a0x, pm);
+  r0.y = barrett128(a0y, pm);
+  r1.x = barrett128(a1x, pm);
+  r1.y = barrett128(a1y, pm);
+  st2(prod + (size_t)I * N + n, r0);
+  st2(prod + ((size_t)(l + 1) + I) * N + n, r1);
+}
+
+template <int P, int LR>
+static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scratch, const KsBatch &kb, u64 *prod, uint32_t l) {
+  ProfScope ps(c, KC_KSMAC);
+  const uint32_t max_tile = (uint32_t)c->tun.ks_threads << LR;
+  const uint32_t tile = c->N < max_tile ? c->N : max_tile;
+  const int logC = (int)ilog2(tile) - P;
+  if (logC < 0) throw std::runtime_error("ks_inner tile smaller than one sub-transform");
+  // coefficients tile + per-sub twiddle heaps (16 B per node)
+  const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) +
+                     ((size_t)1 << (logC + P)) * sizeof(ulonglong2);
+  const uint32_t n_tiles = c->N / tile;
+  // the one-wave workgroup (the default) is compiled with its own launch bound: the register
+  // allocator is not held to the 256-thread budget
+  auto go = [&](auto kernel, const auto &mt) {
+    hipLaunchKernelGGL(kernel, dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev, target, kb.target_bs, scratch,
+                       kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n, kb.targets, mt, kb.istep,
+                       kb.nout ? kb.nout : l + 1, kb.r_out);
+  };
+  if (kb.r_out && ((tile >> LR) > 64 || kb.istep != 1)) throw std::logic_error("fused special-row inverse pass needs the one-wave key-switch kernel");
+  if (kb.r_out) {
+    if (kb.mul) go(ks_inner_kernel<P, LR, 64, true, true>, *kb.mul);
+    else go(ks_inner_kernel<P, LR, 64, false, true>, NoMul{});
+  } else if ((tile >> LR) <= 64) {
+    if (kb.mul) go(ks_inner_kernel<P, LR, 64, true>, *kb.mul);
+    else go(ks_inner_kernel<P, LR, 64, false>, NoMul{});
+  } else {
+    if (kb.mul) go(ks_inner_kernel<P, LR, NTT_THREADS, true>, *kb.mul);
+    else go(ks_inner_kernel<P, LR, NTT_THREADS, false>, NoMul{});
+  }
+  HIPCHK(hipGetLastError());
+}
+template <int LR>
+static void launch_ks_inner_lr(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const KsBatch &key, u64 *prod, uint32_t l) {
+  switch (P) {
+  case 5: launch_ks_inner_plr<5, LR>(c, target, scratch, key, prod, l); break;
+  case 6: launch_ks_inner_plr<6, LR>(c, target, scratch, key, prod, l); break;
+  case 7: launch_ks_inner_plr<7, LR>(c, target, scratch, key, prod, l); break;
+  case 8: launch_ks_inner_plr<8, LR>(c, target, scratch, key, prod, l); break;
+  default: throw std::runtime_error("unsupported poly_modulus_degree for the key-switch kernel");
+  }
+}
+void launch_ks_inner(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const KsBatch &key, u64 *prod, uint32_t l) {
+  launch_ks_inner_lr<2>(c, P, target, scratch, key, prod, l); // 4 coefficients per thread: 32 accumulator VGPRs
+}
+
+// SEAL Evaluator::switch_key_inplace, device version.
+//   out[K] = (add && K < add_polys ? add[K] : 0) + keyswitch(target)[K],  K in {0,1}
+// steps 1-2 of switch_key for a batch of n (target, key) pairs in one set of launches:
+// prod[b][K][I] (I <= l, slot l = special prime) = sum_J op_b(I,J) * key_b[J][K].
+// target_b = target + b * target_bs; prod_b = prod_d + b * 2 (l+1) N.
+// r_small != nullptr: the caller will mod-down through the latency-bound launch form and offers
+// r_small[2 n][N] for the special rows' first inverse pass; returns true when that pass was done
+// here (fused into the key-switch kernel) — the special rows of prod are then NOT written.
+bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t target_bs, const KeyDev *const *keys,
+                         uint32_t n, u64 *prod_d, const PtrTab *target_tab, const MulTab *mul, u64 *r_small) {
+  const size_t N = c->N;
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::runtime_error("key-switch batch out of range");
+  KsBatch kb;
+  kb.n = n;
+  kb.target_bs = target_bs;
+  kb.scratch_bs = (size_t)(l + 1) * l * N;
+  kb.prod_bs = (size_t)2 * (l + 1) * N;
+  for (uint32_t b = 0; b < n; b++) {
+    if (keys[b]->n_digits < l) throw std::runtime_error("key switching key has too few digits");
+    kb.keys.key[b] = keys[b]->d;
+  }
+  if (target_tab) kb.targets = *target_tab; // target == nullptr: separately allocated targets
+  kb.mul = mul;
+  if (mul && !c->tun.fuse_mac) throw std::logic_error("the fused multiply needs the fused key-switch kernel");
+  Scratch t(c, (size_t)n * l * N);        // coefficient-form digits
+  Scratch sc(c, n * kb.scratch_bs);       // converted digits, NTT form per output limb
+  // 1. digits to coefficient form (job -> (b, J))
+  OpKsDigit::Params dp{t.d, sc.d, l, (size_t)l * N, kb.scratch_bs, 0, l + 1};
+  // a small key switch is latency-bound: the digits' strided inverse pass and the first pass of the
+  // digit conversion then run as one launch
+  const bool small = c->tun.fuse_mac && std::max(1, c->tun.ks_groups) == 1 && fuse_small_launch(c, n * (l + 1) * l);
+  if (mul) { // the target is the product's d2, formed on load
+    OpMulIntt::Params ip{*mul, t.d, (size_t)l * N, l};
+    if (small) launch_pass_p<false, true, OpMulIntt>(c, c->logN / 2, ip, n * l);
+    else ntt_inverse<OpMulIntt>(c, ip, n * l);
+  } else {
+    OpPlain::Params ip{target, t.d, target_bs, (size_t)l * N, l, 0, 0, {}};
+    if (target_tab) ip.src_tab = *target_tab;
+    if (small) launch_pass_p<false, true, OpPlain>(c, c->logN / 2, ip, n * l);
+    else ntt_inverse<OpPlain>(c, ip, n * l);
+  }
+  if (small) {
+    dp.i0 = kb.i0 = 0;
+    dp.ni = kb.ni = l + 1;
+    launch_inv_fwd<OpKsDigit>(c, dp, n * (l + 1) * l);
+    const uint32_t max_tile = (uint32_t)c->tun.ks_threads << 2;
+    if (r_small && c->tun.fuse_special_inv && (std::min<uint32_t>(c->N, max_tile) >> 2) <= 64) kb.r_out = r_small;
+    launch_ks_inner(c, c->logN / 2, target, sc.d, kb, prod_d, l);
+    return kb.r_out != nullptr;
+  }
+  if (c->tun.fuse_mac) { // 128-bit accumulation of lazy (<16q) products, folded every 16 digits
+    // Output limbs are processed in slices so that a slice's converted digits (ni * l * N words)
+    // are still in L2 / Infinity Cache when the fused second pass consumes them.
+    const int a = (c->logN + 1) / 2, b = c->logN / 2;
+    const uint32_t groups = std::min<uint32_t>(std::max(1, c->tun.ks_groups), l + 1);
+    for (uint32_t g = 0; g < groups; g++) {
+      const uint32_t i0 = (uint32_t)((uint64_t)(l + 1) * g / groups), i1 = (uint32_t)((uint64_t)(l + 1) * (g + 1) / groups);
+      if (i1 == i0) continue;
+      dp.i0 = kb.i0 = i0;
+      dp.ni = kb.ni = i1 - i0;
+      // 2a. base-convert + first (strided) NTT pass of every digit under the slice's output primes
+      launch_pass_p<true, false, OpKsDigit>(c, a, dp, n * (i1 - i0) * l);
+      // 2b. second (contiguous) pass fused with the inner product with the key
+      launch_ks_inner(c, b, target, sc.d, kb, prod_d, l);
+    }
+  } else {
+    // unfused reference path (EVAH_FUSE_MAC=0): full digit NTTs, then a separate MAC kernel
+    ntt_forward<OpKsDigit>(c, dp, n * (l + 1) * l);
+    for (uint32_t b = 0; b < n; b++) {
+      ProfScope ps(c, KC_KSMAC);
+      hipLaunchKernelGGL(k_ks_mac, dim3(c->N / 512, l + 1), dim3(256), 0, c->stream, c->dev,
+                         target ? target + b * target_bs : target_tab->p[b], sc.d + b * kb.scratch_bs, keys[b]->d,
+                         prod_d + b * kb.prod_bs, l);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  return false;
+}
+
+void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev &key, const u64 *add,
+                       size_t add_ps, uint32_t add_polys, u64 *out, size_t out_ps) {
+  const size_t N = c->N;
+  Scratch prod(c, (size_t)2 * (l + 1) * N);    // [K][l+1][N]
+  Scratch r(c, 2 * N);
+  const KeyDev *kp = &key;
+  const bool inv1 = switch_key_products(c, l, target, 0, &kp, 1, prod.d, nullptr, nullptr, fuse_small_launch(c, 2 * l) ? r.d : nullptr);
+  // 3. mod-down by the special prime: INTT(special limb) + P/2, then per-limb NTT + combine
+  OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
+    OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, add, add_ps, add_polys, out, out_ps,
+                       c->k - 1, l};
+  inverse_then_forward<OpPlain, OpModDown>(c, sp, 2, mp, 2 * l, inv1);
+}
+
+} // namespace evah
+
+extern "C" {
+
+int evah_relinearize(evah_ctx *c, const evah_ct *a, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  acquire(c, a->buf);
+  if (a->size != 3) throw std::invalid_argument("relinearize expects a size-3 ciphertext");
+  if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
+  evah_ct *o = ct_new(c, 2, a->limbs, a->scale, a->batch);
+  try {
+    if (a->batch == 1) {
+      switch_key(c, a->limbs, a->d + 2 * a->ps, c->sh->relin, a->d, a->ps, 2, o->d, o->ps);
+    } else { // all instances in one launch set (chunks of KS_BATCH_MAX)
+      const uint32_t l = a->limbs;
+      const size_t N = c->N, pps = (size_t)(l + 1) * N;
+      for (uint32_t b0 = 0; b0 < a->batch; b0 += KS_BATCH_MAX) {
+        const uint32_t n = std::min<uint32_t>(KS_BATCH_MAX, a->batch - b0);
+        const u64 *a0 = a->d + (size_t)b0 * 3 * a->ps;
+        Scratch prod(c, (size_t)n * 2 * pps);
+        std::vector<const KeyDev *> keys(n, &c->sh->relin);
+        switch_key_products(c, l, a0 + 2 * a->ps, 3 * a->ps, keys.data(), n, prod.d);
+        Scratch r(c, (size_t)n * 2 * N);
+        OpPlain::Params sp{prod.d + (size_t)l * N, r.d, pps, N, 1, c->k - 1, 1, {}};
+        OpModDown::Params mp{r.d, N, prod.d, pps, a0, a->ps, 2, o->d + (size_t)b0 * 2 * o->ps, o->ps, c->k - 1, l};
+        mp.add_bs = 3 * a->ps;
+        inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * n, mp, 2 * n * l);
+      }
+    }
+  } catch (...) {
+    evah_ct_free(c, o);
+    throw;
+  }
+  *out = o;
+  API_END
+}
+
+static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n, u64 *out_d, const MulTab *mul = nullptr,
+                               uint32_t mul_limbs = 0);
+
+int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bits, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  acquire(c, a->buf);
+  if (a->size != 3) throw std::invalid_argument("relinearize expects a size-3 ciphertext");
+  if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
+  if (a->limbs < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  const uint32_t l = a->limbs, last = l - 1, sp = c->k - 1;
+  const size_t N = c->N, pps = (size_t)(l + 1) * N;
+  evah_ct *o = ct_new(c, 2, l - 1, a->scale / std::pow(2.0, (double)divisor_bits), a->batch);
+  if (a->batch > 1) { // every instance through the batched form, KS_BATCH_MAX at a time
+    try {
+      std::vector<evah_ct> views(a->batch, *a);
+      std::vector<const evah_ct *> ptrs(a->batch);
+      for (uint32_t b = 0; b < a->batch; b++) {
+        views[b].d = a->d + (size_t)b * 3 * a->ps;
+        views[b].batch = 1;
+        ptrs[b] = &views[b];
+      }
+      for (uint32_t b0 = 0; b0 < a->batch; b0 += KS_BATCH_MAX)
+        relin_rescale_core(c, ptrs.data() + b0, std::min<uint32_t>(KS_BATCH_MAX, a->batch - b0),
+                           o->d + (size_t)b0 * 2 * o->ps);
+    } catch (...) {
+      evah_ct_free(c, o);
+      throw;
+    }
+    *out = o;
+    g_err.clear();
+    return 0;
+  }
+  try {
+    Scratch prod(c, 2 * pps);
+    const KeyDev *kp = &c->sh->relin;
+    switch_key_products(c, l, a->d + 2 * a->ps, 0, &kp, 1, prod.d);
+    Scratch r(c, 2 * N), t(c, 2 * N);
+    // r_K = INTT_P(prod[K][special]) + P/2
+    OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
+    ntt_inverse<OpPlain>(c, spp, 2);
+    // t_K = INTT_last(a[K][last] + prod[K][last] P^-1) - u_K,last P^-1 + q_last/2
+    OpRRLast::Params lp{a->d + (size_t)last * N, a->ps, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, {}};
+    ntt_inverse<OpRRLast>(c, lp, 2);
+    // out[K][i] = (a[K][i] + prod[K][i] P^-1 - NTT_i(u P^-1 + v)) q_last^-1
+    OpRR::Params rp{r.d, N, t.d, N, a->d, a->ps, prod.d, pps, o->d, o->ps, sp, last, l - 1, {}};
+    ntt_forward<OpRR>(c, rp, 2 * (l - 1));
+  } catch (...) {
+    evah_ct_free(c, o);
+    throw;
+  }
+  *out = o;
+  API_END
+}
+
+// n (<= 64) independent size-3 ciphertexts at the same level, all relinearized with the (shared)
+// relinearization key and rescaled: one set of n-times-wider launches; instances are co-scheduled
+// per XCD so the key tiles are read from HBM once per XCD, not once per instance.
+// core of the batched form: n (<= KS_BATCH_MAX) size-3 ciphertexts at one level -> out_d[n][2][(l-1) N]
+// mul != nullptr: instance b is the product a[b] x b[b] of mul (size-2 operands at mul_limbs limbs),
+// its polynomials d0, d1, d2 evaluated where they are consumed (as == nullptr then)
+static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n, u64 *out_d, const MulTab *mul, uint32_t mul_limbs) {
+  const uint32_t l = mul ? mul_limbs : as[0]->limbs;
+  const uint32_t last = l - 1, sp = c->k - 1;
+  const size_t N = c->N, pps = (size_t)(l + 1) * N, ops = (size_t)(l - 1) * N;
+  PtrTab c2{}, a_last{}, a_polys{};
+  for (uint32_t b = 0; b < n && !mul; b++) {
+    const evah_ct *a = as[b];
+    c2.p[b] = a->d + 2 * a->ps;
+    for (uint32_t K = 0; K < 2; K++) {
+      a_last.p[2 * b + K] = a->d + K * a->ps + (size_t)last * N;
+      a_polys.p[2 * b + K] = a->d + K * a->ps;
+    }
+  }
+  Scratch prod(c, (size_t)n * 2 * pps);
+  std::vector<const KeyDev *> keys(n, &c->sh->relin);
+  switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2, mul);
+  Scratch r(c, (size_t)n * 2 * N), t(c, (size_t)n * 2 * N);
+  OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
+  ntt_inverse<OpPlain>(c, spp, 2 * n);
+  if (mul) {
+    OpRRLastMul::Params lp{nullptr, 0, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, a_last, *mul};
+    ntt_inverse<OpRRLastMul>(c, lp, 2 * n);
+    OpRRMul::Params rp{r.d, N, t.d, N, nullptr, 0, prod.d, pps, out_d, ops, sp, last, l - 1, a_polys, *mul};
+    ntt_forward<OpRRMul>(c, rp, 2 * n * (l - 1));
+  } else {
+    OpRRLast::Params lp{nullptr, 0, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, a_last};
+    ntt_inverse<OpRRLast>(c, lp, 2 * n);
+    OpRR::Params rp{r.d, N, t.d, N, nullptr, 0, prod.d, pps, out_d, ops, sp, last, l - 1, a_polys};
+    ntt_forward<OpRR>(c, rp, 2 * n * (l - 1));
+  }
+}
+
+// multiply (size 2 x size 2) -> relinearize -> rescale_to_next for n (<= 64) independent pairs at one
+// level, the three SEAL calls of seal_executor.h:164, :200, :213-214 evaluated together: the size-3
+// product is never materialised — d2 = a1 b1 is formed in the load of the digit inverse
+// transform (and in the key-switch kernel where the NTT-form digit is used as is), d0 and d1 in
+// the epilogue that combines them with the key-switch result.  Same ciphertext, bit for bit.
+static void mul_relin_rescale(evah_ctx *c, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n, uint32_t divisor_bits,
+                              evah_ct **outs) {
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("multiply_relinearize_rescale_many handles 1..64 products per call");
+  if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
+  const uint32_t l = as[0]->limbs;
+  if (l < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  const size_t N = c->N, ops = (size_t)(l - 1) * N;
+  MulTab tab{};
+  std::vector<double> scales(n);
+  for (uint32_t i = 0; i < n; i++) {
+    const evah_ct *a = as[i], *b = bs[i];
+    if (a->size != 2 || b->size != 2) throw std::invalid_argument("multiply supports size-2 operands only (relinearize first)");
+    if (a->batch != 1 || b->batch != 1) throw std::invalid_argument("multiply_relinearize_rescale_many takes single ciphertexts");
+    if (a->limbs != l || b->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    scales[i] = a->scale * b->scale;
+    check_scale(c, scales[i], l);
+    acquire(c, a->buf);
+    acquire(c, b->buf);
+    tab.a[i] = a->d;
+    tab.b[i] = b->d;
+    tab.a_ps[i] = (uint32_t)(a->ps / N);
+    tab.b_ps[i] = (uint32_t)(b->ps / N);
+  }
+  Buffer *ob = buf_new(c, (size_t)n * 2 * ops);
+  try {
+    relin_rescale_core(c, nullptr, n, ob->d, &tab, l);
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)n;
+  for (uint32_t b = 0; b < n; b++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)b * 2 * ops;
+    t->size = 2;
+    t->limbs = l - 1;
+    t->ps = ops;
+    t->scale = scales[b] / std::pow(2.0, (double)divisor_bits);
+    outs[b] = t;
+  }
+}
+
+int evah_relinearize_rescale_many(evah_ctx *c, const evah_ct *const *as, uint32_t n, uint32_t divisor_bits, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("relinearize_rescale_many handles 1..64 ciphertexts per call");
+  if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
+  const uint32_t l = as[0]->limbs;
+  if (l < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  const size_t N = c->N, ops = (size_t)(l - 1) * N;
+  for (uint32_t b = 0; b < n; b++) {
+    const evah_ct *a = as[b];
+    if (a->size != 3) throw std::invalid_argument("relinearize expects a size-3 ciphertext");
+    if (a->batch != 1) throw std::invalid_argument("relinearize_rescale_many takes single ciphertexts (a batched handle goes through evah_relinearize_rescale)");
+    if (a->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    acquire(c, a->buf);
+  }
+  Buffer *ob = buf_new(c, (size_t)n * 2 * ops);
+  try {
+    relin_rescale_core(c, as, n, ob->d);
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)n;
+  for (uint32_t b = 0; b < n; b++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)b * 2 * ops;
+    t->size = 2;
+    t->limbs = l - 1;
+    t->ps = ops;
+    t->scale = as[b]->scale / std::pow(2.0, (double)divisor_bits);
+    outs[b] = t;
+  }
+  API_END
+}
+
+int evah_multiply_relinearize_rescale_many(evah_ctx *c, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n,
+                                           uint32_t divisor_bits, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  if (!c->tun.fuse_mac) { // EVAH_FUSE_MAC=0 (the unfused reference path): the three calls one after the other
+    std::vector<evah_ct *> ms(n, nullptr);
+    if (evah_multiply_many(c, as, bs, n, ms.data())) throw std::runtime_error(g_err);
+    int rc = evah_relinearize_rescale_many(c, ms.data(), n, divisor_bits, outs);
+    std::string err = g_err;
+    for (evah_ct *m : ms) evah_ct_free(c, m);
+    if (rc) throw std::runtime_error(err);
+  } else {
+    mul_relin_rescale(c, as, bs, n, divisor_bits, outs);
+  }
+  API_END
+}
+
+int evah_multiply_relinearize_rescale(evah_ctx *c, const evah_ct *a, const evah_ct *b, uint32_t divisor_bits, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  if (a->batch != 1 || b->batch != 1 || !c->tun.fuse_mac) { // batched handles: the separate (already batched) calls
+    evah_ct *m = nullptr;
+    if (evah_multiply(c, a, b, &m)) throw std::runtime_error(g_err);
+    int rc = evah_relinearize_rescale(c, m, divisor_bits, out);
+    std::string err = g_err;
+    evah_ct_free(c, m);
+    if (rc) throw std::runtime_error(err);
+  } else {
+    mul_relin_rescale(c, &a, &b, 1, divisor_bits, out);
+  }
+  API_END
+}
+
+// n independent ciphertexts of one size and level rescaled in one launch set (n * size <= 128)
+int evah_rescale_many(evah_ctx *c, const evah_ct *const *cts, uint32_t n, uint32_t divisor_bits, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  const uint32_t size = cts[0]->size, l = cts[0]->limbs;
+  if (n < 1 || (size_t)n * size > 2 * KS_BATCH_MAX) throw std::invalid_argument("rescale_many: too many polynomials for one call");
+  if (l < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  const size_t N = c->N, ops = (size_t)(l - 1) * N;
+  const uint32_t polys = n * size;
+  PtrTab last{}, all{};
+  for (uint32_t b = 0; b < n; b++) {
+    const evah_ct *a = cts[b];
+    if (a->size != size || a->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    if (a->batch != 1) throw std::invalid_argument("rescale_many takes single ciphertexts");
+    acquire(c, a->buf);
+    for (uint32_t p = 0; p < size; p++) {
+      all.p[b * size + p] = a->d + (size_t)p * a->ps;
+      last.p[b * size + p] = a->d + (size_t)p * a->ps + (size_t)(l - 1) * N;
+    }
+  }
+  Buffer *ob = buf_new(c, (size_t)polys * ops);
+  try {
+    Scratch r(c, (size_t)polys * N);
+    OpPlain::Params ip{nullptr, r.d, 0, N, 1, l - 1, 1, last};
+        OpModDown::Params mp{r.d, N, nullptr, 0, nullptr, 0, 0, ob->d, ops, l - 1, l - 1};
+    mp.c_tab = all;
+    inverse_then_forward<OpPlain, OpModDown>(c, ip, polys, mp, polys * (l - 1));
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)n;
+  for (uint32_t b = 0; b < n; b++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)b * size * ops;
+    t->size = size;
+    t->limbs = l - 1;
+    t->ps = ops;
+    t->scale = cts[b]->scale / std::pow(2.0, (double)divisor_bits);
+    outs[b] = t;
+  }
+  API_END
+}
+
+// n (<= 64) independent size-3 ciphertexts of one level relinearized in one launch set
+int evah_relinearize_many(evah_ctx *c, const evah_ct *const *cts, uint32_t n, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("relinearize_many handles 1..64 ciphertexts per call");
+  if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
+  const uint32_t l = cts[0]->limbs;
+  const size_t N = c->N, pps = (size_t)(l + 1) * N, ops = (size_t)l * N;
+  PtrTab c2{}, c01{};
+  for (uint32_t b = 0; b < n; b++) {
+    const evah_ct *a = cts[b];
+    if (a->size != 3) throw std::invalid_argument("relinearize expects a size-3 ciphertext");
+    if (a->batch != 1) throw std::invalid_argument("relinearize_many takes single ciphertexts");
+    if (a->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    acquire(c, a->buf);
+    c2.p[b] = a->d + 2 * a->ps;
+    c01.p[2 * b] = a->d;
+    c01.p[2 * b + 1] = a->d + a->ps;
+  }
+  Buffer *ob = buf_new(c, (size_t)n * 2 * ops);
+  try {
+    Scratch prod(c, (size_t)n * 2 * pps);
+    std::vector<const KeyDev *> keys(n, &c->sh->relin);
+    switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2);
+    Scratch r(c, (size_t)n * 2 * N);
+    OpPlain::Params sp{prod.d + (size_t)l * N, r.d, pps, N, 1, c->k - 1, 1, {}};
+        OpModDown::Params mp{r.d, N, prod.d, pps, nullptr, 0, 0, ob->d, ops, c->k - 1, l};
+    mp.use_add_tab = true;
+    mp.add_tab = c01;
+    inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * n, mp, 2 * n * l);
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)n;
+  for (uint32_t b = 0; b < n; b++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)b * 2 * ops;
+    t->size = 2;
+    t->limbs = l;
+    t->ps = ops;
+    t->scale = cts[b]->scale;
+    outs[b] = t;
+  }
+  API_END
+}
+
+int evah_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bits, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  acquire(c, a->buf);
+  if (a->limbs < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  const uint32_t l = a->limbs;
+  const size_t N = c->N;
+  const uint32_t polys = a->size * a->batch; // a batched handle is batch * size polynomials at stride ps
+  evah_ct *o = ct_new(c, a->size, l - 1, a->scale / std::pow(2.0, (double)divisor_bits), a->batch);
+  Scratch r(c, (size_t)polys * N);
+  OpPlain::Params ip{a->d + (size_t)(l - 1) * N, r.d, a->ps, N, 1, l - 1, 1, {}};
+    OpModDown::Params mp{r.d, N, a->d, a->ps, nullptr, 0, 0, o->d, o->ps, l - 1, l - 1};
+  inverse_then_forward<OpPlain, OpModDown>(c, ip, polys, mp, polys * (l - 1));
+  *out = o;
+  API_END
+}
+
+} // extern "C"

@@ -1,0 +1,167 @@
+// launch.hip.h — launch plumbing of the transform kernels (ntt.hip.h), shared by the translation
+// units of libeva_hip.so that issue transforms: pass selection by size (8 / 4 coefficients per thread,
+// the fused inverse + forward form for latency-bound launches), profiling classes, and the entry
+// points of the key-switch core that keyswitch.hip defines for rotate.hip and shard.hip.
+#pragma once
+#include "internal.hip.h"
+#include "ntt.hip.h"
+
+namespace evah {
+
+// 2 coefficients per thread (16-byte accesses); grid = (N/512, limbs, polys)
+#define EW_SETUP                                                                                 \
+  const uint32_t p = blockIdx.z, i = blockIdx.y;                                                 \
+  const size_t off = (size_t)i * cx.N + 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);    \
+  const DevPrime pm = cx.primes[cx.prime_of(i)];                                                 \
+  (void)p;                                                                                        \
+  (void)pm;
+
+__device__ __forceinline__ ulonglong2 ld2(const u64 *p) { return *reinterpret_cast<const ulonglong2 *>(p); }
+__device__ __forceinline__ void st2(u64 *p, ulonglong2 v) { *reinterpret_cast<ulonglong2 *>(p) = v; }
+
+// ---- NTT launch plumbing
+template <class Op> struct OpClass;
+template <bool Z> struct OpClass<OpPlainT<Z>> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
+template <> struct OpClass<OpMulIntt> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
+template <> struct OpClass<OpKsDigit> { static constexpr int fwd_a = KC_KSDIGIT_A, fwd_b = KC_KSDIGIT_B; };
+template <> struct OpClass<OpModDown> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
+template <bool M> struct OpClass<OpRRT<M>> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
+template <bool M> struct OpClass<OpRRLastT<M>> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
+
+template <int P, int LR, bool STRIDED, bool INVERSE, class Op>
+static void launch_pass(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  ProfScope ps(c, INVERSE ? (STRIDED ? KC_INTT_B : KC_INTT_A)
+                          : (STRIDED ? OpClass<Op>::fwd_a : OpClass<Op>::fwd_b));
+  const uint32_t max_tile = (uint32_t)NTT_THREADS << LR;
+  const uint32_t tile = c->N < max_tile ? c->N : max_tile;
+  const int logC = (int)ilog2(tile) - P;
+  size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64);
+  if (STRIDED) lds += ((size_t)1 << P) * sizeof(ulonglong2); // staged twiddles
+  const uint32_t n_tiles = c->N / tile;
+  const int log_tiles = (int)ilog2(n_tiles);
+  dim3 grid = Op::grid(prm, jobs), block(tile >> LR);
+  grid.x *= n_tiles;
+  if (tile == max_tile) {
+    hipLaunchKernelGGL((ntt_pass_kernel<P, LR, STRIDED, INVERSE, Op, true>), grid, block, lds, c->stream, c->dev,
+                       prm, logC, log_tiles);
+  } else if constexpr (P == 5) { // N = 1024: one partial tile per polynomial
+    hipLaunchKernelGGL((ntt_pass_kernel<P, LR, STRIDED, INVERSE, Op, false>), grid, block, lds, c->stream, c->dev,
+                       prm, logC, log_tiles);
+  } else {
+    throw std::logic_error("partial NTT tile with P != 5");
+  }
+  HIPCHK(hipGetLastError());
+}
+
+template <int LR, bool STRIDED, bool INVERSE, class Op>
+static void launch_pass_lr(evah_ctx *c, int P, const typename Op::Params &prm, uint32_t jobs) {
+  switch (P) {
+  case 5: launch_pass<5, LR, STRIDED, INVERSE, Op>(c, prm, jobs); break;
+  case 6: launch_pass<6, LR, STRIDED, INVERSE, Op>(c, prm, jobs); break;
+  case 7: launch_pass<7, LR, STRIDED, INVERSE, Op>(c, prm, jobs); break;
+  case 8: launch_pass<8, LR, STRIDED, INVERSE, Op>(c, prm, jobs); break;
+  case 9:
+    if constexpr (STRIDED) { launch_pass<9, LR, STRIDED, INVERSE, Op>(c, prm, jobs); break; }
+    [[fallthrough]];
+  default: throw std::runtime_error("unsupported poly_modulus_degree for the NTT kernels");
+  }
+}
+// 8 coefficients per thread measured best for the stand-alone passes on MI355X (vs 4: +12 %,
+// vs 16: +10 %, profiles/r01_tuning_notes.md); the fused key-switch kernel uses 4.
+template <bool STRIDED, bool INVERSE, class Op>
+static void launch_pass_p(evah_ctx *c, int P, const typename Op::Params &prm, uint32_t jobs) {
+  // a launch that cannot fill the chip is bound by ONE wave's instruction stream (a thread's 8
+  // coefficients are ~600 integer instructions per pass): with 4 coefficients per thread the same
+  // tile work is spread over twice the workgroups and the critical path of a workgroup shrinks
+  if (c->tun.small_lr == 2 && (uint64_t)jobs * (c->N >> 11) <= c->tun.small_lr_blocks && c->N >= 2048) {
+    launch_pass_lr<2, STRIDED, INVERSE, Op>(c, P, prm, jobs);
+    return;
+  }
+  launch_pass_lr<3, STRIDED, INVERSE, Op>(c, P, prm, jobs);
+}
+
+struct KsBatch { // one launch worth of key-switches: regular strides, irregular keys
+  uint32_t n = 1;
+  uint32_t i0 = 0, ni = 0; // output-limb slice
+  size_t target_bs = 0, scratch_bs = 0, prod_bs = 0;
+  KsKeys keys{};
+  PtrTab targets{}; // used when the targets are separate allocations (target == nullptr)
+  const MulTab *mul = nullptr; // fused multiply: the target of instance b is d2 = a1 b1 of product b
+  uint32_t istep = 1, nout = 0; // output limbs I = i0 + y * istep; nout = rows per polynomial of prod (0: l + 1)
+  u64 *r_out = nullptr; // != nullptr: the special row leaves as the first inverse pass of the mod-down (INVSP)
+};// second (contiguous) pass of the digit transforms fused with the key inner product (keyswitch.hip)
+void launch_ks_inner(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const KsBatch &key, u64 *prod, uint32_t l);
+
+template <class Op> static void ntt_forward(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  const int a = (c->logN + 1) / 2, b = c->logN / 2;
+  launch_pass_p<true, false, Op>(c, a, prm, jobs);
+  launch_pass_p<false, false, Op>(c, b, prm, jobs);
+}
+template <class Op> static void ntt_inverse(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  const int a = (c->logN + 1) / 2, b = c->logN / 2;
+  launch_pass_p<false, true, Op>(c, b, prm, jobs);
+  launch_pass_p<true, true, Op>(c, a, prm, jobs);
+}
+
+// ---- latency-bound launches: inverse strided pass + forward strided pass as one launch (ntt_inv_fwd_kernel)
+static inline bool fuse_small_launch(evah_ctx *c, uint32_t fwd_jobs) {
+  const uint32_t tile = (uint32_t)NTT_THREADS << 3;
+  if (!c->tun.fuse_small_blocks || c->N < tile) return false; // partial tiles (N = 1024) keep the two-launch form
+  if (c->dev.guard) return true; // a guarded (normally skipped) launch set: the fewest launches, whatever the size
+  return (uint64_t)fwd_jobs * (c->N / tile) <= c->tun.fuse_small_blocks;
+}
+template <int P, class Op, int LR> static void launch_inv_fwd_plr(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  ProfScope ps(c, OpClass<Op>::fwd_a);
+  const uint32_t tile = (uint32_t)NTT_THREADS << LR, n_tiles = c->N / tile;
+  const int logC = (int)ilog2(tile) - P;
+  const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) + 2 * ((size_t)1 << P) * sizeof(ulonglong2);
+  dim3 grid = Op::grid(prm, jobs);
+  grid.x *= n_tiles;
+  hipLaunchKernelGGL((ntt_inv_fwd_kernel<P, LR, Op>), grid, dim3(NTT_THREADS), lds, c->stream, c->dev, prm, (int)ilog2(n_tiles));
+  HIPCHK(hipGetLastError());
+}
+template <int P, class Op> static void launch_inv_fwd_p(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  if (c->tun.small_lr == 2) launch_inv_fwd_plr<P, Op, 2>(c, prm, jobs);
+  else launch_inv_fwd_plr<P, Op, 3>(c, prm, jobs);
+}
+template <class Op> static void launch_inv_fwd(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  switch ((c->logN + 1) / 2) {
+  case 6: launch_inv_fwd_p<6, Op>(c, prm, jobs); break;
+  case 7: launch_inv_fwd_p<7, Op>(c, prm, jobs); break;
+  case 8: launch_inv_fwd_p<8, Op>(c, prm, jobs); break;
+  case 9: launch_inv_fwd_p<9, Op>(c, prm, jobs); break;
+  default: throw std::runtime_error("unsupported poly_modulus_degree for the fused inverse/forward pass");
+  }
+}
+// inverse transform of the source limb(s) (InvOp jobs) followed by the forward transforms of Op:
+// four launches, or three when the forward launch is too small to fill the chip
+// inv_pass1_done: the contiguous inverse pass already left its intermediate in ip.dst (fused into the
+// key-switch kernel); only ever set when fuse_small_launch(c, fwd_jobs) holds
+template <class InvOp, class Op>
+static void inverse_then_forward(evah_ctx *c, const typename InvOp::Params &ip, uint32_t inv_jobs, const typename Op::Params &fp,
+                                 uint32_t fwd_jobs, bool inv_pass1_done = false) {
+  if (inv_pass1_done && !fuse_small_launch(c, fwd_jobs)) throw std::logic_error("fused inverse pass outside the small-launch form");
+  if (fuse_small_launch(c, fwd_jobs)) {
+    if (!inv_pass1_done) launch_pass_p<false, true, InvOp>(c, c->logN / 2, ip, inv_jobs); // contiguous inverse pass: lazy intermediate in ip.dst
+    launch_inv_fwd<Op>(c, fp, fwd_jobs);
+    launch_pass_p<false, false, Op>(c, c->logN / 2, fp, fwd_jobs);
+  } else {
+    ntt_inverse<InvOp>(c, ip, inv_jobs);
+    ntt_forward<Op>(c, fp, fwd_jobs);
+  }
+}
+
+// ---- defined in keyswitch.hip
+// steps 1-2 of SEAL's switch_key_inplace for a batch of n (target, key) pairs (see the definition)
+bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t target_bs, const KeyDev *const *keys, uint32_t n,
+                         u64 *prod_d, const PtrTab *target_tab = nullptr, const MulTab *mul = nullptr, u64 *r_small = nullptr);
+void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev &key, const u64 *add, size_t add_ps, uint32_t add_polys,
+                u64 *out, size_t out_ps);
+// ---- defined in rotate.hip: NTT-domain permutation table of a Galois element, cached per device state
+const uint32_t *perm_table(evah_ctx *c, uint32_t elt);
+// out[p][i][n] = a[p][i][perm[n]] for p < polys over `limbs` limbs (the NTT-domain Galois automorphism)
+void galois_perm_launch(evah_ctx *c, const u64 *a, size_t a_ps, uint32_t limbs, uint32_t polys, const uint32_t *perm, u64 *out, size_t o_ps);
+// ---- defined in elementwise.hip: FP64 root / slot tables of the CKKS encoder, built on first use
+void enc_tables(evah_ctx *c);
+
+} // namespace evah

@@ -292,7 +292,7 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC_rt, int log_tiles) 
 // and goes straight on with the forward stages under its own prime: one launch and one HBM round
 // trip fewer per operation.  The inverse tile is recomputed by every job that shares the source
 // limb, so the host uses this form only while the launch is far from filling the chip
-// (fuse_small_launch in evaluator.hip); results are the same canonical residues either way.
+// (fuse_small_launch in launch.hip.h); results are the same canonical residues either way.
 template <int P, int LR, class Op>
 __global__ void __launch_bounds__(NTT_THREADS)
 ntt_inv_fwd_kernel(DevCtx cx, typename Op::Params prm, int log_tiles) {

@@ -1,0 +1,516 @@
+// rotate.hip — libeva_hip.so: rotate_vector (/root/reference/eva/seal/seal_executor.h:177-189): the NTT-domain Galois permutation, single
+// rotations, and rotation sets — sibling rotations as one launch set, hoisted when throughput-sized (one digit
+// decomposition per source) with the exact guarded fallback.
+#include "launch.hip.h"
+
+namespace evah {
+
+// K8: NTT-domain Galois automorphism out[p][i][n] = in[p][i][perm[n]]
+__global__ void __launch_bounds__(256)
+k_galois_perm(DevCtx cx, const u64 *a, size_t a_ps, const uint32_t *perm, u64 *out, size_t o_ps) {
+  EW_SETUP
+  const uint32_t n = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+  const uint2 pi = *reinterpret_cast<const uint2 *>(perm + n);
+  const u64 *src = a + p * a_ps + (size_t)i * cx.N;
+  ulonglong2 r;
+  r.x = src[pi.x];
+  r.y = src[pi.y];
+  st2(out + p * o_ps + off, r);
+}
+
+void galois_perm_launch(evah_ctx *c, const u64 *a, size_t a_ps, uint32_t limbs, uint32_t polys, const uint32_t *perm, u64 *out, size_t o_ps) {
+  EW_LAUNCH(k_galois_perm, ew_grid(c, limbs, polys), dim3(256), 0, c->stream, c->dev, a, a_ps, perm, out, o_ps);
+  HIPCHK(hipGetLastError());
+}
+
+// K8 for (ciphertext, rotation) pairs: pair r reads its own source; grid.z = r * 2 + p
+struct PermPairs {
+  const uint32_t *perm[KS_BATCH_MAX];
+  const u64 *src[KS_BATCH_MAX];
+  uint32_t src_ps[KS_BATCH_MAX]; // poly strides in units of N coefficients
+};
+__global__ void __launch_bounds__(256)
+k_galois_perm_pairs(DevCtx cx, PermPairs pt, u64 *out, size_t o_ps, uint32_t polys) {
+  // polys == 2: z = 2 r + K, polynomial K of pair r; polys == 1: z = r and only c0 is permuted (the
+  // hoisted form never needs the permuted c1).  Output slot 2 r + K either way.
+  if (cx.skipped()) return;
+  const uint32_t z = blockIdx.z, r = polys == 2 ? z >> 1 : z, p = polys == 2 ? z & 1 : 0, i = blockIdx.y;
+  const uint32_t n = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+  const uint2 pi = *reinterpret_cast<const uint2 *>(pt.perm[r] + n);
+  const u64 *src = pt.src[r] + ((size_t)p * pt.src_ps[r] + i) * cx.N;
+  ulonglong2 v;
+  v.x = src[pi.x];
+  v.y = src[pi.y];
+  st2(out + (size_t)(2 * r + p) * o_ps + (size_t)i * cx.N + n, v);
+}
+
+// ---- Hoisted rotations: n rotations of ONE ciphertext share the digit decomposition of c1.
+// SEAL rotates first and decomposes sigma(c1) (Evaluator::rotate_internal -> apply_galois_ntt ->
+// switch_key_inplace; seal_executor.h:181/:188): digit J of the rotated polynomial is
+// sigma(t_J) with the sign flips taken modulo q_J, i.e. as an integer polynomial
+//     t'_J = sigma_Z(t_J) + q_J * s,   s[k'] = 1 where sigma flips the sign at k' and t_J[k] != 0
+// (sigma_Z = the automorphism with integer negation).  NTT_I is linear and commutes with sigma
+// as the NTT-domain index permutation, so under every output prime q_I
+//     NTT_I(t'_J) = perm(NTT_I(t_J)) + (q_J mod q_I) * NTT_I(s)
+// and the key inner product of the rotated ciphertext is
+//     sum_J perm(D[I][J]) * key[J][K][I]  +  NTT_I(s) * sum_J (q_J mod q_I) * key[J][K][I]
+// with D = the transformed digits of the UNROTATED c1 (computed once) and a second term that is a
+// constant of (Galois element, level): the same residues SEAL gets, 1/n of the transforms.
+// The identity needs t_J[k] != 0 at the flipped positions: where t_J[k] = 0 the true digit is 0, not
+// q_J, so the sum above is too large by (q_J mod q_I) * NTT_I(X^k') * key[J][K][I].  Zero coefficients
+// are rare (N / q_J per limb: ~2^-44 at 60 bits, but 6 % of the ciphertexts for N = 2^16 and one of
+// EVA's 20-bit primes), so the inverse transform records them and k_hoist_fix subtracts their terms
+// one by one (NTT_I(X^k')[n] = psi_I^((2 brv(n) + 1) k')).  More than HOIST_ZERO_CAP zeros (a
+// transparent ciphertext) make the guarded, unhoisted launch set recompute the outputs instead.
+struct HoistTab { // per (source, rotation) pair of the launch
+  const uint32_t *perm[KS_BATCH_MAX];
+  const u64 *key[KS_BATCH_MAX];
+  const u64 *corr[KS_BATCH_MAX]; // [2][l+1][N]
+  const u64 *c1[KS_BATCH_MAX];   // the source's own c1 (NTT form): the digit used as is where I == J
+  uint32_t elt[KS_BATCH_MAX];
+  uint8_t src[KS_BATCH_MAX];     // index of the source among the set's transformed digits
+};
+// corr[K][I][n] = sign[kap][n] * sum_J (q_J mod q_kap) * key[J][K][kap][n]   (kap = prime of row I)
+__global__ void __launch_bounds__(256)
+k_hoist_corr(DevCtx cx, const u64 *sign, const u64 *key, u64 *corr, uint32_t l) {
+  const uint32_t I = blockIdx.y, K = blockIdx.z, kap = (I == l) ? cx.k - 1 : I;
+  const size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const DevPrime pm = cx.primes[kap];
+  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
+  u64 acc = 0;
+  for (uint32_t J = 0; J < l; J++) {
+    const u64 qj = cx.primes[J].q % pm.q; // 0 when J == I
+    acc = addmod(acc, mulmod(qj, key[J * key_digit + ((size_t)K * cx.k + kap) * N + n], pm), pm.q);
+  }
+  corr[((size_t)K * (l + 1) + I) * N + n] = mulmod(sign[(size_t)kap * N + n], acc, pm);
+}
+// prod[z][K][I][n] = sum_J D_s[I][J][perm_z[n]] * key_z[J][K][I][n] + corr_z[K][I][n] for pair z with source s.
+// D_s[I][J] is row (I * l + J) of source s's converted digits, or limb J of the source's own c1
+// when I == J (SEAL's shortcut: the NTT-form limb is used as is).  grid = (N/512, l+1, pairs).
+__global__ void __launch_bounds__(256)
+k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistTab tab, u64 *prod, size_t prod_bs, uint32_t l) {
+  const uint32_t I = blockIdx.y, kap = (I == l) ? cx.k - 1 : I;
+  const uint32_t z = blockIdx.z;
+  const size_t n = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
+  const DevPrime pm = cx.primes[kap];
+  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
+  const uint2 pi = *reinterpret_cast<const uint2 *>(tab.perm[z] + n);
+  const u64 *key = tab.key[z] + (size_t)kap * N + n;
+  const u64 *dg = digits + tab.src[z] * dg_bs + (size_t)I * l * N, *own = tab.c1[z];
+  u128_t a0x = {0, 0}, a0y = {0, 0}, a1x = {0, 0}, a1y = {0, 0};
+  // operands are canonical (< q < 2^60): 256 products fit the 128-bit accumulators, l <= k - 1 < 64
+  for (uint32_t J = 0; J < l; J++) {
+    const u64 *op = (I == J) ? own + (size_t)J * N : dg + (size_t)J * N;
+    const u64 ox = op[pi.x], oy = op[pi.y];
+    const ulonglong2 k0 = ld2(key + J * key_digit), k1 = ld2(key + J * key_digit + (size_t)cx.k * N);
+    acc128(a0x, ox, k0.x);
+    acc128(a0y, oy, k0.y);
+    acc128(a1x, ox, k1.x);
+    acc128(a1y, oy, k1.y);
+  }
+  const u64 *cr = tab.corr[z] + (size_t)I * N + n;
+  const ulonglong2 c0 = ld2(cr), c1c = ld2(cr + (size_t)(l + 1) * N);
+  ulonglong2 r0, r1;
+  r0.x = addmod(barrett128(a0x, pm), c0.x, pm.q);
+  r0.y = addmod(barrett128(a0y, pm), c0.y, pm.q);
+  r1.x = addmod(barrett128(a1x, pm), c1c.x, pm.q);
+  r1.y = addmod(barrett128(a1y, pm), c1c.y, pm.q);
+  u64 *pr = prod + z * prod_bs + (size_t)I * N + n;
+  st2(pr, r0);
+  st2(pr + (size_t)(l + 1) * N, r1);
+}
+
+// zeros[0] (low word) = number of zero digit coefficients seen, zeros[1 + e] = (source << 48 | J << 32 | k).
+// Same grid as k_hoist_mac with one coefficient per thread; every test below is block-uniform.
+__global__ void __launch_bounds__(256)
+k_hoist_fix(DevCtx cx, const u64 *zeros, HoistTab tab, u64 *prod, size_t prod_bs, uint32_t l) {
+  const uint32_t count = *reinterpret_cast<const uint32_t *>(zeros);
+  if (count == 0 || count > HOIST_ZERO_CAP) return;
+  const uint32_t I = blockIdx.y, kap = (I == l) ? cx.k - 1 : I;
+  const uint32_t z = blockIdx.z, b = tab.src[z];
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  const DevPrime pm = cx.primes[kap];
+  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
+  const uint32_t en = 2u * (__brev(n) >> (32 - cx.logN)) + 1u; // slot n holds the evaluation at psi^en
+  const ulonglong2 *tw = cx.tw_fwd + (size_t)kap * N;
+  const u64 *key = tab.key[z] + (size_t)kap * N + n;
+  u64 acc0 = 0, acc1 = 0;
+  bool any = false;
+  for (uint32_t e = 0; e < count; e++) {
+    const u64 ent = zeros[1 + e];
+    const uint32_t J = (uint32_t)(ent >> 32) & 0xffffu, k = (uint32_t)ent;
+    if ((uint32_t)(ent >> 48) != b || J >= l || J == kap) continue; // q_J mod q_J = 0
+    const u64 raw = (u64)k * tab.elt[z];
+    if (!((raw >> cx.logN) & 1)) continue; // the automorphism does not flip this coefficient
+    const uint32_t kp = (uint32_t)raw & (uint32_t)(N - 1);
+    const uint32_t m = (uint32_t)(((u64)en * kp) & (2 * N - 1));
+    u64 w = tw[__brev(m & (uint32_t)(N - 1)) >> (32 - cx.logN)].x; // psi^(m mod N)
+    if (m >= N) w = negmod(w, pm.q);
+    const u64 t = mulmod(cx.primes[J].q % pm.q, w, pm);
+    acc0 = addmod(acc0, mulmod(t, key[J * key_digit], pm), pm.q);
+    acc1 = addmod(acc1, mulmod(t, key[J * key_digit + (size_t)cx.k * N], pm), pm.q);
+    any = true;
+  }
+  if (!any) return;
+  u64 *pr = prod + z * prod_bs + (size_t)I * N + n;
+  pr[0] = submod(pr[0], acc0, pm.q);
+  pr[(size_t)(l + 1) * N] = submod(pr[(size_t)(l + 1) * N], acc1, pm.q);
+}
+
+bool hoist_wanted(const evah_ctx *c, uint32_t l, uint32_t n, uint32_t B) {
+  // hoisting pays when the digit transforms it saves are throughput, not latency (the exact fallback
+  // costs a set of empty launches); limb-sharded contexts go through the shard phases instead
+  return c->tun.hoist && n >= 2 && c->dev.pstep == 1 && c->N >= 2048 &&
+         (uint64_t)n * B * l * (l + 1) * (c->N >> 11) >= c->tun.hoist_min_tiles;
+}
+
+} // namespace evah
+
+extern "C" {
+
+// NTT-domain permutation table of a Galois element (SEAL GaloisTool::generate_table_ntt), cached
+} // extern "C"
+namespace evah {
+const uint32_t *perm_table(evah_ctx *c, uint32_t elt) {
+  auto pit = c->sh->perms.find(elt);
+  if (pit != c->sh->perms.end()) return pit->second;
+  if (c->capturing) throw std::logic_error("first use of a Galois element cannot be captured into a graph");
+  const size_t N = c->N;
+  std::vector<uint32_t> tab(N);
+  for (uint32_t i = 0; i < N; i++) {
+    uint32_t reversed = bitrev((uint32_t)N + i, c->logN + 1);
+    u64 raw = (((u64)elt * reversed) >> 1) & (u64)(N - 1);
+    tab[i] = bitrev((uint32_t)raw, c->logN);
+  }
+  uint32_t *d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(uint32_t) * N));
+  HIPCHK(hipMemcpy(d, tab.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+  c->sh->perms.emplace(elt, d);
+  return d;
+}
+} // namespace evah
+extern "C" {
+
+// Hoisted rotations, tables (first use of a Galois element / level: not capturable, like perm_table).
+// sign[k][N]: NTT under every prime of the 0/1 polynomial marking the coefficients whose sign the
+// automorphism flips (SEAL GaloisTool::apply_galois: index_raw = i * elt, bit logN of it set).
+static const u64 *hoist_sign(evah_ctx *c, uint32_t elt) {
+  auto it = c->sh->hoist_sign.find(elt);
+  if (it != c->sh->hoist_sign.end()) return it->second;
+  if (c->capturing) throw std::logic_error("first hoisted use of a Galois element cannot be captured into a graph");
+  const size_t N = c->N;
+  std::vector<u64> s(N * c->k, 0);
+  for (uint32_t i = 0; i < N; i++) {
+    const u64 raw = (u64)i * elt;
+    if ((raw >> c->logN) & 1) s[raw & (N - 1)] = 1;
+  }
+  for (uint32_t p = 1; p < c->k; p++) std::copy_n(s.begin(), N, s.begin() + (size_t)p * N);
+  u64 *d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(u64) * N * c->k));
+  try {
+    HIPCHK(hipMemcpyAsync(d, s.data(), sizeof(u64) * N * c->k, hipMemcpyHostToDevice, c->stream));
+    OpPlain::Params p{d, d, 0, 0, c->k, 0, 0, {}};
+    ntt_forward<OpPlain>(c, p, c->k);
+    HIPCHK(hipStreamSynchronize(c->stream)); // `s` goes out of scope; other queues may use the table next
+  } catch (...) {
+    (void)hipFree(d);
+    throw;
+  }
+  c->sh->hoist_sign.emplace(elt, d);
+  return d;
+}
+static const u64 *hoist_corr(evah_ctx *c, uint32_t elt, uint32_t l, const KeyDev &key) {
+  auto it = c->sh->hoist_corr.find({elt, l});
+  if (it != c->sh->hoist_corr.end()) return it->second;
+  if (c->capturing) throw std::logic_error("first hoisted use of a Galois element cannot be captured into a graph");
+  const u64 *sign = hoist_sign(c, elt);
+  u64 *d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(u64) * 2 * (l + 1) * c->N));
+  hipLaunchKernelGGL(k_hoist_corr, dim3(c->N / 256, l + 1, 2), dim3(256), 0, c->stream, c->dev, sign, key.d, d, l);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    HIPCHK(e);
+  }
+  c->sh->hoist_corr.emplace(std::make_pair(elt, l), d);
+  return d;
+}
+
+// ---- rotation sets.  A set is a list of (source ciphertext, Galois element) pairs at one level,
+// issued KS_BATCH_MAX pairs at a time; pair r of a chunk writes out_d[r][2][l N].
+struct RotPair {
+  const u64 *src;   // c0 of the source ciphertext; c1 = src + src_ps
+  size_t src_ps;
+  uint32_t src_idx; // index into the set's distinct sources (hoisted digits)
+  uint32_t elt;
+  const KeyDev *key;
+  const uint32_t *perm;
+  const u64 *corr;  // hoisting constant of (elt, l); null when the set is not hoisted
+};
+struct RotChunk {
+  uint32_t first, count; // pairs [first, first + count)
+  u64 *out;
+};
+static RotPair rot_pair(evah_ctx *c, const u64 *src, size_t src_ps, uint32_t src_idx, int32_t step, uint32_t l, const char *who) {
+  if (step == 0) throw std::invalid_argument(std::string(who) + ": zero steps are copies, not key switches");
+  RotPair p{src, src_ps, src_idx, 0, nullptr, nullptr, nullptr};
+  if (evah_galois_elt_from_step(c, step, &p.elt)) throw std::invalid_argument(g_err);
+  auto kit = c->sh->galois.find(p.elt);
+  if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
+  if (kit->second.n_digits < l) throw std::runtime_error("key switching key has too few digits");
+  p.key = &kit->second;
+  p.perm = perm_table(c, p.elt);
+  return p;
+}
+static void rot_perm_launch(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t np, u64 *perm_d, uint32_t polys) {
+  PermPairs pt{};
+  for (uint32_t r = 0; r < np; r++) {
+    pt.perm[r] = pr[r].perm;
+    pt.src[r] = pr[r].src;
+    pt.src_ps[r] = (uint32_t)(pr[r].src_ps / c->N);
+  }
+  ProfScope ps(c, KC_EW);
+  hipLaunchKernelGGL(k_galois_perm_pairs, dim3(c->N / 512, l, polys * np), dim3(256), 0, c->stream, c->dev, pt, perm_d, (size_t)l * c->N,
+                     polys);
+  HIPCHK(hipGetLastError());
+}
+// mod-down of a chunk's products (step 3 of switch_key); c0' = perm_d[2r] is added to the even polys
+static void rot_mod_down(evah_ctx *c, uint32_t l, uint32_t np, u64 *prod_d, const u64 *perm_d, u64 *out_d, u64 *r_d, bool inv1) {
+  const size_t N = c->N, pps = (size_t)l * N;
+  // INTT of the special limbs, job = r*2 + K
+  OpPlain::Params sp{prod_d + (size_t)l * N, r_d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
+  // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
+  OpModDown::Params mp{r_d, N, prod_d, (size_t)(l + 1) * N, perm_d, pps, ~0u, out_d, pps, c->k - 1, l};
+  inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * np, mp, 2 * np * l, inv1);
+}
+// SEAL's order — rotate, then decompose the rotated c1 (every launch honours c->dev.guard)
+static void rot_chunk_plain(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t np, u64 *out_d) {
+  const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
+  std::vector<const KeyDev *> keys(np);
+  for (uint32_t r = 0; r < np; r++) keys[r] = pr[r].key;
+  Scratch perm(c, (size_t)np * 2 * pps); // [r][c0 permuted | c1 permuted = key-switch target]
+  rot_perm_launch(c, l, pr, np, perm.d, 2);
+  Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N);
+  const bool inv1 = switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), np, prod.d, nullptr, nullptr,
+                                        fuse_small_launch(c, 2 * np * l) ? r.d : nullptr);
+  rot_mod_down(c, l, np, prod.d, perm.d, out_d, r.d, inv1);
+}
+// The whole set.  hoisted: the digits of every distinct source are transformed once and each pair's
+// key inner product is formed from them (k_hoist_mac / k_hoist_fix), then the unhoisted launches
+// follow under the device-side guard.  srcs[i] = c0 of distinct source i (poly stride src_ps[i]).
+static void rotation_set(evah_ctx *c, uint32_t l, const std::vector<RotPair> &pairs, const std::vector<RotChunk> &chunks,
+                         const std::vector<const u64 *> &srcs, const std::vector<size_t> &src_ps, bool hoisted) {
+  const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
+  if (!hoisted) {
+    for (const RotChunk &ch : chunks) rot_chunk_plain(c, l, pairs.data() + ch.first, ch.count, ch.out);
+    return;
+  }
+  const uint32_t n_src = (uint32_t)srcs.size();
+  if (n_src > (uint32_t)KS_BATCH_MAX) throw std::logic_error("hoisted rotation set with too many sources");
+  Scratch flag(c, 1 + HOIST_ZERO_CAP); // [0]: zero-coefficient count, then the recorded positions
+  HIPCHK(hipMemsetAsync(flag.d, 0, sizeof(u64), c->stream));
+  const size_t dg_bs = (size_t)(l + 1) * l * N;
+  {
+    // digits of the unrotated c1 of every source, once: coefficient form (zeros recorded), then the
+    // full transforms under every output prime
+    Scratch t(c, (size_t)n_src * l * N), dg(c, n_src * dg_bs);
+    PtrTab c1{};
+    for (uint32_t i = 0; i < n_src; i++) c1.p[i] = srcs[i] + src_ps[i];
+    OpPlainZ::Params ip{nullptr, t.d, 0, (size_t)l * N, l, 0, 0, c1};
+    ip.zero_list = flag.d;
+    ntt_inverse<OpPlainZ>(c, ip, n_src * l);
+    OpKsDigit::Params dp{t.d, dg.d, l, (size_t)l * N, dg_bs, 0, l + 1};
+    ntt_forward<OpKsDigit>(c, dp, n_src * (l + 1) * l);
+    for (const RotChunk &ch : chunks) {
+      const RotPair *pr = pairs.data() + ch.first;
+      const uint32_t np = ch.count;
+      HoistTab ht{};
+      for (uint32_t r = 0; r < np; r++) {
+        ht.perm[r] = pr[r].perm;
+        ht.key[r] = pr[r].key->d;
+        ht.corr[r] = pr[r].corr;
+        ht.elt[r] = pr[r].elt;
+        ht.c1[r] = pr[r].src + pr[r].src_ps;
+        ht.src[r] = (uint8_t)pr[r].src_idx;
+      }
+      Scratch perm(c, (size_t)np * 2 * pps); // only the c0 slots (even polys) are filled and read
+      rot_perm_launch(c, l, pr, np, perm.d, 1);
+      Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N);
+      {
+        ProfScope ps(c, KC_KSMAC);
+        hipLaunchKernelGGL(k_hoist_mac, dim3(c->N / 512, l + 1, np), dim3(256), 0, c->stream, c->dev, dg.d, dg_bs, ht, prod.d, prod_bs, l);
+        HIPCHK(hipGetLastError());
+        // the terms of recorded zero coefficients (returns at once when there are none)
+        hipLaunchKernelGGL(k_hoist_fix, dim3(c->N / 256, l + 1, np), dim3(256), 0, c->stream, c->dev, flag.d, ht, prod.d, prod_bs, l);
+        HIPCHK(hipGetLastError());
+      }
+      rot_mod_down(c, l, np, prod.d, perm.d, ch.out, r.d, false);
+    }
+  }
+  // exact fallback: the same outputs through the unhoisted launches, each a no-op unless there
+  // were more zero digit coefficients than k_hoist_fix handles
+  struct GuardScope {
+    evah_ctx *c;
+    GuardScope(evah_ctx *c_, const uint32_t *g) : c(c_) { c->dev.guard = g; c->dev.guard_min = HOIST_ZERO_CAP; }
+    ~GuardScope() { c->dev.guard = nullptr; }
+  } gs(c, reinterpret_cast<const uint32_t *>(flag.d));
+  for (const RotChunk &ch : chunks) rot_chunk_plain(c, l, pairs.data() + ch.first, ch.count, ch.out);
+  if (!c->capturing && c->tun.hoist_debug) { // diagnostics: how many zero coefficients did this set see?
+    uint32_t f = 0;
+    HIPCHK(hipMemcpyAsync(&f, flag.d, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::fprintf(stderr, "rotation set: hoisted %zu rotations of %u sources, l = %u, zero coefficients = %u\n", pairs.size(), n_src, l, f);
+  }
+}
+
+// Several rotations of ONE ciphertext (the convolution pattern: image << i*w+j for a 3x3
+// window) issued as one set of wide launches: same results as n evah_rotate calls, 1/n of the
+// kernel launches, each launch n times wider.  Large launch sets are hoisted (see k_hoist_mac).
+int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32_t n, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  acquire(c, a->buf);
+  if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("rotate_many handles 1..64 rotations per call");
+  const uint32_t l = a->limbs, B = a->batch;
+  const size_t pps = (size_t)l * c->N;
+  const bool hoisted = hoist_wanted(c, l, n, B);
+  // (rotation j, instance b) pairs go out KS_BATCH_MAX at a time: m rotations x B instances per
+  // launch set; pair index r = j * B + b, so rotation j's B outputs are one batched handle.
+  std::vector<RotPair> pairs;
+  pairs.reserve((size_t)n * B);
+  for (uint32_t j = 0; j < n; j++) {
+    RotPair p = rot_pair(c, a->d, a->ps, 0, steps[j], l, "rotate_many");
+    if (hoisted) p.corr = hoist_corr(c, p.elt, l, *p.key);
+    for (uint32_t b = 0; b < B; b++) {
+      p.src = a->d + (size_t)b * 2 * a->ps;
+      p.src_idx = b;
+      pairs.push_back(p);
+    }
+  }
+  std::vector<const u64 *> srcs(B);
+  std::vector<size_t> src_ps(B, a->ps);
+  for (uint32_t b = 0; b < B; b++) srcs[b] = a->d + (size_t)b * 2 * a->ps;
+  const uint32_t m_max = std::max<uint32_t>(1, KS_BATCH_MAX / B);
+  std::vector<evah_ct *> made;
+  std::vector<Buffer *> chunk_buf;
+  std::vector<RotChunk> chunks;
+  try {
+    for (uint32_t j0 = 0; j0 < n; j0 += m_max) {
+      const uint32_t m = std::min(m_max, n - j0), np = m * B;
+      Buffer *ob = buf_new(c, (size_t)np * 2 * pps); // one buffer for the chunk; the m handles are views into it
+      ob->refs = 0;
+      chunk_buf.push_back(ob);
+      chunks.push_back({j0 * B, np, ob->d});
+      for (uint32_t j = 0; j < m; j++) {
+        evah_ct *t = new evah_ct;
+        t->buf = ob;
+        ob->refs++;
+        t->d = ob->d + (size_t)j * B * 2 * pps;
+        t->size = 2;
+        t->limbs = l;
+        t->ps = pps;
+        t->scale = a->scale;
+        t->batch = B;
+        made.push_back(t);
+      }
+    }
+    rotation_set(c, l, pairs, chunks, srcs, src_ps, hoisted);
+  } catch (...) {
+    for (evah_ct *t : made) evah_ct_free(c, t);
+    if (made.empty())
+      for (Buffer *b : chunk_buf) { b->refs = 1; buf_unref(c, b); }
+    throw;
+  }
+  for (uint32_t r = 0; r < n; r++) outs[r] = made[r];
+  API_END
+}
+
+// n (<= 64) independent (ciphertext, step) rotations at one level as one launch set: the sibling
+// rotations of SEVERAL ciphertexts (independent convolutions of one program level).  Sources that
+// appear more than once share their digit decomposition when the set is large enough to hoist.
+int evah_rotate_pairs(evah_ctx *c, const evah_ct *const *cts, const int32_t *steps, uint32_t n, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("rotate_pairs handles 1..64 rotations per call");
+  const uint32_t l = cts[0]->limbs;
+  const size_t pps = (size_t)l * c->N;
+  std::vector<RotPair> pairs;
+  std::vector<const u64 *> srcs;
+  std::vector<size_t> src_ps;
+  for (uint32_t r = 0; r < n; r++) {
+    const evah_ct *a = cts[r];
+    if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
+    if (a->batch != 1) throw std::invalid_argument("rotate_pairs takes single ciphertexts");
+    if (a->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    acquire(c, a->buf);
+    uint32_t si = 0;
+    while (si < srcs.size() && !(srcs[si] == a->d && src_ps[si] == a->ps)) si++;
+    if (si == srcs.size()) {
+      srcs.push_back(a->d);
+      src_ps.push_back(a->ps);
+    }
+    pairs.push_back(rot_pair(c, a->d, a->ps, si, steps[r], l, "rotate_pairs"));
+  }
+  // worth hoisting when sources repeat and the digit transforms of the set are throughput-sized
+  const bool hoisted = srcs.size() < n && hoist_wanted(c, l, n, 1);
+  if (hoisted)
+    for (RotPair &p : pairs) p.corr = hoist_corr(c, p.elt, l, *p.key);
+  Buffer *ob = buf_new(c, (size_t)n * 2 * pps);
+  try {
+    rotation_set(c, l, pairs, {RotChunk{0, n, ob->d}}, srcs, src_ps, hoisted);
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)n;
+  for (uint32_t r = 0; r < n; r++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)r * 2 * pps;
+    t->size = 2;
+    t->limbs = l;
+    t->ps = pps;
+    t->scale = cts[r]->scale;
+    outs[r] = t;
+  }
+  API_END
+}
+
+int evah_rotate(evah_ctx *c, const evah_ct *a, int32_t steps, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  acquire(c, a->buf);
+  if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
+  const size_t N = c->N;
+  if (steps == 0) { // SEAL rotate_internal: no-op — the result is the operand; handles are immutable, so share the buffer
+    evah_ct *o = new evah_ct(*a);
+    o->buf->refs++;
+    *out = o;
+  } else if (a->batch > 1) {
+    if (evah_rotate_many(c, a, &steps, 1, out)) throw std::runtime_error(g_err);
+  } else {
+    uint32_t elt = 0;
+    if (evah_galois_elt_from_step(c, steps, &elt)) throw std::invalid_argument(g_err);
+    auto kit = c->sh->galois.find(elt);
+    if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
+    const uint32_t *ptab = perm_table(c, elt);
+    Scratch perm(c, (size_t)2 * a->limbs * N); // [c0 permuted][c1 permuted = key-switch target]
+    const size_t pps = (size_t)a->limbs * N;
+    EW_LAUNCH(k_galois_perm, ew_grid(c, a->limbs, 2), dim3(256), 0, c->stream, c->dev, a->d, a->ps,
+                       ptab, perm.d, pps);
+    HIPCHK(hipGetLastError());
+    evah_ct *o = ct_new(c, 2, a->limbs, a->scale);
+    try {
+      switch_key(c, a->limbs, perm.d + pps, kit->second, perm.d, pps, 1, o->d, o->ps);
+    } catch (...) {
+      evah_ct_free(c, o);
+      throw;
+    }
+    *out = o;
+  }
+  API_END
+}
+
+} // extern "C"

@@ -58,20 +58,7 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     c->logN = ilog2(N);
     c->k = k;
     c->primes.assign(primes, primes + k);
-    if (const char *e = std::getenv("EVAH_FUSE_MAC")) c->fuse_mac = std::atoi(e) != 0;
-    if (const char *e = std::getenv("EVAH_KS_GROUPS")) c->ks_groups = std::max(1, std::atoi(e));
-    c->fuse_mul = N <= 8192;
-    if (const char *e = std::getenv("EVAH_FUSE_MUL")) c->fuse_mul = std::atoi(e) != 0;
-    if (const char *e = std::getenv("EVAH_SMALL_LR")) c->small_lr = std::atoi(e) == 3 ? 3 : 2;
-    if (const char *e = std::getenv("EVAH_SMALL_LR_BLOCKS")) c->small_lr_blocks = (uint32_t)std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("EVAH_FUSE_SMALL")) c->fuse_small_blocks = (uint32_t)std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("EVAH_HOIST")) c->hoist = std::atoi(e) != 0;
-    if (const char *e = std::getenv("EVAH_FUSE_SPECIAL_INV")) c->fuse_special_inv = std::atoi(e) != 0;
-    if (const char *e = std::getenv("EVAH_HOIST_MIN_TILES")) c->hoist_min_tiles = (uint32_t)std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("EVAH_KS_THREADS")) {
-      int t = std::atoi(e);
-      if (t == 64 || t == 128 || t == 256) c->ks_threads = t;
-    }
+    c->tun = Tunables::from_env(N);
     for (u64 q : c->primes)
       if (q >= ((u64)1 << 60) || (q - 1) % (2ull * N) || !is_prime(q)) // SEAL_USER_MOD_BIT_COUNT_MAX = 60
         throw std::invalid_argument("coeff modulus primes must be at most 60 bits, prime and 1 mod 2N");
@@ -166,16 +153,7 @@ int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
     c->primes = parent->primes;
     c->total_bits = parent->total_bits;
     c->dev = parent->dev;
-    c->fuse_mac = parent->fuse_mac;
-    c->fuse_mul = parent->fuse_mul;
-    c->fuse_small_blocks = parent->fuse_small_blocks;
-    c->small_lr = parent->small_lr;
-    c->small_lr_blocks = parent->small_lr_blocks;
-    c->hoist = parent->hoist;
-    c->fuse_special_inv = parent->fuse_special_inv;
-    c->hoist_min_tiles = parent->hoist_min_tiles;
-    c->ks_threads = parent->ks_threads;
-    c->ks_groups = parent->ks_groups;
+    c->tun = parent->tun;
     HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     HIPCHK(hipEventCreate(&c->ev0));

@@ -2,7 +2,7 @@
 // ProgramTraversal::forwardPass / MulticoreProgramTraversal::forwardPass + SEALExecutor::operator()
 // (/root/reference/eva/common/program_traversal.h:36-93, multicore_program_traversal.h:24-83,
 // /root/reference/eva/seal/seal_executor.h:279-404) for the encrypted part of a program.  Host code
-// only: every device action goes through the entry points of evaluator.hip / runtime.hip.
+// only: every device action goes through the entry points of the evaluator units / runtime.hip.
 #include "internal.hip.h"
 
 extern "C" {
@@ -236,7 +236,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         // Mul read only by a Relinearize that is read only by a Rescale (the commonest CKKS
         // pattern): nothing is computed here, the three run as one fused call at the Rescale
         evah_ct *x = ct_of(o.src0), *y = ct_of(o.src1);
-        const bool chain = o.src0 != o.src1 && c->fuse_mac && c->fuse_mul && feeds_only(o.dst, 20) && feeds_only(ops[only_reader[o.dst]].dst, 22);
+        const bool chain = o.src0 != o.src1 && c->tun.fuse_mac && c->tun.fuse_mul && feeds_only(o.dst, 20) && feeds_only(ops[only_reader[o.dst]].dst, 22);
         if (chain && x->size == 2 && y->size == 2 && x->limbs == y->limbs && x->limbs >= 2 && x->batch == 1 && y->batch == 1) {
           check_scale(c, x->scale * y->scale, x->limbs);
           st.prods[o.dst] = {alias_ct(x), alias_ct(y)};

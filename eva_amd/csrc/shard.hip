@@ -1,7 +1,7 @@
-// shard.hip.h — limb-sharded execution (BASELINE config 5): the RNS limbs
+// shard.hip — limb-sharded execution (BASELINE config 5): the RNS limbs
 // of every ciphertext and plaintext are dealt over G shards, limb i to shard i mod G, the special
-// prime's limb of the key-switch products to shard l mod G.  Included at the end of
-// evaluator.hip: the launch plumbing above is shared.
+// prime's limb of the key-switch products to shard l mod G.  A translation unit of libeva_hip.so (launch plumbing:
+// launch.hip.h, key-switch core: keyswitch.hip).
 //
 // A shard is an evah_ctx with a limb -> prime map (evah_ctx_set_shard): its values hold the local
 // limbs only, and every per-limb entry point of the evaluator (add, sub, negate, multiply, square,
@@ -21,6 +21,8 @@
 //        -- broadcast of r (size N 8 bytes) --
 //     2. evah_shard_rescale_finish  divide-and-round on the local limbs of the next level
 // Every stored word is the canonical residue the unsharded path stores for that limb.
+
+#include "launch.hip.h"
 
 struct evah_buf {
   Buffer *buf;
@@ -133,7 +135,7 @@ int evah_shard_galois_perm(evah_ctx *c, const evah_ct *a, uint32_t galois_elt, e
   const uint32_t *ptab = perm_table(c, galois_elt);
   evah_ct *o = ct_new(c, 2, a->limbs, a->scale);
   if (a->limbs) {
-    EW_LAUNCH(k_galois_perm, ew_grid(c, a->limbs, 2), dim3(256), 0, c->stream, c->dev, a->d, a->ps, ptab, o->d, o->ps);
+    galois_perm_launch(c, a->d, a->ps, a->limbs, 2, ptab, o->d, o->ps);
     HIPCHK(hipGetLastError());
   }
   *out = o;
@@ -165,7 +167,7 @@ int evah_shard_ks_products(evah_ctx *c, const evah_ct *a, uint32_t poly, uint32_
   API_BEGIN
   use(c);
   need_shard(c);
-  if (!c->fuse_mac) throw std::logic_error("limb-sharded key switching needs the fused key-switch kernel (EVAH_FUSE_MAC=1)");
+  if (!c->tun.fuse_mac) throw std::logic_error("limb-sharded key switching needs the fused key-switch kernel (EVAH_FUSE_MAC=1)");
   if (a) acquire(c, a->buf); // a == NULL: a shard that owns only the special limb at this level
   acquire(c, digits->buf);
   acquire(c, prod->buf);
