@@ -655,6 +655,10 @@ def main():
             cpu = {"value": round(n / cdt, 3), "unit": "op-triples/s", "cores": 1, "kind": "port",
                    "seal": "present: " + ",".join(seal.get("paths", [])[:2]) if seal.get("present") else
                            "SEAL absent on this host (tools/seal_probe.py): the oracle restatement is the baseline",
+                   "pin_with_seal": "on a host with Microsoft SEAL >= 3.6: python tests/golden/export_seal_vectors.py /tmp/vec 65536 "
+                                    + ",".join(["60"] * (l + 1)) + " && cmake -S tools -B build/seal_parity && cmake --build build/seal_parity"
+                                    " && build/seal_parity/seal_parity /tmp/vec --time-triple   (diffs primes, psi, NTT, every evaluator call, "
+                                    "the op-triple, encode, decrypt and decode with SEAL's own bits; prints SEAL's op-triples/s)",
                    "all_cores": {"value": round(len(done) / mdt, 2), "cores": threads,
                                  "sample": f"{threads} op-triples, one per thread, concurrently"},
                    "sample": f"{n} op-triples (multiply+relinearize+rescale) at N=2^{args.logn}, "

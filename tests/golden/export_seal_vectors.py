@@ -5,7 +5,8 @@ development container).
 
   python tests/golden/export_seal_vectors.py OUT_DIR            # the committed N = 1024 set
   python tests/golden/export_seal_vectors.py OUT_DIR N b0,b1,.. # a fresh set from the CPU oracle
-                                                                # (e.g. 65536 60,60,...,60)
+                                                                # (e.g. 65536 60,60,...,60; 8192 60,20,60,60 puts
+                                                                # one of EVA's 20-bit output primes in the chain)
 OUT_DIR/manifest.txt  : `key v0 v1 ...` lines (N, bits, scale_log2, rot_steps, enc_scale_bits)
 OUT_DIR/<name>.u64    : uint64 arrays, C order ([size][limbs][N] for ciphertexts,
                         [digit][2][k][N] for keys); OUT_DIR/<name>.f64 : float64 arrays
@@ -55,6 +56,14 @@ def fresh(N, bits, seed=20260927):
     for c, sb in enumerate(d["enc_scale_bits"]):
         d[f"enc_values_{c}"] = rng.uniform(-3, 3, N // 2)
         d[f"out_encode_{c}"] = o.encode(l, d[f"enc_values_{c}"], 2.0 ** int(sb))
+    # Decryptor::decrypt / CKKSEncoder::decode (as in make_golden.py)
+    small = rng.integers(-1, 2, size=N)
+    d["sk_ntt"] = np.stack([o.ntt(i, np.array([int(v) % primes[i] for v in small], dtype=np.uint64)) for i in range(k)])
+    d["out_decrypt2"], d["out_decrypt3"] = o.decrypt(a2, d["sk_ntt"]), o.decrypt(a3, d["sk_ntt"])
+    for c, sb in enumerate(d["enc_scale_bits"]):
+        d[f"out_decode_{c}"] = o.decode(d[f"out_encode_{c}"], 2.0 ** int(sb))
+    d["out_decode_pt"] = o.decode(pt, 2.0 ** 10)
+    d["out_decode_dec3"] = o.decode(d["out_decrypt3"], 2.0 ** 10)
     return d, bits
 
 

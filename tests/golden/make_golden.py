@@ -7,7 +7,9 @@
                       tests/features.py:129,133), with the program and configuration of each.
   ops_n1024.npz       inputs and expected outputs of every evaluator call on the path (N = 1024,
                       primes [60, 40, 60] -> 2 data limbs + the special prime), from seeded inputs,
-                      and of CKKSEncoder::encode at five scales.  tests/golden/export_seal_vectors.py
+                      of CKKSEncoder::encode at five scales, and of Decryptor::decrypt / CKKSEncoder::decode
+                      (a ternary secret key, sizes 2 and 3, decode of encoded and of random plaintexts).
+                      tests/golden/export_seal_vectors.py
                       turns the same vectors into raw files for tools/seal_parity.cpp, which diffs
                       them against a real SEAL >= 3.6 wherever one is installed.
 
@@ -112,6 +114,17 @@ def main():
     for c, sb in enumerate(d["enc_scale_bits"]):
         d[f"enc_values_{c}"] = rng.uniform(-3, 3, N // 2)
         d[f"out_encode_{c}"] = o.encode(l, d[f"enc_values_{c}"], 2.0 ** int(sb))
+    # Decryptor::decrypt + CKKSEncoder::decode (/root/reference/eva/seal/seal.cpp:132-135); drawn last, so
+    # every vector above keeps its value.  The secret key is ternary under every key prime, NTT form.
+    small = rng.integers(-1, 2, size=N)
+    d["sk_ntt"] = np.stack([o.ntt(i, np.array([int(v) % primes[i] for v in small], dtype=np.uint64)) for i in range(k)])
+    d["out_decrypt2"] = o.decrypt(a2, d["sk_ntt"])
+    d["out_decrypt3"] = o.decrypt(a3, d["sk_ntt"])
+    for c, sb in enumerate(d["enc_scale_bits"]):  # decode of the encoder's own plaintexts: small coefficients of both signs
+        d[f"out_decode_{c}"] = o.decode(d[f"out_encode_{c}"], 2.0 ** int(sb))
+    # decode of uniformly random residues: every coefficient a random element of [0, Q) — multi-word, both halves
+    d["out_decode_pt"] = o.decode(pt, 2.0 ** 10)
+    d["out_decode_dec3"] = o.decode(d["out_decrypt3"], 2.0 ** 10)
     np.savez_compressed(os.path.join(HERE, "ops_n1024.npz"), **d)
     print("wrote", sorted(os.listdir(HERE)))
 

@@ -61,6 +61,18 @@ def test_oracle_reproduces_golden_vectors(vec):
     for c, sb in enumerate(vec["enc_scale_bits"]):  # CKKSEncoder::encode vectors
         assert np.array_equal(o.encode(2, vec[f"enc_values_{c}"], 2.0 ** int(sb)), vec[f"out_encode_{c}"]), f"encode {c}"
     assert [o.psi(i) for i in range(3)] == [int(x) for x in vec["psi"]]
+    # Decryptor::decrypt / CKKSEncoder::decode vectors (float64 results compared as bit patterns)
+    assert np.array_equal(o.decrypt(vec["a2"], vec["sk_ntt"]), vec["out_decrypt2"])
+    assert np.array_equal(o.decrypt(vec["a3"], vec["sk_ntt"]), vec["out_decrypt3"])
+    for name, pt, sb in _decode_cases(vec):
+        assert np.array_equal(o.decode(pt, 2.0 ** sb).view(np.uint64), vec[name].view(np.uint64)), name
+
+
+def _decode_cases(vec):
+    for c, sb in enumerate(vec["enc_scale_bits"]):
+        yield f"out_decode_{c}", vec[f"out_encode_{c}"], int(sb)
+    yield "out_decode_pt", vec["pt"], 10
+    yield "out_decode_dec3", vec["out_decrypt3"], 10
 
 
 def test_reference_constants(consts):
@@ -138,3 +150,16 @@ def test_gpu_reproduces_golden_vectors(vec):
     for c, sb in enumerate(vec["enc_scale_bits"]):  # the device encoder against the stored plaintexts
         got = o.g.encode_pt(vec[f"enc_values_{c}"], 2, 2.0 ** int(sb)).download()
         assert np.array_equal(got, vec[f"out_encode_{c}"]), f"encode {c}"
+    # the device decryptor + decoder: a plaintext is its own message as a size-1 ciphertext
+    o.g.upload_secret_key(vec["sk_ntt"])
+    for name, pt, sb in _decode_cases(vec):
+        got = o.g.decrypt_decode(o.g.upload_ct(pt[None], 2.0 ** sb), N // 2)
+        assert np.array_equal(got.view(np.uint64), vec[name].view(np.uint64)), name
+    for ct, want in ((vec["a2"], "out_decrypt2"), (vec["a3"], "out_decrypt3")):
+        got = o.g.decrypt_decode(o.g.upload_ct(ct, 2.0 ** 10), N // 2)
+        assert np.array_equal(got.view(np.uint64), o_decode(vec[want], 10).view(np.uint64)), want
+
+
+def o_decode(pt, scale_bits):
+    from oracle import pyoracle as po
+    return po.Oracle(N, po.coeff_modulus_create(N, [60, 40, 60])).decode(pt, 2.0 ** scale_bits)

@@ -39,6 +39,34 @@ def test_exporter_writes_every_vector_the_checker_reads(tmp_path):
     assert man["N"] == "1024" and man["bits"] == "60 40 60"
 
 
+def test_checker_compiles_against_the_declared_seal_api():
+    """tools/seal_parity.cpp has never met a real SEAL where this repository is developed: at least it must
+    parse and type-check against the SEAL 3.6 declarations it uses (tools/seal_api_stub: declarations only,
+    compile-check only — it pins nothing and cannot be linked)."""
+    import shutil
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "tools", "seal_api_stub"),
+                        os.path.join(ROOT, "tools", "seal_parity.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    stub = open(os.path.join(ROOT, "tools", "seal_api_stub", "seal", "seal.h")).read()
+    assert "COMPILE-CHECK ONLY" in stub
+
+
+def test_fresh_vector_sets_cover_the_cases_the_verdicts_named(tmp_path):
+    """N = 2^13 with one of EVA's 20-bit output primes, a size-3 rescale, a negative rotation, an encode at
+    2^60, decrypt and decode: all in one exported set (what a SEAL-equipped host replays)."""
+    out = str(tmp_path / "vec8192")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "golden", "export_seal_vectors.py"), out, "8192", "60,20,60,60"])
+    files = set(os.listdir(out))
+    for name in ("out_rescale3.u64", "out_rotate_-3.u64", "out_encode_4.u64", "out_decrypt3.u64", "out_decode_pt.f64", "sk_ntt.u64"):
+        assert name in files, name
+    man = dict(ln.split(" ", 1) for ln in open(os.path.join(out, "manifest.txt")).read().splitlines() if not ln.startswith("#"))
+    assert man["N"] == "8192" and man["bits"] == "60 20 60 60" and man["enc_scale_bits"].split()[-1] == "60"
+    primes = np.fromfile(os.path.join(out, "primes.u64"), dtype="<u8")
+    assert int(primes[1]) == 0xFC001  # SURVEY.md Appendix B: the 20-bit prime of (8192, [60, 20, 60, 60])
+
+
 def test_real_seal_reproduces_the_golden_vectors(tmp_path):
     res = seal_probe.build_and_run(_export(tmp_path))
     if not res["present"]:

@@ -12,6 +12,7 @@
 //   4. every Evaluator call EVA's SEALExecutor makes (seal_executor.h:114-243) on the exported
 //      inputs and keys                                      == exported outputs
 //   5. CKKSEncoder::encode on the exported value vectors   == exported plaintexts
+//   6. Decryptor::decrypt / CKKSEncoder::decode            == exported plaintexts / slot values (as bits)
 // and prints one PASS/FAIL line per item plus a summary; exit status 0 only when all pass.
 // With --time-triple it also times multiply + relinearize + rescale_to_next (BASELINE.json's
 // metric) on one thread, so bench.py can report a `cpu_baseline` of kind "reference".
@@ -210,6 +211,42 @@ int main(int argc, char **argv) {
       encoder.encode(vals, pid, std::pow(2.0, (double)sb[c]), p);
       report("CKKSEncoder::encode at 2^" + std::to_string(sb[c]) + " [:242]", same(p.data(), load_u64("out_encode_" + std::to_string(c))));
     }
+  }
+
+  // 6. Decryptor::decrypt and CKKSEncoder::decode (eva/seal/seal.cpp:132-135).  The secret key object is
+  // generated for its structure and overwritten with the exported NTT-form key (k limbs); decode results
+  // are float64 and compared as bit patterns — the oracle restates decode_internal's operation order.
+  auto file_exists = [&](const std::string &name) { return (bool)std::ifstream(g_dir + "/" + name); };
+  if (file_exists("sk_ntt.u64")) {
+    SecretKey sk = keygen.secret_key();
+    {
+      auto d = load_u64("sk_ntt");
+      if (d.size() != k * N) throw std::runtime_error("unexpected length of sk_ntt");
+      std::memcpy(sk.data().data(), d.data(), d.size() * 8);
+    }
+    Decryptor decryptor(context, sk);
+    Plaintext p;
+    decryptor.decrypt(a2, p);
+    report("Decryptor::decrypt size 2 [seal.cpp:132]", same(p.data(), load_u64("out_decrypt2")));
+    decryptor.decrypt(a3, p);
+    report("Decryptor::decrypt size 3 [seal.cpp:132]", same(p.data(), load_u64("out_decrypt3")));
+    auto check_decode = [&](const std::string &what, Plaintext &plain, const std::string &want_name) {
+      std::vector<double> got;
+      encoder.decode(plain, got);
+      auto want = load_f64(want_name);
+      report("CKKSEncoder::decode " + what + " [seal.cpp:134]", got.size() == want.size() && std::memcmp(got.data(), want.data(), want.size() * 8) == 0);
+    };
+    if (mf.count("enc_scale_bits")) {
+      auto &sb = mf.at("enc_scale_bits");
+      for (size_t c = 0; c < sb.size(); c++) {
+        Plaintext q = make_pt("out_encode_" + std::to_string(c));
+        q.scale() = std::pow(2.0, (double)sb[c]);
+        check_decode("of the encoding at 2^" + std::to_string(sb[c]), q, "out_decode_" + std::to_string(c));
+      }
+    }
+    check_decode("of uniformly random residues", pt, "out_decode_pt");
+    decryptor.decrypt(a3, p);
+    check_decode("of a decrypted size-3 ciphertext", p, "out_decode_dec3");
   }
 
   if (time_triple) {
