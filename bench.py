@@ -3,9 +3,11 @@
 (multiply + relinearize + rescale) at N = 2^16, L = 10 data limbs (k = 11 key primes).
 
 One "step" = one batch of --batch independent op-triples through the C-ABI of libeva_hip.so
-(per group of --group triples: evah_multiply_many, then evah_relinearize_rescale_many = relinearize
-and rescale_to_next evaluated together; --fused-multiply takes the one-call form
-evah_multiply_relinearize_rescale_many — all bit-identical to the three separate SEAL calls), inputs and the relinearization key already resident in HBM.  One process
+(per group of --group triples ONE evah_multiply_relinearize_rescale_many: multiply, relinearize and
+rescale_to_next evaluated together, the size-3 product never stored; --separate-multiply takes
+evah_multiply_many + evah_relinearize_rescale_many — all bit-identical to the three separate SEAL
+calls), groups alternating between --streams issue queues, inputs and the relinearization key already
+resident in HBM.  One process
 per GPU; ranks run independent batches (the path shards over independent ciphertexts — no data-path
 collective), `value` = triples of all ranks / max time over ranks.
 
@@ -408,13 +410,16 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="independent op-triples per step")
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--limbs", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=1,
-                    help="issue queues (forked contexts = HIP streams) the independent triples are spread over")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="issue queues (forked contexts = HIP streams) the groups of a step alternate between: with two, the "
+                         "VALU-bound key-switch launches of one group overlap the HBM-bound passes of the other (+2.5 %% "
+                         "over one queue in the same run, profiles/r03_tuning_notes.md); per-launch times then include that overlap")
     ap.add_argument("--group", type=int, default=32,
                     help="triples handed to one batched call (wide launches, shared key)")
-    ap.add_argument("--fused-multiply", action="store_true",
-                    help="evah_multiply_relinearize_rescale_many (no size-3 product in HBM; measured 1.5 %% slower at this size: "
-                         "the combine pass re-reads both operands) instead of multiply_many + relinearize_rescale_many")
+    ap.add_argument("--separate-multiply", action="store_true",
+                    help="evah_multiply_many + evah_relinearize_rescale_many instead of the one-call op-triple "
+                         "evah_multiply_relinearize_rescale_many (no size-3 product in HBM).  r02 measured the one-call form 1.6 %% "
+                         "slower; with the r03 128-bit reduction it is 1.9 %% faster (same run), so it is the default")
     ap.add_argument("--shard", choices=["ciphertexts", "limb", "subdag"], default="ciphertexts",
                     help="ciphertexts: independent triples per GPU, no collective (default, weak scaling); "
                          "limb: every triple on all GPUs, RNS limbs dealt over them (strong scaling); "
@@ -462,7 +467,7 @@ def main():
     primes = coeff_modulus_create(N, [60] * k)
     g = backend.Context(N, primes, device=local)
     queues = [g] + [g.fork() for _ in range(max(1, args.streams) - 1)]
-    fused = args.fused_multiply
+    fused = not args.separate_multiply
 
     # synthetic inputs: uniform residues; every triple of a step has its own
     # operand pair (distinct HBM data: no triple finds its inputs in cache because another used them)

@@ -199,9 +199,11 @@ struct Tunables {
   // EVAH_FUSE_MAC (1): key switch — fuse the key inner product into the digit transforms' second pass
   // (ks_inner_kernel); 0 = separate digit transforms + k_ks_mac, the unfused reference path
   bool fuse_mac = true;
-  // EVAH_FUSE_MUL (N <= 8192): evah_execute runs Mul -> Relinearize -> Rescale chains as ONE
-  // evah_multiply_relinearize_rescale_many where launches, not bytes, bound the chain
-  bool fuse_mul = false;
+  // EVAH_FUSE_MUL (1): evah_execute runs Mul -> Relinearize -> Rescale chains as ONE
+  // evah_multiply_relinearize_rescale_many (the size-3 product never reaches HBM).  r02 measured it 1.6 %
+  // slower at N = 2^16 and kept it for N <= 8192; with the r03 128-bit reduction its on-the-fly products
+  // are cheap enough that it wins at every size (op-triple 13 383 -> 13 635 /s)
+  bool fuse_mul = true;
   // EVAH_FUSE_SMALL (2048): launches of at most this many 2048-coefficient tiles are latency-bound — an
   // inverse transform followed by forward transforms of the result runs its two strided passes as one
   // launch (ntt_inv_fwd_kernel); 0 disables.  r03 sweep at the BASELINE sizes: Harris L=8 1.18 -> 1.15 ms,
@@ -229,7 +231,7 @@ struct Tunables {
     Tunables t;
     auto flag = [](const char *name, bool &v) { if (const char *e = std::getenv(name)) v = std::atoi(e) != 0; };
     auto count = [](const char *name, uint32_t &v) { if (const char *e = std::getenv(name)) v = (uint32_t)std::max(0, std::atoi(e)); };
-    t.fuse_mul = N <= 8192;
+    (void)N;
     flag("EVAH_FUSE_MAC", t.fuse_mac);
     flag("EVAH_FUSE_MUL", t.fuse_mul);
     count("EVAH_FUSE_SMALL", t.fuse_small_blocks);
