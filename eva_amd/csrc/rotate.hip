@@ -86,38 +86,71 @@ k_hoist_corr(DevCtx cx, const u64 *sign, const u64 *key, u64 *corr, uint32_t l) 
 }
 // prod[z][K][I][n] = sum_J D_s[I][J][perm_z[n]] * key_z[J][K][I][n] + corr_z[K][I][n] for pair z with source s.
 // D_s[I][J] is row (I * l + J) of source s's converted digits, or limb J of the source's own c1
-// when I == J (SEAL's shortcut: the NTT-form limb is used as is).  grid = (N/512, l+1, pairs).
+// when I == J (SEAL's shortcut: the NTT-form limb is used as is).
+// The key is two thirds of what a pair reads (2 l (l+1) N words against l (l+1) N digit words), and pairs
+// with the same Galois element share it (the same rotation of several sources: the three convolutions of
+// Harris, the 32 instances of a batched handle): a workgroup therefore serves a GROUP of up to
+// HOIST_GROUP pairs of one element — permutation indices, key words and the correction loaded once, one
+// gather + 128-bit accumulator set per member.  grid = (N/512, l+1, groups).
+#ifndef EVAH_HOIST_GROUP
+#define EVAH_HOIST_GROUP 4 // 1: one pair per workgroup (the r2 form; A/B switch of the build)
+#endif
+constexpr int HOIST_GROUP = EVAH_HOIST_GROUP;
+struct HoistGroups {
+  uint8_t first[KS_BATCH_MAX], count[KS_BATCH_MAX]; // group g = member[first[g] .. first[g] + count[g])
+  uint8_t member[KS_BATCH_MAX];                     // pair indices, grouped by Galois element
+};
 __global__ void __launch_bounds__(256)
-k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistTab tab, u64 *prod, size_t prod_bs, uint32_t l) {
+k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistTab tab, HoistGroups grp, u64 *prod, size_t prod_bs, uint32_t l) {
   const uint32_t I = blockIdx.y, kap = (I == l) ? cx.k - 1 : I;
-  const uint32_t z = blockIdx.z;
+  // the group's pair indices are made wave-uniform scalars explicitly: indexing the kernel-argument tables with
+  // a byte that was loaded from another kernel-argument table otherwise compiles to scalar loads whose base
+  // register is not dword-aligned (base = table + z, offset = 7 z) — a memory aperture violation on gfx950
+  const uint32_t g = blockIdx.z, first = __builtin_amdgcn_readfirstlane(grp.first[g]), cnt = __builtin_amdgcn_readfirstlane(grp.count[g]);
+  const uint32_t z0 = __builtin_amdgcn_readfirstlane(grp.member[first]);
   const size_t n = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
   const DevPrime pm = cx.primes[kap];
   const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
-  const uint2 pi = *reinterpret_cast<const uint2 *>(tab.perm[z] + n);
-  const u64 *key = tab.key[z] + (size_t)kap * N + n;
-  const u64 *dg = digits + tab.src[z] * dg_bs + (size_t)I * l * N, *own = tab.c1[z];
-  u128_t a0x = {0, 0}, a0y = {0, 0}, a1x = {0, 0}, a1y = {0, 0};
+  const uint2 pi = *reinterpret_cast<const uint2 *>(tab.perm[z0] + n);
+  const u64 *key = tab.key[z0] + (size_t)kap * N + n;
+  const u64 *dg[HOIST_GROUP], *own[HOIST_GROUP];
+  u128_t a0x[HOIST_GROUP], a0y[HOIST_GROUP], a1x[HOIST_GROUP], a1y[HOIST_GROUP];
+#pragma unroll
+  for (int t = 0; t < HOIST_GROUP; t++) {
+    const uint32_t z = __builtin_amdgcn_readfirstlane(grp.member[first + (t < (int)cnt ? t : 0)]);
+    dg[t] = digits + tab.src[z] * dg_bs + (size_t)I * l * N;
+    own[t] = tab.c1[z];
+    a0x[t] = a0y[t] = a1x[t] = a1y[t] = {0, 0};
+  }
   // operands are canonical (< q < 2^60): 256 products fit the 128-bit accumulators, l <= k - 1 < 64
   for (uint32_t J = 0; J < l; J++) {
-    const u64 *op = (I == J) ? own + (size_t)J * N : dg + (size_t)J * N;
-    const u64 ox = op[pi.x], oy = op[pi.y];
     const ulonglong2 k0 = ld2(key + J * key_digit), k1 = ld2(key + J * key_digit + (size_t)cx.k * N);
-    acc128(a0x, ox, k0.x);
-    acc128(a0y, oy, k0.y);
-    acc128(a1x, ox, k1.x);
-    acc128(a1y, oy, k1.y);
+#pragma unroll
+    for (int t = 0; t < HOIST_GROUP; t++) {
+      if (t >= (int)cnt) break; // block-uniform
+      const u64 *op = (I == J) ? own[t] + (size_t)J * N : dg[t] + (size_t)J * N;
+      const u64 ox = op[pi.x], oy = op[pi.y];
+      acc128(a0x[t], ox, k0.x);
+      acc128(a0y[t], oy, k0.y);
+      acc128(a1x[t], ox, k1.x);
+      acc128(a1y[t], oy, k1.y);
+    }
   }
-  const u64 *cr = tab.corr[z] + (size_t)I * N + n;
+  const u64 *cr = tab.corr[z0] + (size_t)I * N + n;
   const ulonglong2 c0 = ld2(cr), c1c = ld2(cr + (size_t)(l + 1) * N);
-  ulonglong2 r0, r1;
-  r0.x = addmod(barrett128(a0x, pm), c0.x, pm.q);
-  r0.y = addmod(barrett128(a0y, pm), c0.y, pm.q);
-  r1.x = addmod(barrett128(a1x, pm), c1c.x, pm.q);
-  r1.y = addmod(barrett128(a1y, pm), c1c.y, pm.q);
-  u64 *pr = prod + z * prod_bs + (size_t)I * N + n;
-  st2(pr, r0);
-  st2(pr + (size_t)(l + 1) * N, r1);
+#pragma unroll
+  for (int t = 0; t < HOIST_GROUP; t++) {
+    if (t >= (int)cnt) break;
+    const uint32_t z = __builtin_amdgcn_readfirstlane(grp.member[first + t]);
+    ulonglong2 r0, r1;
+    r0.x = addmod(barrett128(a0x[t], pm), c0.x, pm.q);
+    r0.y = addmod(barrett128(a0y[t], pm), c0.y, pm.q);
+    r1.x = addmod(barrett128(a1x[t], pm), c1c.x, pm.q);
+    r1.y = addmod(barrett128(a1y[t], pm), c1c.y, pm.q);
+    u64 *pr = prod + z * prod_bs + (size_t)I * N + n;
+    st2(pr, r0);
+    st2(pr + (size_t)(l + 1) * N, r1);
+  }
 }
 
 // zeros[0] (low word) = number of zero digit coefficients seen, zeros[1 + e] = (source << 48 | J << 32 | k).
@@ -334,12 +367,34 @@ static void rotation_set(evah_ctx *c, uint32_t l, const std::vector<RotPair> &pa
         ht.c1[r] = pr[r].src + pr[r].src_ps;
         ht.src[r] = (uint8_t)pr[r].src_idx;
       }
+      // pairs of one Galois element (same key, permutation and correction) go to one workgroup, HOIST_GROUP at a time
+      HoistGroups hg{};
+      uint32_t n_groups = 0, filled = 0;
+      {
+        std::vector<char> taken(np, 0);
+        for (uint32_t r = 0; r < np; r++) {
+          if (taken[r]) continue;
+          uint32_t in_group = 0;
+          for (uint32_t q = r; q < np; q++) {
+            if (taken[q] || pr[q].elt != pr[r].elt) continue;
+            if (in_group == (uint32_t)HOIST_GROUP) { // start the next group of this element
+              hg.count[n_groups++] = (uint8_t)in_group;
+              in_group = 0;
+            }
+            if (in_group == 0) hg.first[n_groups] = (uint8_t)filled;
+            hg.member[filled++] = (uint8_t)q;
+            taken[q] = 1;
+            in_group++;
+          }
+          hg.count[n_groups++] = (uint8_t)in_group;
+        }
+      }
       Scratch perm(c, (size_t)np * 2 * pps); // only the c0 slots (even polys) are filled and read
       rot_perm_launch(c, l, pr, np, perm.d, 1);
       Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N);
       {
         ProfScope ps(c, KC_KSMAC);
-        hipLaunchKernelGGL(k_hoist_mac, dim3(c->N / 512, l + 1, np), dim3(256), 0, c->stream, c->dev, dg.d, dg_bs, ht, prod.d, prod_bs, l);
+        hipLaunchKernelGGL(k_hoist_mac, dim3(c->N / 512, l + 1, n_groups), dim3(256), 0, c->stream, c->dev, dg.d, dg_bs, ht, hg, prod.d, prod_bs, l);
         HIPCHK(hipGetLastError());
         // the terms of recorded zero coefficients (returns at once when there are none)
         hipLaunchKernelGGL(k_hoist_fix, dim3(c->N / 256, l + 1, np), dim3(256), 0, c->stream, c->dev, flag.d, ht, prod.d, prod_bs, l);
