@@ -167,3 +167,24 @@ def test_output_that_is_an_input_keeps_its_handle():
         assert np.abs(np.array(res['same']) - np.array(inputs['x'])).max() < 1e-4
         assert np.abs(np.array(res['twice']) - 2 * np.array(inputs['x'])).max() < 1e-4
     assert np.array_equal(out.get('same')[4], enc.get('x')[4])
+
+
+def test_unreduced_input_words_are_an_error_at_execute():
+    """a ciphertext handed over as words (a file, a numpy array) is untrusted: a word >= its prime breaks the
+    kernels' lazy-reduction bounds, so execute() refuses it (r2 advisor finding) — checked once per value"""
+    from eva.seal import SEALValuation
+    compiled, params, sig = _prog()
+    pub, sec = generate_keys(params, 5)
+    enc = pub.encrypt(_inputs(1), sig)
+    good = enc.get('x')
+    words = np.array(good[4], dtype=np.uint64).reshape(good[1], good[2], -1)
+    v = SEALValuation()
+    v._set_cipher('y', np.array(enc.get('y')[4], dtype=np.uint64).reshape(words.shape), enc.get('y')[3])
+    bad = words.copy()
+    bad[1, 0, 17] = np.uint64(2 ** 63)
+    v._set_cipher('x', bad, good[3])
+    with pytest.raises(RuntimeError, match="not reduced modulo its prime"):
+        pub.execute(compiled, v)
+    v._set_cipher('x', words, good[3])
+    out = pub.execute(compiled, v)
+    _same(out, pub.execute(compiled, enc))

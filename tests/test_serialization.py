@@ -177,3 +177,56 @@ def test_malformed_files_and_values_are_rejected(tmp_path):
     open(vpath, "wb").write(rawv)
     with pytest.raises(RuntimeError, match="shape"):
         load(vpath)
+
+
+def test_key_files_with_unreduced_words_are_rejected(tmp_path):
+    """the kernels' lazy-reduction bounds assume canonical residues: a key file with a word >= its prime, or a
+    secret key that is not ternary, is an error at load time (r2 advisor finding), not a silently wrong result"""
+    import struct
+    from eva import EvaProgram, Input, Output, save, load
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    prog = EvaProgram('p', vec_size=8)
+    with prog:
+        Output('y', Input('x') * Input('x'))
+    prog.set_input_scales(30)
+    prog.set_output_ranges(20)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    pub, sec = generate_keys(params, 3)
+    pp, sp = str(tmp_path / "pub"), str(tmp_path / "sec")
+    save(pub, pp)
+    save(sec, sp)
+    assert load(pp).poly_modulus_degree == pub.poly_modulus_degree
+    raw = bytearray(open(pp, "rb").read())
+    assert struct.unpack("<Q", raw[-8:])[0] == 0   # no Galois keys in this program: the file ends with their count
+    raw[-16:-8] = struct.pack("<Q", 2 ** 64 - 1)  # the last word of the relinearization key: above any 60-bit prime
+    open(pp, "wb").write(raw)
+    with pytest.raises(RuntimeError, match="not reduced modulo its prime"):
+        load(pp)
+    raw = bytearray(open(sp, "rb").read())
+    N = pub.poly_modulus_degree
+    at = 12 + 4 + 8 + 8 * len(list(pub.primes)) + 8   # header, N, prime vector, length of s
+    raw[at] = 5                                        # first coefficient of s := 5
+    open(sp, "wb").write(raw)
+    with pytest.raises(RuntimeError, match="ternary"):
+        load(sp)
+    raw = bytearray(open(sp, "rb").read())
+    raw[at] = 1
+    raw[-8:] = struct.pack("<Q", 2 ** 63)
+    open(sp, "wb").write(raw)
+    with pytest.raises(RuntimeError, match="not reduced modulo its prime"):
+        load(sp)
+
+
+def test_integral_exponents_of_any_type():
+    from eva import EvaProgram, Input, Output, evaluate
+    prog = EvaProgram('pow', vec_size=4)
+    with prog:
+        x = Input('x')
+        Output('a', x ** np.int64(3))
+        Output('b', x ** 2)
+        for bad in (0, -1, 2.0, True, "2"):
+            with pytest.raises(ValueError):
+                x ** bad
+    out = evaluate(prog, {'x': [1.0, 2.0, 3.0, -1.0]})
+    assert out['a'] == [1.0, 8.0, 27.0, -1.0] and out['b'] == [1.0, 4.0, 9.0, 1.0]

@@ -191,3 +191,56 @@ def test_round_trip_and_rejects(tmp_path):
         load(path)
     with pytest.raises(ValueError):
         save(compiled, path, format="json")
+
+
+def test_untrusted_sizes_and_signatures_are_bounded_before_use(schema, tmp_path):
+    """r2 advisor findings: a ConstantValue's `size` comes from the file and used to size an allocation before it
+    was compared with the program's vec_size (a 30-byte file asking for 32 GiB); signatures / parameters were
+    loaded without range checks (vec_size 0 divided by zero in encrypt)."""
+    P, CV = schema["Program"], schema["ConstantValue"]
+
+    def program_with(cv, vec_size=8):
+        m = P(ir_version=2, name="hostile", vec_size=vec_size)
+        t = m.terms.add(op=3)
+        a = t.attributes.add(key=3)
+        a.constant_value.CopyFrom(cv)
+        o = m.terms.add(op=2, operands=[0])
+        m.outputs.add(term=1, name="y")
+        kt = schema["KnownType"](creator="x")
+        kt.contents.Pack(m)
+        path = str(tmp_path / "hostile")
+        open(path, "wb").write(kt.SerializeToString())
+        return path
+    # sparse constant expanding to 2^32 - 1 doubles: rejected by the size check, nothing allocated
+    with pytest.raises(RuntimeError, match="does not fit the vector size"):
+        load(program_with(CV(size=2 ** 32 - 1, values=[1.0], sparse_indices=[0])))
+    with pytest.raises(RuntimeError, match="does not fit the vector size"):
+        load(program_with(CV(size=3, values=[1.0, 2.0, 3.0])))            # 3 does not divide 8
+    with pytest.raises(RuntimeError, match="does not divide its size"):
+        load(program_with(CV(size=8, values=[1.0, 2.0, 3.0])))            # dense values must tile `size`
+    assert load(program_with(CV(size=4, values=[1.0, 2.0]))).vec_size == 8  # the legal shapes still load
+    path = str(tmp_path / "sig")
+    for bad in (dict(vec_size=0), dict(vec_size=12), dict(vec_size=-8)):
+        S = schema["CKKSSignature"](**bad)
+        kt = schema["KnownType"]()
+        kt.contents.Pack(S)
+        open(path, "wb").write(kt.SerializeToString())
+        with pytest.raises(RuntimeError, match="power of two"):
+            load(path)
+    for field, val in (("input_type", 7), ("scale", -1), ("level", -2)):
+        S = schema["CKKSSignature"](vec_size=16)
+        S.inputs["a"].input_type, S.inputs["a"].scale, S.inputs["a"].level = 1, 30, 0
+        setattr(S.inputs["a"], field, val)
+        kt = schema["KnownType"]()
+        kt.contents.Pack(S)
+        open(path, "wb").write(kt.SerializeToString())
+        with pytest.raises(RuntimeError, match="invalid encoding info"):
+            load(path)
+    for kw in (dict(prime_bits=[60, 61], poly_modulus_degree=8192), dict(prime_bits=[60, 60], poly_modulus_degree=3000),
+               dict(prime_bits=[], poly_modulus_degree=8192), dict(prime_bits=[60] * 70, poly_modulus_degree=8192)):
+        Q = schema["CKKSParameters"](**kw)
+        kt = schema["KnownType"]()
+        kt.contents.Pack(Q)
+        open(path, "wb").write(kt.SerializeToString())
+        with pytest.raises(RuntimeError, match="parse message"):
+            load(path)
