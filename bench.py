@@ -342,7 +342,9 @@ def limb_sharded(args, dist):
                            "parallelism": f"RNS limbs over {G} shard(s) on {world} GPU(s): limb i on shard i mod G; per key switch "
                                           "all-gather of the digits + broadcast of the special limb, per rescale one broadcast",
                            "exchange": "RCCL (torch.distributed nccl) on device buffers" if world > 1 else "device copies between the shards' queues (one GPU)",
-                           "exchange_bytes_per_gpu_per_triple": int(xbytes)},
+                           "exchange_bytes_per_gpu_per_triple": int(xbytes),
+                           "key_bytes": {"whole_key": int(key_host.nbytes),
+                                         "per_shard_here": [int(sh.ctx.key_bytes()) for sh in ev.shards.values() if hasattr(sh, "ctx")]}},
                 "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "achieved": round(triple_bytes(N, l) * value / max(world, 1) / 1e9, 1),
                              "frac": round(triple_bytes(N, l) * value / max(world, 1) / 1e9 / HBM_PEAK_GBPS, 4),

@@ -42,6 +42,7 @@ _SIGS = {
     "evah_ct_assign": [_vp, _vp, _vp],
     "evah_ctx_wait": [_vp, _vp],
     "evah_ctx_transfer_stats": [_vp, _u64p],
+    "evah_ctx_key_bytes": [_vp, _u64p],
     "evah_pt_copy": [_vp, _vp, _vpp],
     "evah_pt_write": [_vp, _vp, _u64p],
     "evah_capture_begin": [_vp, _vpp, C.c_uint32],
@@ -439,6 +440,12 @@ class Context:
         out = (C.c_uint64 * 6)()
         _chk(_lib.evah_ctx_transfer_stats(self.h, out))
         return tuple(int(x) for x in out)
+
+    def key_bytes(self):
+        """bytes of HBM the evaluation keys of this device state occupy (a limb shard holds its prime rows only)"""
+        out = C.c_uint64()
+        _chk(_lib.evah_ctx_key_bytes(self.h, C.byref(out)))
+        return int(out.value)
 
     def mem_info(self):
         a, b = C.c_size_t(), C.c_size_t()

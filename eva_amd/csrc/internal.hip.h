@@ -129,6 +129,10 @@ struct KeyDev {
   u64 *d = nullptr;
   uint32_t n_digits = 0;
   size_t bytes = 0;
+  // prime rows stored per (digit, polynomial): k for a whole key [digits][2][k][N]; a limb shard that
+  // set its map before the upload keeps only its own data limbs and the special prime
+  // ([digits][2][rows][N], row y = prime shard + y * shards, last row = the special prime)
+  uint32_t rows = 0;
 };
 
 } // namespace evah
@@ -174,6 +178,7 @@ struct SharedDev {
   double2 *enc_roots = nullptr;     // CKKS encoder: inverse-FFT roots in the order the stages consume them
   double enc_last_root[2] = {0, 0}; // the single root of the last stage (scaled by fix on the host per call)
   uint32_t *enc_slot_map = nullptr; // slot i (and its conjugate, at slots + i) -> FFT input index
+  uint32_t key_rows = 0, key_shard = 0; // evaluation keys: 0 none yet, 1 whole, 2 the prime rows of limb shard `key_shard`
   uint64_t xfer[6] = {0, 0, 0, 0, 0, 0}; // evah_ctx_transfer_stats: ct up / down, pt up / down, bytes up / down
   ~SharedDev() {
     (void)hipSetDevice(device);

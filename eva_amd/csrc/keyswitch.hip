@@ -100,6 +100,7 @@ bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t targ
   kb.prod_bs = (size_t)2 * (l + 1) * N;
   for (uint32_t b = 0; b < n; b++) {
     if (keys[b]->n_digits < l) throw std::runtime_error("key switching key has too few digits");
+    if (keys[b]->rows != c->k) throw std::logic_error("this context holds a limb shard's key rows: use the evah_shard_* entry points");
     kb.keys.key[b] = keys[b]->d;
   }
   if (target_tab) kb.targets = *target_tab; // target == nullptr: separately allocated targets

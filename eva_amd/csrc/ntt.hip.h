@@ -359,6 +359,7 @@ constexpr int KS_BATCH_MAX = 64;
 #endif
 struct KsKeys {
   const u64 *key[KS_BATCH_MAX];
+  uint32_t rows; // 0: whole keys (k prime rows); else a limb shard's rows (KeyDev::rows), indexed by local limb
 };
 // Base pointers of a batch of separately allocated polynomials (2 per instance), passed by value.
 struct PtrTab {
@@ -437,7 +438,10 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   const int T = blockDim.x;
   const uint32_t pre = cx.logN - P;
   const uint32_t sub0 = tile_idx << logC, gbase = sub0 << P;
-  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
+  // key rows: by prime for a whole key; by local limb (last row: the special prime) for a shard's rows
+  const uint32_t krows = keys.rows ? keys.rows : cx.k;
+  const uint32_t krow = keys.rows ? (kap == cx.k - 1 ? krows - 1 : blockIdx.y) : kap;
+  const size_t N = cx.N, key_digit = (size_t)2 * krows * N;
   const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
 
   // The twiddles of this tile's sub-transforms are the same for every digit J: stage them in LDS
@@ -480,12 +484,12 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   load_digits(0, dreg);
   for (uint32_t J = 0; J < l; J++) {
     ulonglong2 k0r[NPAIR], k1r[NPAIR];
-    const u64 *kp = key + J * key_digit + (size_t)kap * N + gbase;
+    const u64 *kp = key + J * key_digit + (size_t)krow * N + gbase;
 #pragma unroll
     for (int it = 0; it < NPAIR; it++) {
       const int idx = 2 * (threadIdx.x + it * T);
       k0r[it] = *reinterpret_cast<const ulonglong2 *>(kp + idx);
-      k1r[it] = *reinterpret_cast<const ulonglong2 *>(kp + (size_t)cx.k * N + idx);
+      k1r[it] = *reinterpret_cast<const ulonglong2 *>(kp + (size_t)krows * N + idx);
     }
     u64 val[NTT_R];
     const uint32_t Jn = J + 1 < l ? J + 1 : J;

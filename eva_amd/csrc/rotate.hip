@@ -292,6 +292,7 @@ static RotPair rot_pair(evah_ctx *c, const u64 *src, size_t src_ps, uint32_t src
   auto kit = c->sh->galois.find(p.elt);
   if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
   if (kit->second.n_digits < l) throw std::runtime_error("key switching key has too few digits");
+  if (kit->second.rows != c->k) throw std::logic_error("this context holds a limb shard's key rows: use the evah_shard_* entry points");
   p.key = &kit->second;
   p.perm = perm_table(c, p.elt);
   return p;

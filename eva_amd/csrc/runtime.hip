@@ -228,9 +228,35 @@ int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digit
   if (n_digits == 0 || n_digits > c->k - 1) throw std::invalid_argument("invalid key digit count");
   KeyDev kd;
   kd.n_digits = n_digits;
-  kd.bytes = sizeof(u64) * (size_t)n_digits * 2 * c->k * c->N;
+  // A limb shard (evah_ctx_set_shard before the upload) multiplies digits only into its own limbs and,
+  // when it owns it at that level, the special prime: it keeps those prime rows of the key and nothing else
+  // — (ceil((k-1)/G) + 1) / k of the key per shard.
+  const uint32_t s = c->dev.p0, G = c->dev.pstep;
+  const bool local_rows = G > 1;
+  if (c->sh->key_rows && c->sh->key_rows != (local_rows ? 1u : 0u) + 1u)
+    throw std::logic_error("the keys of this device state were uploaded under a different shard map");
+  kd.rows = local_rows ? (c->k - 1 > s ? (c->k - 1 - s + G - 1) / G : 0) + 1 : c->k;
+  kd.bytes = sizeof(u64) * (size_t)n_digits * 2 * kd.rows * c->N;
   HIPCHK(hipMalloc(&kd.d, kd.bytes));
-  HIPCHK(hipMemcpy(kd.d, data, kd.bytes, hipMemcpyHostToDevice));
+  if (!local_rows) {
+    HIPCHK(hipMemcpy(kd.d, data, kd.bytes, hipMemcpyHostToDevice));
+  } else {
+    const size_t row = sizeof(u64) * c->N;
+    hipError_t e = hipSuccess;
+    for (uint32_t dk = 0; dk < 2 * n_digits && e == hipSuccess; dk++) {
+      // rows s, s + G, ... of this (digit, polynomial): one strided copy; then the special prime's row
+      const u64 *src = (const u64 *)data + (size_t)dk * c->k * c->N;
+      u64 *dst = kd.d + (size_t)dk * kd.rows * c->N;
+      if (kd.rows > 1) e = hipMemcpy2D(dst, row, src + (size_t)s * c->N, row * G, row, kd.rows - 1, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(dst + (size_t)(kd.rows - 1) * c->N, src + (size_t)(c->k - 1) * c->N, row, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+      (void)hipFree(kd.d);
+      HIPCHK(e);
+    }
+  }
+  c->sh->key_rows = local_rows ? 2 : 1;
+  c->sh->key_shard = s;
   if (kind == EVAH_KEY_RELIN) {
     if (c->sh->relin.d) (void)hipFree(c->sh->relin.d);
     c->sh->relin = kd;
@@ -498,6 +524,14 @@ int evah_ctx_wait(evah_ctx *waiter, evah_ctx *signaller) {
 int evah_ctx_transfer_stats(evah_ctx *c, uint64_t out[6]) {
   API_BEGIN
   for (int i = 0; i < 6; i++) out[i] = c->sh->xfer[i];
+  API_END
+}
+
+int evah_ctx_key_bytes(evah_ctx *c, uint64_t *bytes) {
+  API_BEGIN
+  uint64_t b = c->sh->relin.d ? c->sh->relin.bytes : 0;
+  for (auto &kv : c->sh->galois) b += kv.second.bytes;
+  *bytes = b;
   API_END
 }
 

@@ -42,6 +42,7 @@ void need_shard(evah_ctx *c) {
   if (c->dev.pstep < 1 || (c->dev.pstep == 1 && c->dev.p0 != 0)) throw std::logic_error("context has no shard map");
 }
 const KeyDev &shard_key(evah_ctx *c, int kind, uint32_t elt) {
+  if (c->sh->key_rows == 2 && c->sh->key_shard != c->dev.p0) throw std::logic_error("the keys of this device state hold another shard's prime rows");
   if (kind == EVAH_KEY_RELIN) {
     if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
     return c->sh->relin;
@@ -58,6 +59,8 @@ extern "C" {
 int evah_ctx_set_shard(evah_ctx *c, uint32_t shard, uint32_t n_shards) {
   API_BEGIN
   if (n_shards < 1 || n_shards > 64 || shard >= n_shards) throw std::invalid_argument("invalid shard index / count");
+  if (c->sh->key_rows == 2 && (shard != c->dev.p0 || n_shards != c->dev.pstep))
+    throw std::logic_error("the keys of this device state hold the prime rows of its current shard map");
   c->dev.p0 = shard;
   c->dev.pstep = n_shards;
   // scale checks see local limb counts: allow what the largest level with that many local limbs allows
@@ -193,6 +196,7 @@ int evah_shard_ks_products(evah_ctx *c, const evah_ct *a, uint32_t poly, uint32_
     kb.istep = G;
     kb.nout = ni;
     kb.keys.key[0] = key.d;
+    kb.keys.rows = key.rows == c->k ? 0 : key.rows;
     launch_ks_inner(c, c->logN / 2, a ? a->d + (size_t)poly * a->ps : nullptr, sc.d, kb, prod->buf->d, l);
   }
   if (owner) {

@@ -888,9 +888,12 @@ public:
   // captured hipGraph: per call the host refills the input slots, launches one graph, downloads.
   bool use_graphs = true; // EVA_GRAPH=0 disables
   HipValuation execute(Program &program, const HipValuation &inputs) {
-    ensure_device();
     const bool multi = devices.size() > 1;
-    if (multi && shard_mode == "limb") return execute_limb(program, inputs);
+    if (multi && shard_mode == "limb") {
+      ensure_device(false);
+      return execute_limb(program, inputs);
+    }
+    ensure_device();
     const bool subdag = multi && shard_mode == "subdag";
     if (!subdag && graphs_enabled() && graphable(program, inputs) && resident_bytes(inputs) <= graph_copy_limit) {
       auto it = plans.find(&program);
@@ -986,6 +989,21 @@ public:
     std::array<uint64_t, 6> st{0, 0, 0, 0, 0, 0};
     if (dev) chk(evah_ctx_transfer_stats(dev->h, st.data()));
     return st;
+  }
+
+  // HBM bytes of evaluation keys per limb shard (after a limb-sharded execute()), then of this device's whole keys
+  std::vector<uint64_t> key_bytes() {
+    std::vector<uint64_t> out;
+    if (limb)
+      for (size_t s = 0; s < limb->group().size(); s++) {
+        uint64_t b = 0;
+        chk(evah_ctx_key_bytes(limb->group().ctx[s], &b));
+        out.push_back(b);
+      }
+    uint64_t b = 0;
+    if (dev) chk(evah_ctx_key_bytes(dev->h, &b));
+    out.push_back(b);
+    return out;
   }
 
   // A batch of independent executions of one program (BASELINE config 4): instances are grouped
@@ -1158,7 +1176,7 @@ private:
       check_devices();
       limb.reset();
       limb_const.clear();
-      limb = std::make_unique<LimbShardEvaluator>(*host, make_device_group(devices, dev, device, *host, [this](evah_ctx *c) { upload_eval_keys(c); }, true));
+      limb = std::make_unique<LimbShardEvaluator>(*host, make_limb_group(devices, *host, [this](evah_ctx *c) { upload_eval_keys(c); }));
       limb_ids = devices;
     }
     LimbShardEvaluator &ev = *limb;
@@ -1550,7 +1568,7 @@ private:
   }
   // coeff_pt: the host encoder's coefficient-form plaintext, or (null) values: the slot values for the device encoder
   HostCipher encrypt_on_device(const HostPlain *coeff_pt, const std::vector<double> *values, double scale, uint32_t limbs, SecureRng &rng) {
-    ensure_device();
+    ensure_device(false);
     if (!pk_uploaded) {
       chk(evah_client_key_upload(dev->h, EVAH_KEY_PUBLIC, (const uint64_t *)pk.data.data()));
       pk_uploaded = true;
@@ -1585,13 +1603,18 @@ private:
     return out;
   }
 
-  void ensure_device() {
-    if (dev) return;
-    if (!holder->dev) holder->dev = std::make_shared<DeviceCtx>(host->N, host->primes, device);
-    dev = holder->dev; // may have been created by the secret half of the key pair (decrypt first)
-    chk(evah_key_upload(dev->h, EVAH_KEY_RELIN, 0, relin.n_digits, (const uint64_t *)relin.data.data()));
-    for (auto &kv : galois)
-      chk(evah_key_upload(dev->h, EVAH_KEY_GALOIS, kv.first, kv.second.n_digits, (const uint64_t *)kv.second.data.data()));
+  // eval_keys = false: encryption and limb-sharded execution (whose shards hold their own rows of the
+  // keys) do not need the whole evaluation keys in this device's memory
+  bool eval_keys_uploaded = false;
+  void ensure_device(bool eval_keys = true) {
+    if (!dev) {
+      if (!holder->dev) holder->dev = std::make_shared<DeviceCtx>(host->N, host->primes, device);
+      dev = holder->dev; // may have been created by the secret half of the key pair (decrypt first)
+    }
+    if (eval_keys && !eval_keys_uploaded) {
+      upload_eval_keys(dev->h);
+      eval_keys_uploaded = true;
+    }
   }
 };
 

@@ -249,6 +249,7 @@ PYBIND11_MODULE(_eva, m) {
       .def_readwrite("devices", &HipPublic::devices, "device index per member of the multi-GPU modes (a repeated index = several contexts on one GPU)")
       .def_readwrite("shard_mode", &HipPublic::shard_mode, "'' (one device) | 'subdag' | 'limb' | 'dag' — how execute() / execute_batch() use `devices`")
       .def_readonly("last_subdag_plan", &HipPublic::last_subdag_plan, "(member, ops) per piece of the last sub-DAG split: prefix, components..., suffix")
+      .def("key_bytes", &HipPublic::key_bytes, "HBM bytes of evaluation keys: one entry per limb shard (when limb-sharded), then the whole keys on the context's own device (0 if never uploaded)")
       .def_readonly("last_exchanged_words", &HipPublic::last_exchanged_words, "uint64 words moved between shards by the last limb-sharded execute()")
       .def_readwrite("resident", &HipPublic::resident, "keep valuations in HBM: encrypt/execute return device handles and execute does not wait for the GPU (EVA_RESIDENT=0: host valuations)")
       .def_readwrite("graph_copy_limit", &HipPublic::graph_copy_limit, "device-resident inputs above this many bytes are walked eagerly instead of copied into a captured graph's slots")

@@ -60,6 +60,25 @@ inline DeviceGroup make_device_group(const std::vector<int> &ids, const std::sha
   return g;
 }
 
+// Limb sharding: member s is shard s of G = ids.size(), each with a device state of its own whose shard
+// map is set BEFORE the keys go up — the library then keeps only that shard's prime rows of every key
+// (evah_key_upload: its data limbs + the special prime, (ceil((k-1)/G) + 1)/k of the key), so a key set
+// that does not fit one device's memory is spread over the group.
+inline DeviceGroup make_limb_group(const std::vector<int> &ids, const HostContext &host, const std::function<void(evah_ctx *)> &upload_keys) {
+  DeviceGroup g;
+  g.ids = ids;
+  const uint32_t G = (uint32_t)ids.size();
+  for (uint32_t s = 0; s < G; s++) {
+    auto root = std::make_shared<DeviceCtx>(host.N, host.primes, ids[s]);
+    chk(evah_ctx_set_shard(root->h, s, G));
+    upload_keys(root->h);
+    g.roots.push_back(root);
+    g.forks.push_back(nullptr);
+    g.ctx.push_back(root->h);
+  }
+  return g;
+}
+
 // ------------------------------------------------------------------------------------ sub-DAG split
 
 inline uint32_t op_arity(uint32_t op) { return (op == (uint32_t)Op::Add || op == (uint32_t)Op::Sub || op == (uint32_t)Op::Mul) ? 2u : 1u; }
@@ -292,6 +311,7 @@ public:
     for (uint32_t s = 0; s < G; s++) chk(evah_ctx_set_shard(g.ctx[s], s, G));
   }
   uint32_t shards() const { return G; }
+  const DeviceGroup &group() const { return g; }
 
   // data: all limbs, [size][l][N] (plaintext: [l][N], size 0)
   ShardedValue upload(const u64 *data, uint32_t size, uint32_t l, double scale) {

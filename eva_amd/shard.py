@@ -49,12 +49,13 @@ class ShardedValue:
 class HipShard:
     """One shard on the MI355X backend: an evah_ctx with the limb -> prime map (shard, G)."""
 
-    def __init__(self, N, primes, shard, G, device=0, parent=None):
+    def __init__(self, N, primes, shard, G, device=0):
         from . import backend
         self.backend = backend
         self.N, self.primes, self.k, self.shard, self.G = N, list(primes), len(primes), shard, G
-        self.ctx = parent.fork() if parent is not None else backend.Context(N, primes, device=device)
-        self.shares_keys = parent is not None  # a fork shares its parent's tables and keys
+        # a device state of its own, and the shard map goes in BEFORE any key: evah_key_upload then keeps only
+        # this shard's prime rows (its data limbs + the special prime) of every key
+        self.ctx = backend.Context(N, primes, device=device)
         self.ctx.set_shard(shard, G)
 
     # ---- values: arrays hold the LOCAL limbs
@@ -161,17 +162,11 @@ class ShardedEvaluator:
     # ---- construction helpers
     @classmethod
     def in_process(cls, N, primes, G, make_shard=None, devices=None):
-        """All G shards here.  devices: one device index per shard (default: all on device 0, the
-        shards then share tables and keys)."""
+        """All G shards here.  devices: one device index per shard (default: all on device 0)."""
         shards = {}
         if make_shard is None:
-            root = None
             for s in range(G):
-                dev = devices[s] if devices else 0
-                same = root is not None and (not devices or devices[s] == devices[0])
-                shards[s] = HipShard(N, primes, s, G, device=dev, parent=root.ctx if same else None)
-                if root is None:
-                    root = shards[s]
+                shards[s] = HipShard(N, primes, s, G, device=devices[s] if devices else 0)
         else:
             for s in range(G):
                 shards[s] = make_shard(s)
@@ -211,16 +206,12 @@ class ShardedEvaluator:
         return ShardedValue(parts, 0, l, scale)
 
     def upload_relin_key(self, key):
-        for sh in self._key_holders():
+        for sh in self.shards.values():
             sh.upload_key(KEY_RELIN, 0, key)
 
     def upload_galois_key(self, elt, key):
-        for sh in self._key_holders():
+        for sh in self.shards.values():
             sh.upload_key(KEY_GALOIS, elt, key)
-
-    def _key_holders(self):
-        """shards that need their own copy of a key (forks of an earlier shard share its device state)"""
-        return [sh for sh in self.shards.values() if not getattr(sh, "shares_keys", False)]
 
     def download(self, v):
         """-> [size][l][N] (plaintext: [l][N]) assembled from the shards of THIS process; in the

@@ -127,6 +127,10 @@ int evah_ctx_wait(evah_ctx *waiter, evah_ctx *signaller);
  * The valuation of the reference "may hold device handles" (SURVEY.md 8(b)); tests assert that
  * encrypt -> execute -> decrypt moves no ciphertext across. */
 int evah_ctx_transfer_stats(evah_ctx *ctx, uint64_t out[6]);
+/* bytes of HBM the evaluation keys (relinearization + Galois) of this context's device state occupy.  After
+ * evah_ctx_set_shard(ctx, s, G) an upload keeps only shard s's prime rows of a key (its data limbs and the
+ * special prime): (ceil((k-1)/G) + 1) / k of the whole key. */
+int evah_ctx_key_bytes(evah_ctx *ctx, uint64_t *bytes);
 int evah_ct_info(const evah_ct *ct, uint32_t *size, uint32_t *limbs, double *scale);
 int evah_ct_download(evah_ctx *ctx, const evah_ct *ct, uint64_t *out /* [size][limbs][N] */);
 void evah_ct_free(evah_ctx *ctx, evah_ct *ct);

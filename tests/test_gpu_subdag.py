@@ -102,10 +102,45 @@ def test_limb_sharded_execute_bit_exact(G):
         out = pub.execute(compiled, enc)
         _same_as(out, ref, single)
     assert pub.last_exchanged_words > 0
+    # every shard holds its own prime rows of the keys and nothing else: its data limbs + the special prime
+    kb = pub.key_bytes()
+    k = len(list(pub.primes))
+    assert len(kb) == G + 1 and kb[-1] > 0
+    for s in range(G):
+        rows = len(range(s, k - 1, G)) + 1
+        assert kb[s] * k == kb[-1] * rows, (s, kb, rows, k)
+    assert sum(kb[:G]) == kb[-1] // k * (k - 1 + G)
     res = sec.decrypt(out, sig)
     from eva import evaluate
     want = evaluate(compiled, inputs)
     assert np.abs(np.array(res['y']) - np.array(want['y'])).max() < 1e-2
+
+
+def test_limb_sharded_context_never_uploads_the_whole_keys():
+    """limb mode chosen at key generation: the whole evaluation keys are never resident on one device"""
+    compiled, params, sig = _conv_chain(2)
+    params.poly_modulus_degree = 8192
+    pub, sec = generate_keys(params, 6, devices=[0, 0], shard="limb")
+    enc = pub.encrypt({'x': [0.5] * 1024}, sig)
+    out = pub.execute(compiled, enc)
+    kb = pub.key_bytes()
+    assert kb[-1] == 0 and all(b > 0 for b in kb[:2])
+    ref, _ = c_walk(pub, compiled, enc)
+    for name in out.names():
+        assert np.array_equal(out.get(name)[4], ref[name])
+    # library rules: a shard's rows cannot serve the unsharded entry points, and its map is fixed once keys are up
+    primes = [int(q) for q in pub.primes]
+    k, N = len(primes), 8192
+    ctx = backend.Context(N, primes)
+    ctx.set_shard(1, 2)
+    ctx.upload_relin_key(np.zeros((k - 1, 2, k, N), dtype=np.uint64))
+    assert ctx.key_bytes() == (k - 1) * 2 * (len(range(1, k - 1, 2)) + 1) * N * 8
+    ctx.set_shard(1, 2)
+    with pytest.raises(RuntimeError, match="current shard map"):
+        ctx.set_shard(0, 2)
+    ct = ctx.upload_ct(np.zeros((3, 1, N), dtype=np.uint64), 2.0 ** 30)
+    with pytest.raises(RuntimeError, match="limb shard's key rows"):
+        ctx.relinearize(ct)
 
 
 def test_dag_mode_deals_a_batch_over_the_members():
