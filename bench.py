@@ -545,6 +545,24 @@ def main():
     triples = args.steps * args.batch * world
     value = triples / dt
 
+    # With more than one issue queue the launches of the queues overlap, so a launch's HIP-event duration in the
+    # timed region is the time it SHARED the GPU for.  Outside the timed region: two steps on queue 0 alone, every
+    # launch bracketed, for the duration a kernel takes with the GPU to itself (what a rocprofv3 PMC pass, which
+    # serialises the kernels, reports as well).
+    prof_excl = None
+    if len(queues) > 1:
+        q0 = queues[0]
+        q0.profile_reset()
+        for _ in range(2):
+            for i0 in range(0, args.batch, G):
+                q0.profile(True)
+                hs, _outs = run_group(q0, range(i0, min(i0 + G, args.batch)))
+                q0.profile(False)
+                for h in hs:
+                    h.free()
+        q0.sync()
+        prof_excl = q0.profile_get()
+
     # ---- outside the timed region: one more step whose first output per group is downloaded and
     # compared with the CPU oracle on the same operands
     got = {}
@@ -587,6 +605,16 @@ def main():
                 "achieved": round(cb.get(dom, 0) / (avg_us * 1e-6) / 1e9, 1) if avg_us else None,
                 "sampling": (f"HIP events on the launch stream around every launch of 1 in {max(1, PROF_EVERY // G)} "
                              f"groups of {G} triples inside the timed region")}
+            if prof_excl and prof_excl.get(dom, (0, 0))[0]:
+                ex_us = prof_excl[dom][1] * 1e3 / prof_excl[dom][0]
+                roofline["dominant"].update({
+                    "concurrent_queues": len(queues),
+                    "avg_launch_us_alone": round(ex_us, 2), "launches_sampled_alone": prof_excl[dom][0],
+                    "achieved_alone": round(cb.get(dom, 0) / (ex_us * 1e-6) / 1e9, 1),
+                    "note": (f"{len(queues)} issue queues: launches of the queues overlap in the timed region, so avg_launch_us is the "
+                             "time a launch shared the GPU for; *_alone = the same launches on one queue, measured right after "
+                             "the timed region")})
+                roofline["by_class_us_alone"] = {c: round(v[1] * 1e3 / max(v[0], 1), 2) for c, v in prof_excl.items() if v[0]}
             roofline["by_class_us"] = {c: round(v[1] * 1e3 / max(v[0], 1), 2) for c, v in prof.items() if v[0]}
             roofline["by_class_share"] = {c: round(v[1] / kern_total_ms, 3) for c, v in prof.items() if v[0]}
 
