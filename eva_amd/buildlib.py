@@ -85,7 +85,7 @@ def build_host(force=False, verbose=False):
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-march=x86-64-v3", "-ffp-contract=off",
            "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
            "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", CSRC, "-I", hdir,
-           "-o", out] + cpps + ["-L", LIBDIR, "-leva_hip", "-Wl,-rpath,$ORIGIN/lib", "-lpthread"]
+           "-o", out] + cpps + ["-L", LIBDIR, "-leva_hip", "-Wl,-rpath,$ORIGIN/lib", "-lpthread", "-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

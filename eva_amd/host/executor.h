@@ -101,6 +101,9 @@ inline Valuation evaluate(Program &p, const Valuation &inputs) {
 using SchemeValue = std::variant<HostCipher, HostPlain, std::vector<double>>;
 struct HipValuation {
   std::unordered_map<std::string, SchemeValue> values;
+  // the encryption parameters the values belong to (SEALValuation::params, seal.h:23-27): set by encrypt(),
+  // execute() and load(); needed to write the valuation in the reference's SEAL wire format
+  std::shared_ptr<const HostContext> params;
 };
 
 // RAII device handles

@@ -124,9 +124,87 @@ PYBIND11_MODULE(_eva, m) {
     if (want_wire(format)) save_wire_to_file("CKKSSignature", wire::encode(o), path);
     else save_to_file(Kind::Signature, o, path);
   }, py::arg("obj"), py::arg("path"), py::arg("format") = "eva");
-  m.def("save", [](const HipValuation &o, const std::string &path) { save_to_file(Kind::Valuation, o, path); }, py::arg("obj"), py::arg("path"));
-  m.def("save", [](const HipPublic &o, const std::string &path) { save_to_file(Kind::Public, o, path); }, py::arg("obj"), py::arg("path"));
-  m.def("save", [](const HipSecret &o, const std::string &path) { save_to_file(Kind::Secret, o, path); }, py::arg("obj"), py::arg("path"));
+  // valuations and key contexts: this repo's container by default; format="seal" (or "seal+zlib" / "seal+zstd") = the
+  // reference's protobuf messages around SEAL's binary object format (seal.proto, seal_format.h)
+  auto seal_compr = [](const std::string &format, bool &seal) {
+    seal = true;
+    if (format == "seal") return sealfmt::None;
+    if (format == "seal+zlib") return sealfmt::Zlib;
+    if (format == "seal+zstd") return sealfmt::Zstd;
+    seal = false;
+    if (format == "native") return sealfmt::None;
+    throw std::invalid_argument("format must be 'native', 'seal', 'seal+zlib' or 'seal+zstd'");
+  };
+  m.def("save", [seal_compr](const HipValuation &o, const std::string &path, const std::string &format) {
+    bool seal = false;
+    const sealfmt::Compr c = seal_compr(format, seal);
+    if (seal) save_wire_to_file("SEALValuation", sealfmt::encode_valuation(o, c), path);
+    else save_to_file(Kind::Valuation, o, path);
+  }, py::arg("obj"), py::arg("path"), py::arg("format") = "native");
+  m.def("save", [seal_compr](const HipPublic &o, const std::string &path, const std::string &format) {
+    bool seal = false;
+    const sealfmt::Compr c = seal_compr(format, seal);
+    if (seal) save_wire_to_file("SEALPublic", sealfmt::encode_public(o, c), path);
+    else save_to_file(Kind::Public, o, path);
+  }, py::arg("obj"), py::arg("path"), py::arg("format") = "native");
+  m.def("save", [seal_compr](const HipSecret &o, const std::string &path, const std::string &format) {
+    bool seal = false;
+    const sealfmt::Compr c = seal_compr(format, seal);
+    if (seal) save_wire_to_file("SEALSecret", sealfmt::encode_secret(o, c), path);
+    else save_to_file(Kind::Secret, o, path);
+  }, py::arg("obj"), py::arg("path"), py::arg("format") = "native");
+  // test hooks of the SEAL object format
+  m.def("_blake2b_256", [](py::bytes data) {
+    const std::string s = data;
+    uint8_t out[32];
+    sealfmt::blake2b(out, 32, (const uint8_t *)s.data(), s.size());
+    return py::bytes((const char *)out, 32);
+  });
+  m.def("_seal_zstd_available", []() { return sealfmt::ZstdLib::get().ok(); });
+  // one SEAL object (the bytes of a SEALObject.data) from raw words: what tests/golden/export_seal_vectors.py hands to
+  // tools/seal_parity.cpp, which loads them with SEAL itself and compares SEAL's own save() with them
+  m.def("_seal_blob", [](const std::string &kind, uint32_t N, const std::vector<uint64_t> &primes,
+                         py::array_t<uint64_t, py::array::c_style | py::array::forcecast> data, double scale) {
+    HostContext h(N, std::vector<u64>(primes.begin(), primes.end()));
+    const u64 *d = (const u64 *)data.data();
+    auto shape_is = [&](std::initializer_list<py::ssize_t> want) {
+      if ((size_t)data.ndim() != want.size()) throw std::invalid_argument("wrong number of dimensions for a SEAL " + kind);
+      size_t i = 0;
+      for (py::ssize_t w : want) {
+        if (w >= 0 && data.shape(i) != w) throw std::invalid_argument("wrong shape for a SEAL " + kind);
+        i++;
+      }
+    };
+    std::string out;
+    if (kind == "parms") out = sealfmt::parms_obj(h, sealfmt::None);
+    else if (kind == "ciphertext") { shape_is({-1, -1, (py::ssize_t)N}); out = sealfmt::ciphertext_obj(h, (uint32_t)data.shape(0), (uint32_t)data.shape(1), scale, d, sealfmt::None); }
+    else if (kind == "plaintext") { shape_is({-1, (py::ssize_t)N}); out = sealfmt::plaintext_obj(h, (uint32_t)data.shape(0), scale, d, sealfmt::None); }
+    else if (kind == "public_key") { shape_is({2, (py::ssize_t)h.k, (py::ssize_t)N}); out = sealfmt::public_key_obj(h, d, sealfmt::None); }
+    else if (kind == "secret_key") { shape_is({(py::ssize_t)h.k, (py::ssize_t)N}); out = sealfmt::secret_key_obj(h, d, sealfmt::None); }
+    else if (kind == "relin_keys") {
+      shape_is({-1, 2, (py::ssize_t)h.k, (py::ssize_t)N});
+      SwitchKey k;
+      k.n_digits = (uint32_t)data.shape(0);
+      k.data.assign(d, d + data.size());
+      out = sealfmt::kswitch_obj(h, 1, {{0, &k}}, sealfmt::None);
+    } else throw std::invalid_argument("unknown SEAL object kind " + kind);
+    return py::bytes(out);
+  }, py::arg("kind"), py::arg("N"), py::arg("primes"), py::arg("data"), py::arg("scale") = 1.0);
+  m.def("_seal_galois_blob", [](uint32_t N, const std::vector<uint64_t> &primes, const std::map<uint32_t, py::array_t<uint64_t, py::array::c_style | py::array::forcecast>> &keys) {
+    HostContext h(N, std::vector<u64>(primes.begin(), primes.end()));
+    std::map<uint64_t, SwitchKey> own;
+    for (auto &kv : keys) {
+      if (kv.second.ndim() != 4 || kv.second.shape(1) != 2 || kv.second.shape(2) != (py::ssize_t)h.k || kv.second.shape(3) != (py::ssize_t)N || !(kv.first & 1) || kv.first >= 2 * N)
+        throw std::invalid_argument("wrong shape / element for a SEAL Galois key");
+      SwitchKey k;
+      k.n_digits = (uint32_t)kv.second.shape(0);
+      k.data.assign((const u64 *)kv.second.data(), (const u64 *)kv.second.data() + kv.second.size());
+      own.emplace((uint64_t)(kv.first - 1) / 2, std::move(k));
+    }
+    std::map<uint64_t, const SwitchKey *> slots;
+    for (auto &kv : own) slots.emplace(kv.first, &kv.second);
+    return py::bytes(sealfmt::kswitch_obj(h, slots.empty() ? 0 : N, slots, sealfmt::None));
+  }, py::arg("N"), py::arg("primes"), py::arg("keys"));
   m.def("load", [](const std::string &path) -> py::object {
     KnownType k = load_from_file(path);
     if (auto *p = std::get_if<std::unique_ptr<Program>>(&k)) return py::cast(std::move(*p));
@@ -234,10 +312,20 @@ PYBIND11_MODULE(_eva, m) {
         return py::make_tuple("raw", 0, 0, 1.0, py::cast(std::get<std::vector<double>>(it->second)));
       });
   py::class_<HipPublic, std::shared_ptr<HipPublic>>(mseal, "SEALPublic", "Public context: encryption and execution on the MI355X")
-      .def("encrypt", &HipPublic::encrypt, py::arg("inputs"), py::arg("signature"))
-      .def("execute", &HipPublic::execute, py::arg("program"), py::arg("inputs"))
+      .def("encrypt", [](HipPublic &p, const Valuation &inputs, const CKKSSignature &sig) {
+        HipValuation v = p.encrypt(inputs, sig);
+        v.params = p.host;
+        return v;
+      }, py::arg("inputs"), py::arg("signature"))
+      .def("execute", [](HipPublic &p, Program &program, const HipValuation &inputs) {
+        HipValuation v = p.execute(program, inputs);
+        v.params = p.host;
+        return v;
+      }, py::arg("program"), py::arg("inputs"))
       .def("execute_batch", [](HipPublic &p, Program &program, const std::vector<const HipValuation *> &inputs) {
-        return p.execute_batch(program, inputs);
+        std::vector<HipValuation> out = p.execute_batch(program, inputs);
+        for (HipValuation &v : out) v.params = p.host;
+        return out;
       }, py::arg("program"), py::arg("inputs"),
            "execute() for a list of independent input valuations of one program; instances run batch_chunk at a time as batched device handles")
       .def_readwrite("library_scheduler", &HipPublic::library_scheduler, "run the encrypted part of a program as one evah_execute (default) instead of the node-by-node host walk")
@@ -283,6 +371,7 @@ PYBIND11_MODULE(_eva, m) {
       .def("relin_key", [](const HipPublic &p) {
         return to_numpy(p.relin.data, {(py::ssize_t)p.relin.n_digits, 2, (py::ssize_t)p.host->k, (py::ssize_t)p.host->N});
       })
+      .def("public_key", [](const HipPublic &p) { return to_numpy(p.pk.data, {2, (py::ssize_t)p.host->k, (py::ssize_t)p.host->N}); })
       .def("galois_keys", [](const HipPublic &p) {
         py::dict d;
         for (auto &kv : p.galois)

@@ -301,6 +301,7 @@ template <class T> void save_to_file(Kind kind, const T &obj, const std::string 
 
 } // namespace evahost
 #include "wire.h"
+#include "seal_format.h"
 namespace evahost {
 
 // Program / CKKSParameters / CKKSSignature in the reference's own wire format (protobuf KnownType
@@ -325,8 +326,11 @@ inline KnownType load_from_file(const std::string &path) {
     if (type == "Program") return wire::decode_program(wire::In(payload));
     if (type == "CKKSParameters") return wire::decode_parameters(wire::In(payload));
     if (type == "CKKSSignature") return wire::decode_signature(wire::In(payload));
-    throw std::runtime_error("Unknown inner message type eva.msg." + type +
-                             " (SEAL-object messages of the reference are not readable here: seal.proto wraps SEAL's binary format)");
+    // the SEAL-object messages (seal.proto): SEAL's own binary object format inside, seal_format.h
+    if (type == "SEALValuation") return sealfmt::decode_valuation(wire::In(payload));
+    if (type == "SEALPublic") return sealfmt::decode_public(wire::In(payload));
+    if (type == "SEALSecret") return sealfmt::decode_secret(wire::In(payload));
+    throw std::runtime_error("Unknown inner message type eva.msg." + type);
   }
   if (r.pod<uint32_t>() != FORMAT_MAGIC) throw std::runtime_error("Could not parse message: not an eva_amd file");
   if (r.pod<uint32_t>() != FORMAT_VERSION) throw std::runtime_error("Serialization format version is not compatible");

@@ -9,7 +9,7 @@
 // (key = 1, value = 2) messages.  tests/test_wire_format.py checks every byte stream against the
 // official Python protobuf runtime built from the same schema.
 // The SEAL-object kinds (valuation, public and secret context: seal.proto wraps SEAL's binary
-// blobs) are NOT covered: those stay in this repo's container (serialization.h).
+// blobs) are in seal_format.h, which builds on the primitives here.
 #pragma once
 #include <cstring>
 #include <string>

@@ -10,6 +10,9 @@ development container).
 OUT_DIR/manifest.txt  : `key v0 v1 ...` lines (N, bits, scale_log2, rot_steps, enc_scale_bits)
 OUT_DIR/<name>.u64    : uint64 arrays, C order ([size][limbs][N] for ciphertexts,
                         [digit][2][k][N] for keys); OUT_DIR/<name>.f64 : float64 arrays
+OUT_DIR/seal_*.bin    : the same parameters, values and keys as SEAL objects, written by THIS REPO's writer of
+                        SEAL's binary format (eva_amd/host/seal_format.h) — seal_parity section 7 loads them with
+                        SEAL and compares SEAL's own save() with them byte for byte
 Test infrastructure only (it may import oracle/)."""
 import os
 import sys
@@ -67,6 +70,38 @@ def fresh(N, bits, seed=20260927):
     return d, bits
 
 
+def write_seal_objects(out, d, N):
+    """parameters, two ciphertexts, a plaintext, a public / secret key and both key sets in SEAL's object format"""
+    sys.path.insert(0, ROOT)
+    try:
+        from eva_amd import _eva
+    except Exception as e:  # the host module is not built: the arrays are still exported
+        print(f"SEAL objects not written ({e})")
+        return 0
+    primes = [int(q) for q in d["primes"]]
+    k = len(primes)
+    scale = 2.0 ** 10
+    if "pk" not in d:  # any residues serve: the public key is only carried, never used
+        rng = np.random.default_rng(7)
+        d["pk"] = np.stack([rng.integers(0, primes[i], size=(2, N), dtype=np.uint64) for i in range(k)], axis=1)
+
+    def elt_of(step):
+        return pow(3, step if step > 0 else N // 2 + step, 2 * N)
+    blobs = {
+        "seal_parms": _eva._seal_blob("parms", N, primes, np.zeros((1,), dtype=np.uint64)),
+        "seal_ct_a2": _eva._seal_blob("ciphertext", N, primes, d["a2"], scale),
+        "seal_ct_a3": _eva._seal_blob("ciphertext", N, primes, d["a3"], scale),
+        "seal_pt": _eva._seal_blob("plaintext", N, primes, d["pt"], scale),
+        "seal_pk": _eva._seal_blob("public_key", N, primes, d["pk"]),
+        "seal_sk": _eva._seal_blob("secret_key", N, primes, d["sk_ntt"]),
+        "seal_relin": _eva._seal_blob("relin_keys", N, primes, d["relin_key"]),
+        "seal_galois": _eva._seal_galois_blob(N, primes, {elt_of(int(s)): d[f"galois_key_{int(s)}"] for s in d["rot_steps"]}),
+    }
+    for name, b in blobs.items():
+        open(os.path.join(out, name + ".bin"), "wb").write(b)
+    return len(blobs)
+
+
 def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
@@ -82,6 +117,7 @@ def main():
         f.write(f"N {N}\nbits {' '.join(str(b) for b in bits)}\nscale_log2 10\n")
         f.write("rot_steps " + " ".join(str(int(s)) for s in d["rot_steps"]) + "\n")
         f.write("enc_scale_bits " + " ".join(str(int(s)) for s in d["enc_scale_bits"]) + "\n")
+    n_blobs = write_seal_objects(out, d, N)
     n = 0
     for name, a in d.items():
         if name in ("rot_steps", "enc_scale_bits"):
@@ -89,7 +125,7 @@ def main():
         ext = ".f64" if a.dtype == np.float64 else ".u64"
         np.ascontiguousarray(a).astype("<f8" if ext == ".f64" else "<u8").tofile(os.path.join(out, name + ext))
         n += 1
-    print(f"wrote {n} arrays + manifest.txt to {out}")
+    print(f"wrote {n} arrays + {n_blobs} SEAL objects + manifest.txt to {out}")
 
 
 if __name__ == "__main__":

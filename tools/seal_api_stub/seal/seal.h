@@ -12,6 +12,7 @@
 #pragma once
 #include <array>
 #include <cstddef>
+#include <ios>
 #include <cstdint>
 #include <memory>
 #include <vector>
@@ -26,6 +27,14 @@ using parms_id_type = std::array<std::uint64_t, 4>;
 extern const parms_id_type parms_id_zero;
 enum class scheme_type : std::uint8_t { none = 0, bfv = 1, ckks = 2 };
 enum class sec_level_type : int { none = 0, tc128 = 128, tc192 = 192, tc256 = 256 };
+using seal_byte = std::byte;
+enum class compr_mode_type : std::uint8_t { none = 0, zlib = 1, zstd = 2 };
+class SEALContext;
+// every serialisable SEAL class has these three (Serialization::Save / Load behind them)
+#define SEAL_STUB_SERIALIZABLE                                                                                          \
+  std::streamoff save_size(compr_mode_type compr_mode) const;                                                           \
+  std::streamoff save(seal_byte *out, std::size_t size, compr_mode_type compr_mode) const;                              \
+  std::streamoff load(const SEALContext &context, const seal_byte *in, std::size_t size);
 
 class Modulus {
 public:
@@ -37,7 +46,11 @@ public:
 };
 class EncryptionParameters {
 public:
-  EncryptionParameters(scheme_type scheme);
+  EncryptionParameters(scheme_type scheme = scheme_type::none);
+  std::streamoff save_size(compr_mode_type compr_mode) const;
+  std::streamoff save(seal_byte *out, std::size_t size, compr_mode_type compr_mode) const;
+  std::streamoff load(const seal_byte *in, std::size_t size);
+  bool operator==(const EncryptionParameters &other) const;
   void set_poly_modulus_degree(std::size_t poly_modulus_degree);
   void set_coeff_modulus(const std::vector<Modulus> &coeff_modulus);
   const std::vector<Modulus> &coeff_modulus() const;
@@ -72,6 +85,10 @@ public:
 
 class Plaintext {
 public:
+  SEAL_STUB_SERIALIZABLE
+  std::size_t coeff_count() const;
+  const parms_id_type &parms_id() const;
+  const double &scale() const;
   void resize(std::size_t coeff_count);
   std::uint64_t *data();
   const std::uint64_t *data() const;
@@ -80,6 +97,11 @@ public:
 };
 class Ciphertext {
 public:
+  SEAL_STUB_SERIALIZABLE
+  std::size_t size() const;
+  const parms_id_type &parms_id() const;
+  bool is_ntt_form() const;
+  const double &scale() const;
   void resize(const SEALContext &context, parms_id_type parms_id, std::size_t size);
   std::uint64_t *data();
   const std::uint64_t *data() const;
@@ -88,14 +110,19 @@ public:
 };
 class SecretKey {
 public:
+  SEAL_STUB_SERIALIZABLE
   Plaintext &data();
+  const parms_id_type &parms_id() const;
 };
 class PublicKey {
 public:
+  SEAL_STUB_SERIALIZABLE
   Ciphertext &data();
+  const parms_id_type &parms_id() const;
 };
 class KSwitchKeys {
 public:
+  SEAL_STUB_SERIALIZABLE
   std::vector<std::vector<PublicKey>> &data();
 };
 class RelinKeys : public KSwitchKeys {};

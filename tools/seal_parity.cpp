@@ -13,6 +13,10 @@
 //      inputs and keys                                      == exported outputs
 //   5. CKKSEncoder::encode on the exported value vectors   == exported plaintexts
 //   6. Decryptor::decrypt / CKKSEncoder::decode            == exported plaintexts / slot values (as bits)
+//   7. SEAL's binary object format (what the reference's files carry, seal_serialization.cpp:46-108): the
+//      seal_*.bin objects written by this repository's writer (eva_amd/host/seal_format.h) load with SEAL's
+//      own load() into the exported values, and SEAL's own save(compr_mode_type::none) of those values
+//      reproduces the files byte for byte
 // and prints one PASS/FAIL line per item plus a summary; exit status 0 only when all pass.
 // With --time-triple it also times multiply + relinearize + rescale_to_next (BASELINE.json's
 // metric) on one thread, so bench.py can report a `cpu_baseline` of kind "reference".
@@ -247,6 +251,86 @@ int main(int argc, char **argv) {
     check_decode("of uniformly random residues", pt, "out_decode_pt");
     decryptor.decrypt(a3, p);
     check_decode("of a decrypted size-3 ciphertext", p, "out_decode_dec3");
+  }
+
+  // 7. the object format.  load(context, ...) runs SEAL's own validity checks (parms_id in the chain, data
+  // below the moduli, shapes); the byte comparison pins header, field order and widths, nesting and parms_id.
+  if (file_exists("seal_parms.bin")) {
+    auto load_bytes = [&](const std::string &name) {
+      std::ifstream f(g_dir + "/" + name + ".bin", std::ios::binary | std::ios::ate);
+      if (!f) throw std::runtime_error("missing object file " + name + ".bin");
+      std::vector<seal_byte> v((size_t)f.tellg());
+      f.seekg(0);
+      f.read(reinterpret_cast<char *>(v.data()), (std::streamsize)v.size());
+      return v;
+    };
+    auto saves_as = [&](const auto &obj, const std::vector<seal_byte> &want) {
+      std::vector<seal_byte> buf((size_t)obj.save_size(compr_mode_type::none));
+      const auto n = obj.save(buf.data(), buf.size(), compr_mode_type::none);
+      return (size_t)n == want.size() && std::memcmp(buf.data(), want.data(), want.size()) == 0;
+    };
+    {
+      auto b = load_bytes("seal_parms");
+      EncryptionParameters p2;
+      p2.load(b.data(), b.size());
+      report("EncryptionParameters::load of this repo's object", p2 == parms);
+      report("EncryptionParameters::save == this repo's bytes", saves_as(parms, b));
+    }
+    auto check_ct = [&](const std::string &file, const Ciphertext &want, const std::string &what) {
+      auto b = load_bytes(file);
+      Ciphertext c;
+      c.load(context, b.data(), b.size());
+      report("Ciphertext::load " + what, c.size() == want.size() && c.parms_id() == want.parms_id() && c.is_ntt_form() && c.scale() == want.scale() &&
+                                             std::memcmp(c.data(), want.data(), want.size() * l * N * 8) == 0);
+      report("Ciphertext::save " + what + " == this repo's bytes", saves_as(want, b));
+    };
+    check_ct("seal_ct_a2", a2, "size 2");
+    check_ct("seal_ct_a3", a3, "size 3");
+    {
+      auto b = load_bytes("seal_pt");
+      Plaintext p;
+      p.load(context, b.data(), b.size());
+      report("Plaintext::load", p.parms_id() == pt.parms_id() && p.scale() == pt.scale() && p.coeff_count() == l * N && std::memcmp(p.data(), pt.data(), l * N * 8) == 0);
+      report("Plaintext::save == this repo's bytes", saves_as(pt, b));
+    }
+    {
+      auto b = load_bytes("seal_pk");
+      auto want = load_u64("pk");
+      PublicKey pk;
+      pk.load(context, b.data(), b.size());
+      report("PublicKey::load", pk.data().size() == 2 && pk.parms_id() == key_data->parms_id() && same(pk.data().data(), want));
+      report("PublicKey::save == this repo's bytes", saves_as(pk, b));
+    }
+    if (file_exists("sk_ntt.u64")) {
+      auto b = load_bytes("seal_sk");
+      auto want = load_u64("sk_ntt");
+      SecretKey sk;
+      sk.load(context, b.data(), b.size());
+      report("SecretKey::load", sk.parms_id() == key_data->parms_id() && same(sk.data().data(), want));
+      report("SecretKey::save == this repo's bytes", saves_as(sk, b));
+    }
+    {
+      auto b = load_bytes("seal_relin");
+      RelinKeys r2;
+      r2.load(context, b.data(), b.size());
+      bool ok = r2.data().size() == 1 && r2.data()[0].size() == l;
+      for (size_t J = 0; ok && J < l; J++) ok = std::memcmp(r2.data()[0][J].data().data(), rk.data()[0][J].data().data(), 2 * k * N * 8) == 0;
+      report("RelinKeys::load", ok);
+      report("RelinKeys::save == this repo's bytes", saves_as(rk, b));
+    }
+    {
+      auto b = load_bytes("seal_galois");
+      GaloisKeys g2;
+      g2.load(context, b.data(), b.size());
+      bool ok = g2.data().size() == gk.data().size();
+      for (size_t i = 0; ok && i < gk.data().size(); i++) {
+        ok = g2.data()[i].size() == gk.data()[i].size();
+        for (size_t J = 0; ok && J < gk.data()[i].size(); J++)
+          ok = std::memcmp(g2.data()[i][J].data().data(), gk.data()[i][J].data().data(), 2 * k * N * 8) == 0;
+      }
+      report("GaloisKeys::load", ok);
+      report("GaloisKeys::save == this repo's bytes", saves_as(gk, b));
+    }
   }
 
   if (time_triple) {
