@@ -160,6 +160,11 @@ struct evah_pt {
 struct evah_graph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  // The temporaries of the captured walk were returned to their queues' pools, but every replay writes
+  // them again: the blocks are taken out of the pools for the graph's lifetime, so the queues can go on
+  // allocating (copies of the outputs, on the replay's own stream) without handing that memory out.
+  struct Reserved { evah_ctx *ctx; void *p; size_t bytes; };
+  std::vector<Reserved> reserved;
 };
 
 // Device state shared by a context and its forks: tables, keys, permutation tables.

@@ -598,6 +598,13 @@ int evah_capture_end(evah_ctx *q0, evah_ctx **others, uint32_t n_others, evah_gr
     delete g;
     throw std::runtime_error(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e));
   }
+  for (uint32_t i = 0; i <= n_others; i++) { // the walk's temporaries stay the graph's (see evah_graph)
+    evah_ctx *q = i ? others[i - 1] : q0;
+    for (auto &kv : q->pool.free_)
+      for (void *p : kv.second) g->reserved.push_back({q, p, kv.first});
+    q->pool.free_.clear();
+    q->pool.cached = 0;
+  }
   *out = g;
   API_END
 }
@@ -613,6 +620,14 @@ void evah_graph_free(evah_graph *g) {
   if (!g) return;
   if (g->exec) (void)hipGraphExecDestroy(g->exec);
   if (g->graph) (void)hipGraphDestroy(g->graph);
+  for (auto &r : g->reserved) { // back to the pool it came from, or to the device when that queue is gone
+    if (ctx_alive(r.ctx)) {
+      r.ctx->pool.free_[r.bytes].push_back(r.p);
+      r.ctx->pool.cached += r.bytes;
+    } else {
+      (void)hipFree(r.p);
+    }
+  }
   delete g;
 }
 

@@ -221,6 +221,11 @@ public:
           if (row[j] >= q) throw std::runtime_error("input " + name + ": a word is not reduced modulo its prime");
       }
   }
+  // release every runtime value this executor still holds (handles shared with a plan / a valuation stay alive there)
+  void drop_values() {
+    deferred_free.clear();
+    objects.assign(objects.size(), RuntimeValue{});
+  }
   // a value resident on this executor's device state: its handle, else null
   std::shared_ptr<CtHandle> resident_handle(const HostCipher &c) const {
     if (!c.dev || !root || c.dev->root.get() != root) return nullptr;
@@ -1363,7 +1368,6 @@ private:
     std::vector<HipExecutor::RuntimeValue> persistent; // constants
     std::unordered_map<std::string, HipExecutor::RuntimeValue> outputs;
     evah_graph *graph = nullptr;
-    bool outputs_copied = false; // device copies of the last replay's outputs were enqueued on the root queue
     ~GraphPlan() {
       outputs.clear();
       persistent.clear();
@@ -1459,6 +1463,9 @@ private:
       if (library_scheduler) ex.run_library(&done, true);
       else run_counted(program, ex, &done);
       for (auto &kv : program.outputs()) plan->outputs[kv.first] = ex.value(kv.second);
+      // every other value of the walk goes back to the queues' pools BEFORE the capture ends: the graph takes
+      // the pools' free blocks with it (evah_capture_end), so that nothing allocated later aliases a temporary
+      ex.drop_values();
     } catch (...) {
       evah_graph *g = nullptr;
       (void)evah_capture_end(q0, q.data() + 1, (uint32_t)q.size() - 1, &g);
@@ -1473,10 +1480,8 @@ private:
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
     evah_ctx *q0 = plan.queues[0]->h;
-    // the previous replay's outputs may still be being copied out on the root queue (below): the
-    // graph's kernels are not tracked per buffer, so the replay is ordered after those copies here
-    if (plan.outputs_copied) chk(evah_ctx_wait(q0, dev->h));
-    plan.outputs_copied = false;
+    // Slot refills, the replay and the copies of its outputs are all enqueued on the plan's own queue: one
+    // in-order stream, no cross-queue waits (those cost 10-20 us each against a 5 us kernel at N = 2^13).
     for (auto &kv : inputs.values) {
       // matches() compared the declared shapes with the slots; the data length must agree as well
       if (auto *c = std::get_if<HostCipher>(&kv.second)) {
@@ -1495,20 +1500,16 @@ private:
     }
     auto t1 = clk::now();
     chk(evah_graph_launch(q0, plan.graph));
-    // the copies below run on the root queue: the library orders a queue behind the producer of a buffer
-    // only once per buffer (values are immutable), but a replay rewrites the graph's output buffers
-    if (resident) chk(evah_ctx_wait(dev->h, q0));
     auto t2 = clk::now();
     HipValuation out;
     for (auto &kv : plan.outputs) {
       if (auto *c = std::get_if<std::shared_ptr<CtHandle>>(&kv.second)) {
         HostCipher hc;
         chk(evah_ct_info((*c)->h, &hc.size, &hc.limbs, &hc.scale));
-        if (resident) { // the graph owns its output buffers: hand out a device copy (root queue, ordered after the replay)
+        if (resident) { // the graph owns its output buffers: hand out a device copy, made right behind the replay
           evah_ct *copy = nullptr;
-          chk(evah_ct_copy(dev->h, (*c)->h, &copy));
-          hc.dev = std::make_shared<DeviceResident>(DeviceResident{dev, nullptr, std::make_shared<CtHandle>(dev->h, copy), host->N});
-          plan.outputs_copied = true;
+          chk(evah_ct_copy(q0, (*c)->h, &copy));
+          hc.dev = std::make_shared<DeviceResident>(DeviceResident{dev, plan.queues[0], std::make_shared<CtHandle>(q0, copy), host->N});
           out.values[kv.first] = std::move(hc);
           continue;
         }

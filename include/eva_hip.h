@@ -320,7 +320,9 @@ int evah_shard_rescale_finish(evah_ctx *ctx, const evah_ct *a, uint32_t l, const
  * ordering; evah_graph_launch replays it on q0's stream.  Handles created before the capture
  * (inputs, pre-encoded plaintexts) and handles still alive at the end (outputs) keep their device
  * addresses; calls that synchronise with the host (uploads, downloads) are rejected while
- * capturing.  The queues' pools must not be used by anything else while the graph exists. */
+ * capturing.  The temporaries of the captured walk are taken out of the queues' pools for the graph's
+ * lifetime (every replay writes them again), so the queues stay usable for other work — e.g. copies of
+ * the outputs enqueued on q0 right behind a replay — and evah_graph_free returns the blocks. */
 int evah_capture_begin(evah_ctx *q0, evah_ctx **others, uint32_t n_others);
 int evah_capture_end(evah_ctx *q0, evah_ctx **others, uint32_t n_others, evah_graph **out);
 int evah_graph_launch(evah_ctx *q0, evah_graph *g);
