@@ -1021,26 +1021,32 @@ public:
   // the encrypted part of a program as one evah_execute (EVA_LIBRARY_SCHEDULER=0: the host-side walks)
   bool library_scheduler = std::getenv("EVA_LIBRARY_SCHEDULER") ? std::atoi(std::getenv("EVA_LIBRARY_SCHEDULER")) != 0 : true;
   uint32_t batch_chunk = 32;
+  // groups in flight in execute_batch: group g is enqueued on queue g mod batch_depth, so the copies of one group
+  // overlap the kernels of the others; device memory = batch_depth groups' working sets
+  uint32_t batch_depth = std::getenv("EVA_BATCH_DEPTH") ? (uint32_t)std::atoi(std::getenv("EVA_BATCH_DEPTH")) : 4;
   std::vector<HipValuation> execute_batch(Program &program, const std::vector<const HipValuation *> &inputs) {
     ensure_device();
     if (batch_chunk < 1 || batch_chunk > 64) throw std::runtime_error("batch_chunk must be 1..64");
     std::vector<HipValuation> all(inputs.size());
-    // Groups alternate between two issue queues and nothing waits in between: each group's uploads,
+    // Groups rotate over batch_depth issue queues (default four: +6 % over two on config 4) and nothing waits in between: each group's uploads,
     // launches and downloads are enqueued in queue order (evah_ct_*_instances_async), so the copies
     // of one group overlap the kernels of the other and the host never idles the device.  Device
     // memory stays at two groups' working sets (the pools recycle in queue order); the inputs belong
     // to the caller and the outputs are allocated up front, so both outlive the final synchronisation.
     if (devices.size() > 1 && shard_mode == "dag") return execute_batch_multi(program, inputs);
-    if (!batch_fork) batch_fork = std::make_shared<Fork>(dev);
-    evah_ctx *qs[2] = {dev->h, batch_fork->h};
+    if (batch_depth < 2 || batch_depth > 8) throw std::runtime_error("batch_depth must be 2..8");
+    while (batch_forks.size() + 1 < batch_depth) batch_forks.push_back(std::make_shared<Fork>(dev));
+    std::vector<evah_ctx *> qs{dev->h};
+    for (uint32_t i = 0; i + 1 < batch_depth; i++) qs.push_back(batch_forks[i]->h);
+    const size_t Q = qs.size();
     // constants (Constant / Encode nodes and raw arithmetic on them) are evaluated once, by the
     // first group, and shared by all groups: their plaintexts stay resident for the whole call
     std::vector<char> done;
     std::vector<HipExecutor::RuntimeValue> consts;
     auto finish = [&]() {
-      int rc0 = evah_ctx_sync(qs[0]), rc1 = evah_ctx_sync(qs[1]);
-      chk(rc0);
-      chk(rc1);
+      int rc = 0;
+      for (evah_ctx *q : qs) rc |= evah_ctx_sync(q);
+      if (rc) throw_backend();
     };
     size_t g = 0;
     const bool bounded = std::getenv("EVA_BATCH_BOUNDED") ? std::atoi(std::getenv("EVA_BATCH_BOUNDED")) != 0 : false;
@@ -1048,8 +1054,8 @@ public:
       for (size_t i0 = 0; i0 < inputs.size(); i0 += batch_chunk, g++) {
         const size_t n = std::min<size_t>(batch_chunk, inputs.size() - i0);
         std::vector<const HipValuation *> chunk(inputs.begin() + i0, inputs.begin() + i0 + n);
-        if (bounded && g >= 2) chk(evah_ctx_sync(qs[g & 1])); // group g-2 (same queue) has left the device
-        HipExecutor ex(program, *host, std::vector<evah_ctx *>{qs[g & 1]}, dev.get());
+        if (bounded && g >= Q) chk(evah_ctx_sync(qs[g % Q])); // group g-Q (same queue) has left the device
+        HipExecutor ex(program, *host, std::vector<evah_ctx *>{qs[g % Q]}, dev.get());
         if (g == 0) {
           done = ex.prepare_constants();
           consts.resize(program.size());
@@ -1065,8 +1071,7 @@ public:
         ex.get_outputs_batch(all.data() + i0, n, true);
       }
     } catch (...) {
-      (void)evah_ctx_sync(qs[0]); // copies in flight still target `all` and the caller's inputs
-      (void)evah_ctx_sync(qs[1]);
+      for (evah_ctx *q : qs) (void)evah_ctx_sync(q); // copies in flight still target `all` and the caller's inputs
       throw;
     }
     finish();
@@ -1132,7 +1137,7 @@ public:
   ~HipPublic() {
     const_cache.clear();
     plans.clear();
-    batch_fork.reset();
+    batch_forks.clear();
     batch_queues.clear();
     limb.reset();
     limb_const.clear();
@@ -1147,7 +1152,8 @@ public:
 private:
   std::shared_ptr<DeviceCtx> dev; // == holder->dev once a device is in use
   std::vector<std::shared_ptr<Fork>> forks;
-  std::shared_ptr<Fork> batch_fork; // second issue queue of execute_batch
+  std::vector<std::shared_ptr<Fork>> batch_forks; // the further issue queues of execute_batch
+
   std::shared_ptr<Fork> exec_q[2];  // the two issue queues resident execute() calls alternate between
   unsigned exec_turn = 0;
   std::vector<std::shared_ptr<Fork>> batch_queues; // "dag" mode: two issue queues per member
