@@ -1079,7 +1079,7 @@ public:
   }
 
   // "dag" mode (BASELINE config 4): the groups of a batch are dealt over the members
-  // of `devices` — group g on member g mod G, two issue queues per member so a member's copies overlap its
+  // of `devices` — group g on member g mod G, batch_depth issue queues per member so a member's copies overlap its
   // kernels — with no data-path exchange: instances are independent.  Same results as execute_batch on one
   // device.  (The driver's scaling curve uses one process per GPU, eva_amd/dist.py; this is the same
   // partition inside one execute_batch call.)
@@ -1087,10 +1087,12 @@ public:
     if (batch_chunk < 1 || batch_chunk > 64) throw std::runtime_error("batch_chunk must be 1..64");
     ensure_group(false);
     const size_t G = group->size();
-    if (batch_queues.size() != 2 * G) {
+    if (batch_depth < 2 || batch_depth > 8) throw std::runtime_error("batch_depth must be 2..8");
+    const size_t D = batch_depth;
+    if (batch_queues.size() != D * G) {
       batch_queues.clear();
       for (size_t m = 0; m < G; m++)
-        for (int k = 0; k < 2; k++) batch_queues.push_back(std::make_shared<Fork>(group->roots[m]));
+        for (size_t k = 0; k < D; k++) batch_queues.push_back(std::make_shared<Fork>(group->roots[m]));
     }
     std::vector<HipValuation> all(inputs.size());
     std::vector<std::vector<char>> done(G);
@@ -1106,7 +1108,7 @@ public:
       for (size_t i0 = 0; i0 < inputs.size(); i0 += batch_chunk, g++) {
         const size_t n = std::min<size_t>(batch_chunk, inputs.size() - i0), m = g % G;
         std::vector<const HipValuation *> chunk(inputs.begin() + i0, inputs.begin() + i0 + n);
-        evah_ctx *q = batch_queues[2 * m + (turn[m]++ & 1)]->h;
+        evah_ctx *q = batch_queues[D * m + (turn[m]++ % D)]->h;
         HipExecutor ex(program, *host, std::vector<evah_ctx *>{q}, group->roots[m].get());
         if (done[m].empty()) { // the member's constants: encoded once, by its first group
           done[m] = ex.prepare_constants();
@@ -1156,7 +1158,7 @@ private:
 
   std::shared_ptr<Fork> exec_q[2];  // the two issue queues resident execute() calls alternate between
   unsigned exec_turn = 0;
-  std::vector<std::shared_ptr<Fork>> batch_queues; // "dag" mode: two issue queues per member
+  std::vector<std::shared_ptr<Fork>> batch_queues; // "dag" mode: batch_depth issue queues per member
   std::unique_ptr<DeviceGroup> group;        // sub-DAG split: members of `devices`
   std::vector<int> group_ids;
   std::unique_ptr<LimbShardEvaluator> limb;  // limb sharding: one shard context per member

@@ -339,6 +339,10 @@ inline void open(Cur &c, uint64_t limit, Obj &o) {
     if (size - 16 > limit) throw std::runtime_error("Could not parse message: a SEAL object is larger than its bound");
     o.cur = Cur{body, body + (size - 16)};
   } else if (compr == Zlib || compr == Zstd) {
+    // residues are pseudo-random 60-bit words: a genuine object shrinks by a few percent, only the empty slots of a
+    // Galois key set (zeros) compress well — so the expansion is bounded by the compressed length as well, which
+    // keeps a small hostile file from asking for the memory of a large key set
+    limit = std::min<uint64_t>(limit, 8 * (size - 16) + ((uint64_t)32 << 20));
     o.owned = compr == Zlib ? zlib_inflate(body, size - 16, limit) : zstd_inflate(body, size - 16, limit);
     o.cur = Cur{o.owned.data(), o.owned.data() + o.owned.size()};
   } else {
