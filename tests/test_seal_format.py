@@ -404,3 +404,33 @@ def _no_parms(schema, blob, path):
     m.values['x'].CopyFrom(schema["SEALObject"](seal_type=1, data=blob))
     open(path, "wb").write(_envelope(schema, m))
     return path
+
+
+@pytest.mark.gpu
+def test_all_six_object_kinds_through_the_reference_formats_on_the_gpu(keys, tmp_path):
+    """the reference's own round-trip test (/root/reference/tests/features.py:154-217) with every file in the
+    reference's formats: program / parameters / signature as EVA protobuf, both contexts and both valuations as
+    seal.proto messages around SEAL objects — execute() on the loaded objects gives the same ciphertext bits"""
+    from eva import evaluate
+    compiled, params, sig, pub, sec = keys
+    inputs = {'x': [0.1 * i for i in range(16)], 'y': [0.5] * 16}
+    enc = pub.encrypt(inputs, sig)
+    out = pub.execute(compiled, enc)
+    files = {n: str(tmp_path / n) for n in ("prog", "params", "sig", "pub", "sec", "enc", "out")}
+    save(compiled, files["prog"])
+    save(params, files["params"])
+    save(sig, files["sig"])
+    save(pub, files["pub"], format="seal")
+    save(sec, files["sec"], format="seal+zlib")
+    save(enc, files["enc"], format="seal")
+    save(out, files["out"], format="seal")   # a device-resident result is downloaded for the file
+    prog2, sig2, pub2, sec2, enc2, out2 = (load(files[n]) for n in ("prog", "sig", "pub", "sec", "enc", "out"))
+    assert load(files["params"]).prime_bits == params.prime_bits
+    res = pub2.execute(prog2, enc2)
+    for name in out.names():
+        a, b, c = out.get(name), res.get(name), out2.get(name)
+        assert a[:4] == b[:4] == c[:4] and np.array_equal(a[4], b[4]) and np.array_equal(a[4], c[4])
+    got = sec2.decrypt(res, sig2)
+    want = evaluate(compiled, inputs)
+    assert np.mean((np.array(got['z']) - np.array(want['z'])) ** 2) < 0.01   # the reference's threshold (tests/common.py:34)
+    assert np.allclose(sec.decrypt(out2, sig)['z'], got['z'], atol=1e-9)
