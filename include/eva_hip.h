@@ -59,7 +59,10 @@ int evah_ctx_mem_info(evah_ctx *ctx, size_t *in_use, size_t *cached);
 /* ---- keys ----------------------------------------------------------------------------------
  * Replaces the seal::RelinKeys / seal::GaloisKeys members of SEALPublic (seal.h:62-63).
  * data: [n_digits][2][n_primes][N] uint64, NTT form (one size-2 key-level ciphertext per digit;
- * SEAL KSwitchKeys layout).  galois_elt is ignored for the relinearization key. */
+ * SEAL KSwitchKeys layout).  galois_elt is ignored for the relinearization key.
+ * The caller always passes the whole key.  On a context that is a limb shard (evah_ctx_set_shard called
+ * BEFORE the upload) only the prime rows that shard multiplies into are kept in HBM — its own data limbs
+ * and the special prime — and the context then serves the evah_shard_* entry points only. */
 #define EVAH_KEY_RELIN 0
 #define EVAH_KEY_GALOIS 1
 #define EVAH_KEY_PUBLIC 2 /* evah_client_key_upload */
