@@ -37,6 +37,14 @@ def test_exporter_writes_every_vector_the_checker_reads(tmp_path):
     assert np.array_equal(back, vec["out_triple"])
     man = dict(ln.split(" ", 1) for ln in open(os.path.join(out, "manifest.txt")).read().splitlines() if not ln.startswith("#"))
     assert man["N"] == "1024" and man["bits"] == "60 40 60"
+    # section 7 of the checker: every SEAL object it loads was written (by this repo's writer of SEAL's format),
+    # begins with SEAL's header and says how long it is
+    import struct
+    for name in re.findall(r'load_bytes\("([a-z0-9_]+)"\)', src):
+        blob = open(os.path.join(out, name + ".bin"), "rb").read()
+        magic, hsize, major, minor, compr, _, size = struct.unpack_from("<HBBBBHQ", blob)
+        assert (magic, hsize, major, minor, compr, size) == (0xA15E, 16, 3, 6, 0, len(blob)), name
+    assert "pk.u64" in files
 
 
 def test_checker_compiles_against_the_declared_seal_api():
