@@ -203,7 +203,7 @@ PYBIND11_MODULE(_eva, m) {
     }
     std::map<uint64_t, const SwitchKey *> slots;
     for (auto &kv : own) slots.emplace(kv.first, &kv.second);
-    return py::bytes(sealfmt::kswitch_obj(h, slots.empty() ? 0 : N, slots, sealfmt::None));
+    return py::bytes(sealfmt::kswitch_obj(h, N, slots, sealfmt::None));
   }, py::arg("N"), py::arg("primes"), py::arg("keys"));
   m.def("load", [](const std::string &path) -> py::object {
     KnownType k = load_from_file(path);

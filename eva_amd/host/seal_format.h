@@ -487,8 +487,9 @@ inline std::string encode_public(const HipPublic &p, Compr compr = None) {
   o.bytes(2, seal_object_msg(PUBLIC_KEY, public_key_obj(h, p.pk.data.data(), compr)), true);
   std::map<uint64_t, const SwitchKey *> gal;
   for (auto &kv : p.galois) gal.emplace((uint64_t)(kv.first - 1) / 2, &kv.second);
-  // GaloisKeys of a context without rotations: an empty key set (dim1 = 0), as KSwitchKeys() is
-  o.bytes(3, seal_object_msg(GALOIS_KEYS, kswitch_obj(h, gal.empty() ? 0 : h.N, gal, compr)), true);
+  // KeyGenerator::create_galois_keys sizes keys_ to poly_modulus_degree whatever the steps are (seal.cpp:195
+  // always calls it): a context without rotations carries N empty slots
+  o.bytes(3, seal_object_msg(GALOIS_KEYS, kswitch_obj(h, h.N, gal, compr)), true);
   std::map<uint64_t, const SwitchKey *> rel{{0, &p.relin}};
   o.bytes(4, seal_object_msg(RELIN_KEYS, kswitch_obj(h, 1, rel, compr)), true);
   return o.b;

@@ -238,6 +238,26 @@ def test_public_context_round_trip_and_bytes(schema, keys, tmp_path):
         assert len(open(p3, "rb").read()) < len(open(path, "rb").read())
 
 
+def test_context_without_rotations_carries_n_empty_galois_slots(schema, tmp_path):
+    """KeyGenerator::create_galois_keys sizes the key vector to poly_modulus_degree whatever the steps are, and the
+    reference calls it for every program (/root/reference/eva/seal/seal.cpp:195)"""
+    prog = EvaProgram('norot', vec_size=8)
+    with prog:
+        x = Input('x')
+        Output('y', x * x)
+    prog.set_input_scales(30)
+    prog.set_output_ranges(20)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    params.poly_modulus_degree = 1024
+    pub, sec = generate_keys(params, 2)
+    N, primes = _ctx(pub)
+    path = str(tmp_path / "pub")
+    save(pub, path, format="seal")
+    m = _open(schema, path, "SEALPublic")
+    assert m.galois_keys.data == seal_kswitch(N, primes, N, {})
+    assert load(path).galois_keys() == {}
+
+
 def test_secret_context_round_trip_and_bytes(schema, keys, tmp_path):
     compiled, params, sig, pub, sec = keys
     N, primes = _ctx(pub)
