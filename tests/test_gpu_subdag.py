@@ -164,6 +164,34 @@ def test_dag_mode_deals_a_batch_over_the_members():
     assert np.array_equal(many[7].get('image')[4], ref['image'])
 
 
+@pytest.mark.parametrize("depth", [2, 3, 8])
+def test_groups_in_flight_do_not_change_a_batch(depth):
+    """execute_batch rotates its groups over `batch_depth` issue queues (copies of one group against kernels of the
+    others): any depth gives the ciphertexts of the one-by-one execute(), which equal the oracle walk"""
+    from test_compiler import _sobel
+    prog = _sobel(64, 64, 4096)
+    prog.set_input_scales(25)
+    prog.set_output_ranges(10)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    params.poly_modulus_degree = 8192
+    pub, sec = generate_keys(params, 3)
+    pub.resident = False
+    encs = [pub.encrypt({'image': [((41 * i + 7 * u) % 256) / 255.0 for i in range(4096)]}, sig) for u in range(4)]
+    batch = [encs[(3 * i) % 4] for i in range(19)]
+    pub.batch_chunk = 2          # ten groups: every queue is reused, the last group is ragged
+    pub.batch_depth = depth
+    outs = pub.execute_batch(compiled, batch)
+    assert len(outs) == len(batch)
+    singles = [pub.execute(compiled, e) for e in encs]
+    for i, o in enumerate(outs):
+        assert np.array_equal(o.get('image')[4], singles[(3 * i) % 4].get('image')[4]), i
+    ref, _ = c_walk(pub, compiled, batch[5])
+    assert np.array_equal(outs[5].get('image')[4], ref['image'])
+    pub.batch_depth = 1
+    with pytest.raises(RuntimeError, match="batch_depth"):
+        pub.execute_batch(compiled, batch)
+
+
 @pytest.mark.skipif(backend.device_count() < 2, reason="needs two HIP devices: the cross-device (xGMI peer copy) branch of evah_ct_copy")
 def test_two_real_devices():
     """sub-DAG split and limb sharding with members on DIFFERENT GPUs: peer copies at the cuts / in the exchanges"""
