@@ -276,6 +276,9 @@ PYBIND11_MODULE(_eva, m) {
         v.values[name] = std::move(p);
       })
       .def("_set_raw", [](HipValuation &v, const std::string &name, std::vector<double> data) { v.values[name] = std::move(data); })
+      // a valuation assembled by hand or loaded from this repo's container carries no encryption parameters; the SEAL
+      // wire format needs them (SEALValuation::params, seal.h:23-27)
+      .def("_set_params", [](HipValuation &v, const HipPublic &p) { v.params = p.host; }, py::arg("public_ctx"))
       .def("names", [](const HipValuation &v) { std::vector<std::string> n; for (auto &kv : v.values) n.push_back(kv.first); return n; })
       .def("is_resident", [](const HipValuation &v, const std::string &name) {
         auto it = v.values.find(name);

@@ -340,6 +340,13 @@ def test_valuation_round_trip_and_bytes(schema, keys, tmp_path):
     v._set_cipher('x', ct, cx[3])
     with pytest.raises(RuntimeError, match="no encryption parameters"):
         save(v, str(tmp_path / "none"), format="seal")
+    v._set_params(pub)
+    save(v, str(tmp_path / "byhand"), format="seal")
+    assert np.array_equal(load(str(tmp_path / "byhand")).get('x')[4], ct)
+    # a ciphertext that does not fit the parameters it is filed under is refused at save time
+    v._set_cipher('bad', ct[:, :, :512], cx[3])
+    with pytest.raises(RuntimeError, match="does not match the valuation's encryption parameters"):
+        save(v, str(tmp_path / "bad"), format="seal")
 
 
 def test_hostile_seal_objects_are_errors(schema, keys, tmp_path):
