@@ -98,6 +98,14 @@ def _median(xs):
     return xs[len(xs) // 2]
 
 
+def host_cores():
+    """Cores this process may run on — how the reference sizes its thread pool (python/eva/__init__.py:10-14)."""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
 def execute_leg(N, l, n_products, reps):
     """The op-triples as a compiled program through public_ctx.execute(): z_i = x_i * y_i with eager
     relinearization, so every product is Mul -> Relinearize -> Rescale on l limbs.  Three ways of
@@ -222,6 +230,7 @@ def dag_leg(reps, cpu_threads):
     ref, t1 = c_walk(pub, compiled, enc, threads=1)
     ok = all(np.array_equal(out_h.get(name)[4], ref[name]) and np.array_equal(out.get(name)[4], ref[name]) for name in ref)
     _, tn = c_walk(pub, compiled, enc, threads=cpu_threads)
+    t64 = c_walk(pub, compiled, enc, threads=64)[1] if cpu_threads > 64 else None
     kinds = [str(d["op"]).split(".")[-1] for d in compiled._dump()]
     return {"workload": "Harris corner detector (examples/image_processing.py), 64x64 image, N=2^15, L=8 data limbs",
             "terms": len(kinds), "rotations": kinds.count("RotateLeftConst") + kinds.count("RotateRightConst"),
@@ -229,48 +238,133 @@ def dag_leg(reps, cpu_threads):
             "gpu_execute_ms": round(gpu_ms, 3), "gpu_includes": "input upload, hipGraph replay, output download (host valuations)",
             "gpu_execute_resident_ms": round(res_ms, 3),
             "roofline": rl(nbytes, gpu_ms * 1e-3), "roofline_resident": rl(nbytes, res_ms * 1e-3),
-            "cpu_walk_ms": {"1": round(t1 * 1e3, 1), str(cpu_threads): round(tn * 1e3, 1)},
+            "cpu_walk_ms": dict({"1": round(t1 * 1e3, 1), str(cpu_threads): round(tn * 1e3, 1)},
+                                **({"64": round(t64 * 1e3, 1)} if t64 else {})),
+            "cpu_cores": cpu_threads,
             "cpu_walk": "oracle/eva_oracle_dag.c: serial forwardPass / dependency-counting traversal on pthreads",
-            "speedup_vs_cpu": {"1": round(t1 * 1e3 / gpu_ms, 1), str(cpu_threads): round(tn * 1e3 / gpu_ms, 1)},
+            "speedup_vs_cpu": dict({"1": round(t1 * 1e3 / gpu_ms, 1), str(cpu_threads): round(tn * 1e3 / gpu_ms, 1)},
+                                   **({"64": round(t64 * 1e3 / gpu_ms, 1)} if t64 else {})),
             "bit_exact_vs_oracle": bool(ok)}
 
 
-def dag_batch_leg(batch, reps):
+def dag_batch_leg(batch, reps, dist=None, members=1):
     """BASELINE config 4: a batch of independent Sobel DAGs at N = 2^14, L = 5 through
-    execute_batch (uploads and downloads included); two instances are checked against the C walk of the oracle."""
+    execute_batch (uploads and downloads included); instances are checked against the C walk of the oracle.
+    dist with world > 1: instance b runs on rank b mod world (one process per GPU, no
+    data-path collective), every rank checks one of its own instances, `dags_per_s` = batch / max-over-ranks
+    time.  members > 1 (one process): shard_mode = "dag" over `members` contexts of this rank's GPU."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
     from eva_amd.roofline import dag_bytes, roofline as rl
     from test_compiler import _sobel
+    world = dist.world if dist else 1
+    rank = dist.rank if dist else 0
+    dev = dist.device_index if dist else 0
+    if dist and world > 1:
+        # a rank that fails while the others wait in a barrier would stall the job: set up first, agree, then time
+        err = None
+        try:
+            state = _dag_batch_setup(batch, rank, world, dev, members)
+        except Exception as e:  # noqa: BLE001
+            err, state = repr(e), None
+        if dist.sum_over_ranks(0.0 if err is None else 1.0) > 0:
+            return {"error": err or "set-up failed on another rank"}
+        return _dag_batch_run(state, batch, reps, dist, members)
+    return _dag_batch_run(_dag_batch_setup(batch, rank, world, dev, members), batch, reps, dist, members)
+
+
+def _dag_batch_setup(batch, rank, world, dev, members):
+    import numpy as np  # noqa: F401
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    from eva_amd.roofline import dag_bytes
+    from test_compiler import _sobel
     prog = _sobel(64, 64, 4096)
     prog.set_input_scales(25)
     prog.set_output_ranges(10)
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
     pad_chain(params, 6, 16384)
-    pub, sec = generate_keys(params, 1)
+    if members > 1:
+        pub, sec = generate_keys(params, 1, devices=[dev] * members, shard="dag")
+    elif dev:
+        pub, sec = generate_keys(params, 1, devices=[dev])
+    else:
+        pub, sec = generate_keys(params, 1)
     pub.resident = False  # execute_batch assembles batched handles from host words and returns host words
     nbytes, _ = dag_bytes(compiled, sig, 16384, len(params.prime_bits))
     encs = [pub.encrypt({'image': [((37 * i + u) % 256) / 255.0 for i in range(4096)]}, sig) for u in range(8)]
-    inputs = [encs[i % len(encs)] for i in range(batch)]
+    mine = list(range(rank, batch, world))  # instance b -> rank b mod world
+    inputs = [encs[b % len(encs)] for b in mine]
     pub.execute_batch(compiled, inputs)  # warm-up: tables, constants, the pools of every issue queue
+    return pub, sec, compiled, params, nbytes, inputs, mine
+
+
+def _dag_batch_run(state, batch, reps, dist, members):
+    import numpy as np
+    from eva_amd.roofline import roofline as rl
+    pub, sec, compiled, params, nbytes, inputs, mine = state
+    world = dist.world if dist else 1
     ts, outs = [], None
     for _ in range(reps):
+        if dist:
+            dist.barrier()
         t0 = time.perf_counter()
         outs = pub.execute_batch(compiled, inputs)
-        ts.append(time.perf_counter() - t0)
+        if dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        ts.append(dist.max_over_ranks(dt) if dist else dt)
     med = _median(ts)
     from oracle_executor import c_walk
     ok = True
-    for i in (1, batch - 3):
+    for i in sorted({1 % len(mine), max(0, len(mine) - 3)}):
         ref, _ = c_walk(pub, compiled, inputs[i], threads=1)
         ok = ok and all(np.array_equal(outs[i].get(name)[4], ref[name]) for name in ref)
+    bad = dist.sum_over_ranks(0.0 if ok else 1.0) if dist else (0.0 if ok else 1.0)
     return {"workload": f"{batch} independent Sobel DAGs (examples/image_processing.py), 64x64 images, N=2^14, primes={list(params.prime_bits)}",
             "dags_per_s": round(batch / med, 1), "ms_total": round(med * 1e3, 2), "best_dags_per_s": round(batch / min(ts), 1),
-            "timing": f"median of {reps} calls", "instances_per_device_handle": 32,
-            "roofline": rl(nbytes * batch, med),
-            "includes": "input uploads, one DAG walk per 32 instances, output downloads", "bit_exact_vs_oracle": bool(ok)}
+            "timing": f"median of {reps} calls" + (", barrier + max over ranks per call" if world > 1 else ""),
+            "instances_per_device_handle": 32, "instances_per_rank": len(mine), "ranks": world,
+            "members_per_rank": members, "shard_mode": "dag" if members > 1 else "",
+            "partition": "instance b on rank b mod world (SURVEY.md 8(e) row 1), no data-path collective" if world > 1 else "one rank",
+            "roofline": rl(nbytes * batch / world, med), "roofline_basis": "algorithmic bytes of this rank's DAGs over the time, per GPU",
+            "includes": "input uploads, one DAG walk per 32 instances, output downloads",
+            "instances_checked_per_rank": len({1 % len(mine), max(0, len(mine) - 3)}), "bit_exact_vs_oracle": bad == 0.0}
+
+
+def dag_sharded(args, dist):
+    """--shard dag: BASELINE config 4's scaling leg as the whole job — 256 independent Sobel DAGs at N = 2^14,
+    l = 5, dealt b mod G over the ranks (one process per GPU, eva_amd/dist.py; --members k additionally splits a
+    rank's groups over k contexts of its GPU with shard_mode = "dag").  One JSON line on rank 0: DAGs/s of the
+    whole job and the achieved-HBM fraction per GPU."""
+    import torch
+    world, local = dist.world, dist.local_rank
+    dev_name = torch.cuda.get_device_name(local)
+    rank_devices = [dev_name]
+    if world > 1:
+        import torch.distributed as tdist
+        gathered = [None] * world
+        tdist.all_gather_object(gathered, f"rank {dist.rank}: cuda:{local} {dev_name}")
+        rank_devices = gathered
+    leg = dag_batch_leg(args.dag_batch, max(3, args.steps), dist, members=max(1, args.members))
+    if dist.rank == 0:
+        if not leg["bit_exact_vs_oracle"]:
+            raise SystemExit("bench.py --shard dag: an instance differs from the CPU oracle's walk — number withheld")
+        line = {"metric": "independent Sobel DAGs/s (BASELINE config 4: batch of 256, N=2^14), execute_batch() wall-time",
+                "value": leg["dags_per_s"], "unit": "DAGs/s", "n_gpus": world, "steps": max(3, args.steps), "warmup": 1,
+                "ms_per_step": leg["ms_total"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "u64", "data": "synthetic",
+                "config": {"workload": leg["workload"], "batch": args.dag_batch, "parallelism": leg["partition"],
+                           "members_per_rank": leg["members_per_rank"], "rccl_ranks": world, "rank_devices": rank_devices,
+                           "collectives": "barrier + max-over-ranks of the wall time (torch.distributed nccl = RCCL); none in the data path"},
+                "roofline": dict(leg["roofline"], bound="hbm", basis=leg["roofline_basis"]),
+                "verified": {"instances_checked_per_rank": leg["instances_checked_per_rank"], "bit_exact_vs_oracle": True},
+                "cpu_baseline": None, "dag_batch": leg}
+        print(json.dumps(line), flush=True)
+    dist.close()
 
 
 def limb_sharded(args, dist):
@@ -422,7 +516,10 @@ def main():
                     help="evah_multiply_many + evah_relinearize_rescale_many instead of the one-call op-triple "
                          "evah_multiply_relinearize_rescale_many (no size-3 product in HBM).  r02 measured the one-call form 1.6 %% "
                          "slower; with the r03 128-bit reduction it is 1.9 %% faster (same run), so it is the default")
-    ap.add_argument("--shard", choices=["ciphertexts", "limb", "subdag"], default="ciphertexts",
+    ap.add_argument("--members", type=int, default=1,
+                    help="--shard dag: contexts per rank sharing its GPU (shard_mode='dag' inside execute_batch)")
+    ap.add_argument("--dag-batch", type=int, default=256, help="--shard dag / the dag_batch leg: independent Sobel DAGs in the batch")
+    ap.add_argument("--shard", choices=["ciphertexts", "limb", "subdag", "dag"], default="ciphertexts",
                     help="ciphertexts: independent triples per GPU, no collective (default, weak scaling); "
                          "limb: every triple on all GPUs, RNS limbs dealt over them (strong scaling); "
                          "subdag: one Harris execute() with its independent sub-DAGs on the GPUs")
@@ -452,6 +549,8 @@ def main():
         return limb_sharded(args, dist)
     if args.shard == "subdag":
         return subdag_leg(args, dist)
+    if args.shard == "dag":
+        return dag_sharded(args, dist)
     # what every rank runs on: the driver's multi-GPU runs show that RCCL saw N ranks on N devices
     dev_name = torch.cuda.get_device_name(local)
     rank_devices = [dev_name]
@@ -577,6 +676,13 @@ def main():
         if not verified["bit_exact_vs_oracle"]:
             raise SystemExit("bench.py: the timed path's output differs from the CPU oracle — number withheld")
 
+    # N > 1: BASELINE config 4's scaling leg rides along — every rank runs its share (instance b on rank b mod
+    # world) of the 256 Sobel DAGs, so a multi-GPU run of the default command reports DAGs/s and the achieved-HBM
+    # fraction per GPU count as well (all ranks take part: the timing is barrier-bracketed)
+    dag_batch_multi = None
+    if world > 1 and not args.no_legs:
+        dag_batch_multi = dag_batch_leg(args.dag_batch, 5, dist)
+
     if rank == 0:
         cb = class_bytes(N, l, k, G)
         dom = max(prof, key=lambda c: prof[c][1]) if prof else None
@@ -643,13 +749,15 @@ def main():
             except Exception as e:  # noqa: BLE001 — a leg must not cost the headline line
                 legs["execute_path"] = {"error": repr(e)}
             try:
-                legs["dag"] = dag_leg(15, max(1, min(os.cpu_count() or 1, 64)))
+                legs["dag"] = dag_leg(15, host_cores())
             except Exception as e:  # noqa: BLE001
                 legs["dag"] = {"error": repr(e)}
             try:
-                legs["dag_batch"] = dag_batch_leg(256, 7)
+                legs["dag_batch"] = dag_batch_leg(args.dag_batch, 7)
             except Exception as e:  # noqa: BLE001
                 legs["dag_batch"] = {"error": repr(e)}
+        if dag_batch_multi is not None:
+            legs["dag_batch"] = dag_batch_multi
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
@@ -667,20 +775,27 @@ def main():
             # the same port on many host cores at once (independent triples, one per thread; ctypes
             # releases the GIL) — the analogue of the reference's Galois node-level parallelism
             import threading
-            threads = max(1, min(os.cpu_count() or 1, 64))
-            done = []
 
-            def worker(i):
-                a_, b_ = hp[i % len(hp)]
-                o.op_triple(a_, b_, key_host)
-                done.append(i)
-            ths = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
-            t1 = time.perf_counter()
-            for t in ths:
-                t.start()
-            for t in ths:
-                t.join()
-            mdt = time.perf_counter() - t1
+            def concurrent(threads):
+                """`threads` op-triples, one per thread, at once -> op-triples/s"""
+                done = []
+
+                def worker(i):
+                    a_, b_ = hp[i % len(hp)]
+                    o.op_triple(a_, b_, key_host)
+                    done.append(i)
+                ths = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
+                t1_ = time.perf_counter()
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+                return len(done) / (time.perf_counter() - t1_)
+            # every core the process may run on (the reference sizes its pool from the affinity mask,
+            # /root/reference/python/eva/__init__.py:10-14), and 64 threads beside it when the host has more
+            cores = host_cores()
+            all_rate = concurrent(cores)
+            rate64 = concurrent(64) if cores > 64 else None
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             try:
                 import seal_probe
@@ -694,11 +809,14 @@ def main():
                                     + ",".join(["60"] * (l + 1)) + " && cmake -S tools -B build/seal_parity && cmake --build build/seal_parity"
                                     " && build/seal_parity/seal_parity /tmp/vec --time-triple   (diffs primes, psi, NTT, every evaluator call, "
                                     "the op-triple, encode, decrypt and decode with SEAL's own bits; prints SEAL's op-triples/s)",
-                   "all_cores": {"value": round(len(done) / mdt, 2), "cores": threads,
-                                 "sample": f"{threads} op-triples, one per thread, concurrently"},
+                   "all_cores": {"value": round(all_rate, 2), "cores": cores,
+                                 "sample": f"{cores} op-triples, one per thread, concurrently, on all {cores} cores of the "
+                                           "affinity mask"},
+                   "threads_64": None if rate64 is None else {"value": round(rate64, 2), "cores": 64,
+                                                               "sample": "64 op-triples, one per thread, concurrently"},
                    "sample": f"{n} op-triples (multiply+relinearize+rescale) at N=2^{args.logn}, "
                              f"L={l}, same inputs/key as the GPU run, oracle/libeva_oracle.so, "
-                             f"1 thread of {os.cpu_count()} host cores"}
+                             f"1 thread of {cores} host cores"}
         line = {
             "metric": "homomorphic ops/sec (mul+rescale+relin) at N=2^16, L=10; execute() wall-time",
             "value": round(value, 2), "unit": "op-triples/s", "n_gpus": world,

@@ -236,6 +236,10 @@ struct Tunables {
   // fused key-switch kernel — one wave = one 2^P-point sub-transform measured best (barriers are intra-wave)
   int ks_groups = 1;
   int ks_threads = 64;
+  // EVAH_FOLD_PA (1): relinearize (+ rescale) and the fused multiply add P * (the polynomials the key-switch result
+  // is added to) to the key inner products inside ks_inner_kernel (KS_FOLDMUL / KS_FOLDADD), so the mod-down's
+  // combine pass — which waits for bytes — reads the products only; 0 = the r03 forms (operands read in the epilogue)
+  bool fold_pa = true;
 
   static Tunables from_env(uint32_t N) {
     Tunables t;
@@ -251,6 +255,7 @@ struct Tunables {
     count("EVAH_HOIST_MIN_TILES", t.hoist_min_tiles);
     flag("EVAH_HOIST_DEBUG", t.hoist_debug);
     flag("EVAH_FUSE_SPECIAL_INV", t.fuse_special_inv);
+    flag("EVAH_FOLD_PA", t.fold_pa);
     if (const char *e = std::getenv("EVAH_KS_GROUPS")) t.ks_groups = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {
       const int n = std::atoi(e);

@@ -49,21 +49,28 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   const uint32_t n_tiles = c->N / tile;
   // the one-wave workgroup (the default) is compiled with its own launch bound: the register
   // allocator is not held to the 256-thread budget
-  auto go = [&](auto kernel, const auto &mt) {
+  auto go = [&](auto kernel, const auto &mt, const auto &at) {
     hipLaunchKernelGGL(kernel, dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev, target, kb.target_bs, scratch,
                        kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n, kb.targets, mt, kb.istep,
-                       kb.nout ? kb.nout : l + 1, kb.r_out);
+                       kb.nout ? kb.nout : l + 1, kb.r_out, at);
   };
   if (kb.r_out && ((tile >> LR) > 64 || kb.istep != 1)) throw std::logic_error("fused special-row inverse pass needs the one-wave key-switch kernel");
-  if (kb.r_out) {
-    if (kb.mul) go(ks_inner_kernel<P, LR, 64, true, true>, *kb.mul);
-    else go(ks_inner_kernel<P, LR, 64, false, true>, NoMul{});
-  } else if ((tile >> LR) <= 64) {
-    if (kb.mul) go(ks_inner_kernel<P, LR, 64, true>, *kb.mul);
-    else go(ks_inner_kernel<P, LR, 64, false>, NoMul{});
-  } else {
-    if (kb.mul) go(ks_inner_kernel<P, LR, NTT_THREADS, true>, *kb.mul);
-    else go(ks_inner_kernel<P, LR, NTT_THREADS, false>, NoMul{});
+  if (kb.fold && kb.istep != 1) throw std::logic_error("the folded key-switch forms are not used on limb shards");
+  if (kb.fold && !kb.mul && !kb.adds) throw std::logic_error("folded key switch without polynomials to fold");
+  const int mode = kb.mul ? (kb.fold ? KS_FOLDMUL : KS_MUL) : (kb.fold ? KS_FOLDADD : KS_PLAIN);
+  auto with_mode = [&](auto mode_tag) {
+    constexpr int M = decltype(mode_tag)::value;
+    const KsMulArg<M> mt = [&] { if constexpr (M == KS_MUL || M == KS_FOLDMUL) return *kb.mul; else return NoMul{}; }();
+    const KsAddArg<M> at = [&] { if constexpr (M == KS_FOLDADD) return *kb.adds; else return NoMul{}; }();
+    if (kb.r_out) go(ks_inner_kernel<P, LR, 64, M, true>, mt, at);
+    else if ((tile >> LR) <= 64) go(ks_inner_kernel<P, LR, 64, M>, mt, at);
+    else go(ks_inner_kernel<P, LR, NTT_THREADS, M>, mt, at);
+  };
+  switch (mode) {
+  case KS_PLAIN: with_mode(std::integral_constant<int, KS_PLAIN>{}); break;
+  case KS_MUL: with_mode(std::integral_constant<int, KS_MUL>{}); break;
+  case KS_FOLDMUL: with_mode(std::integral_constant<int, KS_FOLDMUL>{}); break;
+  default: with_mode(std::integral_constant<int, KS_FOLDADD>{}); break;
   }
   HIPCHK(hipGetLastError());
 }
@@ -90,7 +97,8 @@ void launch_ks_inner(evah_ctx *c, int P, const u64 *target, const u64 *scratch, 
 // r_small[2 n][N] for the special rows' first inverse pass; returns true when that pass was done
 // here (fused into the key-switch kernel) — the special rows of prod are then NOT written.
 bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t target_bs, const KeyDev *const *keys,
-                         uint32_t n, u64 *prod_d, const PtrTab *target_tab, const MulTab *mul, u64 *r_small) {
+                         uint32_t n, u64 *prod_d, const PtrTab *target_tab, const MulTab *mul, u64 *r_small, bool fold,
+                         const PtrTab *adds) {
   const size_t N = c->N;
   if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::runtime_error("key-switch batch out of range");
   KsBatch kb;
@@ -105,16 +113,24 @@ bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t targ
   }
   if (target_tab) kb.targets = *target_tab; // target == nullptr: separately allocated targets
   kb.mul = mul;
-  if (mul && !c->tun.fuse_mac) throw std::logic_error("the fused multiply needs the fused key-switch kernel");
+  kb.fold = fold;
+  kb.adds = adds;
+  if ((mul || fold) && !c->tun.fuse_mac) throw std::logic_error("the fused multiply / folded forms need the fused key-switch kernel");
   Scratch t(c, (size_t)n * l * N);        // coefficient-form digits
   Scratch sc(c, n * kb.scratch_bs);       // converted digits, NTT form per output limb
+  // folded fused multiply: d2 is stored by the inverse transform that forms it and is the target from memory
+  Scratch d2(c, mul && fold ? (size_t)n * l * N : 1);
+  if (mul && fold) {
+    target = d2.d;
+    kb.target_bs = target_bs = (size_t)l * N;
+  }
   // 1. digits to coefficient form (job -> (b, J))
   OpKsDigit::Params dp{t.d, sc.d, l, (size_t)l * N, kb.scratch_bs, 0, l + 1};
   // a small key switch is latency-bound: the digits' strided inverse pass and the first pass of the
   // digit conversion then run as one launch
   const bool small = c->tun.fuse_mac && std::max(1, c->tun.ks_groups) == 1 && fuse_small_launch(c, n * (l + 1) * l);
   if (mul) { // the target is the product's d2, formed on load
-    OpMulIntt::Params ip{*mul, t.d, (size_t)l * N, l};
+    OpMulIntt::Params ip{*mul, t.d, (size_t)l * N, l, fold ? d2.d : nullptr};
     if (small) launch_pass_p<false, true, OpMulIntt>(c, c->logN / 2, ip, n * l);
     else ntt_inverse<OpMulIntt>(c, ip, n * l);
   } else {
@@ -167,7 +183,14 @@ void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev &key, c
   Scratch prod(c, (size_t)2 * (l + 1) * N);    // [K][l+1][N]
   Scratch r(c, 2 * N);
   const KeyDev *kp = &key;
-  const bool inv1 = switch_key_products(c, l, target, 0, &kp, 1, prod.d, nullptr, nullptr, fuse_small_launch(c, 2 * l) ? r.d : nullptr);
+  // fold_pa: P * add[K] goes into the inner products (KS_FOLDADD), the combine pass then adds nothing
+  const bool fold = c->tun.fold_pa && c->tun.fuse_mac && add && add_polys >= 1 && add_polys <= 2;
+  PtrTab adds{};
+  if (fold)
+    for (uint32_t K = 0; K < add_polys; K++) adds.p[K] = add + K * add_ps;
+  const bool inv1 = switch_key_products(c, l, target, 0, &kp, 1, prod.d, nullptr, nullptr, fuse_small_launch(c, 2 * l) ? r.d : nullptr,
+                                        fold, fold ? &adds : nullptr);
+  if (fold) add = nullptr;
   // 3. mod-down by the special prime: INTT(special limb) + P/2, then per-limb NTT + combine
   OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
     OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, add, add_ps, add_polys, out, out_ps,
@@ -197,10 +220,14 @@ int evah_relinearize(evah_ctx *c, const evah_ct *a, evah_ct **out) {
         const u64 *a0 = a->d + (size_t)b0 * 3 * a->ps;
         Scratch prod(c, (size_t)n * 2 * pps);
         std::vector<const KeyDev *> keys(n, &c->sh->relin);
-        switch_key_products(c, l, a0 + 2 * a->ps, 3 * a->ps, keys.data(), n, prod.d);
+        const bool fold = c->tun.fold_pa && c->tun.fuse_mac;
+        PtrTab adds{};
+        for (uint32_t b = 0; b < n && fold; b++)
+          for (uint32_t K = 0; K < 2; K++) adds.p[2 * b + K] = a0 + (size_t)b * 3 * a->ps + K * a->ps;
+        switch_key_products(c, l, a0 + 2 * a->ps, 3 * a->ps, keys.data(), n, prod.d, nullptr, nullptr, nullptr, fold, fold ? &adds : nullptr);
         Scratch r(c, (size_t)n * 2 * N);
         OpPlain::Params sp{prod.d + (size_t)l * N, r.d, pps, N, 1, c->k - 1, 1, {}};
-        OpModDown::Params mp{r.d, N, prod.d, pps, a0, a->ps, 2, o->d + (size_t)b0 * 2 * o->ps, o->ps, c->k - 1, l};
+        OpModDown::Params mp{r.d, N, prod.d, pps, fold ? nullptr : a0, a->ps, 2, o->d + (size_t)b0 * 2 * o->ps, o->ps, c->k - 1, l};
         mp.add_bs = 3 * a->ps;
         inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * n, mp, 2 * n * l);
       }
@@ -249,17 +276,28 @@ int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bit
   try {
     Scratch prod(c, 2 * pps);
     const KeyDev *kp = &c->sh->relin;
-    switch_key_products(c, l, a->d + 2 * a->ps, 0, &kp, 1, prod.d);
+    const bool fold = c->tun.fold_pa && c->tun.fuse_mac;
+    PtrTab adds{};
+    adds.p[0] = a->d;
+    adds.p[1] = a->d + a->ps;
+    switch_key_products(c, l, a->d + 2 * a->ps, 0, &kp, 1, prod.d, nullptr, nullptr, nullptr, fold, fold ? &adds : nullptr);
     Scratch r(c, 2 * N), t(c, 2 * N);
     // r_K = INTT_P(prod[K][special]) + P/2
     OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
     ntt_inverse<OpPlain>(c, spp, 2);
-    // t_K = INTT_last(a[K][last] + prod[K][last] P^-1) - u_K,last P^-1 + q_last/2
-    OpRRLast::Params lp{a->d + (size_t)last * N, a->ps, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, {}};
-    ntt_inverse<OpRRLast>(c, lp, 2);
-    // out[K][i] = (a[K][i] + prod[K][i] P^-1 - NTT_i(u P^-1 + v)) q_last^-1
-    OpRR::Params rp{r.d, N, t.d, N, a->d, a->ps, prod.d, pps, o->d, o->ps, sp, last, l - 1, {}};
-    ntt_forward<OpRR>(c, rp, 2 * (l - 1));
+    if (fold) { // prod already carries P a[K]
+      OpRRLastFolded::Params lp{nullptr, 0, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, {}};
+      ntt_inverse<OpRRLastFolded>(c, lp, 2);
+      OpRRFolded::Params rp{r.d, N, t.d, N, nullptr, 0, prod.d, pps, o->d, o->ps, sp, last, l - 1, {}};
+      ntt_forward<OpRRFolded>(c, rp, 2 * (l - 1));
+    } else {
+      // t_K = INTT_last(a[K][last] + prod[K][last] P^-1) - u_K,last P^-1 + q_last/2
+      OpRRLast::Params lp{a->d + (size_t)last * N, a->ps, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, {}};
+      ntt_inverse<OpRRLast>(c, lp, 2);
+      // out[K][i] = (a[K][i] + prod[K][i] P^-1 - NTT_i(u P^-1 + v)) q_last^-1
+      OpRR::Params rp{r.d, N, t.d, N, a->d, a->ps, prod.d, pps, o->d, o->ps, sp, last, l - 1, {}};
+      ntt_forward<OpRR>(c, rp, 2 * (l - 1));
+    }
   } catch (...) {
     evah_ct_free(c, o);
     throw;
@@ -289,11 +327,19 @@ static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n
   }
   Scratch prod(c, (size_t)n * 2 * pps);
   std::vector<const KeyDev *> keys(n, &c->sh->relin);
-  switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2, mul);
+  // r04: P * (the polynomials the key-switch result is added to) goes into the inner products themselves, so the
+  // combine passes below read prod only (Tunables::fold_pa; the r03 forms stay for A/B runs)
+  const bool fold = c->tun.fold_pa;
+  switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2, mul, nullptr, fold, mul ? nullptr : &a_polys);
   Scratch r(c, (size_t)n * 2 * N), t(c, (size_t)n * 2 * N);
   OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
   ntt_inverse<OpPlain>(c, spp, 2 * n);
-  if (mul) {
+  if (fold) {
+    OpRRLastFolded::Params lp{nullptr, 0, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, {}};
+    ntt_inverse<OpRRLastFolded>(c, lp, 2 * n);
+    OpRRFolded::Params rp{r.d, N, t.d, N, nullptr, 0, prod.d, pps, out_d, ops, sp, last, l - 1, {}};
+    ntt_forward<OpRRFolded>(c, rp, 2 * n * (l - 1));
+  } else if (mul) {
     OpRRLastMul::Params lp{nullptr, 0, prod.d + (size_t)last * N, pps, r.d, N, t.d, N, last, sp, a_last, *mul};
     ntt_inverse<OpRRLastMul>(c, lp, 2 * n);
     OpRRMul::Params rp{r.d, N, t.d, N, nullptr, 0, prod.d, pps, out_d, ops, sp, last, l - 1, a_polys, *mul};
@@ -491,11 +537,12 @@ int evah_relinearize_many(evah_ctx *c, const evah_ct *const *cts, uint32_t n, ev
   try {
     Scratch prod(c, (size_t)n * 2 * pps);
     std::vector<const KeyDev *> keys(n, &c->sh->relin);
-    switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2);
+    const bool fold = c->tun.fold_pa && c->tun.fuse_mac;
+    switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2, nullptr, nullptr, fold, fold ? &c01 : nullptr);
     Scratch r(c, (size_t)n * 2 * N);
     OpPlain::Params sp{prod.d + (size_t)l * N, r.d, pps, N, 1, c->k - 1, 1, {}};
         OpModDown::Params mp{r.d, N, prod.d, pps, nullptr, 0, 0, ob->d, ops, c->k - 1, l};
-    mp.use_add_tab = true;
+    mp.use_add_tab = !fold; // folded: P c_K is in prod already
     mp.add_tab = c01;
     inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * n, mp, 2 * n * l);
   } catch (...) {

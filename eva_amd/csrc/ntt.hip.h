@@ -416,16 +416,42 @@ __device__ __forceinline__ u64 product_poly(const MulSrc &m, uint32_t K, size_t 
 
 struct NoMul {}; // placeholder for the operand table in the variants that read a stored product
 
+// Where the key-switch target and the polynomials the result is added to come from (MODE):
+//   KS_PLAIN   target from memory, nothing added
+//   KS_MUL     fused multiply, r03 form: the target d2 = a1 b1 of product `inst` is evaluated where the NTT-form
+//              digit is used as is (I == J); d0, d1 are left to the combine epilogue of the mod-down
+//   KS_FOLDMUL fused multiply, r04 form: the target is read from memory (OpMulIntt stores d2 next to its inverse
+//              transform) and P * d0, P * d1 (P = the special prime) are added to the inner products of the data
+//              limbs right here:  prod'[K][I] = prod[K][I] + P d_K[I]  mod q_I.  The mod-down computes
+//              (prod' - U) P^-1 = d_K + (prod - U) P^-1, the same canonical residue, without reading the operands
+//              again — its combine pass was waiting for those bytes (6 words per output word) while this
+//              kernel, which is bound by integer issue, has the memory slack to fetch them.  The products are
+//              128-bit MACs of a canonical operand with a lazy Shoup product (< 4q) of the other operand and P.
+//   KS_FOLDADD the same for stored polynomials (relinearize, relinearize + rescale of a size-3 ciphertext; a
+//              rotation's permuted c0): P * c_K is added, c_K = adds.p[2 inst + K] (limb 0; null = nothing to add),
+//              so the mod-down's combine pass no longer reads c_K.
+// (plain ints, not an unnamed enum: the enum's type would be mangled into the kernel's name as a local type and the
+// runtime could not find the symbol)
+constexpr int KS_PLAIN = 0, KS_MUL = 1, KS_FOLDMUL = 2, KS_FOLDADD = 3;
+// kernel-argument types per mode (a traits struct, so the kernel's mangled name carries no constant expression)
+template <int MODE> struct KsArgs { using Mul = NoMul; using Add = NoMul; };
+template <> struct KsArgs<KS_MUL> { using Mul = MulTab; using Add = NoMul; };
+template <> struct KsArgs<KS_FOLDMUL> { using Mul = MulTab; using Add = NoMul; };
+template <> struct KsArgs<KS_FOLDADD> { using Mul = NoMul; using Add = PtrTab; };
+template <int MODE> using KsMulArg = typename KsArgs<MODE>::Mul;
+template <int MODE> using KsAddArg = typename KsArgs<MODE>::Add;
+
 // INVSP (latency-bound launches): the workgroups of the special-prime row (I == l) go straight on
 // with the contiguous pass of that row's inverse transform — the first step of the mod-down that
 // always follows — on the tile they hold, and store its lazy intermediate to r_out[2 inst + K]
 // instead of the row itself: one launch fewer per key switch, same residues.
-template <int P, int LR, int MAXT, bool MUL, bool INVSP = false>
+template <int P, int LR, int MAXT, int MODE, bool INVSP = false>
 __global__ void __launch_bounds__(MAXT)
 ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
                 size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, uint32_t i0,
-                int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets, std::conditional_t<MUL, MulTab, NoMul> mul, uint32_t istep,
-                uint32_t nout, u64 *__restrict__ r_out) {
+                int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets, KsMulArg<MODE> mul, uint32_t istep,
+                uint32_t nout, u64 *__restrict__ r_out, KsAddArg<MODE> adds) {
+  constexpr bool MUL = MODE == KS_MUL;
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   if (cx.skipped()) return;
   // grid.x carries (tile, instance): instances of one tile are placed 8 block ids apart, i.e. on
@@ -484,7 +510,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   // transform starts and the coefficients of digit J+1 as soon as those of J sit in LDS, so both
   // streams are in flight during the register rounds instead of being waited for at their use.
   MulSrc msrc{nullptr, nullptr, 0, 0};
-  if constexpr (MUL) msrc = mul_src(mul, cx.N, inst);
+  if constexpr (MUL || MODE == KS_FOLDMUL) msrc = mul_src(mul, cx.N, inst);
   auto load_digits = [&](uint32_t J, ulonglong2 *d) {
     if (MUL && I == J) { // block-uniform
 #pragma unroll
@@ -501,6 +527,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   };
   ulonglong2 dreg[NPAIR];
   load_digits(0, dreg);
+  uint32_t since_fold = 0;
   for (uint32_t J = 0; J < l; J++) {
     ulonglong2 k0r[NPAIR], k1r[NPAIR];
     const u64 *kp = key + J * key_digit + (size_t)krow * N + gbase;
@@ -548,13 +575,54 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
       acc128(acc1[2 * it], val[2 * it], k1r[it].x);
       acc128(acc1[2 * it + 1], val[2 * it + 1], k1r[it].y);
     }
-    // 16 lazy products (each < 2^124) fill the 128-bit accumulators: with more digits than that,
-    // fold them back to one word every 16 (block-uniform, only ever taken when l > 16)
-    if ((J & 15u) == 15u && J + 1 < l) {
+    // 16 lazy products (each < 16q * q < 2^124) fill the 128-bit accumulators, 15 of them and a folded word leave
+    // room for the P * d_K terms added after the loop (< 12 q^2 together): with more digits than that, fold the
+    // accumulators back to one word every 15 (block-uniform, only ever taken when l > 15)
+    if (++since_fold == 15u && J + 1 < l) {
+      since_fold = 0;
 #pragma unroll
       for (int i = 0; i < NTT_R; i++) {
         acc0[i] = {barrett128(acc0[i], pm), 0};
         acc1[i] = {barrett128(acc1[i], pm), 0};
+      }
+    }
+  }
+  if constexpr (MODE == KS_FOLDMUL || MODE == KS_FOLDADD) {
+    { // after the digit loop, where its prefetch registers are free (as a prologue the block cost 32 VGPRs: 147, 3 waves
+      // per SIMD).  No branch: the special row multiplies by modq[P][P] = (0, 0) — P = 0 mod P — and reads a row that exists
+      const ulonglong2 Pm = cx.modq[(size_t)(cx.k - 1) * cx.k + kap]; // (P mod q_I, Shoup quotient)
+      const size_t off = (size_t)(Irow < l ? Irow : l - 1) * N + gbase;
+#pragma unroll
+      for (int it = 0; it < NPAIR; it++) {
+        const size_t o = off + 2 * (threadIdx.x + it * T);
+        if constexpr (MODE == KS_FOLDMUL) {
+          const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(msrc.a + o);
+          const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(msrc.a + msrc.sa + o);
+          const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(msrc.b + o);
+          const ulonglong2 b1 = *reinterpret_cast<const ulonglong2 *>(msrc.b + msrc.sb + o);
+          // a < q, lazy(b P) < 4q: each term < 2^122, three of them on top of 15 digit products still fit 128 bits
+          const u64 u0x = mul_tw_lazy5(b0.x, Pm.x, Pm.y, pm.nq), u0y = mul_tw_lazy5(b0.y, Pm.x, Pm.y, pm.nq);
+          const u64 u1x = mul_tw_lazy5(b1.x, Pm.x, Pm.y, pm.nq), u1y = mul_tw_lazy5(b1.y, Pm.x, Pm.y, pm.nq);
+          acc128(acc0[2 * it], a0.x, u0x);
+          acc128(acc0[2 * it + 1], a0.y, u0y);
+          acc128(acc1[2 * it], a0.x, u1x);
+          acc128(acc1[2 * it + 1], a0.y, u1y);
+          acc128(acc1[2 * it], a1.x, u0x);
+          acc128(acc1[2 * it + 1], a1.y, u0y);
+        } else {
+          // a null entry: nothing is added to that polynomial (a rotation adds the permuted c0 to K = 0 only)
+          const u64 *p0 = adds.p[2 * inst], *p1 = adds.p[2 * inst + 1]; // block-uniform
+          if (p0) {
+            const ulonglong2 c0 = *reinterpret_cast<const ulonglong2 *>(p0 + o);
+            acc128(acc0[2 * it], c0.x, Pm.x);
+            acc128(acc0[2 * it + 1], c0.y, Pm.x);
+          }
+          if (p1) {
+            const ulonglong2 c1 = *reinterpret_cast<const ulonglong2 *>(p1 + o);
+            acc128(acc1[2 * it], c1.x, Pm.x);
+            acc128(acc1[2 * it + 1], c1.y, Pm.x);
+          }
+        }
       }
     }
   }
@@ -676,12 +744,14 @@ struct OpMulIntt {
     u64 *dst;      // [batch][jl][N] coefficient-form digits
     size_t dst_ps; // batch stride
     uint32_t jl;
+    u64 *d2 = nullptr; // != nullptr: d2 itself (NTT form) is stored too, [batch][jl][N] at the same stride — the
+                       // key-switch kernel reads it where the digit is used as is (I == J) instead of forming it again
   };
   struct Job {
     uint32_t prime;
     size_t off;
     MulSrc mul;
-    u64 *dst;
+    u64 *dst, *d2;
     bool lazy;
   };
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
@@ -690,12 +760,15 @@ struct OpMulIntt {
     j.off = (size_t)i * cx.N;
     j.mul = mul_src(p.mul, cx.N, b);
     j.dst = p.dst + b * p.dst_ps + (size_t)i * cx.N;
+    j.d2 = p.d2 ? p.d2 + b * p.dst_ps + (size_t)i * cx.N : nullptr;
     j.lazy = false;
     return true;
   }
   template <bool LZ>
   static __device__ __forceinline__ u64 load(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n) {
-    return product_poly(j.mul, 2, j.off + n, pm);
+    const u64 v = product_poly(j.mul, 2, j.off + n, pm);
+    if (j.d2) j.d2[n] = v; // block-uniform
+    return v;
   }
   static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &, uint32_t n, u64 v) {
     j.dst[n] = v;
@@ -843,8 +916,16 @@ struct OpModDown {
 // (K,i) instead of two, and t_K = INTT(ct'[K][last]) + q_last/2 needs no NTT of u at all:
 //   t_K = INTT_last(a[K][last] + prod[K][last]*P^-1) - u_K,last*P^-1 + floor(q_last/2).
 
+// Where a[K] (the polynomials the key-switch result is added to) comes from (AM):
+//   RR_MEM    read from memory
+//   RR_MUL    d_K of a fused product, evaluated on load / in the epilogue (r03 form)
+//   RR_FOLDED nowhere: the key-switch kernel already added P * a[K] to prod (KS_FOLDMUL / KS_FOLDADD), so
+//             prod * P^-1 carries it
+constexpr int RR_MEM = 0, RR_MUL = 1, RR_FOLDED = 2;
+
 // inverse transform producing t_K; job = K, prime = last data prime
-template <bool MUL> struct OpRRLastT {
+template <int AM> struct OpRRLastT {
+  static constexpr bool MUL = AM == RR_MUL;
   struct Params {
     const u64 *a;     // a[0][last]
     size_t a_ps;
@@ -876,7 +957,7 @@ template <bool MUL> struct OpRRLastT {
     if constexpr (MUL) j.mul = mul_src(p.mul, cx.N, job >> 1);
     j.K = job & 1u;
     j.off = (size_t)p.last * cx.N;
-    j.a = MUL ? nullptr : (p.a ? p.a + job * p.a_ps : p.a_tab.p[job]);
+    j.a = AM != RR_MEM ? nullptr : (p.a ? p.a + job * p.a_ps : p.a_tab.p[job]);
     j.prod = p.prod + job * p.prod_ps;
     j.r = p.r + job * p.r_ps;
     j.dst = p.t + job * p.t_ps;
@@ -887,8 +968,10 @@ template <bool MUL> struct OpRRLastT {
   }
   template <bool LZ>
   static __device__ __forceinline__ u64 load(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n) {
+    const u64 pv = mul_shoup(j.prod[n], j.pinv.x, j.pinv.y, pm.q);
+    if constexpr (AM == RR_FOLDED) return pv;
     const u64 av = MUL ? product_poly(j.mul, j.K, j.off + n, pm) : j.a[n];
-    return addmod(av, mul_shoup(j.prod[n], j.pinv.x, j.pinv.y, pm.q), pm.q);
+    return addmod(av, pv, pm.q);
   }
   static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 x) {
     const u64 u = submod(barrett64(j.r[n], pm.q, pm.brt), j.halfP, pm.q);
@@ -898,7 +981,8 @@ template <bool MUL> struct OpRRLastT {
 };
 
 // forward transform of u*P^-1 + v with the combined epilogue; job -> (K = job / jl, i = job % jl)
-template <bool MUL> struct OpRRT {
+template <int AM> struct OpRRT {
+  static constexpr bool MUL = AM == RR_MUL;
   struct Params {
     const u64 *r;
     size_t r_ps;
@@ -934,7 +1018,7 @@ template <bool MUL> struct OpRRT {
     if constexpr (MUL) j.mul = mul_src(p.mul, cx.N, K >> 1);
     j.K = K & 1u;
     j.off = (size_t)i * cx.N;
-    j.a = MUL ? nullptr : (p.a ? p.a + K * p.a_ps : p.a_tab.p[K]) + (size_t)i * cx.N;
+    j.a = AM != RR_MEM ? nullptr : (p.a ? p.a + K * p.a_ps : p.a_tab.p[K]) + (size_t)i * cx.N;
     j.prod = p.prod + K * p.prod_ps + (size_t)i * cx.N;
     j.dst = p.dst + K * p.dst_ps + (size_t)i * cx.N;
     j.halfP = cx.halfmod[p.sp * cx.k + i];
@@ -955,7 +1039,8 @@ template <bool MUL> struct OpRRT {
   }
   static __device__ __forceinline__ void store_fwd(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n, u64 W) {
     W += (W >= pm.q8 ? pm.nq8 : 0);                                                  // [0,16q) -> [0,8q)
-    const u64 av = MUL ? product_poly(j.mul, j.K, j.off + n, pm) : j.a[n];
+    u64 av = 0;
+    if constexpr (AM != RR_FOLDED) av = MUL ? product_poly(j.mul, j.K, j.off + n, pm) : j.a[n];
     const u64 x = av + mul_tw_lazy5(j.prod[n], j.pinv.x, j.pinv.y, pm.nq) + pm.q8 - W; // < 14q < 2^64
     j.dst[n] = mul_shoup(x, j.linv.x, j.linv.y, pm.q);                               // exact for any 64-bit operand
   }
@@ -963,9 +1048,11 @@ template <bool MUL> struct OpRRT {
   // 32-triple launch — its on-the-fly products already keep four loads per word in flight)
 };
 
-using OpRRLast = OpRRLastT<false>;
-using OpRRLastMul = OpRRLastT<true>;
-using OpRR = OpRRT<false>;
-using OpRRMul = OpRRT<true>;
+using OpRRLast = OpRRLastT<RR_MEM>;
+using OpRRLastMul = OpRRLastT<RR_MUL>;
+using OpRRLastFolded = OpRRLastT<RR_FOLDED>;
+using OpRR = OpRRT<RR_MEM>;
+using OpRRMul = OpRRT<RR_MUL>;
+using OpRRFolded = OpRRT<RR_FOLDED>;
 
 } // namespace evah

@@ -310,6 +310,7 @@ static void rot_perm_launch(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t
   HIPCHK(hipGetLastError());
 }
 // mod-down of a chunk's products (step 3 of switch_key); c0' = perm_d[2r] is added to the even polys
+// perm_d == nullptr: P c0' was added to the products already (KS_FOLDADD)
 static void rot_mod_down(evah_ctx *c, uint32_t l, uint32_t np, u64 *prod_d, const u64 *perm_d, u64 *out_d, u64 *r_d, bool inv1) {
   const size_t N = c->N, pps = (size_t)l * N;
   // INTT of the special limbs, job = r*2 + K
@@ -326,9 +327,12 @@ static void rot_chunk_plain(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t
   Scratch perm(c, (size_t)np * 2 * pps); // [r][c0 permuted | c1 permuted = key-switch target]
   rot_perm_launch(c, l, pr, np, perm.d, 2);
   Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N);
+  const bool fold = c->tun.fold_pa && c->tun.fuse_mac;
+  PtrTab adds{}; // P * (permuted c0) joins the inner product of K = 0; nothing is added to K = 1
+  for (uint32_t rr = 0; rr < np && fold; rr++) adds.p[2 * rr] = perm.d + (size_t)rr * 2 * pps;
   const bool inv1 = switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), np, prod.d, nullptr, nullptr,
-                                        fuse_small_launch(c, 2 * np * l) ? r.d : nullptr);
-  rot_mod_down(c, l, np, prod.d, perm.d, out_d, r.d, inv1);
+                                        fuse_small_launch(c, 2 * np * l) ? r.d : nullptr, fold, fold ? &adds : nullptr);
+  rot_mod_down(c, l, np, prod.d, fold ? nullptr : perm.d, out_d, r.d, inv1);
 }
 // The whole set.  hoisted: the digits of every distinct source are transformed once and each pair's
 // key inner product is formed from them (k_hoist_mac / k_hoist_fix), then the unhoisted launches
