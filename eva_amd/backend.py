@@ -102,6 +102,8 @@ _SIGS = {
     "evah_ctx_shard_info": [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
     "evah_buf_alloc": [_vp, C.c_size_t, _vpp],
     "evah_buf_copy": [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t],
+    "evah_buf_gather": [_vp, _vp, C.c_uint32, _vpp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t],
+    "evah_ctx_enable_peer": [_vp, _vp],
     "evah_buf_download": [_vp, _vp, C.c_size_t, C.c_size_t, _u64p],
     "evah_buf_upload": [_vp, _vp, C.c_size_t, C.c_size_t, _u64p],
     "evah_shard_galois_perm": [_vp, _vp, C.c_uint32, _vpp],
@@ -306,6 +308,15 @@ class DeviceBuffer:
     def copy_from(self, src, dst_off, src_off, words):
         """device (or peer) copy on this buffer's queue, ordered after the producer of src"""
         _chk(_lib.evah_buf_copy(self.ctx.h, self.h, int(dst_off), src.h, int(src_off), int(words)))
+
+    def gather_from(self, srcs, src_offs, dst_offs, words):
+        """ONE launch on this buffer's queue that pulls a chunk of `words` words from each of srcs (peer reads across
+        devices): srcs[j][src_offs[j]..) -> self[dst_offs[j]..)"""
+        n = len(srcs)
+        hs = (C.c_void_p * n)(*[s.h for s in srcs])
+        so = (C.c_size_t * n)(*[int(x) for x in src_offs])
+        do = (C.c_size_t * n)(*[int(x) for x in dst_offs])
+        _chk(_lib.evah_buf_gather(self.ctx.h, self.h, n, hs, so, do, int(words)))
 
     def download(self, off=0, words=None):
         words = self.words - off if words is None else words

@@ -240,6 +240,15 @@ struct Tunables {
   // is added to) to the key inner products inside ks_inner_kernel (KS_FOLDMUL / KS_FOLDADD), so the mod-down's
   // combine pass — which waits for bytes — reads the products only; 0 = the r03 forms (operands read in the epilogue)
   bool fold_pa = true;
+  // EVAH_LOOP_N (8) / EVAH_LOOP_MIN (2): contiguous transform passes whose launch holds at least loop_min jobs modulo
+  // one prime (both polynomials of a ciphertext, the instances of a batched call, the digits of a hoisted set) run as
+  // ntt_loop_kernel: the twiddle heaps of a tile staged in LDS once per workgroup and reused by up to loop_n jobs;
+  // loop_n = 0: ntt_pass_kernel everywhere (per-thread global twiddle loads)
+  // EVAH_LOOP_MIN_WGS (2048): below this many workgroups (at two jobs per walk) the launch keeps ntt_pass_kernel
+  uint32_t loop_n = 8, loop_min = 2, loop_min_wgs = 2048;
+  // EVAH_LDS_EXTRA (0): bytes of dynamic LDS added to every ntt_pass_kernel launch — an occupancy probe for the
+  // tuning notes (fewer workgroups per CU), never set in production
+  uint32_t lds_extra = 0;
 
   static Tunables from_env(uint32_t N) {
     Tunables t;
@@ -256,6 +265,10 @@ struct Tunables {
     flag("EVAH_HOIST_DEBUG", t.hoist_debug);
     flag("EVAH_FUSE_SPECIAL_INV", t.fuse_special_inv);
     flag("EVAH_FOLD_PA", t.fold_pa);
+    count("EVAH_LOOP_N", t.loop_n);
+    count("EVAH_LOOP_MIN", t.loop_min);
+    count("EVAH_LOOP_MIN_WGS", t.loop_min_wgs);
+    count("EVAH_LDS_EXTRA", t.lds_extra);
     if (const char *e = std::getenv("EVAH_KS_GROUPS")) t.ks_groups = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {
       const int n = std::atoi(e);

@@ -37,6 +37,7 @@ static void launch_pass(evah_ctx *c, const typename Op::Params &prm, uint32_t jo
   const int logC = (int)ilog2(tile) - P;
   size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64);
   if (STRIDED) lds += ((size_t)1 << P) * sizeof(ulonglong2); // staged twiddles
+  lds += c->tun.lds_extra; // occupancy probe (EVAH_LDS_EXTRA), 0 ordinarily
   const uint32_t n_tiles = c->N / tile;
   const int log_tiles = (int)ilog2(n_tiles);
   dim3 grid = Op::grid(prm, jobs), block(tile >> LR);
@@ -66,10 +67,51 @@ static void launch_pass_lr(evah_ctx *c, int P, const typename Op::Params &prm, u
   default: throw std::runtime_error("unsupported poly_modulus_degree for the NTT kernels");
   }
 }
+// Contiguous pass as ntt_loop_kernel: one wave per 256-coefficient tile, the tile's twiddle heaps staged in LDS once
+// and reused by up to loop_n jobs that share the prime (Tunables::loop_n; 0 = off).  Returns false when the launch
+// has fewer than loop_min jobs along the op's loop axis (nothing to share) and the caller takes ntt_pass_kernel.
+template <int P, bool INVERSE, class Op>
+static bool launch_loop_pass(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  constexpr int LR = 2;
+  dim3 grid = Op::grid(prm, jobs);
+  uint32_t ext[3] = {grid.x, grid.y, grid.z};
+  const uint32_t count = ext[Op::loop_axis];
+  if (!c->tun.loop_n || count < c->tun.loop_min || c->N < 256) return false;
+  // a launch that cannot fill the chip is latency-bound: walking jobs one after the other only lengthens it
+  if ((uint64_t)ext[0] * ext[1] * ext[2] / count * (c->N / 256) * ((count + 1) / 2) < c->tun.loop_min_wgs) return false;
+  ProfScope ps(c, INVERSE ? KC_INTT_A : OpClass<Op>::fwd_b);
+  const uint32_t tile = 256, n_tiles = c->N / tile;
+  const int logC = 8 - P, log_tiles = (int)ilog2(n_tiles);
+  // enough workgroups to fill the chip several times over before twiddle sharing is taken further
+  uint32_t nloop = std::min<uint32_t>(c->tun.loop_n, count);
+  const uint64_t others = (uint64_t)ext[0] * ext[1] * ext[2] / count * n_tiles;
+  while (nloop > 2 && others * ((count + nloop - 1) / nloop) < 8192) nloop = (nloop + 1) / 2;
+  ext[Op::loop_axis] = (count + nloop - 1) / nloop;
+  const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) +
+                     ((size_t)1 << (logC + P)) * sizeof(ulonglong2);
+  hipLaunchKernelGGL((ntt_loop_kernel<P, LR, INVERSE, Op>), dim3(ext[0] * n_tiles, ext[1], ext[2]), dim3(tile >> LR), lds, c->stream,
+                     c->dev, prm, logC, log_tiles, nloop, count);
+  HIPCHK(hipGetLastError());
+  return true;
+}
+template <bool INVERSE, class Op>
+static bool launch_loop_pass_p(evah_ctx *c, int P, const typename Op::Params &prm, uint32_t jobs) {
+  switch (P) {
+  case 5: return launch_loop_pass<5, INVERSE, Op>(c, prm, jobs);
+  case 6: return launch_loop_pass<6, INVERSE, Op>(c, prm, jobs);
+  case 7: return launch_loop_pass<7, INVERSE, Op>(c, prm, jobs);
+  case 8: return launch_loop_pass<8, INVERSE, Op>(c, prm, jobs);
+  default: return false;
+  }
+}
+
 // 8 coefficients per thread measured best for the stand-alone passes on MI355X (vs 4: +12 %,
 // vs 16: +10 %, profiles/r01_tuning_notes.md); the fused key-switch kernel uses 4.
 template <bool STRIDED, bool INVERSE, class Op>
 static void launch_pass_p(evah_ctx *c, int P, const typename Op::Params &prm, uint32_t jobs) {
+  if constexpr (!STRIDED) {
+    if (launch_loop_pass_p<INVERSE, Op>(c, P, prm, jobs)) return;
+  }
   // a launch that cannot fill the chip is bound by ONE wave's instruction stream (a thread's 8
   // coefficients are ~600 integer instructions per pass): with 4 coefficients per thread the same
   // tile work is spread over twice the workgroups and the critical path of a workgroup shrinks

@@ -46,8 +46,24 @@ template <int P, int LR> struct Rounds {
   }
 };
 
-__device__ __forceinline__ int lds_pad(int e) { return e + (e >> 4); }
-template <int P> constexpr int lds_sub_stride() { return (1 << P) + ((1 << P) >> 4) + 1; }
+// LDS layout of a sub-transform: element e at lds_pad<P>(e).  The pad is a sum of shifts, so it is additive over
+// disjoint bit fields (ntt_round adds the per-element part as an immediate offset).  One word per 16 elements for the
+// short sub-transforms, two for 2^7 points and more: the 64-bit accesses of a round are served in groups of 8 / 16
+// lanes over 32 banks (MI355X_MICROARCH.md, LDS), and with one word the 8-coefficient rounds of a 256-point transform
+// spend 30 % of their LDS cycles in 2-way conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.30 measured, the
+// same from a simulation of the access pattern); two words bring that to 12 % (r04_tuning_notes.md)
+#ifndef EVAH_LDS_PAD2
+#define EVAH_LDS_PAD2 1 // 0: one word per 16 elements everywhere (the r03 layout; A/B switch of the build)
+#endif
+template <int P> __device__ __forceinline__ int lds_pad(int e) {
+  return (EVAH_LDS_PAD2 && P >= 7) ? e + 2 * (e >> 4) : e + (e >> 4);
+}
+template <int P> constexpr int lds_sub_stride() {
+  return (EVAH_LDS_PAD2 && P >= 7) ? (1 << P) + 2 * (((1 << P) - 1) >> 4) : (1 << P) + ((1 << P) >> 4) + 1;
+}
+#ifndef EVAH_ROUND_BARRIER
+#define EVAH_ROUND_BARRIER 1 // 0 (experiment): rounds of a sub-transform worked on by one wave exchange through LDS in program order only
+#endif
 
 // mul_tw_lazy5 (devmath.hip.h): x*w - q~*q in [0, 4q) for any 64-bit x with a 3-multiply quotient estimate.
 // Moduli are < 2^60, so every lazy value below stays < 16q <= 2^64.
@@ -110,7 +126,9 @@ __device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u
 // RED_EVEN: forward passes reduce on even (true) or odd (false) local stage indices — the first
 // (strided) pass starts from canonical input and reduces on odd stages, so it always exits < 16q;
 // the second pass therefore reduces on even stages.
-template <int P, int LR, int RB, int LO, bool INVERSE, bool STRIDED, bool RED_EVEN>
+// LASTFOLD: this pass ends the inverse transform (its very last stage multiplies by N^-1) — the strided pass,
+// unless a contiguous pass borrows the local-heap indexing (ntt_loop_kernel)
+template <int P, int LR, int RB, int LO, bool INVERSE, bool STRIDED, bool RED_EVEN, bool LASTFOLD = STRIDED>
 __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
                                           const ulonglong2 *__restrict__ tw, const DevPrime &pm) {
   constexpr int NTT_R = 1 << LR;
@@ -130,9 +148,9 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
     const int ebase = (o_hi << (LO + RB)) | o_lo;
     // ebase and (u << LO) occupy disjoint bit fields, so pad(ebase | u << LO) = pad(ebase) + pad(u << LO):
     // one padded base per group, the per-element part is an immediate offset of the LDS access
-    u64 *grp = sub_lds + lds_pad(ebase);
+    u64 *grp = sub_lds + lds_pad<P>(ebase);
 #pragma unroll
-    for (int u = 0; u < NU; u++) x[g * NU + u] = grp[lds_pad(u << LO)];
+    for (int u = 0; u < NU; u++) x[g * NU + u] = grp[lds_pad<P>(u << LO)];
     const uint32_t node = STRIDED ? ((1u << S0) | (uint32_t)o_hi)
                                   : ((1u << (pre + S0)) | (h << S0) | (uint32_t)o_hi);
     if (!INVERSE) {
@@ -153,7 +171,7 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
       for (int s = RB - 1; s >= 0; s--) {
         const int half = 1 << (RB - 1 - s);
         // the very last stage of the whole inverse transform folds in N^-1
-        const bool last = STRIDED && (S0 == 0) && (s == 0);
+        const bool last = LASTFOLD && (S0 == 0) && (s == 0);
 #pragma unroll
         for (int u = 0; u < NU; u++) {
           if (u & half) continue;
@@ -171,20 +189,22 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
       }
     }
 #pragma unroll
-    for (int u = 0; u < NU; u++) grp[lds_pad(u << LO)] = x[g * NU + u];
+    for (int u = 0; u < NU; u++) grp[lds_pad<P>(u << LO)] = x[g * NU + u];
   }
 }
 
-template <int P, int LR, int I, bool INVERSE, bool STRIDED, bool RED_EVEN> struct RoundSeq {
+template <int P, int LR, int I, bool INVERSE, bool STRIDED, bool RED_EVEN, bool LASTFOLD = STRIDED> struct RoundSeq {
   // forward: rounds 0..NR-1 (top bits first); inverse: NR-1..0 (low bits first)
   static __device__ __forceinline__ void run(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
                                              const ulonglong2 *tw, const DevPrime &pm) {
     using RS = Rounds<P, LR>;
     constexpr int idx = INVERSE ? (RS::NR - 1 - I) : I;
-    ntt_round<P, LR, RS::bits(idx), RS::lo(idx), INVERSE, STRIDED, RED_EVEN>(sub_lds, tid, h, pre, tw, pm);
+    ntt_round<P, LR, RS::bits(idx), RS::lo(idx), INVERSE, STRIDED, RED_EVEN, LASTFOLD>(sub_lds, tid, h, pre, tw, pm);
     if constexpr (I + 1 < RS::NR) {
-      __syncthreads();
-      RoundSeq<P, LR, I + 1, INVERSE, STRIDED, RED_EVEN>::run(sub_lds, tid, h, pre, tw, pm);
+      // a sub-transform of <= 64 threads lives in one wave: its LDS exchange is ordered by the wave's own DS queue
+      if constexpr (!EVAH_ROUND_BARRIER && ((1 << P) >> LR) <= 64) __builtin_amdgcn_wave_barrier();
+      else __syncthreads();
+      RoundSeq<P, LR, I + 1, INVERSE, STRIDED, RED_EVEN, LASTFOLD>::run(sub_lds, tid, h, pre, tw, pm);
     }
   }
 };
@@ -235,19 +255,19 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC_rt, int log_tiles) 
     const int c = threadIdx.x & (C - 1), e0 = threadIdx.x >> logC;
     n0 = gbase + ((uint32_t)e0 << stride_log) + c;
     nstep = (uint32_t)(T >> logC) << stride_log;
-    l0 = c * SP + lds_pad(e0);
+    l0 = c * SP + lds_pad<P>(e0);
   } else {
     n0 = gbase + threadIdx.x;
     nstep = T;
-    l0 = (threadIdx.x >> P) * SP + lds_pad(threadIdx.x & (S - 1));
+    l0 = (threadIdx.x >> P) * SP + lds_pad<P>(threadIdx.x & (S - 1));
   }
   auto lds_at = [&](int it) -> int {
     if constexpr (LINEAR) {
-      return l0 + it * (STRIDED ? lds_pad(ES) : (NTT_THREADS >> P) * SP);
+      return l0 + it * (STRIDED ? lds_pad<P>(ES) : (NTT_THREADS >> P) * SP);
     } else {
       const int idx = threadIdx.x + it * T;
-      if (STRIDED) return (idx & (C - 1)) * SP + lds_pad(idx >> logC);
-      return (idx >> P) * SP + lds_pad(idx & (S - 1));
+      if (STRIDED) return (idx & (C - 1)) * SP + lds_pad<P>(idx >> logC);
+      return (idx >> P) * SP + lds_pad<P>(idx & (S - 1));
     }
   };
 
@@ -302,6 +322,116 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC_rt, int log_tiles) 
   }
 }
 
+// Contiguous pass, one wave per workgroup, several jobs per workgroup ("looped").  A contiguous pass runs the 2^P-point
+// sub-transforms rooted at heap nodes 2^pre + h: every sub-transform has its OWN 2^P - 1 twiddles, so ntt_pass_kernel
+// fetches 16 bytes of twiddle for every 8-byte coefficient it transforms — per-thread global loads in front of every
+// register round, which is what these passes waited for (VALU busy 0.56-0.66 where the strided passes and the
+// key-switch kernel, whose twiddles sit in LDS, reach 0.76-0.98).  The twiddles depend on (prime, tile) only: all
+// polynomials of a launch that share the prime — both polynomials of a ciphertext, every instance of a batched call —
+// can use one copy.  So a workgroup (64 threads, 4 coefficients per thread, a tile of 256 coefficients: the shape of
+// ks_inner_kernel) stages the local twiddle heaps of its tile in LDS once and walks up to `nloop` jobs along the grid
+// axis Op::loop_axis, the next job's tile in flight while the current one is transformed.
+//   forward (second pass): tile from jb.dst (the strided pass's intermediate), out through Op::store_fwd(_pre)
+//   inverse (first pass) : tile through Op::load, lazy intermediate to jb.dst
+// grid.x = n_tiles * (x-extent), grid.y / grid.z = the op's job coordinates with the loop axis divided by nloop.
+template <int P, int LR, bool INVERSE, class Op>
+__global__ void __launch_bounds__(64)
+ntt_loop_kernel(DevCtx cx, typename Op::Params prm, int logC, int log_tiles, uint32_t nloop, uint32_t loop_count) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  if (cx.skipped()) return;
+  constexpr int NTT_R = 1 << LR, NPAIR = NTT_R / 2;
+  constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
+  constexpr int AX = Op::loop_axis;
+  const uint32_t tile_idx = blockIdx.x & ((1u << log_tiles) - 1u);
+  uint32_t co[3] = {blockIdx.x >> log_tiles, blockIdx.y, blockIdx.z};
+  const uint32_t j0 = co[AX] * nloop, j1 = (j0 + nloop < loop_count) ? j0 + nloop : loop_count;
+  const int T = blockDim.x, C = 1 << logC;
+  const uint32_t pre = cx.logN - P, sub0 = tile_idx << logC, gbase = sub0 << P;
+  const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
+  typename Op::Job jb;
+  // first job that exists (an op may skip coordinates: OpKsDigit's I == J); every job of the walk has the same prime
+  uint32_t j = j0;
+  auto setup = [&](uint32_t jj, typename Op::Job &out) {
+    uint32_t c3[3] = {co[0], co[1], co[2]};
+    c3[AX] = jj;
+    return Op::setup(cx, prm, c3[0], c3[1], c3[2], out);
+  };
+  while (j < j1 && !setup(j, jb)) j++;
+  if (j >= j1) return; // block-uniform
+  const DevPrime pm = cx.primes[jb.prime];
+  const ulonglong2 *tw = (INVERSE ? cx.tw_inv : cx.tw_fwd) + (size_t)jb.prime * cx.N;
+  ulonglong2 *twl = reinterpret_cast<ulonglong2 *>(lds + ((C * SP + 1) & ~1));
+  for (int idx = threadIdx.x; idx < (C << P); idx += T) {
+    const int sb = idx >> P, n = idx & (S - 1);
+    if (n) {
+      const int d = 31 - __clz(n);
+      twl[idx] = tw[((size_t)((1u << pre) + sub0 + sb) << d) + (n - (1 << d))];
+    }
+  }
+  auto load_tile = [&](const typename Op::Job &jj, ulonglong2 *d) {
+#pragma unroll
+    for (int it = 0; it < NPAIR; it++) {
+      const uint32_t n = gbase + 2 * (threadIdx.x + it * T);
+      if constexpr (INVERSE) {
+        d[it].x = Op::template load<false>(cx, jj, pm, n);
+        d[it].y = Op::template load<false>(cx, jj, pm, n + 1);
+      } else {
+        d[it] = *reinterpret_cast<const ulonglong2 *>(jj.dst + n);
+      }
+    }
+  };
+  constexpr bool PREFETCH = EVAH_PREFETCH && !INVERSE && HasPre<Op>::value;
+  ulonglong2 dreg[NPAIR];
+  load_tile(jb, dreg);
+  while (true) {
+    // next existing job of the walk (block-uniform)
+    typename Op::Job jn;
+    uint32_t jnext = j + 1;
+    while (jnext < j1 && !setup(jnext, jn)) jnext++;
+    const bool more = jnext < j1;
+    __syncthreads(); // the previous job's LDS reads are done
+#pragma unroll
+    for (int it = 0; it < NPAIR; it++) {
+      const int idx = 2 * (threadIdx.x + it * T);
+      const int sb = idx >> P, e = idx & (S - 1);
+      lds[sb * SP + lds_pad<P>(e)] = dreg[it].x;
+      lds[sb * SP + lds_pad<P>(e + 1)] = dreg[it].y;
+    }
+    typename PreOf<Op, PREFETCH>::type epi[NTT_R];
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int it = 0; it < NTT_R; it++) epi[it] = Op::prefetch(cx, jb, pm, gbase + 2 * (threadIdx.x + (it >> 1) * T) + (it & 1));
+    }
+    if (more) load_tile(jn, dreg);
+    __syncthreads();
+    // STRIDED = true selects local-heap node indexing (the LDS copy); LASTFOLD = false: N^-1 belongs to the strided pass
+    RoundSeq<P, LR, 0, INVERSE, true, true, false>::run(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NPAIR; it++) {
+      const int idx = 2 * (threadIdx.x + it * T);
+      const int sb = idx >> P, e = idx & (S - 1);
+      const uint32_t n = gbase + idx;
+      const u64 vx = lds[sb * SP + lds_pad<P>(e)], vy = lds[sb * SP + lds_pad<P>(e + 1)];
+      if constexpr (INVERSE) {
+        ulonglong2 v;
+        v.x = vx;
+        v.y = vy;
+        *reinterpret_cast<ulonglong2 *>(jb.dst + n) = v; // lazy intermediate of the inverse transform
+      } else if constexpr (PREFETCH) {
+        Op::store_fwd_pre(cx, jb, pm, n, vx, epi[2 * it]);
+        Op::store_fwd_pre(cx, jb, pm, n + 1, vy, epi[2 * it + 1]);
+      } else {
+        Op::store_fwd(cx, jb, pm, n, vx);
+        Op::store_fwd(cx, jb, pm, n + 1, vy);
+      }
+    }
+    if (!more) break;
+    jb = jn;
+    j = jnext;
+  }
+}
+
 // Inverse strided pass + forward strided pass in one launch, for the latency-bound (small) launches:
 // a mod-down / rescale / digit conversion starts from the inverse transform of ONE source limb and
 // continues with forward transforms of that polynomial under other primes.  The second (strided)
@@ -331,11 +461,11 @@ ntt_inv_fwd_kernel(DevCtx cx, typename Op::Params prm, int log_tiles) {
   constexpr bool LINEAR = (ES % 16 == 0);
   const int c = threadIdx.x & (C - 1), e0 = threadIdx.x >> logC;
   const uint32_t n0 = (tile_idx << logC) + ((uint32_t)e0 << stride_log) + c, nstep = (uint32_t)(T >> logC) << stride_log;
-  const int l0 = c * SP + lds_pad(e0);
+  const int l0 = c * SP + lds_pad<P>(e0);
   auto lds_at = [&](int it) -> int {
-    if constexpr (LINEAR) return l0 + it * lds_pad(ES);
+    if constexpr (LINEAR) return l0 + it * lds_pad<P>(ES);
     const int idx = threadIdx.x + it * T;
-    return (idx & (C - 1)) * SP + lds_pad(idx >> logC);
+    return (idx & (C - 1)) * SP + lds_pad<P>(idx >> logC);
   };
   const u64 *src = Op::pre_src(jb);
 #pragma unroll
@@ -552,8 +682,8 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
       for (int it = 0; it < NPAIR; it++) {
         const int idx = 2 * (threadIdx.x + it * T);
         const int sb = idx >> P, e = idx & (S - 1);
-        lds[sb * SP + lds_pad(e)] = dreg[it].x;
-        lds[sb * SP + lds_pad(e + 1)] = dreg[it].y;
+        lds[sb * SP + lds_pad<P>(e)] = dreg[it].x;
+        lds[sb * SP + lds_pad<P>(e + 1)] = dreg[it].y;
       }
       load_digits(Jn, dreg);
       __syncthreads();
@@ -564,8 +694,8 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
       for (int it = 0; it < NPAIR; it++) {
         const int idx = 2 * (threadIdx.x + it * T);
         const int sb = idx >> P, e = idx & (S - 1);
-        val[2 * it] = lds[sb * SP + lds_pad(e)];       // lazy [0,16q): fine for the 128-bit MAC (folded every 16 digits)
-        val[2 * it + 1] = lds[sb * SP + lds_pad(e + 1)];
+        val[2 * it] = lds[sb * SP + lds_pad<P>(e)];       // lazy [0,16q): fine for the 128-bit MAC (folded every 16 digits)
+        val[2 * it + 1] = lds[sb * SP + lds_pad<P>(e + 1)];
       }
     }
 #pragma unroll
@@ -636,8 +766,8 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
         for (int it = 0; it < NPAIR; it++) {
           const int idx = 2 * (threadIdx.x + it * T);
           const int sb = idx >> P, e = idx & (S - 1);
-          lds[sb * SP + lds_pad(e)] = barrett128(K ? acc1[2 * it] : acc0[2 * it], pm);
-          lds[sb * SP + lds_pad(e + 1)] = barrett128(K ? acc1[2 * it + 1] : acc0[2 * it + 1], pm);
+          lds[sb * SP + lds_pad<P>(e)] = barrett128(K ? acc1[2 * it] : acc0[2 * it], pm);
+          lds[sb * SP + lds_pad<P>(e + 1)] = barrett128(K ? acc1[2 * it + 1] : acc0[2 * it + 1], pm);
         }
         __syncthreads();
         // as ntt_pass_kernel<P, LR, contiguous, inverse>: global twiddle heap of the row's prime
@@ -649,8 +779,8 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
           const int idx = 2 * (threadIdx.x + it * T);
           const int sb = idx >> P, e = idx & (S - 1);
           ulonglong2 v;
-          v.x = lds[sb * SP + lds_pad(e)];
-          v.y = lds[sb * SP + lds_pad(e + 1)];
+          v.x = lds[sb * SP + lds_pad<P>(e)];
+          v.y = lds[sb * SP + lds_pad<P>(e + 1)];
           *reinterpret_cast<ulonglong2 *>(r + idx) = v; // lazy intermediate of the inverse transform
         }
       }
@@ -700,6 +830,7 @@ template <bool ZEROS> struct OpPlainT { // ZEROS: the inverse transform also rec
   };
   // jobs = polys * jl: grid.y = limb i, grid.z = poly
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
+  static constexpr int loop_axis = 2; // jobs that share a prime lie along grid.z (ntt_loop_kernel)
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i,
                                                uint32_t pp, Job &j) {
     j.prime = p.prime0 + i * p.pstep;
@@ -755,6 +886,7 @@ struct OpMulIntt {
     bool lazy;
   };
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
+  static constexpr int loop_axis = 2; // jobs that share a prime lie along grid.z (ntt_loop_kernel)
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i, uint32_t b, Job &j) {
     j.prime = cx.prime_of(i);
     j.off = (size_t)i * cx.N;
@@ -797,6 +929,7 @@ struct OpKsDigit {
   };
   // jobs = batch * ni * l: grid.x carries the digit J, grid.y the output limb, grid.z the batch
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(p.l, p.ni, jobs / (p.ni * p.l)); }
+  static constexpr int loop_axis = 0; // the digits J of one output limb share its prime (ntt_loop_kernel)
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t J, uint32_t iy,
                                                uint32_t b, Job &j) {
     const uint32_t I = p.i0 + iy * p.istep;
@@ -859,6 +992,7 @@ struct OpModDown {
     bool lazy;
   };
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
+  static constexpr int loop_axis = 2; // jobs that share a prime lie along grid.z (ntt_loop_kernel)
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i,
                                                uint32_t pp, Job &j) {
     j.prime = cx.prime_of(i); // limb i of the values (c, add, dst) — the prime itself on an ordinary context
@@ -951,6 +1085,7 @@ template <int AM> struct OpRRLastT {
     size_t off;
   };
   static dim3 grid(const Params &, uint32_t jobs) { return dim3(1, jobs, 1); }
+  static constexpr int loop_axis = 1; // every job is modulo the last data prime (ntt_loop_kernel)
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t job, uint32_t,
                                                Job &j) {
     j.prime = p.last;
@@ -1010,6 +1145,7 @@ template <int AM> struct OpRRT {
     size_t off;
   };
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
+  static constexpr int loop_axis = 2; // jobs that share a prime lie along grid.z (ntt_loop_kernel)
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i, uint32_t K,
                                                Job &j) {
     j.prime = i;

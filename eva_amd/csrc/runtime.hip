@@ -506,6 +506,9 @@ int evah_ct_assign(evah_ctx *c, evah_ct *dst, const evah_ct *src) {
   if (dst->size != src->size || dst->limbs != src->limbs || dst->batch != src->batch)
     throw std::invalid_argument("evah_ct_assign: shapes differ");
   if (dst->ps != (size_t)dst->limbs * c->N) throw std::invalid_argument("cannot write into a mod-switched view");
+  // the per-buffer ordering treats values as immutable after their producer: a rewrite is only ordered on the
+  // queue that owns the buffer (its later reads follow on the same stream)
+  if (dst->buf->owner != c) throw std::invalid_argument("evah_ct_assign: a value is rewritten on the queue that owns it");
   acquire(c, dst->buf);
   acquire(c, src->buf);
   const size_t row = sizeof(u64) * (size_t)src->limbs * c->N, polys = (size_t)src->size * src->batch;

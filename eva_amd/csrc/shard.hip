@@ -108,6 +108,65 @@ int evah_buf_copy(evah_ctx *c, evah_buf *dst, size_t dst_off, const evah_buf *sr
   HIPCHK(hipMemcpyAsync(dst->buf->d + dst_off, src->buf->d + src_off, sizeof(u64) * words, hipMemcpyDefault, c->stream));
   API_END
 }
+// ONE launch that pulls n chunks into dst: chunk j = srcs[j][src_offs[j] .. + words) -> dst[dst_offs[j] ..).  The sources
+// may live on other devices (peer reads over xGMI; evah_ctx_enable_peer must have succeeded for the pair): the all-gather
+// of a key switch is one such launch per shard instead of G - 1 copies with an event wait each.
+struct GatherTab {
+  const u64 *src[KS_BATCH_MAX];
+  uint32_t dst_tile[KS_BATCH_MAX]; // dst offsets in units of 2 words (16-byte accesses)
+};
+__global__ void __launch_bounds__(256) k_buf_gather(GatherTab t, u64 *dst, size_t pairs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pairs) return;
+  const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(t.src[blockIdx.y])[i];
+  reinterpret_cast<ulonglong2 *>(dst)[(size_t)t.dst_tile[blockIdx.y] + i] = v;
+}
+int evah_buf_gather(evah_ctx *c, evah_buf *dst, uint32_t n, const evah_buf *const *srcs, const size_t *src_offs,
+                    const size_t *dst_offs, size_t words) {
+  API_BEGIN
+  use(c);
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("buffer gather takes 1..64 sources");
+  if (!words || (words & 1)) throw std::invalid_argument("buffer gather moves an even, non-zero number of words");
+  if (dst->buf->owner != c) throw std::invalid_argument("buffer gather runs on the queue that owns the destination");
+  GatherTab t{};
+  for (uint32_t j = 0; j < n; j++) {
+    if (src_offs[j] + words > srcs[j]->words || dst_offs[j] + words > dst->words || (src_offs[j] & 1) || (dst_offs[j] & 1))
+      throw std::invalid_argument("buffer gather out of range / misaligned");
+    if ((dst_offs[j] >> 1) > 0xffffffffull) throw std::invalid_argument("buffer gather: destination offset too large");
+    acquire(c, srcs[j]->buf); // ordered after the producer of every source, whatever device it is on
+    t.src[j] = srcs[j]->buf->d + src_offs[j];
+    t.dst_tile[j] = (uint32_t)(dst_offs[j] >> 1);
+  }
+  const size_t pairs = words / 2;
+  ProfScope ps(c, KC_EW);
+  hipLaunchKernelGGL(k_buf_gather, dim3((unsigned)((pairs + 255) / 256), n), dim3(256), 0, c->stream, t, dst->buf->d, pairs);
+  HIPCHK(hipGetLastError());
+  API_END
+}
+
+// Peer access between the devices of two contexts, both directions.  Without it a device-to-device copy may be staged
+// through host memory and a kernel cannot read the other device's buffers at all — on the paths whose whole point is
+// xGMI — so a refusal is an error here, not a silent fallback.  Contexts of one device: nothing to do.
+int evah_ctx_enable_peer(evah_ctx *a, evah_ctx *b) {
+  API_BEGIN
+  if (a->device == b->device) return 0;
+  for (int dir = 0; dir < 2; dir++) {
+    const int from = dir ? b->device : a->device, to = dir ? a->device : b->device;
+    int can = 0;
+    HIPCHK(hipDeviceCanAccessPeer(&can, from, to));
+    if (!can)
+      throw std::runtime_error("device " + std::to_string(from) + " cannot access device " + std::to_string(to) +
+                               " as a peer (hipDeviceCanAccessPeer): the multi-GPU modes need peer access over xGMI / PCIe");
+    HIPCHK(hipSetDevice(from));
+    const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+    if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+    else if (e != hipSuccess)
+      throw std::runtime_error(std::string("hipDeviceEnablePeerAccess(") + std::to_string(to) + ") on device " + std::to_string(from) +
+                               " failed: " + hipGetErrorString(e));
+  }
+  API_END
+}
+
 int evah_buf_download(evah_ctx *c, const evah_buf *b, size_t off, size_t words, uint64_t *host) {
   API_BEGIN
   use(c);

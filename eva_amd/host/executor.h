@@ -203,7 +203,8 @@ public:
   // has to agree with the data length and the context, or the copy would read past the host buffer
   void check_shape(const std::string &name, const HostCipher &c) const {
     if (c.size < 1 || c.size > 3 || c.limbs < 1 || c.limbs > host.k - 1 ||
-        (!resident_only(c) && c.data.size() != (size_t)c.size * c.limbs * host.N))
+        (!resident_only(c) && c.data.size() != (size_t)c.size * c.limbs * host.N) ||
+        (c.dev && c.dev->N != host.N)) // a resident value of another key pair: its download would have the wrong length
       throw std::runtime_error("input " + name + ": ciphertext shape does not match its data or the encryption parameters");
     if (!c.words_checked && !c.data.empty()) { // once per value: files and Python arrays are untrusted
       check_words(name, c.data.data(), c.size, c.limbs);
@@ -835,7 +836,7 @@ public:
   }
   // what the last multi-device execute() did: pieces per member (sub-DAG) / words exchanged (limb)
   std::vector<std::pair<uint32_t, uint32_t>> last_subdag_plan; // (member, ops) with member 0 first = prefix, last = suffix
-  uint64_t last_exchanged_words = 0;
+  uint64_t last_exchanged_words = 0, last_exchange_launches = 0;
   // HIP streams independent DAG nodes are spread over (EVA_NUM_STREAMS).  Default 1: at these
   // kernel sizes a single in-order queue keeps the GPU as busy as the host can feed it; more
   // queues are correct (ordering is enforced per buffer inside libeva_hip.so) and pay off when
@@ -934,6 +935,9 @@ public:
     std::shared_ptr<Fork> rq;
     std::vector<evah_ctx *> qh = queue_handles();
     if (subdag) { // member 0 of the device group is the queue this walk issues on
+      if (devices.empty() || devices[0] != device)
+        throw std::runtime_error("sub-DAG mode: devices[0] must be the context's own device " + std::to_string(device) +
+                                 " (inputs, constants and outputs live there)");
       ensure_group(false);
       rq = group->forks[0];
       qh = {group->ctx[0]};
@@ -1196,7 +1200,7 @@ private:
       limb_ids = devices;
     }
     LimbShardEvaluator &ev = *limb;
-    const uint64_t words0 = ev.exchanged_words;
+    const uint64_t words0 = ev.exchanged_words, launches0 = ev.exchange_launches;
     using Val = std::variant<std::monostate, ShardedValue, std::vector<double>>;
     std::vector<Val> vals(program.size());
     const size_t n_vec = program.vec_size();
@@ -1335,6 +1339,7 @@ private:
       }
     }
     last_exchanged_words = ev.exchanged_words - words0;
+    last_exchange_launches = ev.exchange_launches - launches0;
     return out;
   }
   // does term `t` depend on term `src`?
@@ -1663,7 +1668,7 @@ public:
       if (auto *c = std::get_if<HostCipher>(&kv.second)) {
         if (on_device()) { // dot product with s, inverse transforms, recomposition and the special FFT on the GPU
           if (c->size < 1 || c->size > 3 || c->limbs < 1 || c->limbs > host->k - 1 ||
-              (!resident_only(*c) && c->data.size() != (size_t)c->size * c->limbs * host->N))
+              (!resident_only(*c) && c->data.size() != (size_t)c->size * c->limbs * host->N) || (c->dev && c->dev->N != host->N))
             throw std::runtime_error("output " + kv.first + ": ciphertext shape does not match its data or the encryption parameters");
           v.resize((size_t)sig.vec_size);
           if (c->dev && c->dev->root == dev) { // resident on this key pair's device state: read in place

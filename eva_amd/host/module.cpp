@@ -343,6 +343,8 @@ PYBIND11_MODULE(_eva, m) {
       .def_readonly("last_subdag_plan", &HipPublic::last_subdag_plan, "(member, ops) per piece of the last sub-DAG split: prefix, components..., suffix")
       .def("key_bytes", &HipPublic::key_bytes, "HBM bytes of evaluation keys: one entry per limb shard (when limb-sharded), then the whole keys on the context's own device (0 if never uploaded)")
       .def_readonly("last_exchanged_words", &HipPublic::last_exchanged_words, "uint64 words moved between shards by the last limb-sharded execute()")
+      .def_readonly("last_exchange_launches", &HipPublic::last_exchange_launches,
+                    "launches those words took: one per receiving shard per exchange step (evah_buf_gather)")
       .def_readwrite("resident", &HipPublic::resident, "keep valuations in HBM: encrypt/execute return device handles and execute does not wait for the GPU (EVA_RESIDENT=0: host valuations)")
       .def_readwrite("graph_copy_limit", &HipPublic::graph_copy_limit, "device-resident inputs above this many bytes are walked eagerly instead of copied into a captured graph's slots")
       .def("synchronize", &HipPublic::synchronize, "wait for everything this context has enqueued")

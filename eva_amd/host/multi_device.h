@@ -31,6 +31,13 @@ struct DeviceGroup {
   size_t size() const { return ctx.size(); }
 };
 
+// peer access for every pair of members on different devices; a refusal throws (evah_last_error names the pair)
+inline void enable_peers(const DeviceGroup &g) {
+  for (size_t a = 0; a < g.ctx.size(); a++)
+    for (size_t b = a + 1; b < g.ctx.size(); b++)
+      if (g.ids[a] != g.ids[b]) chk(evah_ctx_enable_peer(g.ctx[a], g.ctx[b]));
+}
+
 // member 0 is `first` (the context the public half already works on); every other distinct device
 // gets its own DeviceCtx with the evaluation keys uploaded by `upload_keys`
 inline DeviceGroup make_device_group(const std::vector<int> &ids, const std::shared_ptr<DeviceCtx> &first, int first_device,
@@ -57,6 +64,7 @@ inline DeviceGroup make_device_group(const std::vector<int> &ids, const std::sha
     g.forks.push_back(own_root ? nullptr : std::make_shared<Fork>(root));
     g.ctx.push_back(own_root ? root->h : g.forks.back()->h);
   }
+  enable_peers(g);
   return g;
 }
 
@@ -76,6 +84,7 @@ inline DeviceGroup make_limb_group(const std::vector<int> &ids, const HostContex
     g.forks.push_back(nullptr);
     g.ctx.push_back(root->h);
   }
+  enable_peers(g);
   return g;
 }
 
@@ -456,6 +465,8 @@ public:
 
   // exchange traffic of this evaluator so far (words moved between shards), for bench / tests
   uint64_t exchanged_words = 0;
+  // launches those words took: per key switch G (all-gather, one per receiving shard) + G - 1 (broadcast), per rescale G - 1
+  uint64_t exchange_launches = 0;
 
 private:
   const HostContext &host;
@@ -512,20 +523,31 @@ private:
     return o;
   }
 
-  // bufs[s]: buffer of G chunks, chunk s filled by shard s -> every buffer complete
+  // bufs[s]: buffer of G chunks, chunk s filled by shard s -> every buffer complete.  ONE launch per receiving shard
+  // (evah_buf_gather: a kernel on the receiver's queue that reads the other shards' chunks as peers), not G - 1 copies
   void all_gather(std::vector<ShardBuf> &bufs, size_t chunk) {
-    for (uint32_t d = 0; d < G; d++)
+    if (G < 2) return;
+    for (uint32_t d = 0; d < G; d++) {
+      std::vector<const evah_buf *> srcs;
+      std::vector<size_t> offs;
       for (uint32_t s = 0; s < G; s++)
         if (s != d) {
-          chk(evah_buf_copy(g.ctx[d], bufs[d].b, s * chunk, bufs[s].b, s * chunk, chunk));
-          exchanged_words += chunk;
+          srcs.push_back(bufs[s].b);
+          offs.push_back(s * chunk);
         }
+      chk(evah_buf_gather(g.ctx[d], bufs[d].b, (uint32_t)srcs.size(), srcs.data(), offs.data(), offs.data(), chunk));
+      exchanged_words += chunk * srcs.size();
+      exchange_launches++;
+    }
   }
   void broadcast(std::vector<ShardBuf> &bufs, uint32_t owner, size_t words) {
+    const size_t zero = 0;
     for (uint32_t d = 0; d < G; d++)
       if (d != owner) {
-        chk(evah_buf_copy(g.ctx[d], bufs[d].b, 0, bufs[owner].b, 0, words));
+        const evah_buf *src = bufs[owner].b;
+        chk(evah_buf_gather(g.ctx[d], bufs[d].b, 1, &src, &zero, &zero, words));
         exchanged_words += words;
+        exchange_launches++;
       }
   }
   // target.ct[s] holds the key-switch target as polynomial `poly`; returns the size-2 result

@@ -16,7 +16,10 @@
 //   Plaintext               parms_id (4 x u64) | u64 coeff_count | f64 scale | DynArray object
 //   Ciphertext              parms_id | u8 is_ntt_form | u64 size | u64 poly_modulus_degree | u64 coeff_modulus_size |
 //                           f64 scale | (SEAL 4.x only: u64 correction_factor) | DynArray object
-//   PublicKey / SecretKey   one Ciphertext / Plaintext object (own header, uncompressed) at the key level
+//   PublicKey / SecretKey   exactly the bytes of their Ciphertext / Plaintext member at the key level — SEAL >= 3.5:
+//                           PublicKey::save is pk_.save(stream, compr_mode), SecretKey::save is sk_.save(...): ONE header
+//                           (r03 of this file wrapped them in a second header, as SEAL <= 3.4 did; the reader still
+//                           accepts that nesting, the writer no longer produces it)
 //   KSwitchKeys             parms_id | u64 dim1 | dim1 x ( u64 dim2 | dim2 x PublicKey object )
 //                           RelinKeys: dim1 = 1; GaloisKeys: dim1 = poly_modulus_degree, index (galois_elt - 1) / 2
 //   parms_id                BLAKE2b-256 over the u64 words [scheme, degree, q_0 .. q_{n-1}, plain_modulus = 0]
@@ -278,11 +281,12 @@ inline std::string plaintext_obj(const HostContext &h, uint32_t limbs, double sc
   m += dynarray_obj(data, (size_t)limbs * h.N);
   return wrap(m, compr);
 }
+// PublicKey::save = pk_.save, SecretKey::save = sk_.save (SEAL >= 3.5): the member's own object, nothing around it
 inline std::string public_key_obj(const HostContext &h, const u64 *data /* [2][k][N] */, Compr compr) {
-  return wrap(ciphertext_obj(h, 2, h.k, 1.0, data, None), compr);
+  return ciphertext_obj(h, 2, h.k, 1.0, data, compr);
 }
 inline std::string secret_key_obj(const HostContext &h, const u64 *s_ntt /* [k][N] */, Compr compr) {
-  return wrap(plaintext_obj(h, h.k, 1.0, s_ntt, None), compr);
+  return plaintext_obj(h, h.k, 1.0, s_ntt, compr);
 }
 // slots: (index into keys_, key) pairs; dim1 = length of keys_
 inline std::string kswitch_obj(const HostContext &h, uint64_t dim1, const std::map<uint64_t, const SwitchKey *> &slots, Compr compr) {
@@ -386,9 +390,25 @@ struct CtFields {
   std::vector<u64> data;
 };
 // max_limbs: h.k for a key-level object (public key), h.k - 1 for a value
+// does a complete SEAL object start here and fill the rest of the cursor?  (A key object written with the pre-3.5
+// nesting holds its member as an inner object; a member's own first bytes are a parms_id hash, which passes this test
+// with probability 2^-80.)
+inline bool nested_object(const Cur &c) {
+  if (c.end - c.p < 16) return false;
+  uint16_t magic, reserved;
+  uint64_t size;
+  std::memcpy(&magic, c.p, 2);
+  std::memcpy(&reserved, c.p + 6, 2);
+  std::memcpy(&size, c.p + 8, 8);
+  return magic == SEAL_MAGIC && c.p[2] == 0x10 && (c.p[3] == 3 || c.p[3] == 4) && c.p[5] <= 2 && reserved == 0 && size == (uint64_t)(c.end - c.p);
+}
+inline CtFields ciphertext_members(Obj &o, const HostContext &h, uint32_t max_limbs, uint32_t max_size);
 inline CtFields read_ciphertext(Cur &c, const HostContext &h, uint32_t max_limbs, uint32_t max_size) {
   Obj o;
   open(c, (uint64_t)max_size * max_limbs * h.N * 8 + 4096, o);
+  return ciphertext_members(o, h, max_limbs, max_size);
+}
+inline CtFields ciphertext_members(Obj &o, const HostContext &h, uint32_t max_limbs, uint32_t max_size) {
   const ParmsId id = o.cur.id();
   const uint8_t ntt = o.cur.pod<uint8_t>();
   const uint64_t size = o.cur.pod<uint64_t>(), N = o.cur.pod<uint64_t>(), cms = o.cur.pod<uint64_t>();
@@ -404,9 +424,13 @@ inline CtFields read_ciphertext(Cur &c, const HostContext &h, uint32_t max_limbs
   f.data = read_dynarray(o.cur, size * cms * N);
   return f;
 }
+inline CtFields plaintext_members(Obj &o, const HostContext &h, uint32_t max_limbs);
 inline CtFields read_plaintext(Cur &c, const HostContext &h, uint32_t max_limbs) {
   Obj o;
   open(c, (uint64_t)max_limbs * h.N * 8 + 4096, o);
+  return plaintext_members(o, h, max_limbs);
+}
+inline CtFields plaintext_members(Obj &o, const HostContext &h, uint32_t max_limbs) {
   const ParmsId id = o.cur.id();
   const uint64_t cc = o.cur.pod<uint64_t>();
   CtFields f;
@@ -422,7 +446,8 @@ inline CtFields read_plaintext(Cur &c, const HostContext &h, uint32_t max_limbs)
 inline std::vector<u64> read_public_key(Cur &c, const HostContext &h) {
   Obj o;
   open(c, (uint64_t)2 * h.k * h.N * 8 + 8192, o);
-  CtFields f = read_ciphertext(o.cur, h, h.k, 2);
+  // SEAL >= 3.5: the object IS the ciphertext; the pre-3.5 nesting (and r03 files of this repo) holds it one level down
+  CtFields f = nested_object(o.cur) ? read_ciphertext(o.cur, h, h.k, 2) : ciphertext_members(o, h, h.k, 2);
   if (f.size != 2 || f.limbs != h.k) throw std::runtime_error("Could not parse message: public key has the wrong size for its context");
   check_residues(f.data, h, "public key");
   return std::move(f.data);
@@ -565,7 +590,7 @@ inline std::shared_ptr<HipSecret> decode_secret(wire::In in) {
   Cur c = cur_of(d);
   Obj o;
   open(c, (uint64_t)h.k * h.N * 8 + 8192, o);
-  CtFields f = read_plaintext(o.cur, h, h.k);
+  CtFields f = nested_object(o.cur) ? read_plaintext(o.cur, h, h.k) : plaintext_members(o, h, h.k);
   if (f.limbs != h.k) throw std::runtime_error("Could not parse message: secret key has the wrong size for its context");
   check_residues(f.data, h, "secret key");
   s->sk.s_ntt = std::move(f.data);

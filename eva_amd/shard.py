@@ -102,16 +102,18 @@ class LocalExchange:
     receiving shard's queue and ordered after the producing shard's work by the library."""
 
     def all_gather(self, bufs, chunk):
-        """bufs[s]: buffer of G chunks, chunk s filled by shard s -> every buffer complete"""
+        """bufs[s]: buffer of G chunks, chunk s filled by shard s -> every buffer complete; ONE launch per
+        receiving shard (evah_buf_gather: a kernel on its queue reading the other shards' chunks as peers)"""
         for d, dst in bufs.items():
-            for s, src in bufs.items():
-                if s != d:
-                    dst.copy_from(src, s * chunk, s * chunk, chunk)
+            others = [s for s in bufs if s != d]
+            if others:
+                offs = [s * chunk for s in others]
+                dst.gather_from([bufs[s] for s in others], offs, offs, chunk)
 
     def broadcast(self, bufs, owner, words):
         for d, dst in bufs.items():
             if d != owner:
-                dst.copy_from(bufs[owner], 0, 0, words)
+                dst.gather_from([bufs[owner]], [0], [0], words)
 
 
 class DistExchange:

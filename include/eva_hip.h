@@ -299,6 +299,16 @@ void evah_buf_free(evah_ctx *ctx, evah_buf *buf);
 void *evah_buf_ptr(evah_buf *buf);
 size_t evah_buf_words(const evah_buf *buf);
 int evah_buf_copy(evah_ctx *dst_ctx, evah_buf *dst, size_t dst_off, const evah_buf *src, size_t src_off, size_t words);
+/* one launch on dst's queue that pulls n (<= 64) chunks of `words` words: srcs[j][src_offs[j]..) -> dst[dst_offs[j]..)
+ * (offsets and words even); sources on other devices are read as peers — the all-gather / broadcast of the phases above
+ * as ONE kernel per receiving shard.  Stands where the reference's workers share memory
+ * (multicore_program_traversal.h:55-78). */
+int evah_buf_gather(evah_ctx *dst_ctx, evah_buf *dst, uint32_t n, const evah_buf *const *srcs, const size_t *src_offs,
+                    const size_t *dst_offs, size_t words);
+/* peer access between the devices of two contexts, both directions (hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess);
+ * a refusal is an error (evah_last_error names the pair), never a silent staging through the host.  Every multi-device
+ * group calls it for each pair of its members before the first cross-device copy. */
+int evah_ctx_enable_peer(evah_ctx *a, evah_ctx *b);
 int evah_buf_download(evah_ctx *ctx, const evah_buf *buf, size_t off, size_t words, uint64_t *host);
 int evah_buf_upload(evah_ctx *ctx, evah_buf *buf, size_t off, size_t words, const uint64_t *host);
 /* (perm(c0), perm(c1)) on the local limbs: the NTT-domain Galois automorphism of rotate_vector */

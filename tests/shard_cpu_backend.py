@@ -19,6 +19,10 @@ class HostBuffer:
     def copy_from(self, src, dst_off, src_off, words):
         self.a[dst_off:dst_off + words] = src.a[src_off:src_off + words]
 
+    def gather_from(self, srcs, src_offs, dst_offs, words):
+        for src, so, do in zip(srcs, src_offs, dst_offs):
+            self.copy_from(src, do, so, words)
+
     def download(self, off=0, words=None):
         words = self.words - off if words is None else words
         return self.a[off:off + words].copy()

@@ -102,6 +102,13 @@ def test_limb_sharded_execute_bit_exact(G):
         out = pub.execute(compiled, enc)
         _same_as(out, ref, single)
     assert pub.last_exchanged_words > 0
+    # one launch per receiving shard per exchange step: a key switch = all-gather (G) + broadcast (G - 1), a rescale
+    # = broadcast (G - 1) — not the G (G - 1) + (G - 1) copies of the r03 exchange
+    kinds = [(str(d["op"]).split(".")[-1], d) for d in compiled._dump()]
+    n_ks = sum(1 for kk, d in kinds if kk == "Relinearize" or (kk in ("RotateLeftConst", "RotateRightConst") and d.get("rotation", 1) != 0))
+    n_rs = sum(1 for kk, _ in kinds if kk == "Rescale")
+    assert n_ks > 0 and n_rs > 0
+    assert pub.last_exchange_launches == n_ks * (2 * G - 1) + n_rs * (G - 1), (pub.last_exchange_launches, n_ks, n_rs, G)
     # every shard holds its own prime rows of the keys and nothing else: its data limbs + the special prime
     kb = pub.key_bytes()
     k = len(list(pub.primes))

@@ -84,15 +84,21 @@ def seal_plaintext(N, primes, data, scale, compr=0):
     return seal_wrap(seal_parms_id(N, primes[:limbs]) + struct.pack("<Qd", limbs * n, scale) + seal_dynarray(data), compr)
 
 
-def seal_public_key(N, primes, data, compr=0):
-    return seal_wrap(seal_ciphertext(N, primes, data, 1.0), compr)
+def seal_public_key(N, primes, data, compr=0, nested=False):
+    """SEAL >= 3.5: PublicKey::save is pk_.save — the ciphertext object itself (nested: the pre-3.5 double header,
+    which the reader still accepts)"""
+    if nested:
+        return seal_wrap(seal_ciphertext(N, primes, data, 1.0), compr)
+    return seal_ciphertext(N, primes, data, 1.0, compr)
 
 
-def seal_secret_key(N, primes, s_ntt, compr=0):
-    return seal_wrap(seal_plaintext(N, primes, s_ntt, 1.0), compr)
+def seal_secret_key(N, primes, s_ntt, compr=0, nested=False):
+    if nested:
+        return seal_wrap(seal_plaintext(N, primes, s_ntt, 1.0), compr)
+    return seal_plaintext(N, primes, s_ntt, 1.0, compr)
 
 
-def seal_kswitch(N, primes, dim1, slots, compr=0):
+def seal_kswitch(N, primes, dim1, slots, compr=0, nested=False):
     """slots: {index: key array [digits][2][k][N]}"""
     m = seal_parms_id(N, primes) + struct.pack("<Q", dim1)
     for i in range(dim1):
@@ -100,7 +106,7 @@ def seal_kswitch(N, primes, dim1, slots, compr=0):
         if key is None:
             m += struct.pack("<Q", 0)
         else:
-            m += struct.pack("<Q", key.shape[0]) + b"".join(seal_public_key(N, primes, key[j]) for j in range(key.shape[0]))
+            m += struct.pack("<Q", key.shape[0]) + b"".join(seal_public_key(N, primes, key[j], nested=nested) for j in range(key.shape[0]))
     return seal_wrap(m, compr)
 
 
@@ -231,6 +237,17 @@ def test_public_context_round_trip_and_bytes(schema, keys, tmp_path):
         got = load(p2)
         assert np.array_equal(got.public_key(), pub.public_key()) and np.array_equal(got.relin_key(), pub.relin_key())
         assert sorted(got.galois_keys()) == sorted(pub.galois_keys())
+    # the pre-3.5 nesting (a second header around the key's ciphertext — what r03 of this repo wrote) still loads
+    nested_gal = {i: key for i, key in gal.items()}
+    old = schema["SEALPublic"](
+        encryption_parameters=T(seal_type=7, data=seal_parms(N, primes)),
+        public_key=T(seal_type=4, data=seal_public_key(N, primes, pub.public_key(), nested=True)),
+        galois_keys=T(seal_type=5, data=seal_kswitch(N, primes, N, nested_gal, nested=True)),
+        relin_keys=T(seal_type=6, data=seal_kswitch(N, primes, 1, {0: pub.relin_key()}, nested=True)))
+    p_old = str(tmp_path / "nested")
+    open(p_old, "wb").write(_envelope(schema, old))
+    got = load(p_old)
+    assert np.array_equal(got.public_key(), pub.public_key()) and np.array_equal(got.relin_key(), pub.relin_key())
     for fmt in ("seal+zlib",) + (("seal+zstd",) if _eva._seal_zstd_available() else ()):
         p3 = str(tmp_path / fmt)
         save(pub, p3, format=fmt)
@@ -268,6 +285,11 @@ def test_secret_context_round_trip_and_bytes(schema, keys, tmp_path):
     assert m.secret_key.seal_type == 3 and m.secret_key.data == seal_secret_key(N, primes, sec._secret_key_ntt())
     again = load(path)
     assert np.array_equal(again._secret_key_ntt(), sec._secret_key_ntt())
+    nested = schema["SEALSecret"](encryption_parameters=schema["SEALObject"](seal_type=7, data=seal_parms(N, primes)),
+                                  secret_key=schema["SEALObject"](seal_type=3, data=seal_secret_key(N, primes, sec._secret_key_ntt(), nested=True)))
+    p_old = str(tmp_path / "nested_secret")
+    open(p_old, "wb").write(_envelope(schema, nested))
+    assert np.array_equal(load(p_old)._secret_key_ntt(), sec._secret_key_ntt())
     # the reloaded key decrypts what the original public context encrypts
     enc = pub.encrypt({'x': [0.5 * i for i in range(16)], 'y': [1.0] * 16}, sig)
     vals = again.decrypt(enc, sig)
