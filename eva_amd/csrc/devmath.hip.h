@@ -29,6 +29,10 @@ struct DevPrime {
   u64 q4, q8;   // 4q (forward difference offset), 8q (forward reduction threshold)
   u64 nq5, nq8; // 2^64 - 5q, 2^64 - 8q: conditional subtraction as select + one 64-bit add (data, as nq)
   u64 c64, c64s; // 2^64 mod q and its Shoup quotient: folds the high word of a 128-bit value (barrett128)
+  // q = 2^b - c (b = bit length): x = (X mod 2^b) + (X >> b) c is congruent to X and < q + 16c for X < 16q.
+  // tb_c = c when it fits 32 bits and b > 32 (every CoeffModulus::Create prime of 33..60 bits), else 0
+  uint32_t tb_c, tb_sh;   // c, b - 32
+  uint32_t tb_mask, tb_pad; // 2^(b-32) - 1
 };
 
 // Device-side view of a context (passed by value to kernels).

@@ -108,9 +108,25 @@ __device__ __forceinline__ u64 mul_tw_lazy5_add_mad(u64 x, u64 w, u64 ws, u64 nq
 //   plain stage  : X < 12q            -> outputs < 16q
 // (Y only feeds the multiply, which accepts any 64-bit value.)  X' = x + t comes out of the mad
 // chain; Y' = x + 4q - t = (2x + 4q) - X' (mod 2^64; the true value is < 16q).
-template <bool REDUCE, bool MAD = false>
-__device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q4, u64 q8, u64 nq8) {
-  u64 x = REDUCE ? X + (X >= q8 ? nq8 : 0) : X;
+#ifndef EVAH_TOPBIT
+#define EVAH_TOPBIT 1 // 0: compare-and-subtract reductions for every prime (the r03 butterflies; A/B switch of the build)
+#endif
+// TB ("top bits"): for q = 2^b - c with b > 32 and c < 2^32 — every CoeffModulus::Create prime of 33..60 bits, the
+// search walks down from 2^b in steps of 2N — the reduction is  x = (X mod 2^b) + (X >> b) c :  congruent to X and
+// < q + 16c for any X < 16q, in a shift, a mask and one v_mad_u64_u32 where the compare-and-subtract form takes four
+// instructions to get below 8q.  Starting from ~q instead of 8q, THREE stages fit before the next reduction (5q, 9q,
+// 13q) instead of two, so a pass reduces on every third stage (ntt_round).  Primes of another shape (DevPrime::tb_c
+// == 0) take the compare-and-subtract butterflies; the choice is block-uniform, made once per transform.
+template <bool REDUCE, bool MAD = false, bool TB = false>
+__device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u64 q4, u64 q8, u64 nq8, uint32_t tbc = 0,
+                                         uint32_t tbs = 0, uint32_t tbm = 0) {
+  u64 x = X;
+  if constexpr (REDUCE && TB) {
+    const uint32_t hi = (uint32_t)(X >> 32);
+    x = mad64(hi >> tbs, tbc, ((u64)(hi & tbm) << 32) | (uint32_t)X); // < q + 16c
+  } else if constexpr (REDUCE) {
+    x = X + (X >= q8 ? nq8 : 0);
+  }
   X = MAD ? mul_tw_lazy5_add_mad(Y, w.x, w.y, nq, x) : mul_tw_lazy5_add(Y, w.x, w.y, nq, x);
   Y = ((x << 1) + q4) - X;
 }
@@ -128,7 +144,14 @@ __device__ __forceinline__ void bfly_inv(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u
 // the second pass therefore reduces on even stages.
 // LASTFOLD: this pass ends the inverse transform (its very last stage multiplies by N^-1) — the strided pass,
 // unless a contiguous pass borrows the local-heap indexing (ntt_loop_kernel)
-template <int P, int LR, int RB, int LO, bool INVERSE, bool STRIDED, bool RED_EVEN, bool LASTFOLD = STRIDED>
+// TB forward passes reduce on every third stage.  First pass (RED_EVEN false; input canonical or lazy < 12q, output
+// < 9q): stages s = P - 2 (mod 3), and stage 0 as well when that leaves stages 0 and 1 unreduced; second pass (input
+// < 9q): stages s = 1 (mod 3), output < 13q.  Every value stays below 16q < 2^64.
+template <int P, bool RED_EVEN> constexpr bool tb_reduce_stage(int s) {
+  if (RED_EVEN) return s % 3 == 1;
+  return s % 3 == (P - 2) % 3 || (s == 0 && (P - 2) % 3 == 2);
+}
+template <int P, int LR, int RB, int LO, bool INVERSE, bool STRIDED, bool RED_EVEN, bool LASTFOLD = STRIDED, bool TB = false>
 __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
                                           const ulonglong2 *__restrict__ tw, const DevPrime &pm) {
   constexpr int NTT_R = 1 << LR;
@@ -162,8 +185,9 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
           if (u & half) continue;
           const int v = u >> (RB - s);
           const ulonglong2 w = tw[((size_t)node << s) + v];
-          if ((((S0 + s) & 1) == 0) == RED_EVEN) bfly_fwd<true, MAD>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8);
-          else bfly_fwd<false, MAD>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8);
+          const bool red = TB ? tb_reduce_stage<P, RED_EVEN>(S0 + s) : ((((S0 + s) & 1) == 0) == RED_EVEN);
+          if (red) bfly_fwd<true, MAD, TB>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8, pm.tb_c, pm.tb_sh, pm.tb_mask);
+          else bfly_fwd<false, MAD, TB>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8);
         }
       }
     } else {
@@ -193,21 +217,28 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
   }
 }
 
-template <int P, int LR, int I, bool INVERSE, bool STRIDED, bool RED_EVEN, bool LASTFOLD = STRIDED> struct RoundSeq {
+template <int P, int LR, int I, bool INVERSE, bool STRIDED, bool RED_EVEN, bool LASTFOLD = STRIDED, bool TB = false> struct RoundSeq {
   // forward: rounds 0..NR-1 (top bits first); inverse: NR-1..0 (low bits first)
   static __device__ __forceinline__ void run(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
                                              const ulonglong2 *tw, const DevPrime &pm) {
     using RS = Rounds<P, LR>;
     constexpr int idx = INVERSE ? (RS::NR - 1 - I) : I;
-    ntt_round<P, LR, RS::bits(idx), RS::lo(idx), INVERSE, STRIDED, RED_EVEN, LASTFOLD>(sub_lds, tid, h, pre, tw, pm);
+    ntt_round<P, LR, RS::bits(idx), RS::lo(idx), INVERSE, STRIDED, RED_EVEN, LASTFOLD, TB>(sub_lds, tid, h, pre, tw, pm);
     if constexpr (I + 1 < RS::NR) {
       // a sub-transform of <= 64 threads lives in one wave: its LDS exchange is ordered by the wave's own DS queue
       if constexpr (!EVAH_ROUND_BARRIER && ((1 << P) >> LR) <= 64) __builtin_amdgcn_wave_barrier();
       else __syncthreads();
-      RoundSeq<P, LR, I + 1, INVERSE, STRIDED, RED_EVEN, LASTFOLD>::run(sub_lds, tid, h, pre, tw, pm);
+      RoundSeq<P, LR, I + 1, INVERSE, STRIDED, RED_EVEN, LASTFOLD, TB>::run(sub_lds, tid, h, pre, tw, pm);
     }
   }
 };
+// forward rounds of one pass: the top-bit butterflies when the prime has the shape, else compare-and-subtract
+// (block-uniform: pm is the workgroup's prime)
+template <int P, int LR, bool STRIDED, bool RED_EVEN>
+__device__ __forceinline__ void forward_rounds(u64 *sub_lds, int tid, uint32_t h, uint32_t pre, const ulonglong2 *tw, const DevPrime &pm) {
+  if (EVAH_TOPBIT && pm.tb_c) RoundSeq<P, LR, 0, false, STRIDED, RED_EVEN, STRIDED, true>::run(sub_lds, tid, h, pre, tw, pm);
+  else RoundSeq<P, LR, 0, false, STRIDED, RED_EVEN, STRIDED, false>::run(sub_lds, tid, h, pre, tw, pm);
+}
 
 // One pass.  grid.x = (N / tile) * jx-count (tile index in the low log_tiles bits), grid.y / grid.z
 // = the op's job coordinates (no integer division in the kernel), block = tile >> LR threads.
@@ -303,7 +334,8 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC_rt, int log_tiles) 
   // ---- register rounds
   {
     const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
-    RoundSeq<P, LR, 0, INVERSE, STRIDED, !STRIDED>::run(lds + sub * SP, tid, sub0 + sub, pre, STRIDED ? twl : tw, pm);
+    if constexpr (INVERSE) RoundSeq<P, LR, 0, true, STRIDED, !STRIDED>::run(lds + sub * SP, tid, sub0 + sub, pre, STRIDED ? twl : tw, pm);
+    else forward_rounds<P, LR, STRIDED, !STRIDED>(lds + sub * SP, tid, sub0 + sub, pre, STRIDED ? twl : tw, pm);
   }
   __syncthreads();
 
@@ -405,7 +437,8 @@ ntt_loop_kernel(DevCtx cx, typename Op::Params prm, int logC, int log_tiles, uin
     if (more) load_tile(jn, dreg);
     __syncthreads();
     // STRIDED = true selects local-heap node indexing (the LDS copy); LASTFOLD = false: N^-1 belongs to the strided pass
-    RoundSeq<P, LR, 0, INVERSE, true, true, false>::run(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
+    if constexpr (INVERSE) RoundSeq<P, LR, 0, true, true, true, false>::run(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
+    else forward_rounds<P, LR, true, true>(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < NPAIR; it++) {
@@ -488,7 +521,7 @@ ntt_inv_fwd_kernel(DevCtx cx, typename Op::Params prm, int log_tiles) {
   if (jb.lazy) convert(std::true_type{});
   else convert(std::false_type{});
   __syncthreads();
-  RoundSeq<P, LR, 0, false, true, false>::run(lds + sub * SP, tid, 0, 0, twl, pm);
+  forward_rounds<P, LR, true, false>(lds + sub * SP, tid, 0, 0, twl, pm);
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < NTT_R; it++) jb.dst[n0 + it * nstep] = lds[lds_at(it)]; // lazy intermediate of the forward transform
@@ -688,7 +721,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
       load_digits(Jn, dreg);
       __syncthreads();
       // STRIDED=true selects local-heap node indexing, which is what the LDS copy uses
-      RoundSeq<P, LR, 0, false, true, true>::run(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
+      forward_rounds<P, LR, true, true>(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
       __syncthreads();
 #pragma unroll
       for (int it = 0; it < NPAIR; it++) {

@@ -105,6 +105,16 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
       d.nq8 = 0ull - 8 * q;
       d.c64 = (u64)((((u128)1) << 64) % q);
       d.c64s = shoup(d.c64, q);
+      {
+        uint32_t b = 0;
+        while ((q >> b) != 0) b++;
+        const u64 cc = (b < 64 ? ((u64)1 << b) : 0) - q;
+        const bool ok = b > 32 && cc < ((u64)1 << 32);
+        d.tb_c = ok ? (uint32_t)cc : 0;
+        d.tb_sh = ok ? b - 32 : 0;
+        d.tb_mask = ok ? (uint32_t)(((u64)1 << (b - 32)) - 1) : 0;
+        d.tb_pad = 0;
+      }
       for (uint32_t a = 0; a < k; a++) {
         const u64 qa = c->primes[a];
         if (a == i) {
