@@ -118,6 +118,15 @@ __device__ __forceinline__ u64 barrett128(u128_t x, const DevPrime &m) {
   v += (v < t) ? m.c64 : 0; // carried: v = t + lo - 2^64 < t < 4q, and 2^64 = c64 (mod q); no second carry
   return barrett64(v, m.q, m.brt);
 }
+// (hi:lo) -> a 64-bit value congruent to it mod q, NOT canonical: barrett128 without its last Barrett step (~21 VALU
+// instead of ~40).  For consumers that multiply the value by a constant with an exact / lazy Shoup product (those
+// accept any 64-bit operand) — the key inner products on their way into the relinearize + rescale combine passes.
+__device__ __forceinline__ u64 reduce128_lazy(u128_t x, const DevPrime &m) {
+  const u64 t = mul_tw_lazy5(x.hi, m.c64, m.c64s, m.nq);
+  u64 v = t + x.lo;
+  v += (v < t) ? m.c64 : 0;
+  return v;
+}
 __device__ __forceinline__ u64 mulmod(u64 a, u64 b, const DevPrime &m) {
   return barrett128(mul128(a, b), m);
 }

@@ -52,7 +52,7 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   auto go = [&](auto kernel, const auto &mt, const auto &at) {
     hipLaunchKernelGGL(kernel, dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev, target, kb.target_bs, scratch,
                        kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n, kb.targets, mt, kb.istep,
-                       kb.nout ? kb.nout : l + 1, kb.r_out, at);
+                       kb.nout ? kb.nout : l + 1, kb.r_out, at, kb.lazy_out ? 1 : 0);
   };
   if (kb.r_out && ((tile >> LR) > 64 || kb.istep != 1)) throw std::logic_error("fused special-row inverse pass needs the one-wave key-switch kernel");
   if (kb.fold && kb.istep != 1) throw std::logic_error("the folded key-switch forms are not used on limb shards");
@@ -98,7 +98,7 @@ void launch_ks_inner(evah_ctx *c, int P, const u64 *target, const u64 *scratch, 
 // here (fused into the key-switch kernel) — the special rows of prod are then NOT written.
 bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t target_bs, const KeyDev *const *keys,
                          uint32_t n, u64 *prod_d, const PtrTab *target_tab, const MulTab *mul, u64 *r_small, bool fold,
-                         const PtrTab *adds) {
+                         const PtrTab *adds, bool lazy_out) {
   const size_t N = c->N;
   if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::runtime_error("key-switch batch out of range");
   KsBatch kb;
@@ -115,6 +115,7 @@ bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t targ
   kb.mul = mul;
   kb.fold = fold;
   kb.adds = adds;
+  kb.lazy_out = lazy_out;
   if ((mul || fold) && !c->tun.fuse_mac) throw std::logic_error("the fused multiply / folded forms need the fused key-switch kernel");
   Scratch t(c, (size_t)n * l * N);        // coefficient-form digits
   Scratch sc(c, n * kb.scratch_bs);       // converted digits, NTT form per output limb
@@ -280,7 +281,7 @@ int evah_relinearize_rescale(evah_ctx *c, const evah_ct *a, uint32_t divisor_bit
     PtrTab adds{};
     adds.p[0] = a->d;
     adds.p[1] = a->d + a->ps;
-    switch_key_products(c, l, a->d + 2 * a->ps, 0, &kp, 1, prod.d, nullptr, nullptr, nullptr, fold, fold ? &adds : nullptr);
+    switch_key_products(c, l, a->d + 2 * a->ps, 0, &kp, 1, prod.d, nullptr, nullptr, nullptr, fold, fold ? &adds : nullptr, /*lazy_out=*/fold);
     Scratch r(c, 2 * N), t(c, 2 * N);
     // r_K = INTT_P(prod[K][special]) + P/2
     OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
@@ -330,7 +331,7 @@ static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n
   // r04: P * (the polynomials the key-switch result is added to) goes into the inner products themselves, so the
   // combine passes below read prod only (Tunables::fold_pa; the r03 forms stay for A/B runs)
   const bool fold = c->tun.fold_pa;
-  switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2, mul, nullptr, fold, mul ? nullptr : &a_polys);
+  switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2, mul, nullptr, fold, mul ? nullptr : &a_polys, /*lazy_out=*/fold);
   Scratch r(c, (size_t)n * 2 * N), t(c, (size_t)n * 2 * N);
   OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
   ntt_inverse<OpPlain>(c, spp, 2 * n);

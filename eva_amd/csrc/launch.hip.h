@@ -132,6 +132,7 @@ struct KsBatch { // one launch worth of key-switches: regular strides, irregular
   bool fold = false;           // fused multiply: P * d0, P * d1 are added to the products here (KS_FOLDMUL; the target is then
                                // read from memory); without mul: P * adds.p[2b + K] is (KS_FOLDADD)
   const PtrTab *adds = nullptr;
+  bool lazy_out = false;       // the data rows of prod may be any 64-bit representative (consumer: the relinearize + rescale combine)
   uint32_t istep = 1, nout = 0; // output limbs I = i0 + y * istep; nout = rows per polynomial of prod (0: l + 1)
   u64 *r_out = nullptr; // != nullptr: the special row leaves as the first inverse pass of the mod-down (INVSP)
 };// second (contiguous) pass of the digit transforms fused with the key inner product (keyswitch.hip)
@@ -200,7 +201,7 @@ static void inverse_then_forward(evah_ctx *c, const typename InvOp::Params &ip, 
 // steps 1-2 of SEAL's switch_key_inplace for a batch of n (target, key) pairs (see the definition)
 bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t target_bs, const KeyDev *const *keys, uint32_t n,
                          u64 *prod_d, const PtrTab *target_tab = nullptr, const MulTab *mul = nullptr, u64 *r_small = nullptr,
-                         bool fold = false, const PtrTab *adds = nullptr);
+                         bool fold = false, const PtrTab *adds = nullptr, bool lazy_out = false);
 void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev &key, const u64 *add, size_t add_ps, uint32_t add_polys,
                 u64 *out, size_t out_ps);
 // ---- defined in rotate.hip: NTT-domain permutation table of a Galois element, cached per device state

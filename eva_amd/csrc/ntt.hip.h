@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(MAXT)
 ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
                 size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, uint32_t i0,
                 int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets, KsMulArg<MODE> mul, uint32_t istep,
-                uint32_t nout, u64 *__restrict__ r_out, KsAddArg<MODE> adds) {
+                uint32_t nout, u64 *__restrict__ r_out, KsAddArg<MODE> adds, int lazy_out) {
   constexpr bool MUL = MODE == KS_MUL;
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   if (cx.skipped()) return;
@@ -821,6 +821,22 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
     }
   }
   u64 *p0 = prod + (size_t)Irow * N + gbase, *p1 = prod + ((size_t)nout + Irow) * N + gbase;
+  // lazy_out: the data rows go to combine passes that take any 64-bit representative (OpRRT / OpRRLastT multiply prod by
+  // P^-1 first), so their last Barrett step is skipped; the special row feeds an inverse transform and stays canonical
+  if (lazy_out && I != l) { // block-uniform
+#pragma unroll
+    for (int it = 0; it < NPAIR; it++) {
+      const int idx = 2 * (threadIdx.x + it * T);
+      ulonglong2 r0, r1;
+      r0.x = reduce128_lazy(acc0[2 * it], pm);
+      r0.y = reduce128_lazy(acc0[2 * it + 1], pm);
+      r1.x = reduce128_lazy(acc1[2 * it], pm);
+      r1.y = reduce128_lazy(acc1[2 * it + 1], pm);
+      *reinterpret_cast<ulonglong2 *>(p0 + idx) = r0;
+      *reinterpret_cast<ulonglong2 *>(p1 + idx) = r1;
+    }
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < NPAIR; it++) {
     const int idx = 2 * (threadIdx.x + it * T);
