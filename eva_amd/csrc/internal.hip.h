@@ -245,7 +245,8 @@ struct Tunables {
   // ntt_loop_kernel: the twiddle heaps of a tile staged in LDS once per workgroup and reused by up to loop_n jobs;
   // loop_n = 0: ntt_pass_kernel everywhere (per-thread global twiddle loads)
   // EVAH_LOOP_MIN_WGS (2048): below this many workgroups (at two jobs per walk) the launch keeps ntt_pass_kernel
-  uint32_t loop_n = 8, loop_min = 2, loop_min_wgs = 2048;
+  // EVAH_LOOP_TARGET_WGS: the walk is shortened (down to 2 jobs) until the launch has this many one-wave workgroups
+  uint32_t loop_n = 8, loop_min = 2, loop_min_wgs = 2048, loop_target_wgs = 8192;
   // EVAH_LDS_EXTRA (0): bytes of dynamic LDS added to every ntt_pass_kernel launch — an occupancy probe for the
   // tuning notes (fewer workgroups per CU), never set in production
   uint32_t lds_extra = 0;
@@ -268,6 +269,7 @@ struct Tunables {
     count("EVAH_LOOP_N", t.loop_n);
     count("EVAH_LOOP_MIN", t.loop_min);
     count("EVAH_LOOP_MIN_WGS", t.loop_min_wgs);
+    count("EVAH_LOOP_TARGET_WGS", t.loop_target_wgs);
     count("EVAH_LDS_EXTRA", t.lds_extra);
     if (const char *e = std::getenv("EVAH_KS_GROUPS")) t.ks_groups = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {

@@ -85,7 +85,7 @@ static bool launch_loop_pass(evah_ctx *c, const typename Op::Params &prm, uint32
   // enough workgroups to fill the chip several times over before twiddle sharing is taken further
   uint32_t nloop = std::min<uint32_t>(c->tun.loop_n, count);
   const uint64_t others = (uint64_t)ext[0] * ext[1] * ext[2] / count * n_tiles;
-  while (nloop > 2 && others * ((count + nloop - 1) / nloop) < 8192) nloop = (nloop + 1) / 2;
+  while (nloop > 2 && others * ((count + nloop - 1) / nloop) < c->tun.loop_target_wgs) nloop = (nloop + 1) / 2;
   ext[Op::loop_axis] = (count + nloop - 1) / nloop;
   const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) +
                      ((size_t)1 << (logC + P)) * sizeof(ulonglong2);

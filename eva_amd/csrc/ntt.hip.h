@@ -253,6 +253,19 @@ template <class Op> struct HasPre<Op, std::void_t<typename Op::Pre>> : std::true
 struct NoPre {};
 template <class Op, bool ON> struct PreOf { using type = NoPre; };
 template <class Op> struct PreOf<Op, true> { using type = typename Op::Pre; };
+// hooks that only the looped contiguous pass uses (ntt_loop_kernel: one wave walks several jobs, so whatever it waits
+// for at a job's start or end is exposed once per job):
+//   LoopPre / loop_prefetch / store_fwd_loop   the forward epilogue's operands, requested before the job's transform
+//   Raw / raw_load / finish_load               the inverse pass's input transform split into its loads (issued before the
+//                                              PREVIOUS job's transform) and its arithmetic (after it)
+template <class Op, class = void> struct HasLoopPre : std::false_type {};
+template <class Op> struct HasLoopPre<Op, std::void_t<typename Op::LoopPre>> : std::true_type {};
+template <class Op, bool ON> struct LoopPreOf { using type = NoPre; };
+template <class Op> struct LoopPreOf<Op, true> { using type = typename Op::LoopPre; };
+template <class Op, class = void> struct HasRaw : std::false_type {};
+template <class Op> struct HasRaw<Op, std::void_t<typename Op::Raw>> : std::true_type {};
+template <class Op, bool ON> struct RawOf { using type = NoPre; };
+template <class Op> struct RawOf<Op, true> { using type = typename Op::Raw; };
 
 template <int P, int LR, bool STRIDED, bool INVERSE, class Op, bool FULL>
 __global__ void __launch_bounds__(NTT_THREADS)
@@ -413,7 +426,10 @@ ntt_loop_kernel(DevCtx cx, typename Op::Params prm, int logC, int log_tiles, uin
     }
   };
   constexpr bool PREFETCH = EVAH_PREFETCH && !INVERSE && HasPre<Op>::value;
+  constexpr bool LOOPPRE = EVAH_PREFETCH && !INVERSE && !PREFETCH && HasLoopPre<Op>::value;
+  constexpr bool RAW = INVERSE && HasRaw<Op>::value;
   ulonglong2 dreg[NPAIR];
+  typename RawOf<Op, RAW>::type raw[NTT_R];
   load_tile(jb, dreg);
   while (true) {
     // next existing job of the walk (block-uniform)
@@ -434,7 +450,19 @@ ntt_loop_kernel(DevCtx cx, typename Op::Params prm, int logC, int log_tiles, uin
 #pragma unroll
       for (int it = 0; it < NTT_R; it++) epi[it] = Op::prefetch(cx, jb, pm, gbase + 2 * (threadIdx.x + (it >> 1) * T) + (it & 1));
     }
-    if (more) load_tile(jn, dreg);
+    typename LoopPreOf<Op, LOOPPRE>::type lepi[NTT_R];
+    if constexpr (LOOPPRE) {
+#pragma unroll
+      for (int it = 0; it < NTT_R; it++) lepi[it] = Op::loop_prefetch(cx, jb, pm, gbase + 2 * (threadIdx.x + (it >> 1) * T) + (it & 1));
+    }
+    if constexpr (RAW) {
+      if (more) {
+#pragma unroll
+        for (int it = 0; it < NTT_R; it++) raw[it] = Op::raw_load(cx, jn, pm, gbase + 2 * (threadIdx.x + (it >> 1) * T) + (it & 1));
+      }
+    } else {
+      if (more) load_tile(jn, dreg);
+    }
     __syncthreads();
     // STRIDED = true selects local-heap node indexing (the LDS copy); LASTFOLD = false: N^-1 belongs to the strided pass
     if constexpr (INVERSE) RoundSeq<P, LR, 0, true, true, true, false>::run(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
@@ -454,12 +482,23 @@ ntt_loop_kernel(DevCtx cx, typename Op::Params prm, int logC, int log_tiles, uin
       } else if constexpr (PREFETCH) {
         Op::store_fwd_pre(cx, jb, pm, n, vx, epi[2 * it]);
         Op::store_fwd_pre(cx, jb, pm, n + 1, vy, epi[2 * it + 1]);
+      } else if constexpr (LOOPPRE) {
+        Op::store_fwd_loop(cx, jb, pm, n, vx, lepi[2 * it]);
+        Op::store_fwd_loop(cx, jb, pm, n + 1, vy, lepi[2 * it + 1]);
       } else {
         Op::store_fwd(cx, jb, pm, n, vx);
         Op::store_fwd(cx, jb, pm, n + 1, vy);
       }
     }
     if (!more) break;
+    if constexpr (RAW) { // the next job's input transform, on operands that arrived during this job's butterflies
+#pragma unroll
+      for (int it = 0; it < NPAIR; it++) {
+        const uint32_t n = gbase + 2 * (threadIdx.x + it * T);
+        dreg[it].x = Op::finish_load(cx, jn, pm, n, raw[2 * it]);
+        dreg[it].y = Op::finish_load(cx, jn, pm, n + 1, raw[2 * it + 1]);
+      }
+    }
     jb = jn;
     j = jnext;
   }
@@ -955,6 +994,16 @@ struct OpMulIntt {
     j.dst[n] = v;
   }
   static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &, const DevPrime &, uint32_t, u64) {}
+  // ntt_loop_kernel: operands of the NEXT product requested before the current job's transform, multiplied after it
+  struct Raw { u64 a, b; };
+  static __device__ __forceinline__ Raw raw_load(const DevCtx &, const Job &j, const DevPrime &, uint32_t n) {
+    return Raw{j.mul.a[j.off + n + j.mul.sa], j.mul.b[j.off + n + j.mul.sb]};
+  }
+  static __device__ __forceinline__ u64 finish_load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, const Raw &r) {
+    const u64 v = mulmod(r.a, r.b, pm);
+    if (j.d2) j.d2[n] = v; // block-uniform
+    return v;
+  }
 };
 
 // Key-switch digit conversion: job -> (I = job / l, J = job % l);
@@ -1231,6 +1280,21 @@ template <int AM> struct OpRRT {
   }
   // (no Pre here: requesting prod ahead of the tile measured 2 % slower on this pass — 372 against 364 us per
   // 32-triple launch — its on-the-fly products already keep four loads per word in flight)
+  // ntt_loop_kernel (one wave walks the jobs: the epilogue's loads would be waited for once per job): prod, and a when
+  // it comes from memory, requested before the job's transform
+  struct LoopPre { u64 prod, a; };
+  static __device__ __forceinline__ LoopPre loop_prefetch(const DevCtx &, const Job &j, const DevPrime &, uint32_t n) {
+    return LoopPre{j.prod[n], AM == RR_MEM ? j.a[n] : 0};
+  }
+  static __device__ __forceinline__ void store_fwd_loop(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n, u64 W, const LoopPre &p) {
+    if constexpr (AM == RR_MUL) {
+      store_fwd(cx, j, pm, n, W);
+    } else {
+      W += (W >= pm.q8 ? pm.nq8 : 0);
+      const u64 x = p.a + mul_tw_lazy5(p.prod, j.pinv.x, j.pinv.y, pm.nq) + pm.q8 - W;
+      j.dst[n] = mul_shoup(x, j.linv.x, j.linv.y, pm.q);
+    }
+  }
 };
 
 using OpRRLast = OpRRLastT<RR_MEM>;
