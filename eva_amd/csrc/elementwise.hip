@@ -234,6 +234,21 @@ __global__ void __launch_bounds__(256) k_fill_limbs(DevCtx cx, LimbVals vals, u6
 
 } // namespace evah
 
+namespace evah {
+// key words in the layout of the radix-2^30 inner product (ks_inner_kernel<MAC3>)
+__global__ void __launch_bounds__(256) k_key_split(const u64 *__restrict__ src, u64 *__restrict__ dst, size_t words) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < words) {
+    const u64 k = src[i];
+    dst[i] = (k & 0x3fffffffull) | ((k >> 30) << 32);
+  }
+}
+void key_split_launch(evah_ctx *c, const u64 *src, u64 *dst, size_t words) {
+  hipLaunchKernelGGL(k_key_split, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->stream, src, dst, words);
+  HIPCHK(hipGetLastError());
+}
+} // namespace evah
+
 extern "C" {
 
 int evah_pt_upload_coeff(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *data, evah_pt **out) {

@@ -133,6 +133,9 @@ struct KeyDev {
   // set its map before the upload keeps only its own data limbs and the special prime
   // ([digits][2][rows][N], row y = prime shard + y * shards, last row = the special prime)
   uint32_t rows = 0;
+  // the same key words cut at bit 30 — (k mod 2^30) | (k >> 30) << 32 — for the radix-2^30 inner product of
+  // ks_inner_kernel<MAC3>; built at upload for whole keys of contexts whose primes all have the top-bit shape
+  u64 *d_split = nullptr;
 };
 
 } // namespace evah
@@ -190,10 +193,11 @@ struct SharedDev {
     if (enc_roots) (void)hipFree(enc_roots);
     if (enc_slot_map) (void)hipFree(enc_slot_map);
     if (relin.d) (void)hipFree(relin.d);
+    if (relin.d_split) (void)hipFree(relin.d_split);
     if (pk.d) (void)hipFree(pk.d);
     if (sk.d) { (void)hipMemset(sk.d, 0, sk.bytes); (void)hipFree(sk.d); } // key material does not stay behind in freed HBM
     if (dec_roots) (void)hipFree(dec_roots);
-    for (auto &kv : galois) (void)hipFree(kv.second.d);
+    for (auto &kv : galois) { (void)hipFree(kv.second.d); if (kv.second.d_split) (void)hipFree(kv.second.d_split); }
     for (auto &kv : perms) (void)hipFree(kv.second);
     for (auto &kv : hoist_sign) (void)hipFree(kv.second);
     for (auto &kv : hoist_corr) (void)hipFree(kv.second);
@@ -240,6 +244,9 @@ struct Tunables {
   // is added to) to the key inner products inside ks_inner_kernel (KS_FOLDMUL / KS_FOLDADD), so the mod-down's
   // combine pass — which waits for bytes — reads the products only; 0 = the r03 forms (operands read in the epilogue)
   bool fold_pa = true;
+  // EVAH_MAC3 (1): key inner products accumulate in radix 2^30 (ks_inner_kernel<MAC3>) when every prime of the context
+  // has the top-bit shape and the level has at most 15 limbs; the keys are then kept in the split layout as well
+  bool mac3 = true;
   // EVAH_LOOP_N (8) / EVAH_LOOP_MIN (2): contiguous transform passes whose launch holds at least loop_min jobs modulo
   // one prime (both polynomials of a ciphertext, the instances of a batched call, the digits of a hoisted set) run as
   // ntt_loop_kernel: the twiddle heaps of a tile staged in LDS once per workgroup and reused by up to loop_n jobs;
@@ -266,6 +273,7 @@ struct Tunables {
     flag("EVAH_HOIST_DEBUG", t.hoist_debug);
     flag("EVAH_FUSE_SPECIAL_INV", t.fuse_special_inv);
     flag("EVAH_FOLD_PA", t.fold_pa);
+    flag("EVAH_MAC3", t.mac3);
     count("EVAH_LOOP_N", t.loop_n);
     count("EVAH_LOOP_MIN", t.loop_min);
     count("EVAH_LOOP_MIN_WGS", t.loop_min_wgs);
@@ -294,6 +302,7 @@ struct evah_ctx {
   std::vector<hipEvent_t> capture_events; // events consumed by the capture in progress
   std::vector<hipEvent_t> sync_events; // recycled events for cross-queue ordering
   Tunables tun; // launch-shape decisions, read from the environment once when the context is created
+  bool all_tb = false; // every prime is 2^b - c with b > 32, c < 2^32 (DevPrime::tb_c != 0)
   // per-launch profile
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;

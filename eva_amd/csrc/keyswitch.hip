@@ -45,7 +45,8 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   if (logC < 0) throw std::runtime_error("ks_inner tile smaller than one sub-transform");
   // coefficients tile + per-sub twiddle heaps (16 B per node)
   const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) +
-                     ((size_t)1 << (logC + P)) * sizeof(ulonglong2);
+                     ((size_t)1 << (logC + P)) * sizeof(ulonglong2) +
+                     (kb.mac3 ? (size_t)tile * sizeof(u64) : 0); // MAC3: the unpadded tile the LDS-DMA loads fill
   const uint32_t n_tiles = c->N / tile;
   // the one-wave workgroup (the default) is compiled with its own launch bound: the register
   // allocator is not held to the 256-thread budget
@@ -62,6 +63,14 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
     constexpr int M = decltype(mode_tag)::value;
     const KsMulArg<M> mt = [&] { if constexpr (M == KS_MUL || M == KS_FOLDMUL) return *kb.mul; else return NoMul{}; }();
     const KsAddArg<M> at = [&] { if constexpr (M == KS_FOLDADD) return *kb.adds; else return NoMul{}; }();
+    if constexpr (M != KS_MUL) { // radix-2^30 accumulation: the one-wave kernels of the current forms
+      if (kb.mac3 && (tile >> LR) <= 64) {
+        if (kb.r_out) go(ks_inner_kernel<P, LR, 64, M, true, true>, mt, at);
+        else go(ks_inner_kernel<P, LR, 64, M, false, true>, mt, at);
+        return;
+      }
+    }
+    if (kb.mac3) throw std::logic_error("split keys handed to a key-switch kernel that accumulates in 128 bits");
     if (kb.r_out) go(ks_inner_kernel<P, LR, 64, M, true>, mt, at);
     else if ((tile >> LR) <= 64) go(ks_inner_kernel<P, LR, 64, M>, mt, at);
     else go(ks_inner_kernel<P, LR, NTT_THREADS, M>, mt, at);
@@ -106,11 +115,17 @@ bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t targ
   kb.target_bs = target_bs;
   kb.scratch_bs = (size_t)(l + 1) * l * N;
   kb.prod_bs = (size_t)2 * (l + 1) * N;
+  // radix-2^30 accumulation (ks_inner_kernel<MAC3>): every prime of the top-bit shape, every key with its split copy,
+  // at most 15 limbs (the top sum holds 15 digits), the one-wave kernel, not the r03 fused-multiply form
+  const uint32_t ks_tile = std::min<uint32_t>(c->N, (uint32_t)c->tun.ks_threads << 2);
+  bool mac3 = c->tun.mac3 && c->tun.fuse_mac && c->all_tb && l <= 15 && (ks_tile >> 2) <= 64 && !(mul && !fold);
   for (uint32_t b = 0; b < n; b++) {
     if (keys[b]->n_digits < l) throw std::runtime_error("key switching key has too few digits");
     if (keys[b]->rows != c->k) throw std::logic_error("this context holds a limb shard's key rows: use the evah_shard_* entry points");
-    kb.keys.key[b] = keys[b]->d;
+    mac3 = mac3 && keys[b]->d_split;
   }
+  for (uint32_t b = 0; b < n; b++) kb.keys.key[b] = mac3 ? keys[b]->d_split : keys[b]->d;
+  kb.mac3 = mac3;
   if (target_tab) kb.targets = *target_tab; // target == nullptr: separately allocated targets
   kb.mul = mul;
   kb.fold = fold;

@@ -132,6 +132,7 @@ struct KsBatch { // one launch worth of key-switches: regular strides, irregular
   bool fold = false;           // fused multiply: P * d0, P * d1 are added to the products here (KS_FOLDMUL; the target is then
                                // read from memory); without mul: P * adds.p[2b + K] is (KS_FOLDADD)
   const PtrTab *adds = nullptr;
+  bool mac3 = false;           // keys point at the split layout: ks_inner_kernel<MAC3> (radix-2^30 accumulation)
   bool lazy_out = false;       // the data rows of prod may be any 64-bit representative (consumer: the relinearize + rescale combine)
   uint32_t istep = 1, nout = 0; // output limbs I = i0 + y * istep; nout = rows per polynomial of prod (0: l + 1)
   u64 *r_out = nullptr; // != nullptr: the special row leaves as the first inverse pass of the mod-down (INVSP)
@@ -204,6 +205,8 @@ bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t targ
                          bool fold = false, const PtrTab *adds = nullptr, bool lazy_out = false);
 void switch_key(evah_ctx *c, uint32_t l, const u64 *target, const KeyDev &key, const u64 *add, size_t add_ps, uint32_t add_polys,
                 u64 *out, size_t out_ps);
+// ---- defined in elementwise.hip: dst[i] = (src[i] mod 2^30) | (src[i] >> 30) << 32 (KeyDev::d_split)
+void key_split_launch(evah_ctx *c, const u64 *src, u64 *dst, size_t words);
 // ---- defined in rotate.hip: NTT-domain permutation table of a Galois element, cached per device state
 const uint32_t *perm_table(evah_ctx *c, uint32_t elt);
 // out[p][i][n] = a[p][i][perm[n]] for p < polys over `limbs` limbs (the NTT-domain Galois automorphism)

@@ -151,9 +151,13 @@ template <int P, bool RED_EVEN> constexpr bool tb_reduce_stage(int s) {
   if (RED_EVEN) return s % 3 == 1;
   return s % 3 == (P - 2) % 3 || (s == 0 && (P - 2) % 3 == 2);
 }
-template <int P, int LR, int RB, int LO, bool INVERSE, bool STRIDED, bool RED_EVEN, bool LASTFOLD = STRIDED, bool TB = false>
+// lin_in != nullptr: this round's inputs are read from an UNPADDED copy of the sub-transform (element e at lin_in[e] —
+// where an LDS-DMA load put the tile, ks_inner_kernel<MAC3>), its outputs go to the padded tile as usual
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int P, int LR, int RB, int LO, bool INVERSE, bool STRIDED, bool RED_EVEN, bool LASTFOLD = STRIDED, bool TB = false, class AfterLoad = NoHook>
 __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
-                                          const ulonglong2 *__restrict__ tw, const DevPrime &pm) {
+                                          const ulonglong2 *__restrict__ tw, const DevPrime &pm, const u64 *lin_in = nullptr,
+                                          AfterLoad after_load = AfterLoad()) {
   constexpr int NTT_R = 1 << LR;
   constexpr int S = 1 << P, TPS = S / NTT_R, G = NTT_R >> RB, NU = 1 << RB;
   constexpr int S0 = P - LO - RB; // local stages above this round
@@ -172,8 +176,14 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
     // ebase and (u << LO) occupy disjoint bit fields, so pad(ebase | u << LO) = pad(ebase) + pad(u << LO):
     // one padded base per group, the per-element part is an immediate offset of the LDS access
     u64 *grp = sub_lds + lds_pad<P>(ebase);
+    if (lin_in) { // compile-time known at every call site (inlined)
 #pragma unroll
-    for (int u = 0; u < NU; u++) x[g * NU + u] = grp[lds_pad<P>(u << LO)];
+      for (int u = 0; u < NU; u++) x[g * NU + u] = lin_in[ebase | (u << LO)];
+      if (g == G - 1) after_load(); // every input of the round is on its way to registers: `lin_in` may be refilled
+    } else {
+#pragma unroll
+      for (int u = 0; u < NU; u++) x[g * NU + u] = grp[lds_pad<P>(u << LO)];
+    }
     const uint32_t node = STRIDED ? ((1u << S0) | (uint32_t)o_hi)
                                   : ((1u << (pre + S0)) | (h << S0) | (uint32_t)o_hi);
     if (!INVERSE) {
@@ -217,7 +227,10 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
   }
 }
 
-template <int P, int LR, int I, bool INVERSE, bool STRIDED, bool RED_EVEN, bool LASTFOLD = STRIDED, bool TB = false> struct RoundSeq {
+// WAVESYNC: the workgroup is ONE wave (ks_inner_kernel<MAC3>), whose DS operations execute in issue order: the rounds
+// need no s_barrier, and must not use __syncthreads() — with an LDS-DMA load in flight its fence drains vmcnt, i.e. waits
+// for the very loads that are meant to overlap the transform
+template <int P, int LR, int I, bool INVERSE, bool STRIDED, bool RED_EVEN, bool LASTFOLD = STRIDED, bool TB = false, bool WAVESYNC = false> struct RoundSeq {
   // forward: rounds 0..NR-1 (top bits first); inverse: NR-1..0 (low bits first)
   static __device__ __forceinline__ void run(u64 *sub_lds, int tid, uint32_t h, uint32_t pre,
                                              const ulonglong2 *tw, const DevPrime &pm) {
@@ -226,9 +239,9 @@ template <int P, int LR, int I, bool INVERSE, bool STRIDED, bool RED_EVEN, bool 
     ntt_round<P, LR, RS::bits(idx), RS::lo(idx), INVERSE, STRIDED, RED_EVEN, LASTFOLD, TB>(sub_lds, tid, h, pre, tw, pm);
     if constexpr (I + 1 < RS::NR) {
       // a sub-transform of <= 64 threads lives in one wave: its LDS exchange is ordered by the wave's own DS queue
-      if constexpr (!EVAH_ROUND_BARRIER && ((1 << P) >> LR) <= 64) __builtin_amdgcn_wave_barrier();
+      if constexpr (WAVESYNC || (!EVAH_ROUND_BARRIER && ((1 << P) >> LR) <= 64)) __builtin_amdgcn_wave_barrier();
       else __syncthreads();
-      RoundSeq<P, LR, I + 1, INVERSE, STRIDED, RED_EVEN, LASTFOLD, TB>::run(sub_lds, tid, h, pre, tw, pm);
+      RoundSeq<P, LR, I + 1, INVERSE, STRIDED, RED_EVEN, LASTFOLD, TB, WAVESYNC>::run(sub_lds, tid, h, pre, tw, pm);
     }
   }
 };
@@ -647,7 +660,15 @@ template <int MODE> using KsAddArg = typename KsArgs<MODE>::Add;
 // with the contiguous pass of that row's inverse transform — the first step of the mod-down that
 // always follows — on the tile they hold, and store its lazy intermediate to r_out[2 inst + K]
 // instead of the row itself: one launch fewer per key switch, same residues.
-template <int P, int LR, int MAXT, int MODE, bool INVSP = false>
+// MAC3 (contexts whose primes all have the top-bit shape, whole keys in the split layout KeyDev::d_split): the inner
+// product accumulates in radix 2^30.  The transformed digit is brought to < 2^60 + 2^36 with the top-bit reduction and
+// cut at bit 30 (v0, v1), the key word arrives as (k0 | k1 << 32) with k0, k1 < 2^30, and the four partial products
+// — each < 2^60.1 — go into three 64-bit sums A0 += v0 k0, A1 += v0 k1 + v1 k0, A2 += v1 k1 with ONE v_mad_u64_u32
+// each and no carry handling: 13 VALU per coefficient and digit for both key polynomials (3 reduce + 2 split + 8 mad)
+// where the 128-bit accumulation takes 28.  A1 holds 7 digits (14 products < 16 x 2^60), so the sums are normalised
+// (carry words moved up) every 7 digits; after the loop they are recombined into the 128-bit accumulators the
+// epilogue works on.  6 registers per accumulator instead of 4.
+template <int P, int LR, int MAXT, int MODE, bool INVSP = false, bool MAC3 = false>
 __global__ void __launch_bounds__(MAXT)
 ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
                 size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, uint32_t i0,
@@ -668,6 +689,10 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
     inst = blockIdx.x / n_tiles;
     tile_idx = blockIdx.x % n_tiles;
   }
+  // the divisions above go through the vector unit: make the results wave-uniform for the compiler, so that what is
+  // indexed by them (key, operand and product base pointers) lives in SGPRs
+  inst = __builtin_amdgcn_readfirstlane(inst);
+  tile_idx = __builtin_amdgcn_readfirstlane(tile_idx);
   // MUL: the key-switch target is d2 = a1 b1 of product `inst`, evaluated where it is needed (I == J)
   const u64 *__restrict__ target = MUL ? nullptr : (target_b ? target_b + inst * target_bs : targets.p[inst]);
   const u64 *__restrict__ scratch = scratch_b + inst * scratch_bs;
@@ -707,6 +732,10 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   u128_t acc0[NTT_R], acc1[NTT_R];
 #pragma unroll
   for (int i = 0; i < NTT_R; i++) { acc0[i] = {0, 0}; acc1[i] = {0, 0}; }
+  constexpr int NA = MAC3 ? NTT_R : 1;
+  u64 s0[2][NA], s1[2][NA], s2[2][NA]; // MAC3: radix-2^30 partial sums per key polynomial K
+#pragma unroll
+  for (int i = 0; i < NA; i++) { s0[0][i] = s1[0][i] = s2[0][i] = s0[1][i] = s1[1][i] = s2[1][i] = 0; }
 
   // Software pipeline over the digits: the key words of digit J are requested before its
   // transform starts and the coefficients of digit J+1 as soon as those of J sit in LDS, so both
@@ -727,21 +756,81 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
       for (int it = 0; it < NPAIR; it++) d[it] = *reinterpret_cast<const ulonglong2 *>(src + 2 * (threadIdx.x + it * T));
     }
   };
-  ulonglong2 dreg[NPAIR];
-  load_digits(0, dreg);
+  // MAC3: the digit tiles do not pass through registers.  An LDS-DMA load (global_load_lds_dwordx4: 16 bytes per lane,
+  // contiguous) puts tile J + 1 into an unpadded buffer `lin` while tile J is being transformed; the first register
+  // round reads its inputs from `lin`, and the load of the next tile is issued right after that round.  This frees
+  // the 8 prefetch registers (and the tile's ds_write) for the radix-2^30 sums.
+  u64 *lin = reinterpret_cast<u64 *>(twl + (C << P)); // [256] after the twiddle heaps
+  auto dma_digits = [&](uint32_t J) {
+    const u64 *src = (I == J ? target + (size_t)Irow * N : scratch + ((size_t)Irow * l + J) * N) + gbase;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads of `lin` issued so far have returned
+#pragma unroll
+    for (int it = 0; it < NPAIR; it++)
+      __builtin_amdgcn_global_load_lds(src + 2 * (threadIdx.x + it * T), lin + 2 * it * T, 16, 0, 0);
+  };
+  ulonglong2 dreg[MAC3 ? 1 : NPAIR];
+  if constexpr (MAC3) dma_digits(0);
+  else load_digits(0, dreg);
   uint32_t since_fold = 0;
   for (uint32_t J = 0; J < l; J++) {
     ulonglong2 k0r[NPAIR], k1r[NPAIR];
-    const u64 *kp = key + J * key_digit + (size_t)krow * N + gbase;
+    if constexpr (!MAC3) {
+      const u64 *kp = key + J * key_digit + (size_t)krow * N + gbase;
 #pragma unroll
-    for (int it = 0; it < NPAIR; it++) {
-      const int idx = 2 * (threadIdx.x + it * T);
-      k0r[it] = *reinterpret_cast<const ulonglong2 *>(kp + idx);
-      k1r[it] = *reinterpret_cast<const ulonglong2 *>(kp + (size_t)krows * N + idx);
+      for (int it = 0; it < NPAIR; it++) {
+        const int idx = 2 * (threadIdx.x + it * T);
+        k0r[it] = *reinterpret_cast<const ulonglong2 *>(kp + idx);
+        k1r[it] = *reinterpret_cast<const ulonglong2 *>(kp + (size_t)krows * N + idx);
+      }
     }
     u64 val[NTT_R];
     const uint32_t Jn = J + 1 < l ? J + 1 : J;
-    if (I == J) { // already in NTT form mod q_J: use the key-switch target directly
+    if constexpr (MAC3) {
+      using RS = Rounds<P, LR>;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // tile J has landed in `lin` (its load was issued a digit ago)
+      // the key words of this digit: requested now, used after the transform
+      const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<u64 *>(key + (size_t)krow * N + gbase), 0, 0x7fffffff, 0x00020000);
+      const uint32_t voff = 16u * threadIdx.x;
+      const uint32_t soff0 = (uint32_t)(J * key_digit * sizeof(u64)), soff1 = soff0 + (uint32_t)((size_t)krows * N * sizeof(u64));
+#pragma unroll
+      for (int it = 0; it < NPAIR; it++) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(krs, voff + 16u * (uint32_t)(it * T), soff0, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(krs, voff + 16u * (uint32_t)(it * T), soff1, 0);
+        k0r[it].x = ((u64)a.y << 32) | a.x;
+        k0r[it].y = ((u64)a.w << 32) | a.z;
+        k1r[it].x = ((u64)b.y << 32) | b.x;
+        k1r[it].y = ((u64)b.w << 32) | b.z;
+      }
+      if (I == J) { // NTT form already: the tile as it lies in `lin`
+#pragma unroll
+        for (int it = 0; it < NPAIR; it++) {
+          const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(lin + 2 * (threadIdx.x + it * T));
+          val[2 * it] = v.x;
+          val[2 * it + 1] = v.y;
+        }
+        if (J + 1 < l) dma_digits(J + 1);
+      } else {
+        __builtin_amdgcn_wave_barrier(); // (one wave: DS operations are in order; no s_barrier, no vmcnt drain)
+        // first round: from `lin` into the padded tile; then the next tile's load; then the remaining rounds
+        auto next_tile = [&]() { if (J + 1 < l) dma_digits(J + 1); }; // (waits for the round's reads of `lin` first)
+        ntt_round<P, LR, RS::bits(0), RS::lo(0), false, true, true, true, true>(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm,
+                                                                              lin + sub * S, next_tile);
+        if constexpr (RS::NR > 1) {
+          __builtin_amdgcn_wave_barrier();
+          RoundSeq<P, LR, 1, false, true, true, true, true, true>::run(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < NPAIR; it++) {
+          const int idx = 2 * (threadIdx.x + it * T);
+          const int sb = idx >> P, e = idx & (S - 1);
+          val[2 * it] = lds[sb * SP + lds_pad<P>(e)];
+          val[2 * it + 1] = lds[sb * SP + lds_pad<P>(e + 1)];
+        }
+      }
+    } else if (I == J) { // already in NTT form mod q_J: use the key-switch target directly
 #pragma unroll
       for (int it = 0; it < NPAIR; it++) {
         val[2 * it] = dreg[it].x;
@@ -770,6 +859,36 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
         val[2 * it + 1] = lds[sb * SP + lds_pad<P>(e + 1)];
       }
     }
+    if constexpr (MAC3) {
+#pragma unroll
+      for (int i = 0; i < NTT_R; i++) {
+        const uint32_t hi = (uint32_t)(val[i] >> 32);
+        const u64 v = mad64(hi >> pm.tb_sh, pm.tb_c, ((u64)(hi & pm.tb_mask) << 32) | (uint32_t)val[i]); // < 2^60 + 2^36
+        const uint32_t v0 = (uint32_t)v & 0x3fffffffu, v1 = (uint32_t)(v >> 30);
+        const u64 kw0 = (i & 1) ? k0r[i >> 1].y : k0r[i >> 1].x, kw1 = (i & 1) ? k1r[i >> 1].y : k1r[i >> 1].x;
+        s0[0][i] = mad64(v0, (uint32_t)kw0, s0[0][i]);
+        s1[0][i] = mad64(v0, (uint32_t)(kw0 >> 32), s1[0][i]);
+        s1[0][i] = mad64(v1, (uint32_t)kw0, s1[0][i]);
+        s2[0][i] = mad64(v1, (uint32_t)(kw0 >> 32), s2[0][i]);
+        s0[1][i] = mad64(v0, (uint32_t)kw1, s0[1][i]);
+        s1[1][i] = mad64(v0, (uint32_t)(kw1 >> 32), s1[1][i]);
+        s1[1][i] = mad64(v1, (uint32_t)kw1, s1[1][i]);
+        s2[1][i] = mad64(v1, (uint32_t)(kw1 >> 32), s2[1][i]);
+      }
+      if (++since_fold == 7u && J + 1 < l) { // block-uniform: carry words up, 7 more digits fit
+        since_fold = 0;
+#pragma unroll
+        for (int K = 0; K < 2; K++)
+#pragma unroll
+          for (int i = 0; i < NTT_R; i++) {
+            s1[K][i] += s0[K][i] >> 30;
+            s0[K][i] &= 0x3fffffffull;
+            s2[K][i] += s1[K][i] >> 30;
+            s1[K][i] &= 0x3fffffffull;
+          }
+      }
+      continue;
+    }
 #pragma unroll
     for (int it = 0; it < NPAIR; it++) {
       acc128(acc0[2 * it], val[2 * it], k0r[it].x);
@@ -787,6 +906,18 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
         acc0[i] = {barrett128(acc0[i], pm), 0};
         acc1[i] = {barrett128(acc1[i], pm), 0};
       }
+    }
+  }
+  if constexpr (MAC3) { // S = s0 + s1 2^30 + s2 2^60 < 2^125: the 128-bit accumulators of the epilogue
+#pragma unroll
+    for (int i = 0; i < NTT_R; i++) {
+      unsigned __int128 a = s0[0][i], b = s0[1][i];
+      a += (unsigned __int128)s1[0][i] << 30;
+      a += (unsigned __int128)s2[0][i] << 60;
+      b += (unsigned __int128)s1[1][i] << 30;
+      b += (unsigned __int128)s2[1][i] << 60;
+      acc0[i] = {(u64)a, (u64)(a >> 64)};
+      acc1[i] = {(u64)b, (u64)(b >> 64)};
     }
   }
   if constexpr (MODE == KS_FOLDMUL || MODE == KS_FOLDADD) {

@@ -4,6 +4,7 @@
 // seal_executor.h:264-277, 420-435) — see include/eva_hip.h for the per-entry-point mapping.
 // gfx950 only; no CPU fallback: every entry point needs a HIP device and fails otherwise.
 #include "internal.hip.h"
+namespace evah { void key_split_launch(evah_ctx *c, const u64 *src, u64 *dst, size_t words); } // elementwise.hip
 
 namespace evah {
 
@@ -129,6 +130,8 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
         }
       }
     }
+    c->all_tb = true;
+    for (uint32_t i = 0; i < k; i++) c->all_tb = c->all_tb && hp[i].tb_c != 0;
     c->sh = std::make_shared<SharedDev>();
     c->sh->device = device;
     HIPCHK(hipMalloc(&c->sh->d_tables, total));
@@ -168,6 +171,7 @@ int evah_ctx_fork(evah_ctx *parent, evah_ctx **out) {
     c->total_bits = parent->total_bits;
     c->dev = parent->dev;
     c->tun = parent->tun;
+    c->all_tb = parent->all_tb;
     HIPCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     HIPCHK(hipEventCreate(&c->ev0));
@@ -269,18 +273,32 @@ int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digit
       HIPCHK(e);
     }
   }
+  if (!local_rows && c->all_tb && c->tun.mac3) { // the split copy ks_inner_kernel<MAC3> multiplies with
+    if (hipMalloc(&kd.d_split, kd.bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      kd.d_split = nullptr; // no memory for the second copy: the 128-bit accumulation is used
+    } else {
+      key_split_launch(c, kd.d, kd.d_split, kd.bytes / sizeof(u64));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+  }
   c->sh->key_rows = local_rows ? 2 : 1;
   c->sh->key_shard = s;
   if (kind == EVAH_KEY_RELIN) {
     if (c->sh->relin.d) (void)hipFree(c->sh->relin.d);
+    if (c->sh->relin.d_split) (void)hipFree(c->sh->relin.d_split);
     c->sh->relin = kd;
   } else if (kind == EVAH_KEY_GALOIS) {
     if (!(galois_elt & 1) || galois_elt >= 2 * c->N) {
       (void)hipFree(kd.d);
+      if (kd.d_split) (void)hipFree(kd.d_split);
       throw std::invalid_argument("Galois element is not valid");
     }
     auto it = c->sh->galois.find(galois_elt);
-    if (it != c->sh->galois.end()) (void)hipFree(it->second.d);
+    if (it != c->sh->galois.end()) {
+      (void)hipFree(it->second.d);
+      if (it->second.d_split) (void)hipFree(it->second.d_split);
+    }
     c->sh->galois[galois_elt] = kd;
     // the hoisting constants of this element were derived from the key it replaces
     for (auto hc = c->sh->hoist_corr.begin(); hc != c->sh->hoist_corr.end();) {
@@ -293,6 +311,7 @@ int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digit
     }
   } else {
     (void)hipFree(kd.d);
+    if (kd.d_split) (void)hipFree(kd.d_split);
     throw std::invalid_argument("unknown key kind");
   }
   API_END
