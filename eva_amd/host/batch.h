@@ -1,0 +1,116 @@
+// batch.h — HipPublic::execute_batch: many input valuations of ONE program (BASELINE config 4) as batched device
+// handles, groups of batch_chunk instances pipelined over batch_depth issue queues (uploads and downloads of one group
+// overlap the kernels of the others); execute_batch_multi deals the groups over the members of a device group
+// (shard_mode = "dag").  Included by public_ctx.h.
+#pragma once
+
+namespace evahost {
+
+inline std::vector<HipValuation> HipPublic::execute_batch(Program &program, const std::vector<const HipValuation *> &inputs) {
+  ensure_device();
+  if (batch_chunk < 1 || batch_chunk > 64) throw std::runtime_error("batch_chunk must be 1..64");
+  std::vector<HipValuation> all(inputs.size());
+  // Groups rotate over batch_depth issue queues (default four: +6 % over two on config 4) and nothing waits in between: each group's uploads,
+  // launches and downloads are enqueued in queue order (evah_ct_*_instances_async), so the copies
+  // of one group overlap the kernels of the other and the host never idles the device.  Device
+  // memory stays at two groups' working sets (the pools recycle in queue order); the inputs belong
+  // to the caller and the outputs are allocated up front, so both outlive the final synchronisation.
+  if (devices.size() > 1 && shard_mode == "dag") return execute_batch_multi(program, inputs);
+  if (batch_depth < 2 || batch_depth > 8) throw std::runtime_error("batch_depth must be 2..8");
+  while (batch_forks.size() + 1 < batch_depth) batch_forks.push_back(std::make_shared<Fork>(dev));
+  std::vector<evah_ctx *> qs{dev->h};
+  for (uint32_t i = 0; i + 1 < batch_depth; i++) qs.push_back(batch_forks[i]->h);
+  const size_t Q = qs.size();
+  // constants (Constant / Encode nodes and raw arithmetic on them) are evaluated once, by the
+  // first group, and shared by all groups: their plaintexts stay resident for the whole call
+  std::vector<char> done;
+  std::vector<HipExecutor::RuntimeValue> consts;
+  auto finish = [&]() {
+    int rc = 0;
+    for (evah_ctx *q : qs) rc |= evah_ctx_sync(q);
+    if (rc) throw_backend();
+  };
+  size_t g = 0;
+  const bool bounded = std::getenv("EVA_BATCH_BOUNDED") ? std::atoi(std::getenv("EVA_BATCH_BOUNDED")) != 0 : false;
+  try {
+    for (size_t i0 = 0; i0 < inputs.size(); i0 += batch_chunk, g++) {
+      const size_t n = std::min<size_t>(batch_chunk, inputs.size() - i0);
+      std::vector<const HipValuation *> chunk(inputs.begin() + i0, inputs.begin() + i0 + n);
+      if (bounded && g >= Q) chk(evah_ctx_sync(qs[g % Q])); // group g-Q (same queue) has left the device
+      HipExecutor ex(program, *host, std::vector<evah_ctx *>{qs[g % Q]}, dev.get());
+      if (g == 0) {
+        done = ex.prepare_constants();
+        consts.resize(program.size());
+        for (TermId t = 0; t < program.size(); t++)
+          if (done[t]) consts[t] = ex.value(t);
+      } else {
+        for (TermId t = 0; t < program.size(); t++)
+          if (done[t]) ex.set_value(t, consts[t]);
+      }
+      ex.set_inputs_batch(chunk, true);
+      if (library_scheduler) ex.run_library(&done, true);
+      else run_counted(program, ex, &done);
+      ex.get_outputs_batch(all.data() + i0, n, true);
+    }
+  } catch (...) {
+    for (evah_ctx *q : qs) (void)evah_ctx_sync(q); // copies in flight still target `all` and the caller's inputs
+    throw;
+  }
+  finish();
+  return all;
+}
+
+// "dag" mode (BASELINE config 4): the groups of a batch are dealt over the members
+// of `devices` — group g on member g mod G, batch_depth issue queues per member so a member's copies overlap its
+// kernels — with no data-path exchange: instances are independent.  Same results as execute_batch on one
+// device.  (The driver's scaling curve uses one process per GPU, eva_amd/dist.py; this is the same
+// partition inside one execute_batch call.)
+inline std::vector<HipValuation> HipPublic::execute_batch_multi(Program &program, const std::vector<const HipValuation *> &inputs) {
+  if (batch_chunk < 1 || batch_chunk > 64) throw std::runtime_error("batch_chunk must be 1..64");
+  ensure_group(false);
+  const size_t G = group->size();
+  if (batch_depth < 2 || batch_depth > 8) throw std::runtime_error("batch_depth must be 2..8");
+  const size_t D = batch_depth;
+  if (batch_queues.size() != D * G) {
+    batch_queues.clear();
+    for (size_t m = 0; m < G; m++)
+      for (size_t k = 0; k < D; k++) batch_queues.push_back(std::make_shared<Fork>(group->roots[m]));
+  }
+  std::vector<HipValuation> all(inputs.size());
+  std::vector<std::vector<char>> done(G);
+  std::vector<std::vector<HipExecutor::RuntimeValue>> consts(G);
+  std::vector<size_t> turn(G, 0);
+  auto sync_all = [&]() {
+    int rc = 0;
+    for (auto &f : batch_queues) rc |= evah_ctx_sync(f->h);
+    return rc;
+  };
+  try {
+    size_t g = 0;
+    for (size_t i0 = 0; i0 < inputs.size(); i0 += batch_chunk, g++) {
+      const size_t n = std::min<size_t>(batch_chunk, inputs.size() - i0), m = g % G;
+      std::vector<const HipValuation *> chunk(inputs.begin() + i0, inputs.begin() + i0 + n);
+      evah_ctx *q = batch_queues[D * m + (turn[m]++ % D)]->h;
+      HipExecutor ex(program, *host, std::vector<evah_ctx *>{q}, group->roots[m].get());
+      if (done[m].empty()) { // the member's constants: encoded once, by its first group
+        done[m] = ex.prepare_constants();
+        consts[m].resize(program.size());
+        for (TermId t = 0; t < program.size(); t++)
+          if (done[m][t]) consts[m][t] = ex.value(t);
+      } else {
+        for (TermId t = 0; t < program.size(); t++)
+          if (done[m][t]) ex.set_value(t, consts[m][t]);
+      }
+      ex.set_inputs_batch(chunk, true);
+      ex.run_library(&done[m], true);
+      ex.get_outputs_batch(all.data() + i0, n, true);
+    }
+  } catch (...) {
+    (void)sync_all(); // copies in flight still target `all` and the caller's inputs
+    throw;
+  }
+  if (sync_all()) throw_backend();
+  return all;
+}
+
+} // namespace evahost
