@@ -700,7 +700,13 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath))["by_class"].get(dom, {}).get("hbm_bytes_per_launch")
+                    from eva_amd.roofline import csrc_tree_hash
+                    tj = json.load(open(tpath))
+                    traffic = tj["by_class"].get(dom, {}).get("hbm_bytes_per_launch")
+                    # the counter passes are a separate, committed measurement: tie them to the tree being timed
+                    roofline["traffic_source"] = {"file": "profiles/bench_pmc_traffic.json", "tree": tj.get("tree"),
+                                                  "commit": tj.get("commit"), "tree_now": csrc_tree_hash(ROOT)}
+                    roofline["traffic_stale"] = tj.get("tree") != csrc_tree_hash(ROOT)
                 except Exception:
                     traffic = None
             roofline["kernel"] = dom
@@ -732,11 +738,13 @@ def main():
         if os.path.exists(vpath) and (args.logn, l) == (16, 10):
             try:
                 vj = json.load(open(vpath))
+                from eva_amd.roofline import csrc_tree_hash
                 us_per_triple = 1e6 * world / value
                 roofline["secondary"] = {
                     "bound": "valu integer issue", "valu_wave_instructions_per_triple": vj["valu_wave_instructions_per_triple"],
                     "valu_issuing_us_per_triple": vj["valu_issuing_us_per_triple"], "us_per_triple": round(us_per_triple, 2),
                     "frac": round(vj["valu_issuing_us_per_triple"] / us_per_triple, 3),
+                    "stale": vj.get("tree") != csrc_tree_hash(ROOT),
                     "note": "9 integer multiplies + 8 other VALU instructions per butterfly at ~4.5-5.6 SIMD-cycles each: "
                             "the path is issue-bound before it is HBM-bound (DESIGN.md section 4)"}
             except Exception:

@@ -126,3 +126,19 @@ def roofline(total_bytes, seconds, peak_gbps=8000.0):
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": peak_gbps, "unit": "GB/s",
             "frac": round(ach / peak_gbps, 4), "bytes_per_unit": int(total_bytes),
             "basis": "SURVEY.md 8(d) algorithmic bytes summed over the compiled op list (eva_amd/roofline.py) / measured time"}
+
+
+def csrc_tree_hash(root=None):
+    """sha256 (first 16 hex digits) over the device sources the library is built from (eva_amd/csrc/*, sorted by name).
+    The committed counter summaries (profiles/bench_pmc_traffic.json, bench_valu_issue.json) carry the hash of the
+    tree they were measured on; bench.py recomputes it and marks them stale when the kernels have changed since."""
+    import hashlib
+    import os
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "eva_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]

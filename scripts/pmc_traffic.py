@@ -14,6 +14,12 @@ def classify(name):
         if key in name:
             base = cls
             break
+    if "ntt_loop_kernel" in name:  # the looped contiguous pass: inverse = first pass of an INTT, forward = second pass
+        import re
+        m = re.search(r"ntt_loop_kernel<\d+, \d+, (true|false)", name)
+        if m.group(1) == "true":
+            return "intt_pass1"
+        return f"{base or 'ntt'}_pass2"
     if "ntt_pass_kernel" in name:
         import re
         m = re.search(r"ntt_pass_kernel<\d+, \d+, (true|false), (true|false)", name)
@@ -25,12 +31,16 @@ def classify(name):
     return base or name[:40]
 
 
+KERNELS = set()
+
+
 def load(d, counter):
     out = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 out[classify(r["Kernel_Name"])].append(float(r["Counter_Value"]) * 1024.0)
+                KERNELS.add(r["Kernel_Name"].split("(")[0].replace("void ", ""))
     return out
 
 
@@ -41,7 +51,10 @@ for k in sorted(set(fetch) | set(write)):
     w = sum(write[k]) / max(len(write[k]), 1)
     res[k] = {"launches": max(len(fetch[k]), len(write[k])), "fetch_bytes_per_launch": round(f), "write_bytes_per_launch": round(w),
               "hbm_bytes_per_launch": round(f + w)}
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; FETCH_SIZE x2 (gfx950)", "by_class": res}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eva_amd.roofline import csrc_tree_hash  # noqa: E402
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; FETCH_SIZE x2 (gfx950)",
+       "tree": csrc_tree_hash(), "commit": os.environ.get("EVA_COMMIT", ""), "kernel_names": sorted(KERNELS), "by_class": res}
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -70,6 +70,37 @@ def fresh(N, bits, seed=20260927):
     return d, bits
 
 
+def add_shortcut_vectors(d, N, seed=4):
+    """The two places where the HIP product does NOT follow SEAL's order of operations and claims the same bits anyway
+    (DESIGN.md 4.1 and 4): a hoisted rotation set — 8 rotations of ONE source, decomposed once — and the fused
+    multiply -> relinearize -> rescale.  The oracle computes them the way SEAL does (rotate, then switch keys, one call
+    per step; three separate evaluator calls), so these are the first vectors a SEAL host pins.  Sources: a dense
+    ciphertext, one whose c1 has a zero limb (more zero digit coefficients than the hoisted path corrects one by one:
+    its guarded exact fallback), and a transparent one (c1 = 0)."""
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as po
+    primes = [int(q) for q in d["primes"]]
+    o = po.Oracle(N, primes)
+    k, l = len(primes), len(primes) - 1
+    rng = np.random.default_rng(seed)
+    steps = np.array([1, 2, 3, 5, -1, -2, 7, N // 2 - 2], dtype=np.int64)
+    d["hoist_steps"] = steps
+    for s in steps:
+        d[f"galois_key_h{int(s)}"] = np.stack([rng.integers(0, primes[i], size=(l, 2, N), dtype=np.uint64) for i in range(k)], axis=2)
+    dense = np.array(d["a2"])
+    zero_limb = np.array(d["b2"])
+    zero_limb[1, 0, :] = 0
+    transparent = np.array(d["a2"])
+    transparent[1] = 0
+    d["hoist_src_dense"], d["hoist_src_zero_limb"], d["hoist_src_transparent"] = dense, zero_limb, transparent
+    for name in ("dense", "zero_limb", "transparent"):
+        for s in steps:
+            d[f"out_hoist_{name}_{int(s)}"] = o.rotate(d[f"hoist_src_{name}"], int(s), d[f"galois_key_h{int(s)}"])
+    # fused multiply -> relinearize -> rescale, also as a square (seal_executor.h:161-164, :200, :213)
+    d["out_triple_square"] = o.rescale(o.relinearize(o.square(d["a2"]), d["relin_key"]))
+    return d
+
+
 def write_seal_objects(out, d, N):
     """parameters, two ciphertexts, a plaintext, a public / secret key and both key sets in SEAL's object format"""
     sys.path.insert(0, ROOT)
@@ -112,15 +143,17 @@ def main():
         N = int(sys.argv[2])
     else:
         d, bits, N = dict(np.load(os.path.join(HERE, "ops_n1024.npz"))), [60, 40, 60], 1024
+    d = add_shortcut_vectors(d, N)
     with open(os.path.join(out, "manifest.txt"), "w") as f:
         f.write("# vectors for tools/seal_parity.cpp; every ciphertext / plaintext carries scale 2^scale_log2\n")
         f.write(f"N {N}\nbits {' '.join(str(b) for b in bits)}\nscale_log2 10\n")
         f.write("rot_steps " + " ".join(str(int(s)) for s in d["rot_steps"]) + "\n")
         f.write("enc_scale_bits " + " ".join(str(int(s)) for s in d["enc_scale_bits"]) + "\n")
+        f.write("hoist_steps " + " ".join(str(int(s)) for s in d["hoist_steps"]) + "\n")
     n_blobs = write_seal_objects(out, d, N)
     n = 0
     for name, a in d.items():
-        if name in ("rot_steps", "enc_scale_bits"):
+        if name in ("rot_steps", "enc_scale_bits", "hoist_steps"):
             continue
         ext = ".f64" if a.dtype == np.float64 else ".u64"
         np.ascontiguousarray(a).astype("<f8" if ext == ".f64" else "<u8").tofile(os.path.join(out, name + ext))

@@ -233,3 +233,39 @@ def test_the_hoisted_path_is_the_one_that_runs_and_can_be_disabled():
     assert prof["ksdigit_pass2"][0] == 0, prof
     for st, o in zip(steps, outs):
         assert np.array_equal(o.download(), e0.o.rotate(a2, st, e0.keys[st]))
+
+
+def test_exported_shortcut_vectors_through_the_hoisted_and_fused_paths():
+    """The vectors tests/golden/export_seal_vectors.py writes for tools/seal_parity.cpp section 4b — what a SEAL host
+    pins first — run through the product's two shortcuts: ONE hoisted rotation set per source (dense, zero limb in c1,
+    transparent) and ONE fused multiply / square -> relinearize -> rescale.  Same residues as the oracle's SEAL-order
+    evaluation stored in the vectors."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import export_seal_vectors as ex
+    d = ex.add_shortcut_vectors(dict(np.load(os.path.join(here, "golden", "ops_n1024.npz"))), 1024)
+    primes = [int(q) for q in d["primes"]]
+    old = {k: os.environ.get(k) for k in ("EVAH_HOIST", "EVAH_HOIST_MIN_TILES")}
+    os.environ["EVAH_HOIST"], os.environ["EVAH_HOIST_MIN_TILES"] = "1", "0"
+    try:
+        g = backend.Context(1024, primes)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    steps = [int(s) for s in d["hoist_steps"]]
+    for s in steps:
+        g.upload_galois_key(g.galois_elt_from_step(s), d[f"galois_key_h{s}"])
+    g.upload_relin_key(d["relin_key"])
+    for name in ("dense", "zero_limb", "transparent"):
+        src = g.upload_ct(d[f"hoist_src_{name}"], 2.0 ** 10)
+        outs = g.rotate_many(src, steps)
+        for s, o in zip(steps, outs):
+            assert np.array_equal(o.download(), d[f"out_hoist_{name}_{s}"]), (name, s)
+    a, b = g.upload_ct(d["a2"], 2.0 ** 10), g.upload_ct(d["b2"], 2.0 ** 10)
+    assert np.array_equal(g.multiply_relinearize_rescale_many([a], [b], 60)[0].download(), d["out_triple"])
+    assert np.array_equal(g.multiply_relinearize_rescale_many([a], [a], 60)[0].download(), d["out_triple_square"])
+    g.close()

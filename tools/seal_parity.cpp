@@ -166,14 +166,20 @@ int main(int argc, char **argv) {
     for (size_t J = 0; J < l; J++) std::memcpy(rk.data()[0][J].data().data(), d.data() + J * 2 * k * N, 2 * k * N * 8);
   }
   std::vector<int> steps(mf.at("rot_steps").begin(), mf.at("rot_steps").end());
-  GaloisKeys gk;
+  // the steps of the hoisted-set vectors (section 4b) get keys of their own ("galois_key_h<step>")
+  std::vector<int> hoist_steps;
+  if (mf.count("hoist_steps")) hoist_steps.assign(mf.at("hoist_steps").begin(), mf.at("hoist_steps").end());
+  GaloisKeys gk, gk_h;
   keygen.create_galois_keys(steps, gk);
-  for (int s : steps) {
-    auto d = load_u64("galois_key_" + std::to_string(s));
+  if (!hoist_steps.empty()) keygen.create_galois_keys(hoist_steps, gk_h);
+  auto fill_key = [&](GaloisKeys &keys, int s, const std::string &file) {
+    auto d = load_u64(file);
     const std::uint32_t elt = key_data->galois_tool()->get_elt_from_step(s);
-    auto &kv = gk.data()[GaloisKeys::get_index(elt)];
+    auto &kv = keys.data()[GaloisKeys::get_index(elt)];
     for (size_t J = 0; J < l; J++) std::memcpy(kv[J].data().data(), d.data() + J * 2 * k * N, 2 * k * N * 8);
-  }
+  };
+  for (int s : steps) fill_key(gk, s, "galois_key_" + std::to_string(s));
+  for (int s : hoist_steps) fill_key(gk_h, s, "galois_key_h" + std::to_string(s));
 
   // 4. evaluator calls (seal_executor.h line in brackets)
   Evaluator ev(context);
@@ -203,6 +209,30 @@ int main(int argc, char **argv) {
     ev.relinearize(m, rk, r);
     ev.rescale_to_next(r, t);
     report("op-triple multiply+relinearize+rescale", same(t.data(), load_u64("out_triple")));
+  }
+  // 4b. the product's two "exactness" shortcuts, as SEAL computes them.  (i) what the HIP backend evaluates as ONE fused
+  // multiply -> relinearize -> rescale (also as a square); (ii) what it evaluates as ONE hoisted rotation set: 8
+  // rotate_vector calls on one source — dense, with a zero limb in c1 (the hoisted path's guarded fallback), and
+  // transparent (c1 = 0; a SEAL built with SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT refuses that result: reported as SKIP)
+  if (std::ifstream(g_dir + "/out_triple_square.u64")) {
+    Ciphertext m, r, t;
+    ev.square(a2, m);
+    ev.relinearize(m, rk, r);
+    ev.rescale_to_next(r, t);
+    report("fused form: square+relinearize+rescale", same(t.data(), load_u64("out_triple_square")));
+  }
+  for (const char *src_name : {"dense", "zero_limb", "transparent"}) {
+    if (hoist_steps.empty()) break;
+    Ciphertext src = make_ct(std::string("hoist_src_") + src_name, 2);
+    for (int s : hoist_steps) {
+      const std::string what = std::string("hoisted set: rotate_vector ") + std::to_string(s) + " of the " + src_name + " source [:181,:188]";
+      try {
+        ev.rotate_vector(src, s, gk_h, o);
+        report(what, same(o.data(), load_u64(std::string("out_hoist_") + src_name + "_" + std::to_string(s))));
+      } catch (const std::logic_error &e) {
+        std::cout << "SKIP  " << what << " (" << e.what() << ")" << std::endl;
+      }
+    }
   }
 
   // 5. encoder (seal_executor.h:242): full slot vectors at 2^scale_bits, first data level
