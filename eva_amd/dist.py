@@ -102,3 +102,64 @@ def run_sharded(dist, n_units, work):
         return {u: work(u) for u in dist.my_units(n_units)}
     local, secs = dist.timed(body)
     return dist.gather_units(local, n_units), secs
+
+
+class _DevWords:
+    """a library device buffer (pointer, words) as a CUDA array for torch.as_tensor"""
+
+    def __init__(self, ptr, words):
+        self.__cuda_array_interface__ = {"shape": (int(words),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+def attach_limb_dist(pub, dist):
+    """RNS-limb sharding of public_ctx.execute() across the ranks of `dist` (one process per GPU; SURVEY.md 8(e) row 3,
+    north_star: "RCCL all-gather over xGMI reassembling limbs before each key-switch").  The C++ limb-shard evaluator
+    behind execute() (eva_amd/host/multi_device.h) keeps this rank's limbs and calls back here at its exchange steps:
+      nccl (= RCCL)  collectives in place on the library's device buffers, on torch's current stream — which is also
+                     made the stream the shard's kernels run on, so nothing waits for the host between phases
+      gloo           the same steps staged through host memory (tests: several ranks sharing one GPU)"""
+    import numpy as np
+    torch, tdist = dist.torch, dist.dist
+    device_collectives = dist.backend == "nccl"
+    rank, world = dist.rank, dist.world
+
+    def view(ptr, words):
+        return torch.as_tensor(_DevWords(ptr, words), device="cuda")
+
+    def all_gather(ptr, chunk):
+        full = view(ptr, world * chunk)
+        if device_collectives:
+            tdist.all_gather_into_tensor(full, full[rank * chunk:(rank + 1) * chunk])
+            return
+        torch.cuda.synchronize()  # the library's own stream has produced the chunk
+        mine = full[rank * chunk:(rank + 1) * chunk].cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        tdist.all_gather(parts, mine)
+        for r, p in enumerate(parts):
+            if r != rank:
+                full[r * chunk:(r + 1) * chunk].copy_(p)
+        torch.cuda.synchronize()
+
+    def broadcast(ptr, words, owner):
+        t = view(ptr, words)
+        if device_collectives:
+            tdist.broadcast(t, src=owner)
+            return
+        torch.cuda.synchronize()
+        h = t.cpu() if rank == owner else torch.empty(words, dtype=torch.int64)
+        tdist.broadcast(h, src=owner)
+        if rank != owner:
+            t.copy_(h)
+        torch.cuda.synchronize()
+
+    def sum_host(arr):
+        t = torch.from_numpy(np.asarray(arr).view(np.int64))  # shares memory: the all-reduce lands in the caller's words
+        if device_collectives:
+            d = t.cuda()
+            tdist.all_reduce(d)
+            t.copy_(d.cpu())
+        else:
+            tdist.all_reduce(t)
+
+    stream = torch.cuda.current_stream().cuda_stream if device_collectives else 0
+    pub.set_limb_dist(rank, world, all_gather, broadcast, sum_host, stream)

@@ -9,11 +9,18 @@ namespace evahost {
 // (seal_executor.h:279-404) on a LimbShardEvaluator.  Values come in and go out as host words (a
 // sharded value has no single device handle); constants are encoded on the host once per program.
 inline HipValuation HipPublic::execute_limb(Program &program, const HipValuation &inputs) {
-  if (!limb || limb_ids != devices) {
-    check_devices();
+  if (!limb || limb_ids != devices || limb->shards() != (limb_hooks ? limb_world : (uint32_t)devices.size())) {
     limb.reset();
     limb_const.clear();
-    limb = std::make_unique<LimbShardEvaluator>(*host, make_limb_group(devices, *host, [this](evah_ctx *c) { upload_eval_keys(c); }));
+    if (limb_hooks) { // this process is one shard of a group that spans processes: collectives at the exchange steps
+      if (limb_world < 1 || limb_rank >= limb_world) throw std::runtime_error("limb_rank out of range");
+      DeviceGroup g = make_limb_group_rank(device, limb_rank, limb_world, *host, [this](evah_ctx *c) { upload_eval_keys(c); });
+      if (limb_stream) chk(evah_ctx_set_stream(g.ctx[limb_rank], (void *)limb_stream));
+      limb = std::make_unique<LimbShardEvaluator>(*host, std::move(g), limb_hooks);
+    } else {
+      check_devices();
+      limb = std::make_unique<LimbShardEvaluator>(*host, make_limb_group(devices, *host, [this](evah_ctx *c) { upload_eval_keys(c); }));
+    }
     limb_ids = devices;
   }
   LimbShardEvaluator &ev = *limb;

@@ -342,6 +342,22 @@ PYBIND11_MODULE(_eva, m) {
       .def_readwrite("shard_mode", &HipPublic::shard_mode, "'' (one device) | 'subdag' | 'limb' | 'dag' — how execute() / execute_batch() use `devices`")
       .def_readonly("last_subdag_plan", &HipPublic::last_subdag_plan, "(member, ops) per piece of the last sub-DAG split: prefix, components..., suffix")
       .def("key_bytes", &HipPublic::key_bytes, "HBM bytes of evaluation keys: one entry per limb shard (when limb-sharded), then the whole keys on the context's own device (0 if never uploaded)")
+      .def("set_limb_dist", [](HipPublic &p, uint32_t rank, uint32_t world, py::object all_gather, py::object broadcast, py::object sum_host,
+                               uintptr_t stream) {
+        // the exchange steps of limb sharding across processes, as callbacks into torch.distributed (RCCL); called
+        // from execute() with the GIL held
+        p.limb_rank = rank;
+        p.limb_world = world;
+        p.limb_stream = stream;
+        p.limb_hooks.all_gather = [all_gather](void *ptr, size_t chunk) { all_gather((uintptr_t)ptr, chunk); };
+        p.limb_hooks.broadcast = [broadcast](void *ptr, size_t words, uint32_t owner) { broadcast((uintptr_t)ptr, words, owner); };
+        p.limb_hooks.sum_host = [sum_host](evahost::u64 *w, size_t n) {
+          sum_host(py::array_t<uint64_t>({(py::ssize_t)n}, {(py::ssize_t)sizeof(uint64_t)}, (const uint64_t *)w, py::capsule(w, [](void *) {})));
+        };
+        p.shard_mode = "limb";
+      }, py::arg("rank"), py::arg("world"), py::arg("all_gather"), py::arg("broadcast"), py::arg("sum_host"), py::arg("stream") = 0,
+           "limb sharding across processes: this context is shard `rank` of `world`; all_gather(ptr, chunk_words), "
+           "broadcast(ptr, words, owner) act in place on device buffers, sum_host(array) all-reduces a host uint64 array")
       .def_readonly("last_exchanged_words", &HipPublic::last_exchanged_words, "uint64 words moved between shards by the last limb-sharded execute()")
       .def_readonly("last_exchange_launches", &HipPublic::last_exchange_launches,
                     "launches those words took: one per receiving shard per exchange step (evah_buf_gather)")

@@ -88,6 +88,34 @@ inline DeviceGroup make_limb_group(const std::vector<int> &ids, const HostContex
   return g;
 }
 
+// One process per GPU (torchrun): this process is shard `rank` of `world`; the other members of the group are
+// other processes (ctx[s] == nullptr) and the exchange steps go through LimbHooks (RCCL collectives).
+inline DeviceGroup make_limb_group_rank(int device, uint32_t rank, uint32_t world, const HostContext &host,
+                                        const std::function<void(evah_ctx *)> &upload_keys) {
+  DeviceGroup g;
+  g.ids.assign(world, -1);
+  g.roots.assign(world, nullptr);
+  g.forks.assign(world, nullptr);
+  g.ctx.assign(world, nullptr);
+  auto root = std::make_shared<DeviceCtx>(host.N, host.primes, device);
+  chk(evah_ctx_set_shard(root->h, rank, world));
+  upload_keys(root->h);
+  g.ids[rank] = device;
+  g.roots[rank] = root;
+  g.ctx[rank] = root->h;
+  return g;
+}
+
+// Exchange steps of a limb group whose shards live in DIFFERENT processes: collectives on the library's device
+// buffers (RCCL through torch.distributed under torchrun; the bindings call back into Python).  Unset: all shards are
+// here and the exchanges are evah_buf_gather launches.
+struct LimbHooks {
+  std::function<void(void *dev_ptr, size_t chunk_words)> all_gather;                 // in place: chunk r of the buffer from rank r
+  std::function<void(void *dev_ptr, size_t words, uint32_t owner)> broadcast;        // in place, from rank `owner`
+  std::function<void(u64 *host_words, size_t words)> sum_host;                       // in place all-reduce (sum) of host words
+  explicit operator bool() const { return (bool)all_gather; }
+};
+
 // ------------------------------------------------------------------------------------ sub-DAG split
 
 inline uint32_t op_arity(uint32_t op) { return (op == (uint32_t)Op::Add || op == (uint32_t)Op::Sub || op == (uint32_t)Op::Mul) ? 2u : 1u; }
@@ -316,11 +344,18 @@ struct ShardBuf {
 // shard's queue (evah_buf_copy), ordered after the producing shard's work by the library.
 class LimbShardEvaluator {
 public:
-  LimbShardEvaluator(const HostContext &hc, DeviceGroup grp) : host(hc), g(std::move(grp)), G((uint32_t)g.size()) {
-    for (uint32_t s = 0; s < G; s++) chk(evah_ctx_set_shard(g.ctx[s], s, G));
+  LimbShardEvaluator(const HostContext &hc, DeviceGroup grp, LimbHooks hk = LimbHooks())
+      : host(hc), g(std::move(grp)), G((uint32_t)g.size()), hooks(std::move(hk)) {
+    for (uint32_t s = 0; s < G; s++)
+      if (local(s)) chk(evah_ctx_set_shard(g.ctx[s], s, G));
+    for (uint32_t s = 0; s < G; s++)
+      if (!local(s) && !hooks) throw std::logic_error("limb group with remote shards needs exchange hooks");
   }
   uint32_t shards() const { return G; }
   const DeviceGroup &group() const { return g; }
+  // shard s is a context of this process (all of them unless the group spans processes)
+  bool local(uint32_t s) const { return g.ctx[s] != nullptr; }
+  evah_ctx *any_ctx() const { for (uint32_t s = 0; s < G; s++) if (local(s)) return g.ctx[s]; return nullptr; }
 
   // data: all limbs, [size][l][N] (plaintext: [l][N], size 0)
   ShardedValue upload(const u64 *data, uint32_t size, uint32_t l, double scale) {
@@ -334,7 +369,7 @@ public:
     std::vector<u64> local;
     for (uint32_t s = 0; s < G; s++) {
       const uint32_t nl = s < l ? (l - s + G - 1) / G : 0;
-      if (!nl) continue;
+      if (!nl || !this->local(s)) continue;
       local.resize((size_t)polys * nl * N);
       for (uint32_t p = 0; p < polys; p++)
         for (uint32_t j = 0; j < nl; j++)
@@ -360,6 +395,7 @@ public:
     const size_t N = host.N;
     out.data.resize((size_t)v.size * v.limbs * N);
     out.words_checked = true;
+    if (hooks) std::memset(out.data.data(), 0, sizeof(u64) * out.data.size()); // remote limbs arrive through sum_host
     std::vector<u64> local;
     for (uint32_t s = 0; s < G; s++) {
       if (!v.ct[s]) continue;
@@ -370,6 +406,8 @@ public:
         for (uint32_t j = 0; j < nl; j++)
           std::memcpy(out.data.data() + ((size_t)p * v.limbs + s + (size_t)j * G) * N, local.data() + ((size_t)p * nl + j) * N, sizeof(u64) * N);
     }
+    // every limb is owned by exactly one rank and zero elsewhere: the sum over ranks is the whole ciphertext
+    if (hooks) hooks.sum_host(out.data.data(), out.data.size());
     return out;
   }
 
@@ -383,6 +421,7 @@ public:
       chk(evah_pt_download(g.ctx[s], v.pt[s]->h, (uint64_t *)local.data()));
       for (uint32_t j = 0; j < nl; j++) std::memcpy(out.data() + ((size_t)s + (size_t)j * G) * N, local.data() + (size_t)j * N, sizeof(u64) * N);
     }
+    if (hooks) hooks.sum_host(out.data(), out.size()); // the other ranks' limbs (zero here)
     return out;
   }
 
@@ -435,7 +474,7 @@ public:
     if (a.size != 2) throw std::runtime_error("rotate expects a size-2 ciphertext (relinearize first)");
     if (steps == 0) return a;
     uint32_t elt = 0;
-    chk(evah_galois_elt_from_step(g.ctx[0], steps, &elt));
+    chk(evah_galois_elt_from_step(any_ctx(), steps, &elt));
     ShardedValue perm = each1(a, 2, a.limbs, a.scale, [elt](evah_ctx *c, const evah_ct *x, evah_ct **o) { return evah_shard_galois_perm(c, x, elt, o); });
     return key_switch(perm, 1, a.limbs, EVAH_KEY_GALOIS, elt, &perm, 1, a.scale);
   }
@@ -445,8 +484,11 @@ public:
     const uint32_t owner = (l - 1) % G;
     const size_t N = host.N;
     std::vector<ShardBuf> rbuf;
-    for (uint32_t s = 0; s < G; s++) rbuf.emplace_back(g.ctx[s], 3 * N);
-    chk(evah_shard_rescale_last(g.ctx[owner], a.ct[owner]->h, l, rbuf[owner].b));
+    for (uint32_t s = 0; s < G; s++) {
+      if (local(s)) rbuf.emplace_back(g.ctx[s], 3 * N);
+      else rbuf.emplace_back();
+    }
+    if (local(owner)) chk(evah_shard_rescale_last(g.ctx[owner], a.ct[owner]->h, l, rbuf[owner].b));
     broadcast(rbuf, owner, (size_t)a.size * N); // ---- exchange: INTT of the last limb
     ShardedValue o;
     o.size = a.size;
@@ -454,14 +496,14 @@ public:
     o.scale = a.scale / std::pow(2.0, (double)divisor_bits);
     o.ct.resize(G);
     for (uint32_t s = 0; s < G; s++) {
-      if (s >= l - 1) continue;
+      if (s >= l - 1 || !local(s)) continue;
       evah_ct *h = nullptr;
       chk(evah_shard_rescale_finish(g.ctx[s], a.ct[s]->h, l, rbuf[s].b, divisor_bits, &h));
       o.ct[s] = std::make_shared<CtHandle>(g.ctx[s], h);
     }
     return o;
   }
-  void sync() { for (uint32_t s = 0; s < G; s++) chk(evah_ctx_sync(g.ctx[s])); }
+  void sync() { for (uint32_t s = 0; s < G; s++) if (local(s)) chk(evah_ctx_sync(g.ctx[s])); }
 
   // exchange traffic of this evaluator so far (words moved between shards), for bench / tests
   uint64_t exchanged_words = 0;
@@ -472,6 +514,7 @@ private:
   const HostContext &host;
   DeviceGroup g;
   uint32_t G;
+  LimbHooks hooks; // set: the group spans processes, the exchange steps are collectives
 
   void same_level(const ShardedValue &a, const ShardedValue &b, bool scales) const {
     if (a.limbs != b.limbs) throw std::runtime_error("encrypted1 and encrypted2 parameter mismatch");
@@ -487,7 +530,7 @@ private:
     o.scale = scale;
     o.ct.resize(G);
     for (uint32_t s = 0; s < G; s++) {
-      if (!a.ct[s]) continue;
+      if (!a.ct[s] || !local(s)) continue;
       evah_ct *h = nullptr;
       chk(fn(g.ctx[s], a.ct[s]->h, &h));
       o.ct[s] = std::make_shared<CtHandle>(g.ctx[s], h);
@@ -501,7 +544,7 @@ private:
     o.scale = scale;
     o.ct.resize(G);
     for (uint32_t s = 0; s < G; s++) {
-      if (!a.ct[s] || !b.ct[s]) continue;
+      if (!a.ct[s] || !b.ct[s] || !local(s)) continue;
       evah_ct *h = nullptr;
       chk(fn(g.ctx[s], a.ct[s]->h, b.ct[s]->h, &h));
       o.ct[s] = std::make_shared<CtHandle>(g.ctx[s], h);
@@ -515,7 +558,7 @@ private:
     o.scale = scale;
     o.ct.resize(G);
     for (uint32_t s = 0; s < G; s++) {
-      if (!a.ct[s] || !p.pt[s]) continue;
+      if (!a.ct[s] || !p.pt[s] || !local(s)) continue;
       evah_ct *h = nullptr;
       chk(fn(g.ctx[s], a.ct[s]->h, p.pt[s]->h, &h));
       o.ct[s] = std::make_shared<CtHandle>(g.ctx[s], h);
@@ -526,7 +569,14 @@ private:
   // bufs[s]: buffer of G chunks, chunk s filled by shard s -> every buffer complete.  ONE launch per receiving shard
   // (evah_buf_gather: a kernel on the receiver's queue that reads the other shards' chunks as peers), not G - 1 copies
   void all_gather(std::vector<ShardBuf> &bufs, size_t chunk) {
-    if (G < 2) return;
+    if (G < 2 && !hooks) return;
+    if (hooks) { // one collective on this rank's buffer (chunk r from rank r), on the stream its kernels run on
+      for (uint32_t s = 0; s < G; s++)
+        if (local(s)) hooks.all_gather(evah_buf_ptr(bufs[s].b), chunk);
+      exchanged_words += chunk * (G - 1);
+      exchange_launches++;
+      return;
+    }
     for (uint32_t d = 0; d < G; d++) {
       std::vector<const evah_buf *> srcs;
       std::vector<size_t> offs;
@@ -541,6 +591,13 @@ private:
     }
   }
   void broadcast(std::vector<ShardBuf> &bufs, uint32_t owner, size_t words) {
+    if (hooks) {
+      for (uint32_t s = 0; s < G; s++)
+        if (local(s)) hooks.broadcast(evah_buf_ptr(bufs[s].b), words, owner);
+      exchanged_words += words;
+      exchange_launches++;
+      return;
+    }
     const size_t zero = 0;
     for (uint32_t d = 0; d < G; d++)
       if (d != owner) {
@@ -557,18 +614,26 @@ private:
     const uint32_t rows = (l + G - 1) / G;
     const size_t chunk = (size_t)rows * N;
     std::vector<ShardBuf> dig, prod, rbuf;
-    for (uint32_t s = 0; s < G; s++) dig.emplace_back(g.ctx[s], G * chunk);
+    for (uint32_t s = 0; s < G; s++) {
+      if (local(s)) dig.emplace_back(g.ctx[s], G * chunk);
+      else dig.emplace_back();
+    }
     for (uint32_t s = 0; s < G; s++)
-      if (target.ct[s]) chk(evah_shard_ks_digits(g.ctx[s], target.ct[s]->h, poly, l, dig[s].b, rows));
+      if (target.ct[s] && local(s)) chk(evah_shard_ks_digits(g.ctx[s], target.ct[s]->h, poly, l, dig[s].b, rows));
     all_gather(dig, chunk); // ---- exchange 1: the l coefficient-form digits
     const uint32_t owner = l % G;
     for (uint32_t s = 0; s < G; s++) {
       const uint32_t nl = s < l ? (l - s + G - 1) / G : 0;
-      prod.emplace_back(g.ctx[s], (size_t)2 * (nl + 1) * N);
-      rbuf.emplace_back(g.ctx[s], 3 * N);
+      if (local(s)) {
+        prod.emplace_back(g.ctx[s], (size_t)2 * (nl + 1) * N);
+        rbuf.emplace_back(g.ctx[s], 3 * N);
+      } else {
+        prod.emplace_back();
+        rbuf.emplace_back();
+      }
     }
     for (uint32_t s = 0; s < G; s++)
-      if (target.ct[s] || s == owner)
+      if (local(s) && (target.ct[s] || s == owner))
         chk(evah_shard_ks_products(g.ctx[s], target.ct[s] ? target.ct[s]->h : nullptr, poly, l, dig[s].b, rows, kind, elt, prod[s].b, rbuf[s].b));
     broadcast(rbuf, owner, 2 * N); // ---- exchange 2: INTT of the special limb
     ShardedValue o;
@@ -577,6 +642,7 @@ private:
     o.scale = scale;
     o.ct.resize(G);
     for (uint32_t s = 0; s < G && s < l; s++) {
+      if (!local(s)) continue;
       evah_ct *h = nullptr;
       chk(evah_shard_ks_finish(g.ctx[s], l, prod[s].b, rbuf[s].b, add && add->ct[s] ? add->ct[s]->h : nullptr, add_polys, scale, &h));
       o.ct[s] = std::make_shared<CtHandle>(g.ctx[s], h);

@@ -59,6 +59,14 @@ public:
   // what the last multi-device execute() did: pieces per member (sub-DAG) / words exchanged (limb)
   std::vector<std::pair<uint32_t, uint32_t>> last_subdag_plan; // (member, ops) with member 0 first = prefix, last = suffix
   uint64_t last_exchanged_words = 0, last_exchange_launches = 0;
+  // Limb sharding across PROCESSES (one process per GPU under torchrun): this context is shard limb_rank of
+  // limb_world, the exchange steps of a key switch / rescale are collectives on the library's device buffers
+  // (limb_hooks: RCCL through torch.distributed, eva_amd/dist.py attach_limb_dist), issued on limb_stream — the stream
+  // the shard's kernels run on as well, so nothing synchronises with the host between phases.  limb_world <= 1: all
+  // shards are contexts of this process (`devices`).
+  uint32_t limb_rank = 0, limb_world = 1;
+  LimbHooks limb_hooks;
+  uintptr_t limb_stream = 0;
   // HIP streams independent DAG nodes are spread over (EVA_NUM_STREAMS).  Default 1: at these
   // kernel sizes a single in-order queue keeps the GPU as busy as the host can feed it; more
   // queues are correct (ordering is enforced per buffer inside libeva_hip.so) and pay off when
@@ -75,7 +83,7 @@ public:
   bool use_graphs = true; // EVA_GRAPH=0 disables
   HipValuation execute(Program &program, const HipValuation &inputs) {
     const bool multi = devices.size() > 1;
-    if (multi && shard_mode == "limb") {
+    if ((multi || limb_hooks) && shard_mode == "limb") {
       ensure_device(false);
       return execute_limb(program, inputs);
     }
@@ -186,7 +194,7 @@ public:
     if (limb)
       for (size_t s = 0; s < limb->group().size(); s++) {
         uint64_t b = 0;
-        chk(evah_ctx_key_bytes(limb->group().ctx[s], &b));
+        if (limb->group().ctx[s]) chk(evah_ctx_key_bytes(limb->group().ctx[s], &b)); // a shard of another process: 0 here
         out.push_back(b);
       }
     uint64_t b = 0;

@@ -83,7 +83,7 @@ def add_shortcut_vectors(d, N, seed=4):
     o = po.Oracle(N, primes)
     k, l = len(primes), len(primes) - 1
     rng = np.random.default_rng(seed)
-    steps = np.array([1, 2, 3, 5, -1, -2, 7, N // 2 - 2], dtype=np.int64)
+    steps = np.array([1, 2, 3, 5, -1, -2, 7, N // 2 - 3], dtype=np.int64)  # distinct Galois elements (N/2 - s is the element of -s)
     d["hoist_steps"] = steps
     for s in steps:
         d[f"galois_key_h{int(s)}"] = np.stack([rng.integers(0, primes[i], size=(l, 2, N), dtype=np.uint64) for i in range(k)], axis=2)

@@ -184,3 +184,84 @@ def test_rccl_exchange_on_library_buffers_single_rank(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][len("RESULT "):])
     assert r == {"equal": True, "view": True}
+
+
+EXEC_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+    import numpy as np
+    from eva_amd.dist import Dist, attach_limb_dist
+    from eva import EvaProgram, Input, Output
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    from oracle_executor import c_walk
+    backend = os.environ.get("EVA_TEST_BACKEND", "gloo")
+    if backend == "nccl":   # one rank, RCCL collectives in place on the library's buffers
+        import torch, torch.distributed as td
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29647")
+        torch.cuda.set_device(0)
+        td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    d = Dist(backend=backend)
+    prog = EvaProgram('p', vec_size=1024)
+    with prog:
+        x = Input('x')
+        y = (x << 1) * x + (x >> 2)
+        Output('y', y * y * 0.5 + x)
+    prog.set_input_scales(30)
+    prog.set_output_ranges(20)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    params.poly_modulus_degree = 8192
+    pub, sec = generate_keys(params, 6)          # every rank derives the same keys from the seed
+    enc = pub.encrypt({'x': [((7 * i) %% 100) / 50.0 - 1 for i in range(1024)]}, sig)
+    enc.to_host(True)
+    if d.world > 1:   # encryption draws fresh randomness: every rank works on RANK 0's ciphertext
+        import torch.distributed as tdd
+        from eva.seal import SEALValuation
+        box = [enc.get('x') if d.rank == 0 else None]
+        tdd.broadcast_object_list(box, src=0)
+        kind, size, limbs, scale, data = box[0]
+        enc = SEALValuation()
+        enc._set_cipher('x', data, scale)
+    ref, _ = c_walk(pub, compiled, enc)          # the unsharded CPU walk (checker)
+    attach_limb_dist(pub, d)                     # shard_mode = "limb", this rank = shard rank of world
+    out = pub.execute(compiled, enc)             # C++ LimbShardEvaluator; exchanges = the collectives attached above
+    ok = all(np.array_equal(out.get(n)[4], ref[n]) for n in ref)
+    again = pub.execute(compiled, enc)
+    ok = ok and all(np.array_equal(again.get(n)[4], ref[n]) for n in ref)
+    if d.rank == 0:
+        print("RESULT " + json.dumps({"equal": bool(ok), "world": d.world, "launches": int(pub.last_exchange_launches),
+                                      "key_bytes": [int(b) for b in pub.key_bytes()]}))
+    d.close()
+    if backend == "nccl":
+        td.destroy_process_group() if td.is_initialized() else None
+""") % (ROOT, ROOT)
+
+
+def _run_exec_worker(tmp_path, nproc, backend, port):
+    script = tmp_path / "limb_exec_worker.py"
+    script.write_text(EXEC_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", EVA_TEST_BACKEND=backend)
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    else:
+        cmd = [sys.executable, str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][len("RESULT "):])
+
+
+def test_public_ctx_execute_limb_sharded_across_two_processes(tmp_path):
+    """RNS-limb sharding behind public_ctx.execute with the shards in DIFFERENT processes: the C++ evaluator keeps this
+    rank's limbs and the exchange steps are torch.distributed collectives (gloo here: two ranks share the GPU)"""
+    r = _run_exec_worker(tmp_path, 2, "gloo", 29649)
+    assert r["equal"] and r["world"] == 2 and r["launches"] > 0
+    # each process holds its own shard's key rows only (the remote shard reports 0 here, the whole keys were never uploaded)
+    assert r["key_bytes"][0] > 0 and r["key_bytes"][1] == 0 and r["key_bytes"][-1] == 0
+
+
+def test_public_ctx_execute_limb_sharded_with_rccl_collectives(tmp_path):
+    """the same path with nccl (= RCCL): collectives in place on the library's device buffers, on the stream the shard's
+    kernels run on (one rank: what a 1-GPU box can run; the 8-GPU job is bench.py --shard limb / torchrun)"""
+    r = _run_exec_worker(tmp_path, 1, "nccl", 0)
+    assert r["equal"] and r["world"] == 1
