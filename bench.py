@@ -367,6 +367,58 @@ def dag_sharded(args, dist):
     dist.close()
 
 
+def limb_execute_leg(N, l, dist, n_products=8, reps=5):
+    """z_i = x_i * y_i (Mul -> Relinearize -> Rescale each) through public_ctx.execute() with the RNS limbs dealt over
+    the ranks of the job: rank 0's ciphertexts on every rank, the C++ limb-shard evaluator behind execute(), collectives
+    at its exchange steps; rank 0 checks one product against the oracle's op-triple."""
+    import numpy as np
+    import torch.distributed as tdd
+    from eva import EvaProgram, Input, Output
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys, SEALValuation
+    from eva_amd.dist import attach_limb_dist
+    prog = EvaProgram('op_triples', vec_size=1024)
+    with prog:
+        for i in range(n_products):
+            Output(f'z{i}', Input(f'x{i}') * Input(f'y{i}'))
+    prog.set_input_scales(60)
+    prog.set_output_ranges(20)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false', 'lazy_relinearize': 'false'}).compile(prog)
+    params.poly_modulus_degree = N
+    params.prime_bits = [60] * (l + 1)
+    pub, sec = generate_keys(params, 17)  # the same keys on every rank (seeded)
+    pub.device = dist.device_index
+    rng = np.random.default_rng(5)
+    inputs = {}
+    for i in range(n_products):
+        inputs[f'x{i}'] = list(rng.uniform(-1, 1, 1024))
+        inputs[f'y{i}'] = list(rng.uniform(-1, 1, 1024))
+    enc = pub.encrypt(inputs, sig)
+    enc.to_host(True)
+    box = [{n: enc.get(n) for n in enc.names()} if dist.rank == 0 else None]
+    tdd.broadcast_object_list(box, src=0)  # encryption draws fresh randomness: every rank works on rank 0's ciphertexts
+    enc = SEALValuation()
+    for n, (kind, size, limbs, scale, data) in box[0].items():
+        enc._set_cipher(n, data, scale)
+    attach_limb_dist(pub, dist)
+    out = pub.execute(compiled, enc)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = pub.execute(compiled, enc)
+    dist.barrier()
+    dt = dist.max_over_ranks(time.perf_counter() - t0) / reps
+    res = {"program": f"{n_products} products z_i = x_i * y_i through public_ctx.execute(), limbs over {dist.world} ranks",
+           "triples_per_s": round(n_products / dt, 1), "ms_per_execute": round(dt * 1e3, 3),
+           "exchange_launches_per_execute": int(pub.last_exchange_launches), "exchanged_words_per_execute": int(pub.last_exchanged_words),
+           "includes": "input upload and output download (a limb-sharded value has no single device handle)"}
+    if dist.rank == 0:
+        from oracle import pyoracle as po  # checker only
+        o = po.Oracle(N, list(pub.primes))
+        res["bit_exact_vs_oracle"] = bool(np.array_equal(out.get('z0')[4], o.op_triple(enc.get('x0')[4], enc.get('y0')[4], pub.relin_key())))
+    return res
+
+
 def limb_sharded(args, dist):
     """--shard limb: every op-triple is computed by ALL GPUs together, the RNS limbs dealt over them
     (limb i on shard i mod G; SURVEY.md 8(e) row 3, BASELINE config 5's mode): per key switch one
@@ -421,6 +473,14 @@ def limb_sharded(args, dist):
     value = args.steps * args.batch / dt
     first = ev.rescale(ev.relinearize(ev.multiply(*pairs[0])), 60)
     got = ev.gather(first, dist) if world > 1 else ev.download(first)
+    # the same partition behind public_ctx.execute(): the C++ limb-shard evaluator with this rank's limbs, its exchange
+    # steps as RCCL collectives on the library's buffers (eva_amd.dist.attach_limb_dist) — every rank takes part
+    exec_path = None
+    if world > 1 and not args.no_legs:
+        try:
+            exec_path = limb_execute_leg(N, l, dist)
+        except Exception as e:  # noqa: BLE001 — the leg must not cost the line
+            exec_path = {"error": repr(e)}
     if dist.rank == 0:
         from oracle import pyoracle as po  # checker only
         ok = bool(np.array_equal(got, po.Oracle(N, primes).op_triple(host[0][0], host[0][1], key_host)))
@@ -445,6 +505,8 @@ def limb_sharded(args, dist):
                              "bytes_per_unit": triple_bytes(N, l),
                              "basis": "SURVEY.md 8(d) algorithmic bytes of one op-triple x op-triples/s, per GPU"},
                 "verified": {"triples_checked": 1, "bit_exact_vs_oracle": ok}, "cpu_baseline": None}
+        if exec_path is not None:
+            line["execute_path"] = exec_path
         print(json.dumps(line), flush=True)
     ev.close()
     dist.close()
