@@ -1,17 +1,28 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): bench line + rocprofv3 kernel trace + PMC traffic passes of the
-# same bench.py command.  Outputs under gpurun_out/prof_bench/ ; summaries are made by
-# scripts/rocprof_summary.py and scripts/pmc_traffic.py and committed under profiles/.
+# Run on the GPU box (via gpurun):  EVA_COMMIT=<short hash> bash scripts/collect_profiles.sh [round tag, default r04]
+# bench line (the driver's command) + rocprofv3 kernel trace + PMC traffic passes + SQ-counter pass of the same bench.py
+# command, summaries written under gpurun_out/prof_bench/ in the names they are committed under in profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r04}
 OUT=$R/gpurun_out/prof_bench
 rm -rf $OUT; mkdir -p $OUT
+export PYTHONPATH=$R
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 20 --warmup 3 --no-legs"
-python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
-tail -c 600 $OUT/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py $ARGS --no-cpu-baseline > $OUT/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-legs > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-legs > $OUT/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-legs > $OUT/pmc_sq.log 2>&1
-ls $OUT/trace/*/ | head
+timeout 600 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
+tail -c 400 $OUT/${TAG}_bench_line.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py $ARGS --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-legs > $OUT/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-legs > $OUT/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-legs > $OUT/pmc_sq.log 2>&1
+python $R/scripts/rocprof_summary.py $OUT/trace "$TAG bench.py $ARGS (N=2^16, L=10, 64 triples/step, fused op-triple, 2 queues x groups of 32; launches of the two queues overlap, so durations are while sharing the GPU): rocprofv3 --kernel-trace --stats" > $OUT/${TAG}_bench_kernel_trace.md
+cp $OUT/trace/*/*kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null
+python $R/scripts/pmc_sq_summary.py $OUT/pmc_sq "$TAG bench.py --steps 2 --warmup 1 --no-legs (a PMC pass serialises the kernels: durations are with the GPU to itself): SQ counters" > $OUT/${TAG}_bench_sq_counters.md
+python $R/scripts/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/bench_pmc_traffic.json > /dev/null
+python $R/scripts/valu_issue.py $OUT/pmc_sq 32 $OUT/bench_valu_issue.json > /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_batch -- python $R/scripts/prof_legs.py batch 2 > $OUT/trace_batch.log 2>&1
+python $R/scripts/rocprof_summary.py $OUT/trace_batch "$TAG dag_batch leg (256 Sobel DAGs, N=2^14, l=5, 2 repetitions): rocprofv3 --kernel-trace --stats" > $OUT/${TAG}_batch_kernel_trace.md
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_harris -- python $R/scripts/prof_legs.py harris 5 > $OUT/trace_harris.log 2>&1
+python $R/scripts/rocprof_summary.py $OUT/trace_harris "$TAG dag leg (Harris N=2^15 L=8, resident + host-valuation replays): rocprofv3 --kernel-trace --stats" > $OUT/${TAG}_harris_kernel_trace.md
+ls $OUT | grep -v "^trace\|^pmc"
