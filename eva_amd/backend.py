@@ -72,6 +72,7 @@ _SIGS = {
     "evah_execute": [_vp, _vp, C.c_uint32, _vp, C.c_uint32],
     "evah_weighted_sum": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_rotate_pairs": [_vp, _vpp, C.POINTER(C.c_int32), C.c_uint32, _vpp],
+    "evah_rotate_weighted_sums": [_vp, _vpp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, _vpp, _vpp],
     "evah_multiply_plain_many": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_rescale_many": [_vp, _vpp, C.c_uint32, C.c_uint32, _vpp],
     "evah_relinearize_many": [_vp, _vpp, C.c_uint32, _vpp],
@@ -697,6 +698,27 @@ class Context:
         n = len(cts)
         arr = (C.c_int32 * n)(*[int(x) for x in steps])
         return self._many(_lib.evah_rotate_pairs, cts, arr, C.c_uint32(n))
+
+    def rotate_weighted_sums(self, windows):
+        """windows: [(terms, weights)] with terms = [(ciphertext, steps)] and weights = one list per sum of the window,
+        each holding a plaintext (or None = 1) per term -> the sums of all windows in order:
+        out = sum_t weights[s][t] (*) rotate(terms[t])  (steps 0 = the ciphertext itself)"""
+        cts, steps, wt, ws, pts = [], [], [], [], []
+        for terms, weights in windows:
+            wt.append(len(terms))
+            ws.append(len(weights))
+            for ct, st in terms:
+                cts.append(ct.h)
+                steps.append(int(st))
+            for row in weights:
+                assert len(row) == len(terms)
+                pts += [(pt.h if pt is not None else None) for pt in row]
+        n_sums = sum(ws)
+        outs = (C.c_void_p * n_sums)()
+        _chk(_lib.evah_rotate_weighted_sums(self.h, (C.c_void_p * len(cts))(*cts), (C.c_int32 * len(steps))(*steps),
+                                            (C.c_uint32 * len(wt))(*wt), (C.c_uint32 * len(ws))(*ws), len(wt),
+                                            (C.c_void_p * len(pts))(*pts), outs))
+        return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n_sums)]
 
     def rescale_many(self, cts, divisor_bits):
         return self._many(_lib.evah_rescale_many, cts, C.c_uint32(len(cts)), C.c_uint32(int(divisor_bits)))

@@ -244,6 +244,9 @@ struct Tunables {
   // is added to) to the key inner products inside ks_inner_kernel (KS_FOLDMUL / KS_FOLDADD), so the mod-down's
   // combine pass — which waits for bytes — reads the products only; 0 = the r03 forms (operands read in the epilogue)
   bool fold_pa = true;
+  // EVAH_WIN_FUSE (1): evah_rotate_weighted_sums and the scheduler's convolution windows run the mod-down of the
+  // window's rotations fused with the weighted sums (moddown_sum_kernel); 0 = rotation set, then evah_weighted_sum
+  bool win_fuse = true;
   // EVAH_MAC3 (1): key inner products accumulate in radix 2^30 (ks_inner_kernel<MAC3>) when every prime of the context
   // has the top-bit shape and the level has at most 15 limbs; the keys are then kept in the split layout as well
   bool mac3 = true;
@@ -273,6 +276,7 @@ struct Tunables {
     flag("EVAH_HOIST_DEBUG", t.hoist_debug);
     flag("EVAH_FUSE_SPECIAL_INV", t.fuse_special_inv);
     flag("EVAH_FOLD_PA", t.fold_pa);
+    flag("EVAH_WIN_FUSE", t.win_fuse);
     flag("EVAH_MAC3", t.mac3);
     count("EVAH_LOOP_N", t.loop_n);
     count("EVAH_LOOP_MIN", t.loop_min);

@@ -18,9 +18,15 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
   struct LazySum { // unevaluated sum of products; the handles are aliases owned here
     std::vector<evah_ct *> cts;
     std::vector<evah_pt *> pts;
+    // term j is rotate(cts[j], steps[j]) (0: cts[j] itself); rv[j] = the value slot of the deferred rotation it
+    // came from (NONE_V for ordinary terms)
+    std::vector<int32_t> steps;
+    std::vector<uint32_t> rv;
     uint32_t size = 0, limbs = 0;
     double scale = 0;
   };
+  constexpr uint32_t NONE_V = ~0u;
+  struct DRot { evah_ct *src; int32_t step; }; // alias of the source
   struct State {
     evah_ctx *c;
     std::map<uint32_t, LazySum> sums;
@@ -28,7 +34,14 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     // value -> aliases of the two operands of a deferred Mul (prods) / of a Relinearize of one (prodrel):
     // Mul -> Relinearize -> Rescale chains without other readers run as one fused call at the Rescale
     std::map<uint32_t, std::pair<evah_ct *, evah_ct *>> prods, prodrel;
+    // value -> deferred rotation: a Rotate whose readers are all ciphertext x plaintext products inside sums is not
+    // evaluated; the sums carry (source, step) terms and go to evah_rotate_weighted_sums (the convolution window)
+    std::map<uint32_t, DRot> drots;
+    // rotations that sums outside one window share after all: evaluated once, kept until the end of the call
+    std::map<uint32_t, evah_ct *> mat;
     ~State() {
+      for (auto &kv : drots) evah_ct_free(c, kv.second.src);
+      for (auto &kv : mat) evah_ct_free(c, kv.second);
       for (auto &kv : sums) {
         for (evah_ct *h : kv.second.cts) evah_ct_free(c, h);
         for (evah_pt *h : kv.second.pts) evah_pt_free(c, h);
@@ -37,7 +50,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
       for (auto *m : {&prods, &prodrel})
         for (auto &kv : *m) { evah_ct_free(c, kv.second.first); evah_ct_free(c, kv.second.second); }
     }
-  } st{c, {}, {}, {}, {}};
+  } st{c, {}, {}, {}, {}, {}, {}};
   auto chk = [&](int rc) {
     if (rc) throw std::runtime_error(g_err);
   };
@@ -65,15 +78,131 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     for (evah_pt *h : it->second.pts) evah_pt_free(c, h);
     st.sums.erase(it);
   };
+  // ---- sums.  vals: LazySum values to evaluate now.  Sums whose terms are rotations deferred from this walk
+  // (convolution windows) go out as ONE evah_rotate_weighted_sums: sums with the same term list — the two filters of
+  // convolutionXY over one set of rotations — share a window, provided nobody else reads those rotations.
+  std::vector<uint32_t> n_reads; // filled by the analysis below; reads[] counts down, this does not
+  std::function<void(const std::vector<uint32_t> &)> eval_sums = [&](const std::vector<uint32_t> &vals) {
+    auto same_terms = [&](const LazySum &a, const LazySum &b) {
+      if (a.cts.size() != b.cts.size() || a.limbs != b.limbs) return false;
+      for (size_t j = 0; j < a.cts.size(); j++)
+        if (a.cts[j]->d != b.cts[j]->d || a.cts[j]->ps != b.cts[j]->ps || a.steps[j] != b.steps[j] || a.rv[j] != b.rv[j]) return false;
+      return true;
+    };
+    auto rotated = [&](const LazySum &ls) {
+      for (int32_t sstep : ls.steps) if (sstep != 0) return true;
+      return false;
+    };
+    std::vector<std::vector<uint32_t>> groups; // windows: one or two sums over the same terms
+    std::vector<uint32_t> plain;               // evaluated by evah_weighted_sum
+    for (uint32_t v : vals) {
+      LazySum &ls = st.sums.at(v);
+      if (!rotated(ls)) { plain.push_back(v); continue; }
+      bool placed = false;
+      for (auto &g : groups)
+        if (g.size() < 2 && same_terms(st.sums.at(g[0]), ls)) { g.push_back(v); placed = true; break; }
+      if (!placed) groups.push_back({v});
+    }
+    // a window may skip the rotated ciphertexts only if its sums are the only readers of those rotations
+    std::vector<std::vector<uint32_t>> fusedg;
+    for (auto &g : groups) {
+      std::map<uint32_t, uint32_t> occ;
+      for (uint32_t v : g)
+        for (uint32_t r : st.sums.at(v).rv) if (r != NONE_V) occ[r]++;
+      bool exclusive = true;
+      for (auto &kv : occ) exclusive = exclusive && !st.mat.count(kv.first) && kv.second == n_reads[kv.first];
+      if (exclusive) fusedg.push_back(g);
+      else for (uint32_t v : g) plain.push_back(v);
+    }
+    // windows of one (level, batch count) per call
+    while (!fusedg.empty()) {
+      const LazySum &f0 = st.sums.at(fusedg[0][0]);
+      std::vector<std::vector<uint32_t>> now, later;
+      for (auto &g : fusedg) {
+        const LazySum &ls = st.sums.at(g[0]);
+        (ls.limbs == f0.limbs && ls.cts[0]->batch == f0.cts[0]->batch ? now : later).push_back(g);
+      }
+      std::vector<const evah_ct *> cc;
+      std::vector<int32_t> ss;
+      std::vector<const evah_pt *> pp;
+      std::vector<uint32_t> wt, ws, order;
+      for (auto &g : now) {
+        const LazySum &ls = st.sums.at(g[0]);
+        wt.push_back((uint32_t)ls.cts.size());
+        ws.push_back((uint32_t)g.size());
+        cc.insert(cc.end(), ls.cts.begin(), ls.cts.end());
+        ss.insert(ss.end(), ls.steps.begin(), ls.steps.end());
+        for (uint32_t v : g) {
+          const LazySum &m = st.sums.at(v);
+          pp.insert(pp.end(), m.pts.begin(), m.pts.end());
+          order.push_back(v);
+        }
+      }
+      std::vector<evah_ct *> outs(order.size(), nullptr);
+      chk(evah_rotate_weighted_sums(c, cc.data(), ss.data(), wt.data(), ws.data(), (uint32_t)wt.size(), pp.data(), outs.data()));
+      for (size_t i = 0; i < order.size(); i++) {
+        drop_sum(order[i]);
+        put(order[i], outs[i]);
+      }
+      fusedg.swap(later);
+    }
+    // everything else: rotations that are shared beyond a window are evaluated once (st.mat), then the ordinary sums
+    {
+      std::vector<uint32_t> need;
+      for (uint32_t v : plain) {
+        const LazySum &ls = st.sums.at(v);
+        for (size_t j = 0; j < ls.cts.size(); j++)
+          if (ls.steps[j] != 0 && !st.mat.count(ls.rv[j]) && std::find(need.begin(), need.end(), ls.rv[j]) == need.end()) need.push_back(ls.rv[j]);
+      }
+      std::map<uint32_t, std::pair<const evah_ct *, int32_t>> how;
+      for (uint32_t v : plain) {
+        const LazySum &ls = st.sums.at(v);
+        for (size_t j = 0; j < ls.cts.size(); j++)
+          if (ls.steps[j] != 0) how[ls.rv[j]] = {ls.cts[j], ls.steps[j]};
+      }
+      std::vector<uint32_t> singles, pairs;
+      for (uint32_t r : need) (how[r].first->batch > 1 ? singles : pairs).push_back(r);
+      for (uint32_t r : singles) {
+        evah_ct *o = nullptr;
+        chk(evah_rotate(c, how[r].first, how[r].second, &o));
+        st.mat[r] = o;
+      }
+      for (size_t i0 = 0; i0 < pairs.size(); i0 += KS_BATCH_MAX) {
+        const uint32_t n = (uint32_t)std::min<size_t>(KS_BATCH_MAX, pairs.size() - i0);
+        std::vector<const evah_ct *> in(n);
+        std::vector<int32_t> stp(n);
+        std::vector<evah_ct *> outs(n, nullptr);
+        for (uint32_t j = 0; j < n; j++) { in[j] = how[pairs[i0 + j]].first; stp[j] = how[pairs[i0 + j]].second; }
+        const bool same_limbs = std::all_of(in.begin(), in.end(), [&](const evah_ct *a) { return a->limbs == in[0]->limbs; });
+        if (n > 1 && same_limbs) {
+          chk(evah_rotate_pairs(c, in.data(), stp.data(), n, outs.data()));
+        } else {
+          for (uint32_t j = 0; j < n; j++) chk(evah_rotate(c, in[j], stp[j], &outs[j]));
+        }
+        for (uint32_t j = 0; j < n; j++) st.mat[pairs[i0 + j]] = outs[j];
+      }
+      for (uint32_t v : plain) {
+        const LazySum &ls = st.sums.at(v);
+        std::vector<const evah_ct *> cc(ls.cts.begin(), ls.cts.end());
+        std::vector<const evah_pt *> pp(ls.pts.begin(), ls.pts.end());
+        for (size_t j = 0; j < cc.size(); j++)
+          if (ls.steps[j] != 0) cc[j] = st.mat.at(ls.rv[j]);
+        evah_ct *o = nullptr;
+        chk(evah_weighted_sum(c, cc.data(), pp.data(), (uint32_t)cc.size(), &o));
+        drop_sum(v);
+        put(v, o);
+      }
+    }
+  };
   // a value as a device ciphertext: deferred forms are evaluated on first demand
   auto ct_of = [&](uint32_t v) -> evah_ct * {
-    auto ls = st.sums.find(v);
-    if (ls != st.sums.end()) {
+    if (st.sums.count(v)) eval_sums({v});
+    auto dr = st.drots.find(v);
+    if (dr != st.drots.end()) { // a deferred rotation somebody needs as a ciphertext after all
       evah_ct *o = nullptr;
-      std::vector<const evah_ct *> cc(ls->second.cts.begin(), ls->second.cts.end());
-      std::vector<const evah_pt *> pp(ls->second.pts.begin(), ls->second.pts.end());
-      chk(evah_weighted_sum(c, cc.data(), pp.data(), (uint32_t)cc.size(), &o));
-      drop_sum(v);
+      chk(evah_rotate(c, dr->second.src, dr->second.step, &o));
+      evah_ct_free(c, dr->second.src);
+      st.drots.erase(dr);
       put(v, o);
     }
     auto lr = st.relins.find(v);
@@ -88,7 +217,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     if (x.kind != EVAH_VAL_CT || !x.h) throw std::invalid_argument("operand is not a ciphertext");
     return static_cast<evah_ct *>(x.h);
   };
-  auto is_ct = [&](uint32_t v) { return slot(v).kind == EVAH_VAL_CT || st.sums.count(v) || st.relins.count(v); };
+  auto is_ct = [&](uint32_t v) { return slot(v).kind == EVAH_VAL_CT || st.sums.count(v) || st.relins.count(v) || st.drots.count(v); };
   auto is_plain_ct = [&](uint32_t v) { return tab[v].kind == EVAH_VAL_CT && !st.sums.count(v) && !st.relins.count(v); };
 
   API_BEGIN
@@ -97,6 +226,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
   const int NONE = -1;
   std::vector<int> producer(n_vals, NONE), only_reader(n_vals, NONE);
   std::vector<uint32_t> reads(n_vals, 0), level(n_ops, 0);
+  std::vector<std::vector<uint32_t>> readers(n_vals);
   std::vector<char> freeable(n_vals, 0);
   auto arity = [](uint32_t op) { return (op == 11 || op == 12 || op == 13) ? 2 : (op == 1 || op == 3 || op == 23) ? 0 : 1; };
   uint32_t depth = 0;
@@ -117,17 +247,31 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
       if (producer[v] != NONE) level[i] = std::max(level[i], level[producer[v]] + 1);
       only_reader[v] = reads[v] == 0 ? (int)i : -2;
       reads[v]++;
+      readers[v].push_back(i);
       if (o.flags & (k == 0 ? EVAH_OPF_FREE_SRC0 : EVAH_OPF_FREE_SRC1)) freeable[v] = 1;
     }
     producer[o.dst] = (int)i;
     depth = std::max(depth, level[i]);
   }
+  n_reads = reads;
   std::vector<std::vector<uint32_t>> buckets(depth + 1);
   for (uint32_t i = 0; i < n_ops; i++)
     if (arity(ops[i].op)) buckets[level[i]].push_back(i);
   // dst is an intermediate nobody else sees and its one reader is an op of kind `by`
   auto feeds_only = [&](uint32_t dst, uint32_t by) {
     return reads[dst] == 1 && only_reader[dst] >= 0 && ops[only_reader[dst]].op == by && freeable[dst];
+  };
+  // a Rotate all of whose readers are ciphertext x plaintext products that only feed additions (the taps of a
+  // convolution window): the rotated ciphertext need not exist (evah_rotate_weighted_sums)
+  auto window_rotation = [&](const evah_op &o) {
+    if (!c->tun.win_fuse || !freeable[o.dst] || readers[o.dst].empty()) return false;
+    for (uint32_t ri : readers[o.dst]) {
+      const evah_op &m = ops[ri];
+      if (m.op != 13 || m.src0 == m.src1) return false;
+      const uint32_t other = m.src0 == o.dst ? m.src1 : m.src0;
+      if (slot(other).kind != EVAH_VAL_PT || !feeds_only(m.dst, 11)) return false;
+    }
+    return true;
   };
   auto shape = [&](uint32_t v, uint32_t &size, uint32_t &limbs, double &scale) {
     auto ls = st.sums.find(v);
@@ -181,6 +325,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
       }
       put(o.dst, out);
     };
+    std::vector<uint32_t> ready; // sums whose chain of additions ends at this level
     // ---- classify
     for (uint32_t i : lvl) {
       const evah_op &o = ops[i];
@@ -194,6 +339,13 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
       };
       const bool batched = batched_val(o.src0) || ((o.op == 11 || o.op == 12 || o.op == 13) && batched_val(o.src1)) ||
                            (st.relins.count(o.src0) && st.relins[o.src0]->batch > 1);
+      if ((o.op == 14 || o.op == 15) && o.imm != 0 && is_ct(o.src0) && window_rotation(o)) {
+        evah_ct *src = ct_of(o.src0);
+        if (src->size == 2) { // nothing is computed here: the sums that consume the products evaluate the rotation
+          st.drots[o.dst] = DRot{alias_ct(src), o.op == 14 ? o.imm : -o.imm};
+          continue;
+        }
+      }
       if (batched && (o.op == 14 || o.op == 15) && o.imm != 0) {
         batched_rots[o.src0].push_back(i);
         continue;
@@ -245,6 +397,19 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
           muls[limbs].push_back(i);
         }
       } else if (o.op == 13 && feeds_only(o.dst, 11) &&
+                 ((st.drots.count(o.src0) && slot(o.src1).kind == EVAH_VAL_PT) || (st.drots.count(o.src1) && slot(o.src0).kind == EVAH_VAL_PT))) {
+        const uint32_t a = st.drots.count(o.src0) ? o.src0 : o.src1, b = a == o.src0 ? o.src1 : o.src0;
+        const DRot &d = st.drots[a];
+        evah_pt *w = static_cast<evah_pt *>(tab[b].h);
+        if (w->limbs != d.src->limbs) { single(o); continue; } // multiply_plain reports the mismatch
+        LazySum ls;
+        ls.size = d.src->size; ls.limbs = d.src->limbs; ls.scale = d.src->scale * w->scale;
+        ls.cts.push_back(alias_ct(d.src));
+        ls.pts.push_back(alias_pt(w));
+        ls.steps.push_back(d.step);
+        ls.rv.push_back(a);
+        st.sums[o.dst] = std::move(ls);
+      } else if (o.op == 13 && feeds_only(o.dst, 11) &&
                  ((is_plain_ct(o.src0) && slot(o.src1).kind == EVAH_VAL_PT) || (is_plain_ct(o.src1) && slot(o.src0).kind == EVAH_VAL_PT))) {
         const uint32_t a = is_plain_ct(o.src0) ? o.src0 : o.src1, b = a == o.src0 ? o.src1 : o.src0;
         evah_ct *x = static_cast<evah_ct *>(tab[a].h);
@@ -254,6 +419,8 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         ls.size = x->size; ls.limbs = x->limbs; ls.scale = x->scale * w->scale;
         ls.cts.push_back(alias_ct(x));
         ls.pts.push_back(alias_pt(w));
+        ls.steps.push_back(0);
+        ls.rv.push_back(NONE_V);
         st.sums[o.dst] = std::move(ls);
       } else if (o.op == 13 && !batched &&
                  ((is_plain_ct(o.src0) && slot(o.src1).kind == EVAH_VAL_PT) || (is_plain_ct(o.src1) && slot(o.src0).kind == EVAH_VAL_PT))) {
@@ -278,16 +445,26 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
           if (it != st.sums.end()) {
             for (evah_ct *h : it->second.cts) ls.cts.push_back(alias_ct(h));
             for (evah_pt *h : it->second.pts) ls.pts.push_back(h ? alias_pt(h) : nullptr);
+            ls.steps.insert(ls.steps.end(), it->second.steps.begin(), it->second.steps.end());
+            ls.rv.insert(ls.rv.end(), it->second.rv.begin(), it->second.rv.end());
           } else {
-            ls.cts.push_back(alias_ct(static_cast<evah_ct *>(tab[v].h)));
+            ls.cts.push_back(alias_ct(ct_of(v)));
             ls.pts.push_back(nullptr);
+            ls.steps.push_back(0);
+            ls.rv.push_back(NONE_V);
           }
         }
         st.sums[o.dst] = std::move(ls);
-        if (!(feeds_only(o.dst, 11) && nterms < (size_t)KS_BATCH_MAX)) (void)ct_of(o.dst); // the chain ends here
+        // the chain ends here: evaluated with the other sums that end at this level (windows share their rotations)
+        if (!(feeds_only(o.dst, 11) && nterms < (size_t)KS_BATCH_MAX)) ready.push_back(o.dst);
       } else {
         single(o);
       }
+    }
+    {
+      std::vector<uint32_t> pending;
+      for (uint32_t v : ready) if (st.sums.count(v)) pending.push_back(v); // (not forced by another op of the level meanwhile)
+      if (!pending.empty()) eval_sums(pending);
     }
     // ---- the batchable kinds of this level
     auto each_chunk = [&](std::vector<uint32_t> &g, size_t cap, auto &&fn) {
@@ -412,6 +589,8 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         const uint32_t v = srcs[k];
         if (--reads[v] == 0 && freeable[v]) {
           drop_sum(v);
+          auto dr = st.drots.find(v);
+          if (dr != st.drots.end()) { evah_ct_free(c, dr->second.src); st.drots.erase(dr); } // its terms live in the sums now
           auto lr = st.relins.find(v);
           if (lr != st.relins.end()) { evah_ct_free(c, lr->second); st.relins.erase(lr); }
           if (tab[v].kind != EVAH_VAL_NONE) release(v);

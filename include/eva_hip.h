@@ -223,6 +223,21 @@ int evah_rotate_many(evah_ctx *ctx, const evah_ct *a, const int32_t *steps, uint
  * as one launch set; outs[i] == evah_rotate(cts[i], steps[i]) bit for bit.  A ciphertext that occurs
  * in several pairs is decomposed once for all of them when the set is large enough (hoisting, as above). */
 int evah_rotate_pairs(evah_ctx *ctx, const evah_ct *const *cts, const int32_t *steps, uint32_t n, evah_ct **outs);
+/* Sums of plaintext-weighted rotations, the convolution pattern of EVA programs
+ * (/root/reference/examples/image_processing.py:22-34 convolutionXY: rotated = image << (i*w + j);
+ *  Ix += rotated * filter[i][j]; Iy += rotated * filter[j][i]) — the rotate_vector (seal_executor.h:181/188),
+ * multiply_plain (:168) and add (:124) calls of every term in one launch set.
+ *   window w has win_terms[w] terms (cts / steps, consecutive; steps == 0: the ciphertext itself) and
+ *   win_sums[w] sums over those terms; pts holds, window after window, win_sums[w] rows of win_terms[w]
+ *   weights (NULL = 1); outs receives the sums of all windows in order:
+ *     out = sum_t pts[row][t] (*) rotate(cts[t], steps[t])        — bit for bit the op-by-op result.
+ * All ciphertexts: size 2, one level, one batch count; every sum has one product scale (checked as
+ * evah_weighted_sum checks it).  Throughput-sized sets whose windows have one or two sums and at most one
+ * unrotated term are hoisted AND fused: the rotated ciphertexts are never written — the mod-down's last pass
+ * multiplies by the weights and accumulates the sums in registers; other shapes run as
+ * evah_rotate_pairs / evah_rotate_many followed by evah_weighted_sum.  EVAH_WIN_FUSE=0 forces the latter. */
+int evah_rotate_weighted_sums(evah_ctx *ctx, const evah_ct *const *cts, const int32_t *steps, const uint32_t *win_terms,
+                              const uint32_t *win_sums, uint32_t n_windows, const evah_pt *const *pts, evah_ct **outs);
 /* n independent evaluator.rescale_to_next calls (seal_executor.h:213) of one size and level,
  * n * size <= 128, as one launch set */
 int evah_rescale_many(evah_ctx *ctx, const evah_ct *const *cts, uint32_t n, uint32_t divisor_bits, evah_ct **outs);

@@ -269,3 +269,164 @@ def test_exported_shortcut_vectors_through_the_hoisted_and_fused_paths():
     assert np.array_equal(g.multiply_relinearize_rescale_many([a], [b], 60)[0].download(), d["out_triple"])
     assert np.array_equal(g.multiply_relinearize_rescale_many([a], [a], 60)[0].download(), d["out_triple_square"])
     g.close()
+
+
+# ---- window sums: evah_rotate_weighted_sums (rotations of a window fused with the weighted sums that consume them)
+def _window_oracle(e, terms, weights):
+    """terms: [(ciphertext words, step)], weights: rows of plaintext words (None = 1) -> the sums, op by op"""
+    rot = [a if st == 0 else e.o.rotate(a, st, e.keys[st]) for a, st in terms]
+    outs = []
+    for row in weights:
+        acc = None
+        for r, w in zip(rot, row):
+            t = r if w is None else e.o.multiply_plain(r, w)
+            acc = t if acc is None else e.o.add(acc, t)
+        outs.append(acc)
+    return outs
+
+
+def _rand_pt(e, l):
+    return np.stack([e.rng.integers(0, e.primes[i], size=e.N, dtype=np.uint64) for i in range(l)])
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[0], CONFIGS[2], CONFIGS[3], CONFIGS[4], CONFIGS[5], CONFIGS[6], CONFIGS[7]],
+                         ids=lambda c: f"N{c[0]}_k{len(c[1])}")
+def test_window_sums_bit_exact(cfg):
+    """One 3x3 window with two filters over the same rotations (convolutionXY) and, in the same call, windows with one
+    sum, an unrotated term in the middle / absent, and weights of 1."""
+    e = env(cfg)
+    l = e.k - 1
+    steps9 = [0, 1, 2, 64, 65, 66, 128, 129, 130]
+    for st in steps9 + [-3]:
+        if st:
+            e.key_for(st)
+    img, x1, x2 = e.rand(2, l), e.rand(2, l), e.rand(2, l)
+    I, X1, X2 = (e.g.upload_ct(a, 2.0 ** 20) for a in (img, x1, x2))
+    wts = [[_rand_pt(e, l) for _ in steps9] for _ in range(2)]
+    W = [[e.g.upload_pt(w, 2.0 ** 10) for w in row] for row in wts]
+    pool = [_rand_pt(e, l) for _ in range(4)]
+    P = [e.g.upload_pt(w, 2.0 ** 10) for w in pool]
+    windows = [
+        ([(I, st) for st in steps9], W),                                             # two sums, unrotated term first
+        ([(X1, 1), (X1, 65), (X1, 0), (X1, -3)], [P]),                               # one sum, unrotated term in the middle
+        ([(X2, 1), (X2, 2), (X2, 129)], [[None, None, None]]),                       # weights of 1 (a rotate-and-sum)
+        ([(X1, 2), (X2, 64)], [[P[0], P[1]], [P[2], P[3]]]),                        # two sources in one window
+    ]
+    outs = e.g.rotate_weighted_sums(windows)
+    ref = (_window_oracle(e, [(img, st) for st in steps9], wts)
+           + _window_oracle(e, [(x1, 1), (x1, 65), (x1, 0), (x1, -3)], [pool])
+           + _window_oracle(e, [(x2, 1), (x2, 2), (x2, 129)], [[None] * 3])
+           + _window_oracle(e, [(x1, 2), (x2, 64)], [[pool[0], pool[1]], [pool[2], pool[3]]]))
+    assert len(outs) == len(ref) == 6
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        size, limbs, scale = o.info()
+        assert (size, limbs) == (2, l) and scale == (2.0 ** 30 if i != 3 else 2.0 ** 20), (i, o.info())
+        assert np.array_equal(o.download(), r), f"sum {i}"
+
+
+def test_window_sums_general_shapes_take_the_unfused_path():
+    """Three sums over one window and two unrotated terms are outside the fused kernel's tables: same results."""
+    e = env(CONFIGS[2])
+    l = e.k - 1
+    for st in (1, 65, -3):
+        e.key_for(st)
+    a = e.rand(2, l)
+    A = e.g.upload_ct(a, 2.0 ** 20)
+    wts = [[_rand_pt(e, l) for _ in range(4)] for _ in range(3)]
+    W = [[e.g.upload_pt(w, 2.0 ** 10) for w in row] for row in wts]
+    terms = [(A, 1), (A, 0), (A, 65), (A, 0)]
+    outs = e.g.rotate_weighted_sums([(terms, W)])
+    ref = _window_oracle(e, [(a, st) for _, st in terms], wts)
+    for o, r in zip(outs, ref):
+        assert np.array_equal(o.download(), r)
+    with pytest.raises(Exception, match="scale mismatch"):
+        e.g.rotate_weighted_sums([([(A, 1), (A, 65)], [[W[0][0], None]])])
+
+
+@pytest.mark.parametrize("case", ["transparent", "several_zeros"])
+def test_window_sums_with_zero_digit_coefficients(case):
+    """k_hoist_fix's correction and, beyond its capacity, the guarded fallback (unhoisted rotations + k_window_sums)"""
+    e = env(CONFIGS[2])
+    l = e.k - 1
+    steps = [0, 1, 65, -3]
+    for st in steps[1:]:
+        e.key_for(st)
+    a = e.rand(2, l)
+    if case == "transparent":
+        a[1] = 0
+    else:
+        for limb, count in ((0, 5), (2, 3), (l - 1, 1)):
+            x = e.rng.integers(1, e.primes[limb], size=e.N, dtype=np.uint64)
+            x[e.rng.choice(e.N, size=count, replace=False)] = 0
+            a[1][limb] = e.o.ntt(limb, x)
+    A = e.g.upload_ct(a, 2.0 ** 20)
+    wts = [[_rand_pt(e, l) for _ in steps] for _ in range(2)]
+    W = [[e.g.upload_pt(w, 2.0 ** 10) for w in row] for row in wts]
+    outs = e.g.rotate_weighted_sums([([(A, st) for st in steps], W)])
+    for o, r in zip(outs, _window_oracle(e, [(a, st) for st in steps], wts)):
+        assert np.array_equal(o.download(), r), case
+
+
+def test_window_sums_of_a_batched_handle():
+    """B instances of one window (config 4: a batch of DAG instances): more pairs than one launch set holds"""
+    e = env(CONFIGS[3])
+    l = e.k - 1
+    B = 24
+    steps = [0, 1, 2, 64, 65, 66, 128, 129, 130]
+    for st in steps[1:]:
+        e.key_for(st)
+    inst = [e.rand(2, l) for _ in range(B)]
+    x = e.rng.integers(1, e.primes[1], size=e.N, dtype=np.uint64)
+    x[e.rng.choice(e.N, size=2, replace=False)] = 0
+    inst[5][1][1] = e.o.ntt(1, x)
+    H = e.g.upload_ct_batch(np.stack(inst), 2.0 ** 30)
+    wts = [[_rand_pt(e, l) for _ in steps] for _ in range(2)]
+    W = [[e.g.upload_pt(w, 2.0 ** 10) for w in row] for row in wts]
+    outs = e.g.rotate_weighted_sums([([(H, st) for st in steps], W)])
+    got = [o.download() for o in outs]
+    for b in (0, 5, 9, B - 1):
+        ref = _window_oracle(e, [(inst[b], st) for st in steps], wts)
+        for s in range(2):
+            assert np.array_equal(got[s][b], ref[s]), (b, s)
+
+
+def test_window_sums_fused_path_is_the_one_that_runs():
+    """Launch accounting: fused = no weighted-sum launch and no permuted copy of c0; EVAH_WIN_FUSE=0 = the same bits
+    through rotate_pairs + weighted_sum."""
+    cfg = CONFIGS[2]
+    e = env(cfg)
+    l = e.k - 1
+    steps = [0, 1, 65, -3]
+    a = e.rand(2, l)
+    wts = [[_rand_pt(e, l) for _ in steps] for _ in range(2)]
+
+    def run(ctx_env):
+        for st in steps[1:]:
+            ctx_env.g.upload_galois_key(ctx_env.g.galois_elt_from_step(st), e.key_for(st))
+        A = ctx_env.g.upload_ct(a, 2.0 ** 20)
+        W = [[ctx_env.g.upload_pt(w, 2.0 ** 10) for w in row] for row in wts]
+        ctx_env.g.rotate_weighted_sums([([(A, st) for st in steps], W)])  # tables of the first use
+        ctx_env.g.profile(True)
+        ctx_env.g.profile_reset()
+        outs = ctx_env.g.rotate_weighted_sums([([(A, st) for st in steps], W)])
+        ctx_env.g.sync()
+        prof = ctx_env.g.profile_get()
+        ctx_env.g.profile(False)
+        return [o.download() for o in outs], prof
+
+    fused, pf = run(e)
+    old = os.environ.get("EVAH_WIN_FUSE")
+    os.environ["EVAH_WIN_FUSE"] = "0"
+    try:
+        e0 = Env(*cfg)
+    finally:
+        if old is None:
+            os.environ.pop("EVAH_WIN_FUSE", None)
+        else:
+            os.environ["EVAH_WIN_FUSE"] = old
+    unfused, pu = run(e0)
+    for x, y in zip(fused, unfused):
+        assert np.array_equal(x, y)
+    # unfused: the weighted sums are elementwise launches of their own (the guarded fallback's launches are counted on
+    # both sides); fused: the sums ride the mod-down's second pass
+    assert pf["elementwise"][0] < pu["elementwise"][0], (pf, pu)
