@@ -247,6 +247,10 @@ struct Tunables {
   // EVAH_WIN_FUSE (1): evah_rotate_weighted_sums and the scheduler's convolution windows run the mod-down of the
   // window's rotations fused with the weighted sums (moddown_sum_kernel); 0 = rotation set, then evah_weighted_sum
   bool win_fuse = true;
+  // EVAH_FB_PERSIST (1): the exact fallback of a hoisted rotation set is one persistent launch per chunk (k_rot_fallback,
+  // rot_fallback.hip.h) that leaves at once unless the zero counter overflowed; 0 = the ordinary unhoisted launches, each
+  // guarded (about eight launches that return at once per chunk)
+  bool fb_persist = true;
   // EVAH_MAC3 (1): key inner products accumulate in radix 2^30 (ks_inner_kernel<MAC3>) when every prime of the context
   // has the top-bit shape and the level has at most 15 limbs; the keys are then kept in the split layout as well
   bool mac3 = true;
@@ -277,6 +281,7 @@ struct Tunables {
     flag("EVAH_FUSE_SPECIAL_INV", t.fuse_special_inv);
     flag("EVAH_FOLD_PA", t.fold_pa);
     flag("EVAH_WIN_FUSE", t.win_fuse);
+    flag("EVAH_FB_PERSIST", t.fb_persist);
     flag("EVAH_MAC3", t.mac3);
     count("EVAH_LOOP_N", t.loop_n);
     count("EVAH_LOOP_MIN", t.loop_min);

@@ -2,6 +2,7 @@
 // rotations, and rotation sets — sibling rotations as one launch set, hoisted when throughput-sized (one digit
 // decomposition per source) with the exact guarded fallback.
 #include "launch.hip.h"
+#include "rot_fallback.hip.h"
 
 namespace evah {
 
@@ -355,6 +356,40 @@ struct GuardScope {
   GuardScope(evah_ctx *c_, const uint32_t *g) : c(c_) { c->dev.guard = g; c->dev.guard_min = HOIST_ZERO_CAP; }
   ~GuardScope() { c->dev.guard = nullptr; }
 };
+// the exact fallback of one chunk as one persistent launch (rot_fallback.hip.h); call inside a GuardScope.
+// rot_out: the chunk's outputs [np][2][l N] (plain rotation sets) or null with the window tables of the chunk
+static uint32_t cu_count(int device) {
+  static std::mutex mu;
+  static std::map<int, uint32_t> known;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = known.find(device);
+  if (it != known.end()) return it->second;
+  int n = 0;
+  HIPCHK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device));
+  return known[device] = (uint32_t)std::max(n, 1);
+}
+static void rot_fallback_launch(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t np, u64 *rot_out, const WinSumTab *wt, uint32_t n_win, int F,
+                                size_t out_ps, u64 *bar_word) {
+  if (!c->dev.guard) throw std::logic_error("the rotation fallback runs under its guard only");
+  const size_t N = c->N, lN = (size_t)l * N;
+  FbPairs fp{};
+  for (uint32_t r = 0; r < np; r++) {
+    fp.perm[r] = pr[r].perm;
+    fp.src[r] = pr[r].src;
+    fp.key[r] = pr[r].key->d;
+    fp.src_ps[r] = (uint32_t)(pr[r].src_ps / N);
+  }
+  Scratch rc1(c, np * lN), t(c, np * lN), dig(c, np * lN), prod(c, (size_t)np * 2 * (l + 1) * N), r(c, (size_t)np * 2 * N), u(c, (size_t)np * 2 * lN);
+  FbBufs b{rc1.d, t.d, dig.d, prod.d, r.d, u.d, reinterpret_cast<unsigned *>(bar_word)};
+  // one workgroup per CU at most: the whole grid is resident, which the grid-wide barriers rely on
+  const uint32_t grid = std::min<uint32_t>(cu_count(c->device), 256);
+  WinSumTab none{};
+  ProfScope ps(c, KC_EW);
+  if (F == 0) hipLaunchKernelGGL((k_rot_fallback<0>), dim3(grid), dim3(256), 0, c->stream, c->dev, fp, np, l, b, rot_out, none, 0u, (size_t)0);
+  else if (F == 1) hipLaunchKernelGGL((k_rot_fallback<1>), dim3(grid), dim3(256), 0, c->stream, c->dev, fp, np, l, b, (u64 *)nullptr, *wt, n_win, out_ps);
+  else hipLaunchKernelGGL((k_rot_fallback<2>), dim3(grid), dim3(256), 0, c->stream, c->dev, fp, np, l, b, (u64 *)nullptr, *wt, n_win, out_ps);
+  HIPCHK(hipGetLastError());
+}
 // kernel-argument tables of one chunk of hoisted pairs; returns the number of key-sharing groups
 static uint32_t hoist_tables(const RotPair *pr, uint32_t np, size_t N, HoistTab &ht, HoistGroups &hg) {
   for (uint32_t r = 0; r < np; r++) {
@@ -413,8 +448,10 @@ static void rotation_set(evah_ctx *c, uint32_t l, const std::vector<RotPair> &pa
   }
   const uint32_t n_src = (uint32_t)srcs.size();
   if (n_src > (uint32_t)KS_BATCH_MAX) throw std::logic_error("hoisted rotation set with too many sources");
-  Scratch flag(c, 1 + HOIST_ZERO_CAP); // [0]: zero-coefficient count, then the recorded positions
+  // [0]: zero-coefficient count, then the recorded positions, then one barrier word per chunk (k_rot_fallback)
+  Scratch flag(c, 1 + HOIST_ZERO_CAP + chunks.size());
   HIPCHK(hipMemsetAsync(flag.d, 0, sizeof(u64), c->stream));
+  HIPCHK(hipMemsetAsync(flag.d + 1 + HOIST_ZERO_CAP, 0, sizeof(u64) * chunks.size(), c->stream));
   const size_t dg_bs = (size_t)(l + 1) * l * N;
   {
     Scratch t(c, (size_t)n_src * l * N), dg(c, n_src * dg_bs);
@@ -444,7 +481,11 @@ static void rotation_set(evah_ctx *c, uint32_t l, const std::vector<RotPair> &pa
   // exact fallback: the same outputs through the unhoisted launches, each a no-op unless there
   // were more zero digit coefficients than k_hoist_fix handles
   GuardScope gs(c, reinterpret_cast<const uint32_t *>(flag.d));
-  for (const RotChunk &ch : chunks) rot_chunk_plain(c, l, pairs.data() + ch.first, ch.count, ch.out);
+  for (size_t ci = 0; ci < chunks.size(); ci++) {
+    const RotChunk &ch = chunks[ci];
+    if (c->tun.fb_persist) rot_fallback_launch(c, l, pairs.data() + ch.first, ch.count, ch.out, nullptr, 0, 0, 0, flag.d + 1 + HOIST_ZERO_CAP + ci);
+    else rot_chunk_plain(c, l, pairs.data() + ch.first, ch.count, ch.out);
+  }
   if (!c->capturing && c->tun.hoist_debug) { // diagnostics: how many zero coefficients did this set see?
     uint32_t f = 0;
     HIPCHK(hipMemcpyAsync(&f, flag.d, sizeof(f), hipMemcpyDeviceToHost, c->stream));
@@ -810,8 +851,9 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
         wt.out1[wi] = F > 1 ? made[un.s0 + 1]->d + (size_t)un.b * 2 * out_ps : nullptr;
         ch.np += un.count;
       }
-      Scratch flag(c, 1 + HOIST_ZERO_CAP); // [0]: zero-coefficient count, then the recorded positions
+      Scratch flag(c, 1 + HOIST_ZERO_CAP + chunks.size()); // zero-coefficient count, recorded positions, barrier words
       HIPCHK(hipMemsetAsync(flag.d, 0, sizeof(u64), c->stream));
+      HIPCHK(hipMemsetAsync(flag.d + 1 + HOIST_ZERO_CAP, 0, sizeof(u64) * chunks.size(), c->stream));
       const size_t dg_bs = (size_t)(l + 1) * l * N;
       {
         Scratch t(c, srcs.size() * l * N), dg(c, srcs.size() * dg_bs);
@@ -852,7 +894,12 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
       }
       // exact fallback (more zero digit coefficients than k_hoist_fix handles): the unhoisted rotations, then the sums
       GuardScope gs(c, reinterpret_cast<const uint32_t *>(flag.d));
-      for (const Chunk &ch : chunks) {
+      for (size_t ci = 0; ci < chunks.size(); ci++) {
+        const Chunk &ch = chunks[ci];
+        if (c->tun.fb_persist) {
+          rot_fallback_launch(c, l, pairs.data() + ch.first, ch.np, nullptr, &ch.wt, ch.nu, ch.F, out_ps, flag.d + 1 + HOIST_ZERO_CAP + ci);
+          continue;
+        }
         Scratch rot(c, (size_t)ch.np * 2 * pps);
         rot_chunk_plain(c, l, pairs.data() + ch.first, ch.np, rot.d);
         const dim3 grid(c->N / 512, l, 2 * ch.nu);

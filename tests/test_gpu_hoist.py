@@ -430,3 +430,55 @@ def test_window_sums_fused_path_is_the_one_that_runs():
     # unfused: the weighted sums are elementwise launches of their own (the guarded fallback's launches are counted on
     # both sides); fused: the sums ride the mod-down's second pass
     assert pf["elementwise"][0] < pu["elementwise"][0], (pf, pu)
+
+
+def test_fallback_of_a_batched_handle_spans_several_chunks():
+    """One transparent instance among B: every chunk of the set takes the exact fallback (k_rot_fallback, one persistent
+    launch per chunk), the other instances' results must come out the same either way."""
+    e = env(CONFIGS[2])
+    l = e.k - 1
+    B = 24
+    inst = [e.rand(2, l) for _ in range(B)]
+    inst[3][1] = 0
+    steps = [1, 2, 65, -3, -64]
+    for st in steps:
+        e.key_for(st)
+    outs = e.g.rotate_many(e.g.upload_ct_batch(np.stack(inst), 2.0 ** 30), steps)
+    for st, o in zip(steps, outs):
+        got = o.download()
+        for b in (0, 3, 11, B - 1):
+            assert np.array_equal(got[b], e.o.rotate(inst[b], st, e.keys[st])), f"step {st} instance {b}"
+
+
+def test_fallback_forms_agree():
+    """EVAH_FB_PERSIST=0 (the guarded unhoisted launches) and the persistent kernel: same bits on a transparent source,
+    for a plain set and for a window with two sums."""
+    cfg = CONFIGS[3]
+    e = env(cfg)
+    l = e.k - 1
+    steps = [0, 1, 65, -3]
+    a = e.rand(2, l)
+    a[1] = 0
+    wts = [[_rand_pt(e, l) for _ in steps] for _ in range(2)]
+    res = []
+    for persist in ("1", "0"):
+        old = os.environ.get("EVAH_FB_PERSIST")
+        os.environ["EVAH_FB_PERSIST"] = persist
+        try:
+            x = Env(*cfg)
+        finally:
+            if old is None:
+                os.environ.pop("EVAH_FB_PERSIST", None)
+            else:
+                os.environ["EVAH_FB_PERSIST"] = old
+        for st in steps[1:]:
+            x.g.upload_galois_key(x.g.galois_elt_from_step(st), e.key_for(st))
+        A = x.g.upload_ct(a, 2.0 ** 20)
+        W = [[x.g.upload_pt(w, 2.0 ** 10) for w in row] for row in wts]
+        rot = [o.download() for o in x.g.rotate_many(A, steps[1:])]
+        sums = [o.download() for o in x.g.rotate_weighted_sums([([(A, st) for st in steps], W)])]
+        res.append(rot + sums)
+    for u, v in zip(*res):
+        assert np.array_equal(u, v)
+    for st, got in zip(steps[1:], res[0]):
+        assert np.array_equal(got, e.o.rotate(a, st, e.keys[st]))
