@@ -136,6 +136,10 @@ struct KeyDev {
   // the same key words cut at bit 30 — (k mod 2^30) | (k >> 30) << 32 — for the radix-2^30 inner product of
   // ks_inner_kernel<MAC3>; built at upload for whole keys of contexts whose primes all have the top-bit shape
   u64 *d_split = nullptr;
+  // Galois keys used by hoisted rotation sets: the same words with every row read through the inverse of the element's
+  // NTT-domain permutation — d_perm[..][m] = d[..][pi^-1(m)] — so that the hoisted inner product is elementwise in the
+  // source's own index space (rotate.hip, k_hoist_mac); built at the first hoisted use of the key
+  u64 *d_perm = nullptr;
 };
 
 } // namespace evah
@@ -179,6 +183,7 @@ struct SharedDev {
   double2 *dec_roots = nullptr; // CKKS decoder: zeta^br(j) (forward special FFT, heap order)
   std::map<uint32_t, KeyDev> galois;
   std::map<uint32_t, uint32_t *> perms;
+  std::map<uint32_t, uint32_t *> perms_inv; // the inverse tables (hoisted rotation sets)
   // hoisted rotations (rotate.hip): NTT of the sign pattern of a Galois element under every prime
   // ([k][N]) and, per (element, level), the constant it contributes to the key inner product ([2][l+1][N])
   std::map<uint32_t, u64 *> hoist_sign;
@@ -197,8 +202,13 @@ struct SharedDev {
     if (pk.d) (void)hipFree(pk.d);
     if (sk.d) { (void)hipMemset(sk.d, 0, sk.bytes); (void)hipFree(sk.d); } // key material does not stay behind in freed HBM
     if (dec_roots) (void)hipFree(dec_roots);
-    for (auto &kv : galois) { (void)hipFree(kv.second.d); if (kv.second.d_split) (void)hipFree(kv.second.d_split); }
+    for (auto &kv : galois) {
+      (void)hipFree(kv.second.d);
+      if (kv.second.d_split) (void)hipFree(kv.second.d_split);
+      if (kv.second.d_perm) (void)hipFree(kv.second.d_perm);
+    }
     for (auto &kv : perms) (void)hipFree(kv.second);
+    for (auto &kv : perms_inv) (void)hipFree(kv.second);
     for (auto &kv : hoist_sign) (void)hipFree(kv.second);
     for (auto &kv : hoist_corr) (void)hipFree(kv.second);
     if (d_tables) (void)hipFree(d_tables);

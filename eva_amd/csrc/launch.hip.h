@@ -21,10 +21,10 @@ __device__ __forceinline__ void st2(u64 *p, ulonglong2 v) { *reinterpret_cast<ul
 
 // ---- NTT launch plumbing
 template <class Op> struct OpClass;
-template <bool Z> struct OpClass<OpPlainT<Z>> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
+template <bool Z, bool G> struct OpClass<OpPlainT<Z, G>> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
 template <> struct OpClass<OpMulIntt> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
 template <> struct OpClass<OpKsDigit> { static constexpr int fwd_a = KC_KSDIGIT_A, fwd_b = KC_KSDIGIT_B; };
-template <> struct OpClass<OpModDown> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
+template <bool G> struct OpClass<OpModDownT<G>> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 template <int M> struct OpClass<OpRRT<M>> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 template <int M> struct OpClass<OpRRLastT<M>> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 

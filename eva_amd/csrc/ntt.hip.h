@@ -524,12 +524,17 @@ ntt_loop_kernel(DevCtx cx, typename Op::Params prm, int logC, int log_tiles, uin
 // each finished value by the window's weights and keeps the 128-bit partial sums of up to two sums in registers: the
 // rotated ciphertexts never exist in memory.  Same canonical residues as rotate -> multiply_plain -> add one by one.
 //   pair t of the chunk: polynomial pp = 2 t + K; mid[pp][i] = first (strided) pass of NTT_i(u) (OpModDown, dst = mid),
-//   prod[pp][i] = key inner product, P * (rotated c0) already folded in (k_hoist_mac fold_c0): nothing is added here.
-//   value_t = (prod[pp][i] - NTT_i(u)) * P^-1 mod q_i;   out_f[K][i] = sum_t w_f[t][i] * value_t  (+ the unrotated term)
+//   prod[pp][i] = key inner product in the SOURCE's index space (k_hoist_mac), P * c0 already folded in: the pair's
+//   Galois permutation is applied when it is read, nothing is added here.
+//   value_t[n] = (prod[pp][i][perm_t[n]] - NTT_i(u)[n]) * P^-1 mod q_i;   out_f[K][i] = sum_t w_f[t][i] * value_t  (+ the unrotated term)
 #ifndef EVAH_KS_BATCH_MAX_DEFINED
 #define EVAH_KS_BATCH_MAX_DEFINED
 constexpr int KS_BATCH_MAX = 64; // as internal.hip.h (this header is also used alone)
 #endif
+// index tables of a launch's pairs (two polynomials each): data kept in a pair's source index space is read through them
+struct PermTab {
+  const uint32_t *p[KS_BATCH_MAX];
+};
 constexpr int WIN_MAX = 16; // windows per launch (the tables below travel as kernel arguments)
 struct WinSumTab {
   uint8_t first[WIN_MAX], count[WIN_MAX];          // window w = pairs [first, first + count) of the chunk
@@ -543,7 +548,7 @@ struct WinSumTab {
 // twiddle staging and tile pipeline this repeats)
 template <int P, int F>
 __global__ void __launch_bounds__(64)
-moddown_sum_kernel(DevCtx cx, WinSumTab ws, const u64 *mid, size_t mid_ps, const u64 *prod, size_t prod_ps, size_t out_ps, int logC) {
+moddown_sum_kernel(DevCtx cx, WinSumTab ws, PermTab perms, const u64 *mid, size_t mid_ps, const u64 *prod, size_t prod_ps, size_t out_ps, int logC) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   if (cx.skipped()) return;
   constexpr int LR = 2, NTT_R = 1 << LR, NPAIR = NTT_R / 2, T = 64;
@@ -584,8 +589,21 @@ moddown_sum_kernel(DevCtx cx, WinSumTab ws, const u64 *mid, size_t mid_ps, const
     acc128(acc[f][2 * it + 1], v.y, x.y);
   };
   ulonglong2 dreg[NPAIR];
-  if (cnt) load_tile(first, dreg);
+  uint2 pnext[NPAIR]; // the NEXT pair's gather indices (prod is indexed in the source's space): a pair ahead, so that the
+                      // gathers of a pair do not wait for an index load first
+  auto load_perm = [&](uint32_t t) {
+    const uint32_t *pi = perms.p[t] + gbase + 2 * threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < NPAIR; it++) pnext[it] = *reinterpret_cast<const uint2 *>(pi + it * 2 * T);
+  };
+  if (cnt) {
+    load_tile(first, dreg);
+    load_perm(first);
+  }
   for (uint32_t t = first; t < first + cnt; t++) {
+    uint2 at[NPAIR];
+#pragma unroll
+    for (int it = 0; it < NPAIR; it++) at[it] = pnext[it];
     __syncthreads(); // the previous pair's LDS reads are done
 #pragma unroll
     for (int it = 0; it < NPAIR; it++) {
@@ -595,17 +613,21 @@ moddown_sum_kernel(DevCtx cx, WinSumTab ws, const u64 *mid, size_t mid_ps, const
       lds[sb * SP + lds_pad<P>(e + 1)] = dreg[it].y;
     }
     // the epilogue's operands, requested before the transform
-    const u64 *pr = prod + (size_t)(2 * t + K) * prod_ps + row;
+    const u64 *pr = prod + (size_t)(2 * t + K) * prod_ps + (size_t)i * cx.N;
     const u64 *wt0 = ws.w0[t], *wt1 = F > 1 ? ws.w1[t] : nullptr;
     ulonglong2 cp[NPAIR], x0[NPAIR], x1[NPAIR];
 #pragma unroll
     for (int it = 0; it < NPAIR; it++) {
-      cp[it] = *reinterpret_cast<const ulonglong2 *>(pr + it * 2 * T);
+      cp[it].x = pr[at[it].x];
+      cp[it].y = pr[at[it].y];
       x0[it].x = x0[it].y = x1[it].x = x1[it].y = 1;
       if (wt0) x0[it] = *reinterpret_cast<const ulonglong2 *>(wt0 + row + it * 2 * T);
       if (F > 1 && wt1) x1[it] = *reinterpret_cast<const ulonglong2 *>(wt1 + row + it * 2 * T);
     }
-    if (t + 1 < first + cnt) load_tile(t + 1, dreg);
+    if (t + 1 < first + cnt) {
+      load_tile(t + 1, dreg);
+      load_perm(t + 1);
+    }
     __syncthreads();
     forward_rounds<P, LR, true, true>(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
     __syncthreads();
@@ -1155,7 +1177,10 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
 // Plain batched transform over limbs.  job -> (poly p = job / jl, limb i = job % jl),
 // prime = prime0 + i.  addhalf: x <- x + floor(q/2) mod q on store (rounding offset of
 // rescale / key-switch mod-down).
-template <bool ZEROS> struct OpPlainT { // ZEROS: the inverse transform also records zero coefficients
+// GATHER: polynomial pp is read through an index table, x[n] = src[perm_tab.p[pp >> 1][n]] (the special rows of hoisted
+// key inner products, which rotate.hip keeps in the source's index space: the Galois permutation is applied here)
+struct NoGather {};
+template <bool ZEROS, bool GATHER = false> struct OpPlainT { // ZEROS: the inverse transform also records zero coefficients
   struct Params {
     const u64 *src;
     u64 *dst;
@@ -1167,6 +1192,7 @@ template <bool ZEROS> struct OpPlainT { // ZEROS: the inverse transform also rec
     // inverse transforms of hoisted rotations: coefficients that come out 0 are counted in the low
     // word of zero_list[0] and the first HOIST_ZERO_CAP of them recorded as (poly << 48 | limb << 32 | index)
     u64 *zero_list = nullptr;
+    std::conditional_t<GATHER, PermTab, NoGather> perm_tab{};
   };
   struct Job {
     uint32_t prime;
@@ -1176,6 +1202,7 @@ template <bool ZEROS> struct OpPlainT { // ZEROS: the inverse transform also rec
     bool lazy;
     u64 *zero_list;
     uint32_t pp;
+    const uint32_t *perm;
   };
   // jobs = polys * jl: grid.y = limb i, grid.z = poly
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
@@ -1189,10 +1216,13 @@ template <bool ZEROS> struct OpPlainT { // ZEROS: the inverse transform also rec
     j.lazy = false;
     j.zero_list = p.zero_list;
     j.pp = pp;
+    if constexpr (GATHER) j.perm = p.perm_tab.p[pp >> 1];
+    else j.perm = nullptr;
     return true;
   }
   template <bool LZ>
   static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &, uint32_t n) {
+    if constexpr (GATHER) return j.src[j.perm[n]];
     return j.src[n];
   }
   static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm,
@@ -1214,6 +1244,7 @@ template <bool ZEROS> struct OpPlainT { // ZEROS: the inverse transform also rec
 
 using OpPlain = OpPlainT<false>;
 using OpPlainZ = OpPlainT<true>;
+using OpPlainG = OpPlainT<false, true>;
 
 // Inverse transform of d2 = a1 b1 of a batch of products (the key-switch target of a fused
 // multiply -> relinearize): job -> (instance b = job / jl, limb i = job % jl); the product is
@@ -1324,7 +1355,8 @@ struct OpKsDigit {
 // job -> (p = job / jl, i = job % jl).  r[p] is INTT(limb a) + floor(q_a/2) in coefficient form.
 //   load : u = (r mod q_i) - (floor(q_a/2) mod q_i)
 //   store: v = (c[p][i] - NTT(u)) * q_a^-1 mod q_i ;  dst = add ? add + v : v
-struct OpModDown {
+// GATHER: c (the key inner products) is read through the pair's index table, c[perm_tab.p[pp >> 1][n]] (hoisted sets)
+template <bool GATHER> struct OpModDownT {
   struct Params {
     const u64 *r;
     size_t r_ps;
@@ -1341,6 +1373,7 @@ struct OpModDown {
     // use_add_tab; entry pp is limb 0 of polynomial pp, a null add entry means "nothing to add"
     bool use_add_tab = false;
     PtrTab c_tab{}, add_tab{};
+    std::conditional_t<GATHER, PermTab, NoGather> perm_tab{};
   };
   struct Job {
     uint32_t prime;
@@ -1349,6 +1382,7 @@ struct OpModDown {
     u64 halfm;
     ulonglong2 inv;
     bool lazy;
+    const uint32_t *perm;
   };
   static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
   static constexpr int loop_axis = 2; // jobs that share a prime lie along grid.z (ntt_loop_kernel)
@@ -1368,7 +1402,13 @@ struct OpModDown {
     j.halfm = cx.halfmod[p.a * cx.k + j.prime];
     j.inv = cx.invq[p.a * cx.k + j.prime];
     j.lazy = cx.primes[p.a].q <= cx.primes[j.prime].q8; // r < q_a: r + (q_i - halfm) < 9 q_i
+    if constexpr (GATHER) j.perm = p.perm_tab.p[pp >> 1];
+    else j.perm = nullptr;
     return true;
+  }
+  static __device__ __forceinline__ u64 c_at(const Job &j, uint32_t n) {
+    if constexpr (GATHER) return j.c[j.perm[n]];
+    return j.c[n];
   }
   template <bool LZ>
   static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
@@ -1385,13 +1425,13 @@ struct OpModDown {
   static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &j, const DevPrime &pm,
                                                    uint32_t n, u64 U) {
     U += (U >= pm.q8 ? pm.nq8 : 0);                       // [0,16q) -> [0,8q)
-    u64 v = mul_shoup(j.c[n] + pm.q8 - U, j.inv.x, j.inv.y, pm.q); // exact for any 64-bit operand
+    u64 v = mul_shoup(c_at(j, n) + pm.q8 - U, j.inv.x, j.inv.y, pm.q); // exact for any 64-bit operand
     if (j.add) v = addmod(j.add[n], v, pm.q);
     j.dst[n] = v;
   }
   struct Pre { u64 c, add; };
   static __device__ __forceinline__ Pre prefetch(const DevCtx &, const Job &j, const DevPrime &, uint32_t n) {
-    return Pre{j.c[n], j.add ? j.add[n] : 0};
+    return Pre{c_at(j, n), j.add ? j.add[n] : 0};
   }
   static __device__ __forceinline__ void store_fwd_pre(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 U, const Pre &p) {
     U += (U >= pm.q8 ? pm.nq8 : 0);
@@ -1400,6 +1440,9 @@ struct OpModDown {
     j.dst[n] = v;
   }
 };
+
+using OpModDown = OpModDownT<false>;
+using OpModDownG = OpModDownT<true>;
 
 // ---- relinearize followed by rescale, evaluated together (same canonical result as the two
 // SEAL calls in sequence, seal_executor.h:200 then :213).  With ct' = relinearize(a):

@@ -2,6 +2,7 @@
 // rotations, and rotation sets — sibling rotations as one launch set, hoisted when throughput-sized (one digit
 // decomposition per source) with the exact guarded fallback.
 #include "launch.hip.h"
+#include <array>
 #include "rot_fallback.hip.h"
 
 namespace evah {
@@ -63,20 +64,49 @@ k_galois_perm_pairs(DevCtx cx, PermPairs pt, u64 *out, size_t o_ps, uint32_t pol
 // EVA's 20-bit primes), so the inverse transform records them and k_hoist_fix subtracts their terms
 // one by one (NTT_I(X^k')[n] = psi_I^((2 brv(n) + 1) k')).  More than HOIST_ZERO_CAP zeros (a
 // transparent ciphertext) make the guarded, unhoisted launch set recompute the outputs instead.
-struct HoistTab { // per (source, rotation) pair of the launch
-  const uint32_t *perm[KS_BATCH_MAX];
-  const u64 *key[KS_BATCH_MAX];
-  const u64 *corr[KS_BATCH_MAX]; // [2][l+1][N]
-  const u64 *c1[KS_BATCH_MAX];   // the source's own c1 (NTT form): the digit used as is where I == J
-  uint32_t c1_ps[KS_BATCH_MAX];  // the source's c0 = c1 - c1_ps * N (poly stride in units of N coefficients)
-  uint32_t elt[KS_BATCH_MAX];
-  uint8_t src[KS_BATCH_MAX];     // index of the source among the set's transformed digits
+// Where the gathers go.  The first term above reads l (l+1) digit rows per pair THROUGH the permutation — a gather for every
+// multiply.  Substituting m = perm(n):
+//     sum_J D[I][J][m] * key[J][K][I][perm^-1(m)]                       — elementwise in the SOURCE's index space m
+// so with a copy of the key whose rows are read through perm^-1 (KeyDev::d_perm, built at the first hoisted use) and the
+// constant term stored the same way, the whole inner product is coalesced loads and the digits of a source are loaded
+// once for all the rotations a workgroup serves.  The result E[z][K][I][m] stays in the source's index space; the
+// rotated value is E[perm(n)], and its consumers — the mod-down's special-row inverse transform (OpPlainG) and its
+// combine epilogue (OpModDownG / moddown_sum_kernel) — read it through the pair's table: 2 (l+1) gathered rows per pair
+// instead of l (l+1), and none inside the multiply loop.
+//
+// E[z][K][I][m] = sum_J D_s[I][J][m] * keyp_z[J][K][I][m] + corrp_z[K][I][m]  (+ P * c0_s[I][m] for K = 0, I < l: the
+//   rotated c0 the key-switch result is added to, carried through the mod-down by its factor P as KS_FOLDADD does)
+// D_s[I][J] is row (I * l + J) of source s's converted digits, or limb J of the source's own c1 when I == J (SEAL's
+// shortcut: the NTT-form limb is used as is).
+// A workgroup serves a TILE of up to HT_S sources x HT_R Galois elements (every combination that is a pair of the chunk):
+// per digit J it loads HT_S digit words and 2 HT_R key words and does 2 HT_S HT_R multiply-accumulates, so digits are
+// shared by the elements of a tile and keys by its sources (the instances of a batched handle, the three convolutions
+// of Harris).  grid = (N / 256, l + 1, tiles), one coefficient per thread.
+// The tile shape (TS sources x TR elements, TS TR <= 8) is a template parameter chosen per launch from the chunk's
+// shape, and every tile of a launch is full — short ones are padded with repeats whose results are not stored — so the
+// loops below have no exits: all TS + 2 TR loads of a digit step are in flight together.
+constexpr int HT_TILES = 32; // tiles per launch (the tables travel as kernel arguments)
+struct HoistMacTab {
+  const u64 *c1[KS_BATCH_MAX];    // per source of the chunk: its c1 (NTT form); c0 = c1 - c1_ps * N
+  uint32_t c1_ps[KS_BATCH_MAX];   // poly stride in units of N coefficients
+  uint32_t dg[KS_BATCH_MAX];      // index of the source among the set's transformed digits
+  const u64 *keyp[KS_BATCH_MAX];  // per Galois element of the chunk: the permuted key, the permuted constant [2][l+1][N]
+  const u64 *corrp[KS_BATCH_MAX];
+  // per tile, one byte per entry: sources [0..1], elements [2..3], pair (output slot) of combination s * TR + r [4..5]
+  // (0xff: not a pair of the chunk)
+  uint32_t tile[HT_TILES][6];
 };
-// corr[K][I][n] = sign[kap][n] * sum_J (q_J mod q_kap) * key[J][K][kap][n]   (kap = prime of row I)
+struct HoistFixTab { // per pair (k_hoist_fix)
+  const uint32_t *perm[KS_BATCH_MAX];
+  const u64 *key[KS_BATCH_MAX]; // the key as uploaded
+  uint32_t elt[KS_BATCH_MAX];
+  uint8_t src[KS_BATCH_MAX];    // index of the source among the set's transformed digits
+};
+// corrp[K][I][m] = corr[K][I][pinv[m]],  corr[K][I][n] = sign[kap][n] * sum_J (q_J mod q_kap) * key[J][K][kap][n]   (kap = prime of row I)
 __global__ void __launch_bounds__(256)
-k_hoist_corr(DevCtx cx, const u64 *sign, const u64 *key, u64 *corr, uint32_t l) {
+k_hoist_corr(DevCtx cx, const u64 *sign, const u64 *key, const uint32_t *pinv, u64 *corr, uint32_t l) {
   const uint32_t I = blockIdx.y, K = blockIdx.z, kap = (I == l) ? cx.k - 1 : I;
-  const size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = pinv[m];
   const DevPrime pm = cx.primes[kap];
   const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
   u64 acc = 0;
@@ -84,95 +114,87 @@ k_hoist_corr(DevCtx cx, const u64 *sign, const u64 *key, u64 *corr, uint32_t l) 
     const u64 qj = cx.primes[J].q % pm.q; // 0 when J == I
     acc = addmod(acc, mulmod(qj, key[J * key_digit + ((size_t)K * cx.k + kap) * N + n], pm), pm.q);
   }
-  corr[((size_t)K * (l + 1) + I) * N + n] = mulmod(sign[(size_t)kap * N + n], acc, pm);
+  corr[((size_t)K * (l + 1) + I) * N + m] = mulmod(sign[(size_t)kap * N + n], acc, pm);
 }
-// prod[z][K][I][n] = sum_J D_s[I][J][perm_z[n]] * key_z[J][K][I][n] + corr_z[K][I][n] for pair z with source s
-//                  + (K == 0 and I < l, when fold_c0) P * c0_s[I][perm_z[n]]:  the rotated c0 that the key-switch result
-//                    is added to, carried through the mod-down by its factor P (as KS_FOLDADD does in ks_inner_kernel) —
-//                    no permuted copy of c0 is written or read and the mod-down adds nothing.
-// D_s[I][J] is row (I * l + J) of source s's converted digits, or limb J of the source's own c1
-// when I == J (SEAL's shortcut: the NTT-form limb is used as is).
-// The key is two thirds of what a pair reads (2 l (l+1) N words against l (l+1) N digit words), and pairs
-// with the same Galois element share it (the same rotation of several sources: the three convolutions of
-// Harris, the 32 instances of a batched handle): a workgroup therefore serves a GROUP of up to
-// HOIST_GROUP pairs of one element — permutation indices, key words and the correction loaded once, one
-// gather + 128-bit accumulator set per member.  grid = (N/512, l+1, groups).
-#ifndef EVAH_HOIST_GROUP
-#define EVAH_HOIST_GROUP 4 // 1: one pair per workgroup (the r2 form; A/B switch of the build)
-#endif
-constexpr int HOIST_GROUP = EVAH_HOIST_GROUP;
-struct HoistGroups {
-  uint8_t first[KS_BATCH_MAX], count[KS_BATCH_MAX]; // group g = member[first[g] .. first[g] + count[g])
-  uint8_t member[KS_BATCH_MAX];                     // pair indices, grouped by Galois element
-};
+// keyp[row][m] = key[row][pinv[m]] for every row of the key; grid = (N / 256, rows)
 __global__ void __launch_bounds__(256)
-k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistTab tab, HoistGroups grp, u64 *prod, size_t prod_bs, uint32_t l, bool fold_c0) {
+k_key_perm(const u64 *key, const uint32_t *pinv, u64 *out, uint32_t N) {
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  out[(size_t)blockIdx.y * N + m] = key[(size_t)blockIdx.y * N + pinv[m]];
+}
+template <int TS, int TR>
+__global__ void __launch_bounds__(256)
+k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistMacTab tab, uint32_t tile0, u64 *prod, size_t prod_bs, uint32_t l, bool fold_c0) {
   const uint32_t I = blockIdx.y, kap = (I == l) ? cx.k - 1 : I;
-  // the group's pair indices are made wave-uniform scalars explicitly: indexing the kernel-argument tables with
-  // a byte that was loaded from another kernel-argument table otherwise compiles to scalar loads whose base
-  // register is not dword-aligned (base = table + z, offset = 7 z) — a memory aperture violation on gfx950
-  const uint32_t g = blockIdx.z, first = __builtin_amdgcn_readfirstlane(grp.first[g]), cnt = __builtin_amdgcn_readfirstlane(grp.count[g]);
-  const uint32_t z0 = __builtin_amdgcn_readfirstlane(grp.member[first]);
-  const size_t n = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
+  const uint32_t *tw = tab.tile[tile0 + blockIdx.z]; // wave-uniform: scalar loads, the bytes are cut out with scalar shifts
+  const u64 srcs = tw[0] | ((u64)tw[1] << 32), rots = tw[2] | ((u64)tw[3] << 32), outs = tw[4] | ((u64)tw[5] << 32);
+  const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const DevPrime pm = cx.primes[kap];
   const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
-  const uint2 pi = *reinterpret_cast<const uint2 *>(tab.perm[z0] + n);
-  const u64 *key = tab.key[z0] + (size_t)kap * N + n;
-  const u64 *dg[HOIST_GROUP], *own[HOIST_GROUP];
-  u128_t a0x[HOIST_GROUP], a0y[HOIST_GROUP], a1x[HOIST_GROUP], a1y[HOIST_GROUP];
+  const u64 *dgp[TS], *own[TS], *kp[TR];
 #pragma unroll
-  for (int t = 0; t < HOIST_GROUP; t++) {
-    const uint32_t z = __builtin_amdgcn_readfirstlane(grp.member[first + (t < (int)cnt ? t : 0)]);
-    dg[t] = digits + tab.src[z] * dg_bs + (size_t)I * l * N;
-    own[t] = tab.c1[z];
-    a0x[t] = a0y[t] = a1x[t] = a1y[t] = {0, 0};
+  for (int s = 0; s < TS; s++) {
+    const uint32_t si = (uint32_t)(srcs >> (8 * s)) & 0xffu;
+    dgp[s] = digits + tab.dg[si] * dg_bs + (size_t)I * l * N + m;
+    own[s] = tab.c1[si] + m;
   }
-  // operands are canonical (< q < 2^60): 256 products fit the 128-bit accumulators, l <= k - 1 < 64
-  for (uint32_t J = 0; J < l; J++) {
-    const ulonglong2 k0 = ld2(key + J * key_digit), k1 = ld2(key + J * key_digit + (size_t)cx.k * N);
 #pragma unroll
-    for (int t = 0; t < HOIST_GROUP; t++) {
-      if (t >= (int)cnt) break; // block-uniform
-      const u64 *op = (I == J) ? own[t] + (size_t)J * N : dg[t] + (size_t)J * N;
-      const u64 ox = op[pi.x], oy = op[pi.y];
-      acc128(a0x[t], ox, k0.x);
-      acc128(a0y[t], oy, k0.y);
-      acc128(a1x[t], ox, k1.x);
-      acc128(a1y[t], oy, k1.y);
+  for (int r = 0; r < TR; r++) kp[r] = tab.keyp[(uint32_t)(rots >> (8 * r)) & 0xffu] + (size_t)kap * N + m;
+  u128_t a0[TS][TR], a1[TS][TR];
+#pragma unroll
+  for (int s = 0; s < TS; s++)
+#pragma unroll
+    for (int r = 0; r < TR; r++) a0[s][r] = a1[s][r] = {0, 0};
+  // operands are canonical (< q < 2^60): 256 products fit the 128-bit accumulators, l <= k - 1 < 64
+#pragma unroll 2
+  for (uint32_t J = 0; J < l; J++) {
+    u64 d[TS], k0[TR], k1[TR];
+#pragma unroll
+    for (int s = 0; s < TS; s++) d[s] = (I == J) ? own[s][(size_t)J * N] : dgp[s][(size_t)J * N];
+#pragma unroll
+    for (int r = 0; r < TR; r++) {
+      k0[r] = kp[r][J * key_digit];
+      k1[r] = kp[r][J * key_digit + (size_t)cx.k * N];
     }
+    __builtin_amdgcn_sched_barrier(0); // all the loads of the step are issued before the first multiply waits for one
+#pragma unroll
+    for (int r = 0; r < TR; r++)
+#pragma unroll
+      for (int s = 0; s < TS; s++) {
+        acc128(a0[s][r], d[s], k0[r]);
+        acc128(a1[s][r], d[s], k1[r]);
+      }
   }
   if (fold_c0 && I < l) { // block-uniform
     const u64 pmod = cx.modq[(size_t)(cx.k - 1) * cx.k + kap].x; // P mod q_I
 #pragma unroll
-    for (int t = 0; t < HOIST_GROUP; t++) {
-      if (t >= (int)cnt) break;
-      const uint32_t z = __builtin_amdgcn_readfirstlane(grp.member[first + t]);
-      const u64 *c0p = own[t] - (size_t)tab.c1_ps[z] * N + (size_t)I * N;
-      acc128(a0x[t], c0p[pi.x], pmod);
-      acc128(a0y[t], c0p[pi.y], pmod);
+    for (int s = 0; s < TS; s++) {
+      const uint32_t si = (uint32_t)(srcs >> (8 * s)) & 0xffu;
+      const u64 c0v = (own[s] - (size_t)tab.c1_ps[si] * N)[(size_t)I * N];
+#pragma unroll
+      for (int r = 0; r < TR; r++) acc128(a0[s][r], c0v, pmod);
     }
   }
-  const u64 *cr = tab.corr[z0] + (size_t)I * N + n;
-  const ulonglong2 c0 = ld2(cr), c1c = ld2(cr + (size_t)(l + 1) * N);
 #pragma unroll
-  for (int t = 0; t < HOIST_GROUP; t++) {
-    if (t >= (int)cnt) break;
-    const uint32_t z = __builtin_amdgcn_readfirstlane(grp.member[first + t]);
-    ulonglong2 r0, r1;
-    r0.x = addmod(barrett128(a0x[t], pm), c0.x, pm.q);
-    r0.y = addmod(barrett128(a0y[t], pm), c0.y, pm.q);
-    r1.x = addmod(barrett128(a1x[t], pm), c1c.x, pm.q);
-    r1.y = addmod(barrett128(a1y[t], pm), c1c.y, pm.q);
-    u64 *pr = prod + z * prod_bs + (size_t)I * N + n;
-    st2(pr, r0);
-    st2(pr + (size_t)(l + 1) * N, r1);
+  for (int r = 0; r < TR; r++) {
+    const u64 *cr = tab.corrp[(uint32_t)(rots >> (8 * r)) & 0xffu] + (size_t)I * N + m;
+    const u64 c0 = cr[0], c1c = cr[(size_t)(l + 1) * N];
+#pragma unroll
+    for (int s = 0; s < TS; s++) {
+      const uint32_t z = (uint32_t)(outs >> (8 * (s * TR + r))) & 0xffu;
+      if (z == 0xffu) continue; // padding, or a (source, element) combination that is not a pair of the chunk
+      u64 *pr = prod + z * prod_bs + (size_t)I * N + m;
+      pr[0] = addmod(barrett128(a0[s][r], pm), c0, pm.q);
+      pr[(size_t)(l + 1) * N] = addmod(barrett128(a1[s][r], pm), c1c, pm.q);
+    }
   }
 }
 
 // zeros[0] (low word) = number of zero digit coefficients seen, zeros[1 + e] = (source << 48 | J << 32 | k).
-// Same grid as k_hoist_mac with one coefficient per thread; every test below is block-uniform.
+// grid = (N / 256, l + 1, pairs), one coefficient n of the ROTATED polynomial per thread — its term is subtracted where
+// the inner product keeps it, at perm[n]; every test below is block-uniform.
 __global__ void __launch_bounds__(256)
-k_hoist_fix(DevCtx cx, const u64 *zeros, HoistTab tab, u64 *prod, size_t prod_bs, uint32_t l) {
+k_hoist_fix(DevCtx cx, const u64 *zeros, HoistFixTab tab, u64 *prod, size_t prod_bs, uint32_t l) {
   const uint32_t count = *reinterpret_cast<const uint32_t *>(zeros);
   if (count == 0 || count > HOIST_ZERO_CAP) return;
   const uint32_t I = blockIdx.y, kap = (I == l) ? cx.k - 1 : I;
@@ -201,7 +223,7 @@ k_hoist_fix(DevCtx cx, const u64 *zeros, HoistTab tab, u64 *prod, size_t prod_bs
     any = true;
   }
   if (!any) return;
-  u64 *pr = prod + z * prod_bs + (size_t)I * N + n;
+  u64 *pr = prod + z * prod_bs + (size_t)I * N + tab.perm[z][n];
   pr[0] = submod(pr[0], acc0, pm.q);
   pr[(size_t)(l + 1) * N] = submod(pr[(size_t)(l + 1) * N], acc1, pm.q);
 }
@@ -235,6 +257,24 @@ const uint32_t *perm_table(evah_ctx *c, uint32_t elt) {
   HIPCHK(hipMalloc(&d, sizeof(uint32_t) * N));
   HIPCHK(hipMemcpy(d, tab.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
   c->sh->perms.emplace(elt, d);
+  return d;
+}
+// the inverse table: perm_inv[perm[n]] = n
+static const uint32_t *perm_inv_table(evah_ctx *c, uint32_t elt) {
+  auto pit = c->sh->perms_inv.find(elt);
+  if (pit != c->sh->perms_inv.end()) return pit->second;
+  if (c->capturing) throw std::logic_error("first hoisted use of a Galois element cannot be captured into a graph");
+  const size_t N = c->N;
+  std::vector<uint32_t> inv(N);
+  for (uint32_t i = 0; i < N; i++) {
+    uint32_t reversed = bitrev((uint32_t)N + i, c->logN + 1);
+    u64 raw = (((u64)elt * reversed) >> 1) & (u64)(N - 1);
+    inv[bitrev((uint32_t)raw, c->logN)] = i;
+  }
+  uint32_t *d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(uint32_t) * N));
+  HIPCHK(hipMemcpy(d, inv.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+  c->sh->perms_inv.emplace(elt, d);
   return d;
 }
 } // namespace evah
@@ -273,9 +313,10 @@ static const u64 *hoist_corr(evah_ctx *c, uint32_t elt, uint32_t l, const KeyDev
   if (it != c->sh->hoist_corr.end()) return it->second;
   if (c->capturing) throw std::logic_error("first hoisted use of a Galois element cannot be captured into a graph");
   const u64 *sign = hoist_sign(c, elt);
+  const uint32_t *pinv = perm_inv_table(c, elt);
   u64 *d = nullptr;
   HIPCHK(hipMalloc(&d, sizeof(u64) * 2 * (l + 1) * c->N));
-  hipLaunchKernelGGL(k_hoist_corr, dim3(c->N / 256, l + 1, 2), dim3(256), 0, c->stream, c->dev, sign, key.d, d, l);
+  hipLaunchKernelGGL(k_hoist_corr, dim3(c->N / 256, l + 1, 2), dim3(256), 0, c->stream, c->dev, sign, key.d, pinv, d, l);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) {
@@ -283,6 +324,24 @@ static const u64 *hoist_corr(evah_ctx *c, uint32_t elt, uint32_t l, const KeyDev
     HIPCHK(e);
   }
   c->sh->hoist_corr.emplace(std::make_pair(elt, l), d);
+  return d;
+}
+// the key of a Galois element with its rows read through the inverse permutation (KeyDev::d_perm), built once per key
+static const u64 *hoist_key(evah_ctx *c, uint32_t elt, KeyDev &key) {
+  if (key.d_perm) return key.d_perm;
+  if (c->capturing) throw std::logic_error("first hoisted use of a Galois key cannot be captured into a graph");
+  const uint32_t *pinv = perm_inv_table(c, elt);
+  u64 *d = nullptr;
+  HIPCHK(hipMalloc(&d, key.bytes));
+  const uint32_t rows = (uint32_t)(key.bytes / (sizeof(u64) * c->N));
+  hipLaunchKernelGGL(k_key_perm, dim3(c->N / 256, rows), dim3(256), 0, c->stream, key.d, pinv, d, (uint32_t)c->N);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream); // other queues may use the copy next
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    HIPCHK(e);
+  }
+  key.d_perm = d;
   return d;
 }
 
@@ -295,15 +354,22 @@ struct RotPair {
   uint32_t elt;
   const KeyDev *key;
   const uint32_t *perm;
-  const u64 *corr;  // hoisting constant of (elt, l); null when the set is not hoisted
+  const u64 *corr;  // hoisting constant of (elt, l) and the permuted key (hoist_prepare); null when the set is not hoisted
+  const u64 *keyp;
 };
+// the tables a hoisted pair needs (first use of an element / level: not capturable, like perm_table)
+static void hoist_prepare(evah_ctx *c, RotPair &p, uint32_t l) {
+  KeyDev &key = c->sh->galois.at(p.elt);
+  p.corr = hoist_corr(c, p.elt, l, key);
+  p.keyp = hoist_key(c, p.elt, key);
+}
 struct RotChunk {
   uint32_t first, count; // pairs [first, first + count)
   u64 *out;
 };
 static RotPair rot_pair(evah_ctx *c, const u64 *src, size_t src_ps, uint32_t src_idx, int32_t step, uint32_t l, const char *who) {
   if (step == 0) throw std::invalid_argument(std::string(who) + ": zero steps are copies, not key switches");
-  RotPair p{src, src_ps, src_idx, 0, nullptr, nullptr, nullptr};
+  RotPair p{src, src_ps, src_idx, 0, nullptr, nullptr, nullptr, nullptr};
   if (evah_galois_elt_from_step(c, step, &p.elt)) throw std::invalid_argument(g_err);
   auto kit = c->sh->galois.find(p.elt);
   if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
@@ -327,8 +393,18 @@ static void rot_perm_launch(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t
 }
 // mod-down of a chunk's products (step 3 of switch_key); c0' = perm_d[2r] is added to the even polys
 // perm_d == nullptr: P c0' was added to the products already (KS_FOLDADD)
-static void rot_mod_down(evah_ctx *c, uint32_t l, uint32_t np, u64 *prod_d, const u64 *perm_d, u64 *out_d, u64 *r_d, bool inv1) {
+// gather != nullptr: prod is indexed in each pair's SOURCE space (k_hoist_mac), read through gather->p[pair]
+static void rot_mod_down(evah_ctx *c, uint32_t l, uint32_t np, u64 *prod_d, const u64 *perm_d, u64 *out_d, u64 *r_d, bool inv1,
+                         const PermTab *gather = nullptr) {
   const size_t N = c->N, pps = (size_t)l * N;
+  if (gather) {
+    OpPlainG::Params sp{prod_d + (size_t)l * N, r_d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
+    sp.perm_tab = *gather;
+    OpModDownG::Params mp{r_d, N, prod_d, (size_t)(l + 1) * N, perm_d, pps, ~0u, out_d, pps, c->k - 1, l};
+    mp.perm_tab = *gather;
+    inverse_then_forward<OpPlainG, OpModDownG>(c, sp, 2 * np, mp, 2 * np * l, inv1);
+    return;
+  }
   // INTT of the special limbs, job = r*2 + K
   OpPlain::Params sp{prod_d + (size_t)l * N, r_d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
   // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
@@ -350,6 +426,17 @@ static void rot_chunk_plain(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t
                                         fuse_small_launch(c, 2 * np * l) ? r.d : nullptr, fold, fold ? &adds : nullptr);
   rot_mod_down(c, l, np, prod.d, fold ? nullptr : perm.d, out_d, r.d, inv1);
 }
+// the zero-coefficient record of a hoisted set: d[0] = count, d[1..] = positions (OpPlainZ, k_hoist_fix), preceded in the
+// same allocation by one barrier word per chunk for the persistent fallback; everything that must start at zero is
+// cleared by one memset
+struct ZeroFlag {
+  Scratch s;
+  u64 *d;
+  ZeroFlag(evah_ctx *c, size_t chunks) : s(c, chunks + 1 + HOIST_ZERO_CAP), d(s.d + chunks) {
+    HIPCHK(hipMemsetAsync(s.d, 0, sizeof(u64) * (chunks + 1), c->stream));
+  }
+  u64 *bar(size_t chunk) const { return s.d + chunk; }
+};
 // launches issued while one of these lives return at once unless more than HOIST_ZERO_CAP zero digit coefficients were recorded
 struct GuardScope {
   evah_ctx *c;
@@ -390,37 +477,92 @@ static void rot_fallback_launch(evah_ctx *c, uint32_t l, const RotPair *pr, uint
   else hipLaunchKernelGGL((k_rot_fallback<2>), dim3(grid), dim3(256), 0, c->stream, c->dev, fp, np, l, b, (u64 *)nullptr, *wt, n_win, out_ps);
   HIPCHK(hipGetLastError());
 }
-// kernel-argument tables of one chunk of hoisted pairs; returns the number of key-sharing groups
-static uint32_t hoist_tables(const RotPair *pr, uint32_t np, size_t N, HoistTab &ht, HoistGroups &hg) {
+// kernel-argument tables of one chunk of hoisted pairs: the tile shape for the chunk and its tiles
+struct HoistTiles {
+  int TS = 1, TR = 1;
+  uint32_t n_tiles = 0;
+  std::vector<std::array<uint32_t, 6>> tiles; // HT_TILES at a time go into HoistMacTab::tile
+};
+static HoistTiles hoist_tables(const RotPair *pr, uint32_t np, size_t N, HoistMacTab &mt, HoistFixTab &ft) {
+  std::vector<uint32_t> srcs, elts; // the chunk's distinct sources (by digit index) and Galois elements
+  std::vector<uint32_t> ps(np), pe(np);
   for (uint32_t r = 0; r < np; r++) {
-    ht.perm[r] = pr[r].perm;
-    ht.key[r] = pr[r].key->d;
-    ht.corr[r] = pr[r].corr;
-    ht.elt[r] = pr[r].elt;
-    ht.c1[r] = pr[r].src + pr[r].src_ps;
-    ht.c1_ps[r] = (uint32_t)(pr[r].src_ps / N);
-    ht.src[r] = (uint8_t)pr[r].src_idx;
-  }
-  // pairs of one Galois element (same key, permutation and correction) go to one workgroup, HOIST_GROUP at a time
-  uint32_t n_groups = 0, filled = 0;
-  std::vector<char> taken(np, 0);
-  for (uint32_t r = 0; r < np; r++) {
-    if (taken[r]) continue;
-    uint32_t in_group = 0;
-    for (uint32_t q = r; q < np; q++) {
-      if (taken[q] || pr[q].elt != pr[r].elt) continue;
-      if (in_group == (uint32_t)HOIST_GROUP) { // start the next group of this element
-        hg.count[n_groups++] = (uint8_t)in_group;
-        in_group = 0;
-      }
-      if (in_group == 0) hg.first[n_groups] = (uint8_t)filled;
-      hg.member[filled++] = (uint8_t)q;
-      taken[q] = 1;
-      in_group++;
+    ft.perm[r] = pr[r].perm;
+    ft.key[r] = pr[r].key->d;
+    ft.elt[r] = pr[r].elt;
+    ft.src[r] = (uint8_t)pr[r].src_idx;
+    size_t si = std::find(srcs.begin(), srcs.end(), pr[r].src_idx) - srcs.begin();
+    if (si == srcs.size()) {
+      srcs.push_back(pr[r].src_idx);
+      mt.c1[si] = pr[r].src + pr[r].src_ps;
+      mt.c1_ps[si] = (uint32_t)(pr[r].src_ps / N);
+      mt.dg[si] = pr[r].src_idx;
     }
-    hg.count[n_groups++] = (uint8_t)in_group;
+    size_t ei = std::find(elts.begin(), elts.end(), pr[r].elt) - elts.begin();
+    if (ei == elts.size()) {
+      elts.push_back(pr[r].elt);
+      mt.keyp[ei] = pr[r].keyp;
+      mt.corrp[ei] = pr[r].corr;
+    }
+    ps[r] = (uint32_t)si;
+    pe[r] = (uint32_t)ei;
   }
-  return n_groups;
+  // shape: as many sources as the chunk has (1, 2, 3, 4 or 8), then as many elements as 8 accumulator pairs allow
+  HoistTiles ht;
+  const size_t S = srcs.size(), R = elts.size();
+  ht.TS = S >= 8 ? 8 : S >= 4 ? 4 : (int)S;
+  const int tr_max = ht.TS <= 2 ? 4 : ht.TS == 8 ? 1 : 2; // (1, 8) needs 159 VGPRs: three waves per SIMD
+  ht.TR = 1;
+  while (ht.TR < tr_max && (size_t)ht.TR < R) ht.TR *= 2;
+  // tiles: TR elements x TS sources, taken greedily in pair order (a rectangular set — every source with every element —
+  // fills its tiles completely); short tiles repeat their last entry, the repeats' outputs are 0xff (not stored)
+  std::vector<char> taken(np, 0);
+  for (uint32_t r0 = 0; r0 < np; r0++) {
+    if (taken[r0]) continue;
+    std::vector<uint32_t> te, ts;
+    for (uint32_t q = r0; q < np && te.size() < (size_t)ht.TR; q++)
+      if (!taken[q] && ps[q] == ps[r0] && std::find(te.begin(), te.end(), pe[q]) == te.end()) te.push_back(pe[q]);
+    for (uint32_t q = r0; q < np && ts.size() < (size_t)ht.TS; q++)
+      if (!taken[q] && std::find(te.begin(), te.end(), pe[q]) != te.end() && std::find(ts.begin(), ts.end(), ps[q]) == ts.end()) ts.push_back(ps[q]);
+    uint8_t b[24];
+    for (int i = 0; i < 8; i++) {
+      b[i] = (uint8_t)ts[std::min<size_t>(i, ts.size() - 1)];
+      b[8 + i] = (uint8_t)te[std::min<size_t>(i, te.size() - 1)];
+      b[16 + i] = 0xff;
+    }
+    for (size_t si = 0; si < ts.size(); si++)
+      for (size_t ei = 0; ei < te.size(); ei++)
+        for (uint32_t q = r0; q < np; q++)
+          if (!taken[q] && ps[q] == ts[si] && pe[q] == te[ei]) {
+            b[16 + si * ht.TR + ei] = (uint8_t)q;
+            taken[q] = 1;
+            break;
+          }
+    std::array<uint32_t, 6> w{};
+    for (int i = 0; i < 6; i++) w[i] = b[4 * i] | (uint32_t)b[4 * i + 1] << 8 | (uint32_t)b[4 * i + 2] << 16 | (uint32_t)b[4 * i + 3] << 24;
+    ht.tiles.push_back(w);
+  }
+  ht.n_tiles = (uint32_t)ht.tiles.size();
+  return ht;
+}
+// the hoisted inner products of a chunk (k_hoist_mac), HT_TILES tiles per launch
+static void hoist_mac_launch(evah_ctx *c, HoistMacTab &mt, const HoistTiles &ht, const u64 *dg, size_t dg_bs, u64 *prod, size_t prod_bs, uint32_t l,
+                             bool fold) {
+  ProfScope ps(c, KC_KSMAC);
+  for (uint32_t t0 = 0; t0 < ht.n_tiles; t0 += HT_TILES) {
+    const uint32_t n = std::min<uint32_t>(HT_TILES, ht.n_tiles - t0);
+    for (uint32_t t = 0; t < n; t++)
+      for (int i = 0; i < 6; i++) mt.tile[t][i] = ht.tiles[t0 + t][i];
+#define HM(S_, R_)                                                                                                                     \
+  if (ht.TS == S_ && ht.TR == R_) {                                                                                                    \
+    hipLaunchKernelGGL((k_hoist_mac<S_, R_>), dim3(c->N / 256, l + 1, n), dim3(256), 0, c->stream, c->dev, dg, dg_bs, mt, 0u, prod, prod_bs, l, fold); \
+    HIPCHK(hipGetLastError());                                                                                                         \
+    continue;                                                                                                                          \
+  }
+    HM(1, 1) HM(1, 2) HM(1, 4) HM(2, 1) HM(2, 2) HM(2, 4) HM(3, 1) HM(3, 2) HM(4, 1) HM(4, 2) HM(8, 1)
+#undef HM
+    throw std::logic_error("hoisted inner product: no kernel for this tile shape");
+  }
 }
 // digits of the unrotated c1 of every source, once: coefficient form (zeros recorded in flag_d), then the full
 // transforms under every output prime into dg_d[source][(l+1) l N]; t_d: n_src * l * N words of scratch
@@ -448,10 +590,9 @@ static void rotation_set(evah_ctx *c, uint32_t l, const std::vector<RotPair> &pa
   }
   const uint32_t n_src = (uint32_t)srcs.size();
   if (n_src > (uint32_t)KS_BATCH_MAX) throw std::logic_error("hoisted rotation set with too many sources");
-  // [0]: zero-coefficient count, then the recorded positions, then one barrier word per chunk (k_rot_fallback)
-  Scratch flag(c, 1 + HOIST_ZERO_CAP + chunks.size());
-  HIPCHK(hipMemsetAsync(flag.d, 0, sizeof(u64), c->stream));
-  HIPCHK(hipMemsetAsync(flag.d + 1 + HOIST_ZERO_CAP, 0, sizeof(u64) * chunks.size(), c->stream));
+  // one barrier word per chunk (k_rot_fallback), then the zero-coefficient count and the recorded positions: the words
+  // that must start at zero are adjacent (one memset)
+  ZeroFlag flag(c, chunks.size());
   const size_t dg_bs = (size_t)(l + 1) * l * N;
   {
     Scratch t(c, (size_t)n_src * l * N), dg(c, n_src * dg_bs);
@@ -459,23 +600,24 @@ static void rotation_set(evah_ctx *c, uint32_t l, const std::vector<RotPair> &pa
     for (const RotChunk &ch : chunks) {
       const RotPair *pr = pairs.data() + ch.first;
       const uint32_t np = ch.count;
-      HoistTab ht{};
-      HoistGroups hg{};
-      const uint32_t n_groups = hoist_tables(pr, np, N, ht, hg);
+      HoistMacTab mt{};
+      HoistFixTab ft{};
+      const HoistTiles tiles = hoist_tables(pr, np, N, mt, ft);
       // the rotated c0: folded into the inner product (fold_pa), or a permuted copy the mod-down adds (even polys only)
       const bool fold = c->tun.fold_pa;
       Scratch perm(c, fold ? 1 : (size_t)np * 2 * pps);
       if (!fold) rot_perm_launch(c, l, pr, np, perm.d, 1);
       Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N);
+      hoist_mac_launch(c, mt, tiles, dg.d, dg_bs, prod.d, prod_bs, l, fold);
       {
         ProfScope ps(c, KC_KSMAC);
-        hipLaunchKernelGGL(k_hoist_mac, dim3(c->N / 512, l + 1, n_groups), dim3(256), 0, c->stream, c->dev, dg.d, dg_bs, ht, hg, prod.d, prod_bs, l, fold);
-        HIPCHK(hipGetLastError());
         // the terms of recorded zero coefficients (returns at once when there are none)
-        hipLaunchKernelGGL(k_hoist_fix, dim3(c->N / 256, l + 1, np), dim3(256), 0, c->stream, c->dev, flag.d, ht, prod.d, prod_bs, l);
+        hipLaunchKernelGGL(k_hoist_fix, dim3(c->N / 256, l + 1, np), dim3(256), 0, c->stream, c->dev, flag.d, ft, prod.d, prod_bs, l);
         HIPCHK(hipGetLastError());
       }
-      rot_mod_down(c, l, np, prod.d, fold ? nullptr : perm.d, ch.out, r.d, false);
+      PermTab gt{};
+      for (uint32_t q = 0; q < np; q++) gt.p[q] = pr[q].perm;
+      rot_mod_down(c, l, np, prod.d, fold ? nullptr : perm.d, ch.out, r.d, false, &gt);
     }
   }
   // exact fallback: the same outputs through the unhoisted launches, each a no-op unless there
@@ -483,7 +625,7 @@ static void rotation_set(evah_ctx *c, uint32_t l, const std::vector<RotPair> &pa
   GuardScope gs(c, reinterpret_cast<const uint32_t *>(flag.d));
   for (size_t ci = 0; ci < chunks.size(); ci++) {
     const RotChunk &ch = chunks[ci];
-    if (c->tun.fb_persist) rot_fallback_launch(c, l, pairs.data() + ch.first, ch.count, ch.out, nullptr, 0, 0, 0, flag.d + 1 + HOIST_ZERO_CAP + ci);
+    if (c->tun.fb_persist) rot_fallback_launch(c, l, pairs.data() + ch.first, ch.count, ch.out, nullptr, 0, 0, 0, flag.bar(ci));
     else rot_chunk_plain(c, l, pairs.data() + ch.first, ch.count, ch.out);
   }
   if (!c->capturing && c->tun.hoist_debug) { // diagnostics: how many zero coefficients did this set see?
@@ -512,7 +654,7 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
   pairs.reserve((size_t)n * B);
   for (uint32_t j = 0; j < n; j++) {
     RotPair p = rot_pair(c, a->d, a->ps, 0, steps[j], l, "rotate_many");
-    if (hoisted) p.corr = hoist_corr(c, p.elt, l, *p.key);
+    if (hoisted) hoist_prepare(c, p, l);
     for (uint32_t b = 0; b < B; b++) {
       p.src = a->d + (size_t)b * 2 * a->ps;
       p.src_idx = b;
@@ -586,7 +728,7 @@ int evah_rotate_pairs(evah_ctx *c, const evah_ct *const *cts, const int32_t *ste
   // worth hoisting when sources repeat and the digit transforms of the set are throughput-sized
   const bool hoisted = srcs.size() < n && hoist_wanted(c, l, n, 1);
   if (hoisted)
-    for (RotPair &p : pairs) p.corr = hoist_corr(c, p.elt, l, *p.key);
+    for (RotPair &p : pairs) hoist_prepare(c, p, l);
   Buffer *ob = buf_new(c, (size_t)n * 2 * pps);
   try {
     rotation_set(c, l, pairs, {RotChunk{0, n, ob->d}}, srcs, src_ps, hoisted);
@@ -649,14 +791,14 @@ k_window_sums(DevCtx cx, WinSumTab ws, const u64 *rot, size_t rot_ps, size_t out
   }
 }
 template <int P>
-static void launch_moddown_sum(evah_ctx *c, uint32_t l, uint32_t n_win, int F, const WinSumTab &wt, const u64 *mid, size_t mid_ps, const u64 *prod,
-                               size_t prod_ps, size_t out_ps) {
+static void launch_moddown_sum(evah_ctx *c, uint32_t l, uint32_t n_win, int F, const WinSumTab &wt, const PermTab &perms, const u64 *mid, size_t mid_ps,
+                               const u64 *prod, size_t prod_ps, size_t out_ps) {
   ProfScope ps(c, KC_MODDOWN_B);
   const int logC = 8 - P;
   const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) + ((size_t)1 << (logC + P)) * sizeof(ulonglong2);
   const dim3 grid(c->N / 256, l, 2 * n_win);
-  if (F == 1) hipLaunchKernelGGL((moddown_sum_kernel<P, 1>), grid, dim3(64), lds, c->stream, c->dev, wt, mid, mid_ps, prod, prod_ps, out_ps, logC);
-  else hipLaunchKernelGGL((moddown_sum_kernel<P, 2>), grid, dim3(64), lds, c->stream, c->dev, wt, mid, mid_ps, prod, prod_ps, out_ps, logC);
+  if (F == 1) hipLaunchKernelGGL((moddown_sum_kernel<P, 1>), grid, dim3(64), lds, c->stream, c->dev, wt, perms, mid, mid_ps, prod, prod_ps, out_ps, logC);
+  else hipLaunchKernelGGL((moddown_sum_kernel<P, 2>), grid, dim3(64), lds, c->stream, c->dev, wt, perms, mid, mid_ps, prod, prod_ps, out_ps, logC);
   HIPCHK(hipGetLastError());
 }
 } // namespace evah
@@ -787,7 +929,7 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
         for (uint32_t t = 0; t < n_terms; t++) {
           if (steps[t] == 0) continue;
           term_pair[t] = rot_pair(c, cts[t]->d, cts[t]->ps, 0, steps[t], l, "rotate_weighted_sums");
-          term_pair[t].corr = hoist_corr(c, term_pair[t].elt, l, *term_pair[t].key);
+          hoist_prepare(c, term_pair[t], l);
         }
         uint32_t t0 = 0, p0 = 0, s0 = 0;
         for (uint32_t w = 0; w < n_windows; w++) {
@@ -851,9 +993,7 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
         wt.out1[wi] = F > 1 ? made[un.s0 + 1]->d + (size_t)un.b * 2 * out_ps : nullptr;
         ch.np += un.count;
       }
-      Scratch flag(c, 1 + HOIST_ZERO_CAP + chunks.size()); // zero-coefficient count, recorded positions, barrier words
-      HIPCHK(hipMemsetAsync(flag.d, 0, sizeof(u64), c->stream));
-      HIPCHK(hipMemsetAsync(flag.d + 1 + HOIST_ZERO_CAP, 0, sizeof(u64) * chunks.size(), c->stream));
+      ZeroFlag flag(c, chunks.size());
       const size_t dg_bs = (size_t)(l + 1) * l * N;
       {
         Scratch t(c, srcs.size() * l * N), dg(c, srcs.size() * dg_bs);
@@ -861,33 +1001,33 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
         for (const Chunk &ch : chunks) {
           const RotPair *pr = pairs.data() + ch.first;
           const uint32_t np = ch.np;
-          HoistTab ht{};
-          HoistGroups hg{};
-          const uint32_t n_groups = hoist_tables(pr, np, N, ht, hg);
+          HoistMacTab mt{};
+          HoistFixTab ft{};
+          const HoistTiles tiles = hoist_tables(pr, np, N, mt, ft);
           Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N), mid(c, (size_t)np * 2 * pps);
+          hoist_mac_launch(c, mt, tiles, dg.d, dg_bs, prod.d, prod_bs, l, true);
           {
             ProfScope ps(c, KC_KSMAC);
-            hipLaunchKernelGGL(k_hoist_mac, dim3(c->N / 512, l + 1, n_groups), dim3(256), 0, c->stream, c->dev, dg.d, dg_bs, ht, hg, prod.d, prod_bs, l, true);
-            HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(k_hoist_fix, dim3(c->N / 256, l + 1, np), dim3(256), 0, c->stream, c->dev, flag.d, ht, prod.d, prod_bs, l);
+            hipLaunchKernelGGL(k_hoist_fix, dim3(c->N / 256, l + 1, np), dim3(256), 0, c->stream, c->dev, flag.d, ft, prod.d, prod_bs, l);
             HIPCHK(hipGetLastError());
           }
-          // mod-down: INTT of the special rows, first (strided) pass of the forward transforms into mid, then the
-          // second pass with the window's sums as its epilogue
-          OpPlain::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
+          // mod-down: INTT of the special rows (read through the pairs' permutations), first (strided) pass of the
+          // forward transforms into mid, then the second pass with the window's sums as its epilogue
+          OpPlainG::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
+          for (uint32_t q = 0; q < np; q++) sp.perm_tab.p[q] = pr[q].perm;
           OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, nullptr, pps, ~0u, mid.d, pps, c->k - 1, l};
           if (fuse_small_launch(c, 2 * np * l)) {
-            launch_pass_p<false, true, OpPlain>(c, c->logN / 2, sp, 2 * np);
+            launch_pass_p<false, true, OpPlainG>(c, c->logN / 2, sp, 2 * np);
             launch_inv_fwd<OpModDown>(c, mp, 2 * np * l);
           } else {
-            ntt_inverse<OpPlain>(c, sp, 2 * np);
+            ntt_inverse<OpPlainG>(c, sp, 2 * np);
             launch_pass_p<true, false, OpModDown>(c, (c->logN + 1) / 2, mp, 2 * np * l);
           }
           switch (c->logN / 2) {
-          case 5: launch_moddown_sum<5>(c, l, ch.nu, ch.F, ch.wt, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
-          case 6: launch_moddown_sum<6>(c, l, ch.nu, ch.F, ch.wt, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
-          case 7: launch_moddown_sum<7>(c, l, ch.nu, ch.F, ch.wt, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
-          case 8: launch_moddown_sum<8>(c, l, ch.nu, ch.F, ch.wt, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
+          case 5: launch_moddown_sum<5>(c, l, ch.nu, ch.F, ch.wt, sp.perm_tab, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
+          case 6: launch_moddown_sum<6>(c, l, ch.nu, ch.F, ch.wt, sp.perm_tab, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
+          case 7: launch_moddown_sum<7>(c, l, ch.nu, ch.F, ch.wt, sp.perm_tab, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
+          case 8: launch_moddown_sum<8>(c, l, ch.nu, ch.F, ch.wt, sp.perm_tab, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
           default: throw std::runtime_error("unsupported poly_modulus_degree for the window sums");
           }
         }
@@ -897,7 +1037,7 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
       for (size_t ci = 0; ci < chunks.size(); ci++) {
         const Chunk &ch = chunks[ci];
         if (c->tun.fb_persist) {
-          rot_fallback_launch(c, l, pairs.data() + ch.first, ch.np, nullptr, &ch.wt, ch.nu, ch.F, out_ps, flag.d + 1 + HOIST_ZERO_CAP + ci);
+          rot_fallback_launch(c, l, pairs.data() + ch.first, ch.np, nullptr, &ch.wt, ch.nu, ch.F, out_ps, flag.bar(ci));
           continue;
         }
         Scratch rot(c, (size_t)ch.np * 2 * pps);

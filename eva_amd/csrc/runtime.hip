@@ -298,6 +298,7 @@ int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digit
     if (it != c->sh->galois.end()) {
       (void)hipFree(it->second.d);
       if (it->second.d_split) (void)hipFree(it->second.d_split);
+      if (it->second.d_perm) (void)hipFree(it->second.d_perm);
     }
     c->sh->galois[galois_elt] = kd;
     // the hoisting constants of this element were derived from the key it replaces

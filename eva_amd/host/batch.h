@@ -32,6 +32,7 @@ inline std::vector<HipValuation> HipPublic::execute_batch(Program &program, cons
   };
   size_t g = 0;
   const bool bounded = std::getenv("EVA_BATCH_BOUNDED") ? std::atoi(std::getenv("EVA_BATCH_BOUNDED")) != 0 : false;
+  const auto t_begin = std::chrono::steady_clock::now();
   try {
     for (size_t i0 = 0; i0 < inputs.size(); i0 += batch_chunk, g++) {
       const size_t n = std::min<size_t>(batch_chunk, inputs.size() - i0);
@@ -56,7 +57,12 @@ inline std::vector<HipValuation> HipPublic::execute_batch(Program &program, cons
     for (evah_ctx *q : qs) (void)evah_ctx_sync(q); // copies in flight still target `all` and the caller's inputs
     throw;
   }
+  const auto t_issued = std::chrono::steady_clock::now();
   finish();
+  if (std::getenv("EVA_BATCH_TIMING")) // how much of the call the host spends issuing (the rest it waits for the device)
+    std::fprintf(stderr, "EVA: execute_batch issued %zu groups in %.3f ms, done after %.3f ms\n", g,
+                 std::chrono::duration<double, std::milli>(t_issued - t_begin).count(),
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
   return all;
 }
 
