@@ -227,3 +227,73 @@ def test_execute_reports_errors():
     with pytest.raises(RuntimeError, match="relinearization key not present|size-3"):
         g.execute([(int(Op.Relinearize), 1, 0, 0, 0, 0)], {0: a}, n_vals=3)
     assert a.h is not None and a.info()[0] == 2  # a failed submit leaves caller values alone
+
+
+# ---- convolution windows in the scheduler: Rotate -> Mul(plain) -> Add chains whose rotations are deferred into
+# evah_rotate_weighted_sums (eva_amd/csrc/scheduler.hip); the shapes below are the ones its bookkeeping must get right
+def _window_programs():
+    progs = {}
+
+    p = EvaProgram('two_filters', vec_size=64)  # convolutionXY: two sums over the same rotations (one window, F = 2)
+    with p:
+        x = Input('x')
+        taps = [x << 1, x << 2, x << 5, x]
+        a = taps[0] * 0.5 + taps[1] * -1.5 + taps[2] * 0.25 + taps[3] * 2.0
+        b = taps[0] * 1.5 + taps[1] * 0.75 + taps[2] * -0.5 + taps[3] * 0.125
+        Output('a', a)
+        Output('b', b)
+    progs['two_filters'] = p
+
+    p = EvaProgram('shared_rotation_different_sums', vec_size=64)  # r2 feeds two sums with different term lists
+    with p:
+        x = Input('x')
+        r1, r2, r3 = x << 1, x << 2, x << 3
+        Output('a', r1 * 0.5 + r2 * -1.5)
+        Output('b', r2 * 0.75 + r3 * 0.25)
+    progs['shared_rotation_different_sums'] = p
+
+    p = EvaProgram('uneven_chains', vec_size=64)  # the second sum ends one level later than the first
+    with p:
+        x = Input('x')
+        r1, r2 = x << 1, x << 4
+        Output('a', r1 * 0.5 + r2 * -1.5)
+        Output('b', r1 * 1.25 + r2 * 0.75 + x * 0.5 + (x >> 2) * 0.25)
+    progs['uneven_chains'] = p
+
+    p = EvaProgram('rotation_with_other_readers', vec_size=64)  # a tap that is also an output / squared: not deferred
+    with p:
+        x = Input('x')
+        r1, r2 = x << 1, x << 2
+        Output('a', r1 * 0.5 + r2 * -1.5)
+        Output('r', r1)
+        Output('s', r2 * r2)
+    progs['rotation_with_other_readers'] = p
+
+    p = EvaProgram('three_windows_two_levels', vec_size=64)  # Harris in miniature: windows of products of windows
+    with p:
+        x = Input('x')
+        def conv(v, ws):
+            acc = None
+            for k, w in enumerate(ws):
+                t = (v << k) * w
+                acc = t if acc is None else acc + t
+            return acc
+        ix, iy = conv(x, [0.5, -1.0, 0.25]), conv(x, [0.125, 0.75, -0.5])
+        Output('y', conv(ix * ix, [1.0, 1.0, 1.0]) + conv(ix * iy, [1.0, 0.5, 1.0]) - conv(iy * iy, [0.25, 1.0, 1.0]))
+    progs['three_windows_two_levels'] = p
+    for q in progs.values():
+        q.set_output_ranges(20)
+        q.set_input_scales(30)
+    return progs
+
+
+@pytest.mark.parametrize("name", ['two_filters', 'shared_rotation_different_sums', 'uneven_chains', 'rotation_with_other_readers',
+                                  'three_windows_two_levels'])
+@pytest.mark.parametrize("min_tiles", ["0", None], ids=["fused", "default"])
+def test_execute_convolution_windows(name, min_tiles, monkeypatch):
+    """min_tiles = 0 makes every window large enough for the hoisted + fused path; the default leaves these small
+    programs on the general path of evah_rotate_weighted_sums.  Same ciphertexts as the oracle walk either way."""
+    if min_tiles is not None:
+        monkeypatch.setenv("EVAH_HOIST_MIN_TILES", min_tiles)
+    rng = np.random.default_rng(11)
+    _check(_window_programs()[name], {'x': list(rng.uniform(-1, 1, 64))}, N=4096)
