@@ -193,8 +193,13 @@ struct SharedDev {
   uint32_t *enc_slot_map = nullptr; // slot i (and its conjugate, at slots + i) -> FFT input index
   uint32_t key_rows = 0, key_shard = 0; // evaluation keys: 0 none yet, 1 whole, 2 the prime rows of limb shard `key_shard`
   uint64_t xfer[6] = {0, 0, 0, 0, 0, 0}; // evah_ctx_transfer_stats: ct up / down, pt up / down, bytes up / down
+  // one word of mapped host memory the persistent rotation fallback (rot_fallback.hip.h) sets if a grid-wide barrier
+  // gave up — the grid was not resident, its outputs are invalid; every call that waits for the device checks it
+  volatile uint32_t *fb_error = nullptr;
+  uint32_t *fb_error_dev = nullptr;
   ~SharedDev() {
     (void)hipSetDevice(device);
+    if (fb_error) (void)hipHostFree((void *)fb_error);
     if (enc_roots) (void)hipFree(enc_roots);
     if (enc_slot_map) (void)hipFree(enc_slot_map);
     if (relin.d) (void)hipFree(relin.d);
@@ -469,6 +474,15 @@ struct Scratch { // pool-backed temporary, returned on scope exit (stream-ordere
   }
   ~Scratch() { c->pool.free(d, bytes); }
 };
+
+// after a wait for the device: did a persistent rotation fallback give up on a barrier since the last check?
+inline void check_fallback(evah_ctx *c) {
+  if (c->sh->fb_error && *c->sh->fb_error) {
+    *c->sh->fb_error = 0;
+    throw std::runtime_error("rotation fallback: its grid was not resident on the device, the results of this queue are invalid "
+                             "(EVAH_FB_PERSIST=0 selects the multi-launch fallback)");
+  }
+}
 
 inline dim3 ew_grid(evah_ctx *c, uint32_t limbs, uint32_t polys) {
   return dim3(c->N / 512, limbs, polys);

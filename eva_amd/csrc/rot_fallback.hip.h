@@ -34,10 +34,12 @@ struct FbBufs {
   u64 *r;             // [np][2][N]
   u64 *u;             // [np][2][l][N]; the rotated ciphertexts end up here unless rot_out is given
   unsigned *bar;      // [0]: arrivals, [1]: set when a workgroup gave up waiting (never, unless the grid was not resident)
+  uint32_t *err;      // mapped host word, set with it: the host reports the failure at its next wait (check_fallback)
 };
 
 struct GridBar {
   unsigned *bar;
+  uint32_t *err;
   unsigned nb, epoch;
   bool dead;
 };
@@ -51,9 +53,10 @@ __device__ __forceinline__ void fb_grid_sync(GridBar &g) {
     unsigned spins = 0;
     while (__hip_atomic_load(g.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(8);
-      // bounded: a grid that is not fully resident must not hang the queue (the outputs are then wrong and the word says so)
+      // bounded: a grid that is not fully resident must not hang the queue (the outputs are then wrong and the host is told)
       if (++spins > (1u << 20) || __hip_atomic_load(g.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         __hip_atomic_store(g.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         g.dead = true;
         break;
       }
@@ -109,7 +112,7 @@ template <int F>
 __global__ void __launch_bounds__(256)
 k_rot_fallback(DevCtx cx, FbPairs pr, uint32_t np, uint32_t l, FbBufs b, u64 *rot_out, WinSumTab ws, uint32_t n_win, size_t out_ps) {
   if (cx.skipped()) return; // the hoisted results stand: every workgroup leaves before the first barrier
-  GridBar g{b.bar, gridDim.x, 0, false};
+  GridBar g{b.bar, b.err, gridDim.x, 0, false};
   const uint32_t N = cx.N, logN = cx.logN, k = cx.k, sp = k - 1;
   const size_t stride = (size_t)gridDim.x * blockDim.x, gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t lN = (size_t)l * N;

@@ -467,7 +467,16 @@ static void rot_fallback_launch(evah_ctx *c, uint32_t l, const RotPair *pr, uint
     fp.src_ps[r] = (uint32_t)(pr[r].src_ps / N);
   }
   Scratch rc1(c, np * lN), t(c, np * lN), dig(c, np * lN), prod(c, (size_t)np * 2 * (l + 1) * N), r(c, (size_t)np * 2 * N), u(c, (size_t)np * 2 * lN);
-  FbBufs b{rc1.d, t.d, dig.d, prod.d, r.d, u.d, reinterpret_cast<unsigned *>(bar_word)};
+  if (!c->sh->fb_error) { // first use on this device state
+    if (c->capturing) throw std::logic_error("first hoisted rotation set cannot be captured into a graph");
+    void *h = nullptr, *d = nullptr;
+    HIPCHK(hipHostMalloc(&h, sizeof(uint32_t), hipHostMallocMapped));
+    *static_cast<uint32_t *>(h) = 0;
+    HIPCHK(hipHostGetDevicePointer(&d, h, 0));
+    c->sh->fb_error = static_cast<volatile uint32_t *>(h);
+    c->sh->fb_error_dev = static_cast<uint32_t *>(d);
+  }
+  FbBufs b{rc1.d, t.d, dig.d, prod.d, r.d, u.d, reinterpret_cast<unsigned *>(bar_word), c->sh->fb_error_dev};
   // one workgroup per CU at most: the whole grid is resident, which the grid-wide barriers rely on
   const uint32_t grid = std::min<uint32_t>(cu_count(c->device), 256);
   WinSumTab none{};

@@ -214,6 +214,7 @@ int evah_ctx_sync(evah_ctx *c) {
   API_BEGIN
   use(c);
   HIPCHK(hipStreamSynchronize(c->stream));
+  check_fallback(c);
   API_END
 }
 
@@ -363,7 +364,10 @@ void evah_host_free(void *p) {
 // slower — 5.1 k vs 6.9 k Sobel DAGs/s — the pageable staging path of the runtime serialises.)
 static void io_copy(evah_ctx *c, uint32_t n, const std::function<hipError_t(uint32_t, hipStream_t)> &copy_one, bool wait = true) {
   for (uint32_t b = 0; b < n; b++) HIPCHK(copy_one(b, c->stream));
-  if (wait) HIPCHK(hipStreamSynchronize(c->stream));
+  if (wait) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    check_fallback(c);
+  }
 }
 
 int evah_ct_upload(evah_ctx *c, uint32_t size, uint32_t limbs, double scale, const uint64_t *data, evah_ct **out) {
@@ -690,6 +694,7 @@ int evah_ct_download(evah_ctx *c, const evah_ct *ct, uint64_t *out) {
     HIPCHK(hipMemcpy2DAsync(out, row, ct->d, sizeof(u64) * ct->ps, row, (size_t)ct->size * ct->batch, hipMemcpyDeviceToHost,
                             c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  check_fallback(c);
   count_d2h(c, row * ct->size * ct->batch);
   API_END
 }
