@@ -102,6 +102,30 @@ __device__ __forceinline__ u64 mul_tw_lazy5_add_mad(u64 x, u64 w, u64 ws, u64 nq
 #ifndef EVAH_MADLO
 #define EVAH_MADLO 1 // 0: the compiler's form everywhere (A/B switch of the build)
 #endif
+// The same products for q = 2^b - c (b = 32 + sh, c < 2^32: DevPrime::tb_c / tb_sh):  x*w - t*q = x*w + t*c - t*2^b, and
+// t*2^b mod 2^64 is (t0 << sh) in the upper word — the product with the modulus costs TWO multiplies (t0*c, t1*c) plus a
+// 32-bit shift and subtract instead of three.  8 multiplies per butterfly instead of 9; the value is the same 64-bit
+// word, so every lazy bound above holds unchanged.  Measured and NOT kept (r04_tuning_notes.md 15): 14.67-14.77 k against
+// 14.85-15.01 k op-triples/s — the key-switch kernel got slower (841 -> 876 us), the digit pass did not get faster.
+#ifndef EVAH_TBMUL
+#define EVAH_TBMUL 0 // 1: the experiment (A/B switch of the build)
+#endif
+__device__ __forceinline__ u64 mul_tw_tb_add(u64 x, u64 w, u64 ws, uint32_t c, uint32_t sh, u64 a) {
+  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
+  const u64 t = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
+  return ((a + x * w) + t * (u64)c) - ((u64)((uint32_t)t << sh) << 32);
+}
+__device__ __forceinline__ u64 mul_tw_tb_add_mad(u64 x, u64 w, u64 ws, uint32_t c, uint32_t sh, u64 a) {
+  const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
+  const u64 t = (u64)x1 * s1 + (u64)__umulhi(x1, s0) + (u64)__umulhi(x0, s1);
+  const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32), t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32);
+  u64 r = mad64(x0, w0, a);
+  r = mad64(t0, c, r);
+  u64 h = mad64(x0, w1, r >> 32); // from here on only the low word of h matters
+  h = mad64(x1, w0, h);
+  h = mad64(t1, c, h);
+  return ((u64)((uint32_t)h - (t0 << sh)) << 32) | (uint32_t)r;
+}
 // forward Cooley-Tukey butterfly.  The twiddle product is in [0,4q), so each stage grows the
 // bound by 4q; moduli are < 2^60 (16q < 2^64), which leaves room to reduce only every other stage:
 //   REDUCE stage : X < 16q -> x < 8q  -> outputs < 12q
@@ -127,7 +151,8 @@ __device__ __forceinline__ void bfly_fwd(u64 &X, u64 &Y, ulonglong2 w, u64 nq, u
   } else if constexpr (REDUCE) {
     x = X + (X >= q8 ? nq8 : 0);
   }
-  X = MAD ? mul_tw_lazy5_add_mad(Y, w.x, w.y, nq, x) : mul_tw_lazy5_add(Y, w.x, w.y, nq, x);
+  if constexpr (TB && EVAH_TBMUL) X = MAD ? mul_tw_tb_add_mad(Y, w.x, w.y, tbc, tbs, x) : mul_tw_tb_add(Y, w.x, w.y, tbc, tbs, x);
+  else X = MAD ? mul_tw_lazy5_add_mad(Y, w.x, w.y, nq, x) : mul_tw_lazy5_add(Y, w.x, w.y, nq, x);
   Y = ((x << 1) + q4) - X;
 }
 // inverse Gentleman-Sande butterfly, X,Y in [0,5q) -> [0,5q)
@@ -197,7 +222,7 @@ __device__ __forceinline__ void ntt_round(u64 *sub_lds, int tid, uint32_t h, uin
           const ulonglong2 w = tw[((size_t)node << s) + v];
           const bool red = TB ? tb_reduce_stage<P, RED_EVEN>(S0 + s) : ((((S0 + s) & 1) == 0) == RED_EVEN);
           if (red) bfly_fwd<true, MAD, TB>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8, pm.tb_c, pm.tb_sh, pm.tb_mask);
-          else bfly_fwd<false, MAD, TB>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8);
+          else bfly_fwd<false, MAD, TB>(x[g * NU + u], x[g * NU + u + half], w, nq, q4, q8, nq8, pm.tb_c, pm.tb_sh, pm.tb_mask);
         }
       }
     } else {
