@@ -1,4 +1,4 @@
-# GPU box: kernel traces of the DAG legs (per-dispatch CSV kept for the guarded-launch accounting)
+# Run on the GPU box (via gpurun): kernel traces of the DAG legs, bash scripts/trace_legs.sh <out> (per-dispatch CSVs kept under gpurun_out/<out>/)
 set -u
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/${1:-run31}; mkdir -p $O
