@@ -6,7 +6,8 @@
 //                    CKKS encoder, plaintext uploads, mod_switch
 //   keyswitch.hip    the key-switch core (digit decomposition, fused second pass + key inner product,
 //                    mod-down) and relinearize / rescale with their fused and batched forms
-//   rotate.hip       Galois permutation, rotations, hoisted rotation sets with the guarded fallback
+//   rotate.hip       Galois permutation, rotations, rotation sets (machinery: rotation_sets.hip.h, rot_fallback.hip.h)
+//   windows.hip      evah_rotate_weighted_sums: convolution windows over the same machinery
 //   shard.hip        limb-sharded phases (evah_shard_*), exchange buffers
 //   client.hip       encrypt, decrypt + decode
 //   launch.hip.h     launch plumbing of the transform kernels shared by the units above
@@ -138,7 +139,7 @@ struct KeyDev {
   u64 *d_split = nullptr;
   // Galois keys used by hoisted rotation sets: the same words with every row read through the inverse of the element's
   // NTT-domain permutation — d_perm[..][m] = d[..][pi^-1(m)] — so that the hoisted inner product is elementwise in the
-  // source's own index space (rotate.hip, k_hoist_mac); built at the first hoisted use of the key
+  // source's own index space (rotation_sets.hip.h, k_hoist_mac); built at the first hoisted use of the key
   u64 *d_perm = nullptr;
 };
 
@@ -184,7 +185,7 @@ struct SharedDev {
   std::map<uint32_t, KeyDev> galois;
   std::map<uint32_t, uint32_t *> perms;
   std::map<uint32_t, uint32_t *> perms_inv; // the inverse tables (hoisted rotation sets)
-  // hoisted rotations (rotate.hip): NTT of the sign pattern of a Galois element under every prime
+  // hoisted rotations (rotation_sets.hip.h): NTT of the sign pattern of a Galois element under every prime
   // ([k][N]) and, per (element, level), the constant it contributes to the key inner product ([2][l+1][N])
   std::map<uint32_t, u64 *> hoist_sign;
   std::map<std::pair<uint32_t, uint32_t>, u64 *> hoist_corr;

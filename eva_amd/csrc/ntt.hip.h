@@ -1203,7 +1203,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
 // prime = prime0 + i.  addhalf: x <- x + floor(q/2) mod q on store (rounding offset of
 // rescale / key-switch mod-down).
 // GATHER: polynomial pp is read through an index table, x[n] = src[perm_tab.p[pp >> 1][n]] (the special rows of hoisted
-// key inner products, which rotate.hip keeps in the source's index space: the Galois permutation is applied here)
+// key inner products, which rotation_sets.hip.h keeps in the source's index space: the Galois permutation is applied here)
 struct NoGather {};
 template <bool ZEROS, bool GATHER = false> struct OpPlainT { // ZEROS: the inverse transform also records zero coefficients
   struct Params {

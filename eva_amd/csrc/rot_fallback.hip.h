@@ -1,6 +1,6 @@
-// rot_fallback.hip.h — the exact fallback of hoisted rotation sets as ONE launch (included by rotate.hip).
+// rot_fallback.hip.h — the exact fallback of hoisted rotation sets as ONE launch (included by rotation_sets.hip.h).
 //
-// A hoisted set (k_hoist_mac, rotate.hip) corrects up to HOIST_ZERO_CAP zero digit coefficients one by one; a source with
+// A hoisted set (k_hoist_mac, rotation_sets.hip.h) corrects up to HOIST_ZERO_CAP zero digit coefficients one by one; a source with
 // more of them (a transparent ciphertext, a zero limb) needs SEAL's own order — rotate, then decompose
 // (Evaluator::rotate_internal -> switch_key_inplace; /root/reference/eva/seal/seal_executor.h:181/188).  That path is
 // taken once in a blue moon, but its launches used to be issued every time, each returning at once under the device-side

@@ -1,11 +1,11 @@
 // rotate.hip — libeva_hip.so: rotate_vector (/root/reference/eva/seal/seal_executor.h:177-189): the NTT-domain Galois permutation, single
 // rotations, and rotation sets — sibling rotations as one launch set, hoisted when throughput-sized (one digit
-// decomposition per source) with the exact guarded fallback.
-#include "launch.hip.h"
-#include <array>
-#include "rot_fallback.hip.h"
+// decomposition per source) with the exact fallback.  The machinery of the sets is rotation_sets.hip.h
+// (shared with windows.hip, where the sets feed weighted sums).
+#include "rotation_sets.hip.h"
 
 namespace evah {
+
 
 // K8: NTT-domain Galois automorphism out[p][i][n] = in[p][i][perm[n]]
 __global__ void __launch_bounds__(256)
@@ -25,209 +25,6 @@ void galois_perm_launch(evah_ctx *c, const u64 *a, size_t a_ps, uint32_t limbs, 
   HIPCHK(hipGetLastError());
 }
 
-// K8 for (ciphertext, rotation) pairs: pair r reads its own source; grid.z = r * 2 + p
-struct PermPairs {
-  const uint32_t *perm[KS_BATCH_MAX];
-  const u64 *src[KS_BATCH_MAX];
-  uint32_t src_ps[KS_BATCH_MAX]; // poly strides in units of N coefficients
-};
-__global__ void __launch_bounds__(256)
-k_galois_perm_pairs(DevCtx cx, PermPairs pt, u64 *out, size_t o_ps, uint32_t polys) {
-  // polys == 2: z = 2 r + K, polynomial K of pair r; polys == 1: z = r and only c0 is permuted (the
-  // hoisted form never needs the permuted c1).  Output slot 2 r + K either way.
-  if (cx.skipped()) return;
-  const uint32_t z = blockIdx.z, r = polys == 2 ? z >> 1 : z, p = polys == 2 ? z & 1 : 0, i = blockIdx.y;
-  const uint32_t n = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
-  const uint2 pi = *reinterpret_cast<const uint2 *>(pt.perm[r] + n);
-  const u64 *src = pt.src[r] + ((size_t)p * pt.src_ps[r] + i) * cx.N;
-  ulonglong2 v;
-  v.x = src[pi.x];
-  v.y = src[pi.y];
-  st2(out + (size_t)(2 * r + p) * o_ps + (size_t)i * cx.N + n, v);
-}
-
-// ---- Hoisted rotations: n rotations of ONE ciphertext share the digit decomposition of c1.
-// SEAL rotates first and decomposes sigma(c1) (Evaluator::rotate_internal -> apply_galois_ntt ->
-// switch_key_inplace; seal_executor.h:181/:188): digit J of the rotated polynomial is
-// sigma(t_J) with the sign flips taken modulo q_J, i.e. as an integer polynomial
-//     t'_J = sigma_Z(t_J) + q_J * s,   s[k'] = 1 where sigma flips the sign at k' and t_J[k] != 0
-// (sigma_Z = the automorphism with integer negation).  NTT_I is linear and commutes with sigma
-// as the NTT-domain index permutation, so under every output prime q_I
-//     NTT_I(t'_J) = perm(NTT_I(t_J)) + (q_J mod q_I) * NTT_I(s)
-// and the key inner product of the rotated ciphertext is
-//     sum_J perm(D[I][J]) * key[J][K][I]  +  NTT_I(s) * sum_J (q_J mod q_I) * key[J][K][I]
-// with D = the transformed digits of the UNROTATED c1 (computed once) and a second term that is a
-// constant of (Galois element, level): the same residues SEAL gets, 1/n of the transforms.
-// The identity needs t_J[k] != 0 at the flipped positions: where t_J[k] = 0 the true digit is 0, not
-// q_J, so the sum above is too large by (q_J mod q_I) * NTT_I(X^k') * key[J][K][I].  Zero coefficients
-// are rare (N / q_J per limb: ~2^-44 at 60 bits, but 6 % of the ciphertexts for N = 2^16 and one of
-// EVA's 20-bit primes), so the inverse transform records them and k_hoist_fix subtracts their terms
-// one by one (NTT_I(X^k')[n] = psi_I^((2 brv(n) + 1) k')).  More than HOIST_ZERO_CAP zeros (a
-// transparent ciphertext) make the guarded, unhoisted launch set recompute the outputs instead.
-// Where the gathers go.  The first term above reads l (l+1) digit rows per pair THROUGH the permutation — a gather for every
-// multiply.  Substituting m = perm(n):
-//     sum_J D[I][J][m] * key[J][K][I][perm^-1(m)]                       — elementwise in the SOURCE's index space m
-// so with a copy of the key whose rows are read through perm^-1 (KeyDev::d_perm, built at the first hoisted use) and the
-// constant term stored the same way, the whole inner product is coalesced loads and the digits of a source are loaded
-// once for all the rotations a workgroup serves.  The result E[z][K][I][m] stays in the source's index space; the
-// rotated value is E[perm(n)], and its consumers — the mod-down's special-row inverse transform (OpPlainG) and its
-// combine epilogue (OpModDownG / moddown_sum_kernel) — read it through the pair's table: 2 (l+1) gathered rows per pair
-// instead of l (l+1), and none inside the multiply loop.
-//
-// E[z][K][I][m] = sum_J D_s[I][J][m] * keyp_z[J][K][I][m] + corrp_z[K][I][m]  (+ P * c0_s[I][m] for K = 0, I < l: the
-//   rotated c0 the key-switch result is added to, carried through the mod-down by its factor P as KS_FOLDADD does)
-// D_s[I][J] is row (I * l + J) of source s's converted digits, or limb J of the source's own c1 when I == J (SEAL's
-// shortcut: the NTT-form limb is used as is).
-// A workgroup serves a TILE of up to HT_S sources x HT_R Galois elements (every combination that is a pair of the chunk):
-// per digit J it loads HT_S digit words and 2 HT_R key words and does 2 HT_S HT_R multiply-accumulates, so digits are
-// shared by the elements of a tile and keys by its sources (the instances of a batched handle, the three convolutions
-// of Harris).  grid = (N / 256, l + 1, tiles), one coefficient per thread.
-// The tile shape (TS sources x TR elements, TS TR <= 8) is a template parameter chosen per launch from the chunk's
-// shape, and every tile of a launch is full — short ones are padded with repeats whose results are not stored — so the
-// loops below have no exits: all TS + 2 TR loads of a digit step are in flight together.
-constexpr int HT_TILES = 32; // tiles per launch (the tables travel as kernel arguments)
-struct HoistMacTab {
-  const u64 *c1[KS_BATCH_MAX];    // per source of the chunk: its c1 (NTT form); c0 = c1 - c1_ps * N
-  uint32_t c1_ps[KS_BATCH_MAX];   // poly stride in units of N coefficients
-  uint32_t dg[KS_BATCH_MAX];      // index of the source among the set's transformed digits
-  const u64 *keyp[KS_BATCH_MAX];  // per Galois element of the chunk: the permuted key, the permuted constant [2][l+1][N]
-  const u64 *corrp[KS_BATCH_MAX];
-  // per tile, one byte per entry: sources [0..1], elements [2..3], pair (output slot) of combination s * TR + r [4..5]
-  // (0xff: not a pair of the chunk)
-  uint32_t tile[HT_TILES][6];
-};
-struct HoistFixTab { // per pair (k_hoist_fix)
-  const uint32_t *perm[KS_BATCH_MAX];
-  const u64 *key[KS_BATCH_MAX]; // the key as uploaded
-  uint32_t elt[KS_BATCH_MAX];
-  uint8_t src[KS_BATCH_MAX];    // index of the source among the set's transformed digits
-};
-// corrp[K][I][m] = corr[K][I][pinv[m]],  corr[K][I][n] = sign[kap][n] * sum_J (q_J mod q_kap) * key[J][K][kap][n]   (kap = prime of row I)
-__global__ void __launch_bounds__(256)
-k_hoist_corr(DevCtx cx, const u64 *sign, const u64 *key, const uint32_t *pinv, u64 *corr, uint32_t l) {
-  const uint32_t I = blockIdx.y, K = blockIdx.z, kap = (I == l) ? cx.k - 1 : I;
-  const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = pinv[m];
-  const DevPrime pm = cx.primes[kap];
-  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
-  u64 acc = 0;
-  for (uint32_t J = 0; J < l; J++) {
-    const u64 qj = cx.primes[J].q % pm.q; // 0 when J == I
-    acc = addmod(acc, mulmod(qj, key[J * key_digit + ((size_t)K * cx.k + kap) * N + n], pm), pm.q);
-  }
-  corr[((size_t)K * (l + 1) + I) * N + m] = mulmod(sign[(size_t)kap * N + n], acc, pm);
-}
-// keyp[row][m] = key[row][pinv[m]] for every row of the key; grid = (N / 256, rows)
-__global__ void __launch_bounds__(256)
-k_key_perm(const u64 *key, const uint32_t *pinv, u64 *out, uint32_t N) {
-  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-  out[(size_t)blockIdx.y * N + m] = key[(size_t)blockIdx.y * N + pinv[m]];
-}
-template <int TS, int TR>
-__global__ void __launch_bounds__(256)
-k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistMacTab tab, uint32_t tile0, u64 *prod, size_t prod_bs, uint32_t l, bool fold_c0) {
-  const uint32_t I = blockIdx.y, kap = (I == l) ? cx.k - 1 : I;
-  const uint32_t *tw = tab.tile[tile0 + blockIdx.z]; // wave-uniform: scalar loads, the bytes are cut out with scalar shifts
-  const u64 srcs = tw[0] | ((u64)tw[1] << 32), rots = tw[2] | ((u64)tw[3] << 32), outs = tw[4] | ((u64)tw[5] << 32);
-  const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const DevPrime pm = cx.primes[kap];
-  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
-  const u64 *dgp[TS], *own[TS], *kp[TR];
-#pragma unroll
-  for (int s = 0; s < TS; s++) {
-    const uint32_t si = (uint32_t)(srcs >> (8 * s)) & 0xffu;
-    dgp[s] = digits + tab.dg[si] * dg_bs + (size_t)I * l * N + m;
-    own[s] = tab.c1[si] + m;
-  }
-#pragma unroll
-  for (int r = 0; r < TR; r++) kp[r] = tab.keyp[(uint32_t)(rots >> (8 * r)) & 0xffu] + (size_t)kap * N + m;
-  u128_t a0[TS][TR], a1[TS][TR];
-#pragma unroll
-  for (int s = 0; s < TS; s++)
-#pragma unroll
-    for (int r = 0; r < TR; r++) a0[s][r] = a1[s][r] = {0, 0};
-  // operands are canonical (< q < 2^60): 256 products fit the 128-bit accumulators, l <= k - 1 < 64
-#pragma unroll 2
-  for (uint32_t J = 0; J < l; J++) {
-    u64 d[TS], k0[TR], k1[TR];
-#pragma unroll
-    for (int s = 0; s < TS; s++) d[s] = (I == J) ? own[s][(size_t)J * N] : dgp[s][(size_t)J * N];
-#pragma unroll
-    for (int r = 0; r < TR; r++) {
-      k0[r] = kp[r][J * key_digit];
-      k1[r] = kp[r][J * key_digit + (size_t)cx.k * N];
-    }
-    __builtin_amdgcn_sched_barrier(0); // all the loads of the step are issued before the first multiply waits for one
-#pragma unroll
-    for (int r = 0; r < TR; r++)
-#pragma unroll
-      for (int s = 0; s < TS; s++) {
-        acc128(a0[s][r], d[s], k0[r]);
-        acc128(a1[s][r], d[s], k1[r]);
-      }
-  }
-  if (fold_c0 && I < l) { // block-uniform
-    const u64 pmod = cx.modq[(size_t)(cx.k - 1) * cx.k + kap].x; // P mod q_I
-#pragma unroll
-    for (int s = 0; s < TS; s++) {
-      const uint32_t si = (uint32_t)(srcs >> (8 * s)) & 0xffu;
-      const u64 c0v = (own[s] - (size_t)tab.c1_ps[si] * N)[(size_t)I * N];
-#pragma unroll
-      for (int r = 0; r < TR; r++) acc128(a0[s][r], c0v, pmod);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < TR; r++) {
-    const u64 *cr = tab.corrp[(uint32_t)(rots >> (8 * r)) & 0xffu] + (size_t)I * N + m;
-    const u64 c0 = cr[0], c1c = cr[(size_t)(l + 1) * N];
-#pragma unroll
-    for (int s = 0; s < TS; s++) {
-      const uint32_t z = (uint32_t)(outs >> (8 * (s * TR + r))) & 0xffu;
-      if (z == 0xffu) continue; // padding, or a (source, element) combination that is not a pair of the chunk
-      u64 *pr = prod + z * prod_bs + (size_t)I * N + m;
-      pr[0] = addmod(barrett128(a0[s][r], pm), c0, pm.q);
-      pr[(size_t)(l + 1) * N] = addmod(barrett128(a1[s][r], pm), c1c, pm.q);
-    }
-  }
-}
-
-// zeros[0] (low word) = number of zero digit coefficients seen, zeros[1 + e] = (source << 48 | J << 32 | k).
-// grid = (N / 256, l + 1, pairs), one coefficient n of the ROTATED polynomial per thread — its term is subtracted where
-// the inner product keeps it, at perm[n]; every test below is block-uniform.
-__global__ void __launch_bounds__(256)
-k_hoist_fix(DevCtx cx, const u64 *zeros, HoistFixTab tab, u64 *prod, size_t prod_bs, uint32_t l) {
-  const uint32_t count = *reinterpret_cast<const uint32_t *>(zeros);
-  if (count == 0 || count > HOIST_ZERO_CAP) return;
-  const uint32_t I = blockIdx.y, kap = (I == l) ? cx.k - 1 : I;
-  const uint32_t z = blockIdx.z, b = tab.src[z];
-  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-  const DevPrime pm = cx.primes[kap];
-  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
-  const uint32_t en = 2u * (__brev(n) >> (32 - cx.logN)) + 1u; // slot n holds the evaluation at psi^en
-  const ulonglong2 *tw = cx.tw_fwd + (size_t)kap * N;
-  const u64 *key = tab.key[z] + (size_t)kap * N + n;
-  u64 acc0 = 0, acc1 = 0;
-  bool any = false;
-  for (uint32_t e = 0; e < count; e++) {
-    const u64 ent = zeros[1 + e];
-    const uint32_t J = (uint32_t)(ent >> 32) & 0xffffu, k = (uint32_t)ent;
-    if ((uint32_t)(ent >> 48) != b || J >= l || J == kap) continue; // q_J mod q_J = 0
-    const u64 raw = (u64)k * tab.elt[z];
-    if (!((raw >> cx.logN) & 1)) continue; // the automorphism does not flip this coefficient
-    const uint32_t kp = (uint32_t)raw & (uint32_t)(N - 1);
-    const uint32_t m = (uint32_t)(((u64)en * kp) & (2 * N - 1));
-    u64 w = tw[__brev(m & (uint32_t)(N - 1)) >> (32 - cx.logN)].x; // psi^(m mod N)
-    if (m >= N) w = negmod(w, pm.q);
-    const u64 t = mulmod(cx.primes[J].q % pm.q, w, pm);
-    acc0 = addmod(acc0, mulmod(t, key[J * key_digit], pm), pm.q);
-    acc1 = addmod(acc1, mulmod(t, key[J * key_digit + (size_t)cx.k * N], pm), pm.q);
-    any = true;
-  }
-  if (!any) return;
-  u64 *pr = prod + z * prod_bs + (size_t)I * N + tab.perm[z][n];
-  pr[0] = submod(pr[0], acc0, pm.q);
-  pr[(size_t)(l + 1) * N] = submod(pr[(size_t)(l + 1) * N], acc1, pm.q);
-}
-
 bool hoist_wanted(const evah_ctx *c, uint32_t l, uint32_t n, uint32_t B) {
   // hoisting pays when the digit transforms it saves are throughput, not latency (the exact fallback
   // costs a set of empty launches); limb-sharded contexts go through the shard phases instead
@@ -235,13 +32,8 @@ bool hoist_wanted(const evah_ctx *c, uint32_t l, uint32_t n, uint32_t B) {
          (uint64_t)n * B * l * (l + 1) * (c->N >> 11) >= c->tun.hoist_min_tiles;
 }
 
-} // namespace evah
-
-extern "C" {
 
 // NTT-domain permutation table of a Galois element (SEAL GaloisTool::generate_table_ntt), cached
-} // extern "C"
-namespace evah {
 const uint32_t *perm_table(evah_ctx *c, uint32_t elt) {
   auto pit = c->sh->perms.find(elt);
   if (pit != c->sh->perms.end()) return pit->second;
@@ -259,336 +51,10 @@ const uint32_t *perm_table(evah_ctx *c, uint32_t elt) {
   c->sh->perms.emplace(elt, d);
   return d;
 }
-// the inverse table: perm_inv[perm[n]] = n
-static const uint32_t *perm_inv_table(evah_ctx *c, uint32_t elt) {
-  auto pit = c->sh->perms_inv.find(elt);
-  if (pit != c->sh->perms_inv.end()) return pit->second;
-  if (c->capturing) throw std::logic_error("first hoisted use of a Galois element cannot be captured into a graph");
-  const size_t N = c->N;
-  std::vector<uint32_t> inv(N);
-  for (uint32_t i = 0; i < N; i++) {
-    uint32_t reversed = bitrev((uint32_t)N + i, c->logN + 1);
-    u64 raw = (((u64)elt * reversed) >> 1) & (u64)(N - 1);
-    inv[bitrev((uint32_t)raw, c->logN)] = i;
-  }
-  uint32_t *d = nullptr;
-  HIPCHK(hipMalloc(&d, sizeof(uint32_t) * N));
-  HIPCHK(hipMemcpy(d, inv.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
-  c->sh->perms_inv.emplace(elt, d);
-  return d;
-}
 } // namespace evah
+
 extern "C" {
 
-// Hoisted rotations, tables (first use of a Galois element / level: not capturable, like perm_table).
-// sign[k][N]: NTT under every prime of the 0/1 polynomial marking the coefficients whose sign the
-// automorphism flips (SEAL GaloisTool::apply_galois: index_raw = i * elt, bit logN of it set).
-static const u64 *hoist_sign(evah_ctx *c, uint32_t elt) {
-  auto it = c->sh->hoist_sign.find(elt);
-  if (it != c->sh->hoist_sign.end()) return it->second;
-  if (c->capturing) throw std::logic_error("first hoisted use of a Galois element cannot be captured into a graph");
-  const size_t N = c->N;
-  std::vector<u64> s(N * c->k, 0);
-  for (uint32_t i = 0; i < N; i++) {
-    const u64 raw = (u64)i * elt;
-    if ((raw >> c->logN) & 1) s[raw & (N - 1)] = 1;
-  }
-  for (uint32_t p = 1; p < c->k; p++) std::copy_n(s.begin(), N, s.begin() + (size_t)p * N);
-  u64 *d = nullptr;
-  HIPCHK(hipMalloc(&d, sizeof(u64) * N * c->k));
-  try {
-    HIPCHK(hipMemcpyAsync(d, s.data(), sizeof(u64) * N * c->k, hipMemcpyHostToDevice, c->stream));
-    OpPlain::Params p{d, d, 0, 0, c->k, 0, 0, {}};
-    ntt_forward<OpPlain>(c, p, c->k);
-    HIPCHK(hipStreamSynchronize(c->stream)); // `s` goes out of scope; other queues may use the table next
-  } catch (...) {
-    (void)hipFree(d);
-    throw;
-  }
-  c->sh->hoist_sign.emplace(elt, d);
-  return d;
-}
-static const u64 *hoist_corr(evah_ctx *c, uint32_t elt, uint32_t l, const KeyDev &key) {
-  auto it = c->sh->hoist_corr.find({elt, l});
-  if (it != c->sh->hoist_corr.end()) return it->second;
-  if (c->capturing) throw std::logic_error("first hoisted use of a Galois element cannot be captured into a graph");
-  const u64 *sign = hoist_sign(c, elt);
-  const uint32_t *pinv = perm_inv_table(c, elt);
-  u64 *d = nullptr;
-  HIPCHK(hipMalloc(&d, sizeof(u64) * 2 * (l + 1) * c->N));
-  hipLaunchKernelGGL(k_hoist_corr, dim3(c->N / 256, l + 1, 2), dim3(256), 0, c->stream, c->dev, sign, key.d, pinv, d, l);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (e != hipSuccess) {
-    (void)hipFree(d);
-    HIPCHK(e);
-  }
-  c->sh->hoist_corr.emplace(std::make_pair(elt, l), d);
-  return d;
-}
-// the key of a Galois element with its rows read through the inverse permutation (KeyDev::d_perm), built once per key
-static const u64 *hoist_key(evah_ctx *c, uint32_t elt, KeyDev &key) {
-  if (key.d_perm) return key.d_perm;
-  if (c->capturing) throw std::logic_error("first hoisted use of a Galois key cannot be captured into a graph");
-  const uint32_t *pinv = perm_inv_table(c, elt);
-  u64 *d = nullptr;
-  HIPCHK(hipMalloc(&d, key.bytes));
-  const uint32_t rows = (uint32_t)(key.bytes / (sizeof(u64) * c->N));
-  hipLaunchKernelGGL(k_key_perm, dim3(c->N / 256, rows), dim3(256), 0, c->stream, key.d, pinv, d, (uint32_t)c->N);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream); // other queues may use the copy next
-  if (e != hipSuccess) {
-    (void)hipFree(d);
-    HIPCHK(e);
-  }
-  key.d_perm = d;
-  return d;
-}
-
-// ---- rotation sets.  A set is a list of (source ciphertext, Galois element) pairs at one level,
-// issued KS_BATCH_MAX pairs at a time; pair r of a chunk writes out_d[r][2][l N].
-struct RotPair {
-  const u64 *src;   // c0 of the source ciphertext; c1 = src + src_ps
-  size_t src_ps;
-  uint32_t src_idx; // index into the set's distinct sources (hoisted digits)
-  uint32_t elt;
-  const KeyDev *key;
-  const uint32_t *perm;
-  const u64 *corr;  // hoisting constant of (elt, l) and the permuted key (hoist_prepare); null when the set is not hoisted
-  const u64 *keyp;
-};
-// the tables a hoisted pair needs (first use of an element / level: not capturable, like perm_table)
-static void hoist_prepare(evah_ctx *c, RotPair &p, uint32_t l) {
-  KeyDev &key = c->sh->galois.at(p.elt);
-  p.corr = hoist_corr(c, p.elt, l, key);
-  p.keyp = hoist_key(c, p.elt, key);
-}
-struct RotChunk {
-  uint32_t first, count; // pairs [first, first + count)
-  u64 *out;
-};
-static RotPair rot_pair(evah_ctx *c, const u64 *src, size_t src_ps, uint32_t src_idx, int32_t step, uint32_t l, const char *who) {
-  if (step == 0) throw std::invalid_argument(std::string(who) + ": zero steps are copies, not key switches");
-  RotPair p{src, src_ps, src_idx, 0, nullptr, nullptr, nullptr, nullptr};
-  if (evah_galois_elt_from_step(c, step, &p.elt)) throw std::invalid_argument(g_err);
-  auto kit = c->sh->galois.find(p.elt);
-  if (kit == c->sh->galois.end()) throw std::invalid_argument("Galois key not present");
-  if (kit->second.n_digits < l) throw std::runtime_error("key switching key has too few digits");
-  if (kit->second.rows != c->k) throw std::logic_error("this context holds a limb shard's key rows: use the evah_shard_* entry points");
-  p.key = &kit->second;
-  p.perm = perm_table(c, p.elt);
-  return p;
-}
-static void rot_perm_launch(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t np, u64 *perm_d, uint32_t polys) {
-  PermPairs pt{};
-  for (uint32_t r = 0; r < np; r++) {
-    pt.perm[r] = pr[r].perm;
-    pt.src[r] = pr[r].src;
-    pt.src_ps[r] = (uint32_t)(pr[r].src_ps / c->N);
-  }
-  ProfScope ps(c, KC_EW);
-  hipLaunchKernelGGL(k_galois_perm_pairs, dim3(c->N / 512, l, polys * np), dim3(256), 0, c->stream, c->dev, pt, perm_d, (size_t)l * c->N,
-                     polys);
-  HIPCHK(hipGetLastError());
-}
-// mod-down of a chunk's products (step 3 of switch_key); c0' = perm_d[2r] is added to the even polys
-// perm_d == nullptr: P c0' was added to the products already (KS_FOLDADD)
-// gather != nullptr: prod is indexed in each pair's SOURCE space (k_hoist_mac), read through gather->p[pair]
-static void rot_mod_down(evah_ctx *c, uint32_t l, uint32_t np, u64 *prod_d, const u64 *perm_d, u64 *out_d, u64 *r_d, bool inv1,
-                         const PermTab *gather = nullptr) {
-  const size_t N = c->N, pps = (size_t)l * N;
-  if (gather) {
-    OpPlainG::Params sp{prod_d + (size_t)l * N, r_d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
-    sp.perm_tab = *gather;
-    OpModDownG::Params mp{r_d, N, prod_d, (size_t)(l + 1) * N, perm_d, pps, ~0u, out_d, pps, c->k - 1, l};
-    mp.perm_tab = *gather;
-    inverse_then_forward<OpPlainG, OpModDownG>(c, sp, 2 * np, mp, 2 * np * l, inv1);
-    return;
-  }
-  // INTT of the special limbs, job = r*2 + K
-  OpPlain::Params sp{prod_d + (size_t)l * N, r_d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
-  // mod-down + combine, poly index pp = r*2 + K; c0' (even pp) is added, odd pp start from 0
-  OpModDown::Params mp{r_d, N, prod_d, (size_t)(l + 1) * N, perm_d, pps, ~0u, out_d, pps, c->k - 1, l};
-  inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * np, mp, 2 * np * l, inv1);
-}
-// SEAL's order — rotate, then decompose the rotated c1 (every launch honours c->dev.guard)
-static void rot_chunk_plain(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t np, u64 *out_d) {
-  const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
-  std::vector<const KeyDev *> keys(np);
-  for (uint32_t r = 0; r < np; r++) keys[r] = pr[r].key;
-  Scratch perm(c, (size_t)np * 2 * pps); // [r][c0 permuted | c1 permuted = key-switch target]
-  rot_perm_launch(c, l, pr, np, perm.d, 2);
-  Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N);
-  const bool fold = c->tun.fold_pa && c->tun.fuse_mac;
-  PtrTab adds{}; // P * (permuted c0) joins the inner product of K = 0; nothing is added to K = 1
-  for (uint32_t rr = 0; rr < np && fold; rr++) adds.p[2 * rr] = perm.d + (size_t)rr * 2 * pps;
-  const bool inv1 = switch_key_products(c, l, perm.d + pps, 2 * pps, keys.data(), np, prod.d, nullptr, nullptr,
-                                        fuse_small_launch(c, 2 * np * l) ? r.d : nullptr, fold, fold ? &adds : nullptr);
-  rot_mod_down(c, l, np, prod.d, fold ? nullptr : perm.d, out_d, r.d, inv1);
-}
-// the zero-coefficient record of a hoisted set: d[0] = count, d[1..] = positions (OpPlainZ, k_hoist_fix), preceded in the
-// same allocation by one barrier word per chunk for the persistent fallback; everything that must start at zero is
-// cleared by one memset
-struct ZeroFlag {
-  Scratch s;
-  u64 *d;
-  ZeroFlag(evah_ctx *c, size_t chunks) : s(c, chunks + 1 + HOIST_ZERO_CAP), d(s.d + chunks) {
-    HIPCHK(hipMemsetAsync(s.d, 0, sizeof(u64) * (chunks + 1), c->stream));
-  }
-  u64 *bar(size_t chunk) const { return s.d + chunk; }
-};
-// launches issued while one of these lives return at once unless more than HOIST_ZERO_CAP zero digit coefficients were recorded
-struct GuardScope {
-  evah_ctx *c;
-  GuardScope(evah_ctx *c_, const uint32_t *g) : c(c_) { c->dev.guard = g; c->dev.guard_min = HOIST_ZERO_CAP; }
-  ~GuardScope() { c->dev.guard = nullptr; }
-};
-// the exact fallback of one chunk as one persistent launch (rot_fallback.hip.h); call inside a GuardScope.
-// rot_out: the chunk's outputs [np][2][l N] (plain rotation sets) or null with the window tables of the chunk
-static uint32_t cu_count(int device) {
-  static std::mutex mu;
-  static std::map<int, uint32_t> known;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = known.find(device);
-  if (it != known.end()) return it->second;
-  int n = 0;
-  HIPCHK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device));
-  return known[device] = (uint32_t)std::max(n, 1);
-}
-static void rot_fallback_launch(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t np, u64 *rot_out, const WinSumTab *wt, uint32_t n_win, int F,
-                                size_t out_ps, u64 *bar_word) {
-  if (!c->dev.guard) throw std::logic_error("the rotation fallback runs under its guard only");
-  const size_t N = c->N, lN = (size_t)l * N;
-  FbPairs fp{};
-  for (uint32_t r = 0; r < np; r++) {
-    fp.perm[r] = pr[r].perm;
-    fp.src[r] = pr[r].src;
-    fp.key[r] = pr[r].key->d;
-    fp.src_ps[r] = (uint32_t)(pr[r].src_ps / N);
-  }
-  Scratch rc1(c, np * lN), t(c, np * lN), dig(c, np * lN), prod(c, (size_t)np * 2 * (l + 1) * N), r(c, (size_t)np * 2 * N), u(c, (size_t)np * 2 * lN);
-  if (!c->sh->fb_error) { // first use on this device state
-    if (c->capturing) throw std::logic_error("first hoisted rotation set cannot be captured into a graph");
-    void *h = nullptr, *d = nullptr;
-    HIPCHK(hipHostMalloc(&h, sizeof(uint32_t), hipHostMallocMapped));
-    *static_cast<uint32_t *>(h) = 0;
-    HIPCHK(hipHostGetDevicePointer(&d, h, 0));
-    c->sh->fb_error = static_cast<volatile uint32_t *>(h);
-    c->sh->fb_error_dev = static_cast<uint32_t *>(d);
-  }
-  FbBufs b{rc1.d, t.d, dig.d, prod.d, r.d, u.d, reinterpret_cast<unsigned *>(bar_word), c->sh->fb_error_dev};
-  // one workgroup per CU at most: the whole grid is resident, which the grid-wide barriers rely on
-  const uint32_t grid = std::min<uint32_t>(cu_count(c->device), 256);
-  WinSumTab none{};
-  ProfScope ps(c, KC_EW);
-  if (F == 0) hipLaunchKernelGGL((k_rot_fallback<0>), dim3(grid), dim3(256), 0, c->stream, c->dev, fp, np, l, b, rot_out, none, 0u, (size_t)0);
-  else if (F == 1) hipLaunchKernelGGL((k_rot_fallback<1>), dim3(grid), dim3(256), 0, c->stream, c->dev, fp, np, l, b, (u64 *)nullptr, *wt, n_win, out_ps);
-  else hipLaunchKernelGGL((k_rot_fallback<2>), dim3(grid), dim3(256), 0, c->stream, c->dev, fp, np, l, b, (u64 *)nullptr, *wt, n_win, out_ps);
-  HIPCHK(hipGetLastError());
-}
-// kernel-argument tables of one chunk of hoisted pairs: the tile shape for the chunk and its tiles
-struct HoistTiles {
-  int TS = 1, TR = 1;
-  uint32_t n_tiles = 0;
-  std::vector<std::array<uint32_t, 6>> tiles; // HT_TILES at a time go into HoistMacTab::tile
-};
-static HoistTiles hoist_tables(const RotPair *pr, uint32_t np, size_t N, HoistMacTab &mt, HoistFixTab &ft) {
-  std::vector<uint32_t> srcs, elts; // the chunk's distinct sources (by digit index) and Galois elements
-  std::vector<uint32_t> ps(np), pe(np);
-  for (uint32_t r = 0; r < np; r++) {
-    ft.perm[r] = pr[r].perm;
-    ft.key[r] = pr[r].key->d;
-    ft.elt[r] = pr[r].elt;
-    ft.src[r] = (uint8_t)pr[r].src_idx;
-    size_t si = std::find(srcs.begin(), srcs.end(), pr[r].src_idx) - srcs.begin();
-    if (si == srcs.size()) {
-      srcs.push_back(pr[r].src_idx);
-      mt.c1[si] = pr[r].src + pr[r].src_ps;
-      mt.c1_ps[si] = (uint32_t)(pr[r].src_ps / N);
-      mt.dg[si] = pr[r].src_idx;
-    }
-    size_t ei = std::find(elts.begin(), elts.end(), pr[r].elt) - elts.begin();
-    if (ei == elts.size()) {
-      elts.push_back(pr[r].elt);
-      mt.keyp[ei] = pr[r].keyp;
-      mt.corrp[ei] = pr[r].corr;
-    }
-    ps[r] = (uint32_t)si;
-    pe[r] = (uint32_t)ei;
-  }
-  // shape: as many sources as the chunk has (up to 4), then as many elements as 8 accumulator pairs allow
-  HoistTiles ht;
-  const size_t S = srcs.size(), R = elts.size();
-  // (8 x 1 for the instances of a batched handle reads every key once but every digit row eight times: 14.3 k against
-  // 14.5 k DAGs/s with 4 x 2 on config 4; 1 x 8 needs 159 VGPRs; a 64-VGPR ceiling for 8 waves per SIMD spills: 9.8 k)
-  ht.TS = S >= 4 ? 4 : (int)S;
-  const int tr_max = ht.TS <= 2 ? 4 : 2; // (1 x 2 instead of 1 x 4: the same; 3 x 1 instead of 3 x 2: Harris +2.5 %)
-  ht.TR = 1;
-  while (ht.TR < tr_max && (size_t)ht.TR < R) ht.TR *= 2;
-  // tiles: TR elements x TS sources, taken greedily in pair order (a rectangular set — every source with every element —
-  // fills its tiles completely); short tiles repeat their last entry, the repeats' outputs are 0xff (not stored)
-  std::vector<char> taken(np, 0);
-  for (uint32_t r0 = 0; r0 < np; r0++) {
-    if (taken[r0]) continue;
-    std::vector<uint32_t> te, ts;
-    for (uint32_t q = r0; q < np && te.size() < (size_t)ht.TR; q++)
-      if (!taken[q] && ps[q] == ps[r0] && std::find(te.begin(), te.end(), pe[q]) == te.end()) te.push_back(pe[q]);
-    for (uint32_t q = r0; q < np && ts.size() < (size_t)ht.TS; q++)
-      if (!taken[q] && std::find(te.begin(), te.end(), pe[q]) != te.end() && std::find(ts.begin(), ts.end(), ps[q]) == ts.end()) ts.push_back(ps[q]);
-    uint8_t b[24];
-    for (int i = 0; i < 8; i++) {
-      b[i] = (uint8_t)ts[std::min<size_t>(i, ts.size() - 1)];
-      b[8 + i] = (uint8_t)te[std::min<size_t>(i, te.size() - 1)];
-      b[16 + i] = 0xff;
-    }
-    for (size_t si = 0; si < ts.size(); si++)
-      for (size_t ei = 0; ei < te.size(); ei++)
-        for (uint32_t q = r0; q < np; q++)
-          if (!taken[q] && ps[q] == ts[si] && pe[q] == te[ei]) {
-            b[16 + si * ht.TR + ei] = (uint8_t)q;
-            taken[q] = 1;
-            break;
-          }
-    std::array<uint32_t, 6> w{};
-    for (int i = 0; i < 6; i++) w[i] = b[4 * i] | (uint32_t)b[4 * i + 1] << 8 | (uint32_t)b[4 * i + 2] << 16 | (uint32_t)b[4 * i + 3] << 24;
-    ht.tiles.push_back(w);
-  }
-  ht.n_tiles = (uint32_t)ht.tiles.size();
-  return ht;
-}
-// the hoisted inner products of a chunk (k_hoist_mac), HT_TILES tiles per launch
-static void hoist_mac_launch(evah_ctx *c, HoistMacTab &mt, const HoistTiles &ht, const u64 *dg, size_t dg_bs, u64 *prod, size_t prod_bs, uint32_t l,
-                             bool fold) {
-  ProfScope ps(c, KC_KSMAC);
-  for (uint32_t t0 = 0; t0 < ht.n_tiles; t0 += HT_TILES) {
-    const uint32_t n = std::min<uint32_t>(HT_TILES, ht.n_tiles - t0);
-    for (uint32_t t = 0; t < n; t++)
-      for (int i = 0; i < 6; i++) mt.tile[t][i] = ht.tiles[t0 + t][i];
-#define HM(S_, R_)                                                                                                                     \
-  if (ht.TS == S_ && ht.TR == R_) {                                                                                                    \
-    hipLaunchKernelGGL((k_hoist_mac<S_, R_>), dim3(c->N / 256, l + 1, n), dim3(256), 0, c->stream, c->dev, dg, dg_bs, mt, 0u, prod, prod_bs, l, fold); \
-    HIPCHK(hipGetLastError());                                                                                                         \
-    continue;                                                                                                                          \
-  }
-    HM(1, 1) HM(1, 2) HM(1, 4) HM(2, 1) HM(2, 2) HM(2, 4) HM(3, 1) HM(3, 2) HM(4, 1) HM(4, 2)
-#undef HM
-    throw std::logic_error("hoisted inner product: no kernel for this tile shape");
-  }
-}
-// digits of the unrotated c1 of every source, once: coefficient form (zeros recorded in flag_d), then the full
-// transforms under every output prime into dg_d[source][(l+1) l N]; t_d: n_src * l * N words of scratch
-static void hoist_digits(evah_ctx *c, uint32_t l, const std::vector<const u64 *> &srcs, const std::vector<size_t> &src_ps, u64 *flag_d,
-                         u64 *t_d, u64 *dg_d) {
-  const size_t N = c->N, dg_bs = (size_t)(l + 1) * l * N;
-  const uint32_t n_src = (uint32_t)srcs.size();
-  PtrTab c1{};
-  for (uint32_t i = 0; i < n_src; i++) c1.p[i] = srcs[i] + src_ps[i];
-  OpPlainZ::Params ip{nullptr, t_d, 0, (size_t)l * N, l, 0, 0, c1};
-  ip.zero_list = flag_d;
-  ntt_inverse<OpPlainZ>(c, ip, n_src * l);
-  OpKsDigit::Params dp{t_d, dg_d, l, (size_t)l * N, dg_bs, 0, l + 1};
-  ntt_forward<OpKsDigit>(c, dp, n_src * (l + 1) * l);
-}
 // The whole set.  hoisted: the digits of every distinct source are transformed once and each pair's
 // key inner product is formed from them (k_hoist_mac / k_hoist_fix), then the unhoisted launches
 // follow under the device-side guard.  srcs[i] = c0 of distinct source i (poly stride src_ps[i]).
@@ -758,312 +224,6 @@ int evah_rotate_pairs(evah_ctx *c, const evah_ct *const *cts, const int32_t *ste
     t->scale = cts[r]->scale;
     outs[r] = t;
   }
-  API_END
-}
-
-// ---- window sums: sums of plaintext-weighted rotations with the rotated ciphertexts never written (moddown_sum_kernel)
-} // extern "C"
-namespace evah {
-// the guarded fallback's sums: the same outputs from rotated ciphertexts rot[pair][2][l N] (rot_chunk_plain)
-template <int F>
-__global__ void __launch_bounds__(256)
-k_window_sums(DevCtx cx, WinSumTab ws, const u64 *rot, size_t rot_ps, size_t out_ps) {
-  if (cx.skipped()) return;
-  const uint32_t i = blockIdx.y, w = blockIdx.z >> 1, K = blockIdx.z & 1u;
-  const size_t off = (size_t)i * cx.N + 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
-  const DevPrime pm = cx.primes[cx.prime_of(i)];
-  u128_t acc[F][2];
-#pragma unroll
-  for (int f = 0; f < F; f++) acc[f][0] = acc[f][1] = {0, 0};
-  auto mac = [&](int f, const ulonglong2 &v, const u64 *wt) {
-    ulonglong2 x;
-    x.x = x.y = 1;
-    if (wt) x = ld2(wt + off);
-    acc128(acc[f][0], v.x, x.x);
-    acc128(acc[f][1], v.y, x.y);
-  };
-  const uint32_t first = ws.first[w], cnt = ws.count[w];
-  for (uint32_t t = first; t < first + cnt; t++) {
-    const ulonglong2 v = ld2(rot + (size_t)(2 * t + K) * rot_ps + off);
-    mac(0, v, ws.w0[t]);
-    if constexpr (F > 1) mac(1, v, ws.w1[t]);
-  }
-  if (ws.id_src[w]) {
-    const ulonglong2 v = ld2(ws.id_src[w] + (size_t)K * ws.id_ps[w] * cx.N + off);
-    mac(0, v, ws.id_w0[w]);
-    if constexpr (F > 1) mac(1, v, ws.id_w1[w]);
-  }
-#pragma unroll
-  for (int f = 0; f < F; f++) {
-    ulonglong2 r;
-    r.x = barrett128(acc[f][0], pm);
-    r.y = barrett128(acc[f][1], pm);
-    st2((f ? ws.out1[w] : ws.out0[w]) + (size_t)K * out_ps + off, r);
-  }
-}
-template <int P>
-static void launch_moddown_sum(evah_ctx *c, uint32_t l, uint32_t n_win, int F, const WinSumTab &wt, const PermTab &perms, const u64 *mid, size_t mid_ps,
-                               const u64 *prod, size_t prod_ps, size_t out_ps) {
-  ProfScope ps(c, KC_MODDOWN_B);
-  const int logC = 8 - P;
-  const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) + ((size_t)1 << (logC + P)) * sizeof(ulonglong2);
-  const dim3 grid(c->N / 256, l, 2 * n_win);
-  if (F == 1) hipLaunchKernelGGL((moddown_sum_kernel<P, 1>), grid, dim3(64), lds, c->stream, c->dev, wt, perms, mid, mid_ps, prod, prod_ps, out_ps, logC);
-  else hipLaunchKernelGGL((moddown_sum_kernel<P, 2>), grid, dim3(64), lds, c->stream, c->dev, wt, perms, mid, mid_ps, prod, prod_ps, out_ps, logC);
-  HIPCHK(hipGetLastError());
-}
-} // namespace evah
-extern "C" {
-
-// out[s] = sum_t pts[s][t] (*) rotate(cts[t], steps[t]) for the sums s of every window (include/eva_hip.h).
-int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int32_t *steps, const uint32_t *win_terms, const uint32_t *win_sums,
-                              uint32_t n_windows, const evah_pt *const *pts, evah_ct **outs) {
-  API_BEGIN
-  use(c);
-  if (n_windows < 1) throw std::invalid_argument("rotate_weighted_sums needs at least one window");
-  uint32_t n_terms = 0, n_sums = 0;
-  for (uint32_t w = 0; w < n_windows; w++) {
-    if (win_terms[w] < 1 || win_terms[w] > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("a window has 1..64 terms");
-    if (win_sums[w] < 1) throw std::invalid_argument("a window has at least one sum");
-    n_terms += win_terms[w];
-    n_sums += win_sums[w];
-  }
-  const uint32_t l = cts[0]->limbs, B = cts[0]->batch;
-  const size_t N = c->N, pps = (size_t)l * N, prod_bs = (size_t)2 * (l + 1) * N;
-  for (uint32_t t = 0; t < n_terms; t++) {
-    const evah_ct *a = cts[t];
-    if (a->size != 2) throw std::invalid_argument("rotate expects a size-2 ciphertext (relinearize first)");
-    if (a->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
-    if (a->batch != B) throw std::invalid_argument("batch size mismatch");
-    acquire(c, a->buf);
-  }
-  // scales as evah_weighted_sum checks them; shape of every window
-  std::vector<double> scales(n_sums);
-  bool fusable = c->tun.win_fuse && c->tun.fold_pa;
-  uint32_t n_rot = 0;
-  std::vector<const evah_ct *> distinct; // sources of rotated terms
-  std::vector<uint32_t> src_of(n_terms, 0);
-  {
-    uint32_t t0 = 0, p0 = 0, s0 = 0;
-    for (uint32_t w = 0; w < n_windows; w++) {
-      const uint32_t nt = win_terms[w], ns = win_sums[w];
-      for (uint32_t s = 0; s < ns; s++)
-        for (uint32_t j = 0; j < nt; j++) {
-          const evah_pt *pt = pts[p0 + s * nt + j];
-          if (pt && pt->limbs != l) throw std::invalid_argument("encrypted and plain parameter mismatch");
-          const double sj = cts[t0 + j]->scale * (pt ? pt->scale : 1.0);
-          if (pt) {
-            check_scale(c, sj, l);
-            acquire(c, pt->buf);
-          }
-          if (j == 0) scales[s0 + s] = sj;
-          else if (!same_scale(sj, scales[s0 + s])) throw std::invalid_argument("scale mismatch");
-        }
-      uint32_t ids = 0;
-      for (uint32_t j = 0; j < nt; j++) {
-        if (steps[t0 + j] == 0) { ids++; continue; }
-        const evah_ct *a = cts[t0 + j];
-        uint32_t si = 0;
-        while (si < distinct.size() && !(distinct[si]->d == a->d && distinct[si]->ps == a->ps)) si++;
-        if (si == distinct.size()) distinct.push_back(a);
-        src_of[t0 + j] = si;
-      }
-      if (ns > 2 || ids > 1 || ids == nt) fusable = false;
-      n_rot += nt - ids;
-      t0 += nt;
-      p0 += nt * ns;
-      s0 += ns;
-    }
-  }
-  fusable = fusable && distinct.size() * B <= (size_t)KS_BATCH_MAX && hoist_wanted(c, l, n_rot, B);
-  auto chk = [&](int rc) {
-    if (rc) throw std::runtime_error(g_err);
-  };
-  std::vector<evah_ct *> made; // outputs created so far (released if a later step throws)
-  struct Temps {
-    evah_ctx *c;
-    std::vector<evah_ct *> v;
-    ~Temps() { for (evah_ct *t : v) if (t) evah_ct_free(c, t); }
-  } rotated{c, std::vector<evah_ct *>(n_terms, nullptr)};
-  try {
-    if (!fusable) {
-      // the general form: the rotations as launch sets (rotate_pairs / rotate_many), then one weighted sum per sum
-      if (B == 1) {
-        std::vector<uint32_t> idx;
-        for (uint32_t t = 0; t < n_terms; t++) if (steps[t] != 0) idx.push_back(t);
-        for (size_t i0 = 0; i0 < idx.size(); i0 += KS_BATCH_MAX) {
-          const uint32_t n = (uint32_t)std::min<size_t>(KS_BATCH_MAX, idx.size() - i0);
-          std::vector<const evah_ct *> in(n);
-          std::vector<int32_t> st(n);
-          std::vector<evah_ct *> out(n, nullptr);
-          for (uint32_t j = 0; j < n; j++) { in[j] = cts[idx[i0 + j]]; st[j] = steps[idx[i0 + j]]; }
-          chk(evah_rotate_pairs(c, in.data(), st.data(), n, out.data()));
-          for (uint32_t j = 0; j < n; j++) rotated.v[idx[i0 + j]] = out[j];
-        }
-      } else {
-        for (uint32_t si = 0; si < distinct.size(); si++) {
-          std::vector<uint32_t> idx;
-          for (uint32_t t = 0; t < n_terms; t++) if (steps[t] != 0 && src_of[t] == si) idx.push_back(t);
-          for (size_t i0 = 0; i0 < idx.size(); i0 += KS_BATCH_MAX) {
-            const uint32_t n = (uint32_t)std::min<size_t>(KS_BATCH_MAX, idx.size() - i0);
-            std::vector<int32_t> st(n);
-            std::vector<evah_ct *> out(n, nullptr);
-            for (uint32_t j = 0; j < n; j++) st[j] = steps[idx[i0 + j]];
-            chk(evah_rotate_many(c, distinct[si], st.data(), n, out.data()));
-            for (uint32_t j = 0; j < n; j++) rotated.v[idx[i0 + j]] = out[j];
-          }
-        }
-      }
-      uint32_t t0 = 0, p0 = 0;
-      for (uint32_t w = 0; w < n_windows; w++) {
-        const uint32_t nt = win_terms[w], ns = win_sums[w];
-        std::vector<const evah_ct *> cc(nt);
-        for (uint32_t j = 0; j < nt; j++) cc[j] = steps[t0 + j] ? rotated.v[t0 + j] : cts[t0 + j];
-        for (uint32_t s = 0; s < ns; s++) {
-          evah_ct *o = nullptr;
-          chk(evah_weighted_sum(c, cc.data(), pts + p0 + s * nt, nt, &o));
-          made.push_back(o);
-        }
-        t0 += nt;
-        p0 += nt * ns;
-      }
-    } else {
-      for (uint32_t s = 0; s < n_sums; s++) made.push_back(ct_new(c, 2, l, scales[s], B));
-      const size_t out_ps = made[0]->ps;
-      // (window, instance) units: the rotated terms of a window for one instance of the batch
-      struct Unit { uint32_t first, count, w, b, t0, p0, s0; };
-      std::vector<RotPair> pairs;
-      std::vector<uint32_t> pair_term; // pair -> its term (position among cts / steps)
-      std::vector<Unit> units;
-      {
-        std::vector<RotPair> term_pair(n_terms);
-        for (uint32_t t = 0; t < n_terms; t++) {
-          if (steps[t] == 0) continue;
-          term_pair[t] = rot_pair(c, cts[t]->d, cts[t]->ps, 0, steps[t], l, "rotate_weighted_sums");
-          hoist_prepare(c, term_pair[t], l);
-        }
-        uint32_t t0 = 0, p0 = 0, s0 = 0;
-        for (uint32_t w = 0; w < n_windows; w++) {
-          const uint32_t nt = win_terms[w], ns = win_sums[w];
-          for (uint32_t b = 0; b < B; b++) {
-            Unit u{(uint32_t)pairs.size(), 0, w, b, t0, p0, s0};
-            for (uint32_t j = 0; j < nt; j++) {
-              if (steps[t0 + j] == 0) continue;
-              RotPair p = term_pair[t0 + j];
-              p.src = cts[t0 + j]->d + (size_t)b * 2 * cts[t0 + j]->ps;
-              p.src_idx = src_of[t0 + j] * B + b;
-              pairs.push_back(p);
-              pair_term.push_back(t0 + j);
-              u.count++;
-            }
-            units.push_back(u);
-          }
-          t0 += nt;
-          p0 += nt * ns;
-          s0 += ns;
-        }
-      }
-      std::vector<const u64 *> srcs(distinct.size() * B);
-      std::vector<size_t> src_ps(distinct.size() * B);
-      for (uint32_t si = 0; si < distinct.size(); si++)
-        for (uint32_t b = 0; b < B; b++) {
-          srcs[si * B + b] = distinct[si]->d + (size_t)b * 2 * distinct[si]->ps;
-          src_ps[si * B + b] = distinct[si]->ps;
-        }
-      // chunks: whole units, at most KS_BATCH_MAX pairs and WIN_MAX units, one number of sums per launch
-      struct Chunk { uint32_t u0, nu, first, np; int F; WinSumTab wt; };
-      std::vector<Chunk> chunks;
-      for (uint32_t u = 0; u < units.size(); u++) {
-        const int F = (int)win_sums[units[u].w];
-        if (chunks.empty() || chunks.back().F != F || chunks.back().nu == (uint32_t)WIN_MAX ||
-            chunks.back().np + units[u].count > (uint32_t)KS_BATCH_MAX)
-          chunks.push_back(Chunk{u, 0, units[u].first, 0, F, WinSumTab{}});
-        Chunk &ch = chunks.back();
-        WinSumTab &wt = ch.wt;
-        const Unit &un = units[u];
-        const uint32_t wi = ch.nu++, nt = win_terms[un.w];
-        wt.first[wi] = (uint8_t)(un.first - ch.first);
-        wt.count[wi] = (uint8_t)un.count;
-        for (uint32_t q = 0; q < un.count; q++) {
-          const uint32_t j = pair_term[un.first + q] - un.t0;
-          const evah_pt *a0 = pts[un.p0 + j], *a1 = F > 1 ? pts[un.p0 + nt + j] : nullptr;
-          wt.w0[un.first - ch.first + q] = a0 ? a0->d : nullptr;
-          wt.w1[un.first - ch.first + q] = a1 ? a1->d : nullptr;
-        }
-        for (uint32_t j = 0; j < nt; j++) {
-          if (steps[un.t0 + j] != 0) continue;
-          const evah_ct *a = cts[un.t0 + j];
-          const evah_pt *a0 = pts[un.p0 + j], *a1 = F > 1 ? pts[un.p0 + nt + j] : nullptr;
-          wt.id_src[wi] = a->d + (size_t)un.b * 2 * a->ps;
-          wt.id_ps[wi] = (uint32_t)(a->ps / N);
-          wt.id_w0[wi] = a0 ? a0->d : nullptr;
-          wt.id_w1[wi] = a1 ? a1->d : nullptr;
-          // a weight of 1 on the unrotated term is distinguished from "no such term" by id_src
-        }
-        wt.out0[wi] = made[un.s0]->d + (size_t)un.b * 2 * out_ps;
-        wt.out1[wi] = F > 1 ? made[un.s0 + 1]->d + (size_t)un.b * 2 * out_ps : nullptr;
-        ch.np += un.count;
-      }
-      ZeroFlag flag(c, chunks.size());
-      const size_t dg_bs = (size_t)(l + 1) * l * N;
-      {
-        Scratch t(c, srcs.size() * l * N), dg(c, srcs.size() * dg_bs);
-        hoist_digits(c, l, srcs, src_ps, flag.d, t.d, dg.d);
-        for (const Chunk &ch : chunks) {
-          const RotPair *pr = pairs.data() + ch.first;
-          const uint32_t np = ch.np;
-          HoistMacTab mt{};
-          HoistFixTab ft{};
-          const HoistTiles tiles = hoist_tables(pr, np, N, mt, ft);
-          Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N), mid(c, (size_t)np * 2 * pps);
-          hoist_mac_launch(c, mt, tiles, dg.d, dg_bs, prod.d, prod_bs, l, true);
-          {
-            ProfScope ps(c, KC_KSMAC);
-            hipLaunchKernelGGL(k_hoist_fix, dim3(c->N / 256, l + 1, np), dim3(256), 0, c->stream, c->dev, flag.d, ft, prod.d, prod_bs, l);
-            HIPCHK(hipGetLastError());
-          }
-          // mod-down: INTT of the special rows (read through the pairs' permutations), first (strided) pass of the
-          // forward transforms into mid, then the second pass with the window's sums as its epilogue
-          OpPlainG::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
-          for (uint32_t q = 0; q < np; q++) sp.perm_tab.p[q] = pr[q].perm;
-          OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, nullptr, pps, ~0u, mid.d, pps, c->k - 1, l};
-          if (fuse_small_launch(c, 2 * np * l)) {
-            launch_pass_p<false, true, OpPlainG>(c, c->logN / 2, sp, 2 * np);
-            launch_inv_fwd<OpModDown>(c, mp, 2 * np * l);
-          } else {
-            ntt_inverse<OpPlainG>(c, sp, 2 * np);
-            launch_pass_p<true, false, OpModDown>(c, (c->logN + 1) / 2, mp, 2 * np * l);
-          }
-          switch (c->logN / 2) {
-          case 5: launch_moddown_sum<5>(c, l, ch.nu, ch.F, ch.wt, sp.perm_tab, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
-          case 6: launch_moddown_sum<6>(c, l, ch.nu, ch.F, ch.wt, sp.perm_tab, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
-          case 7: launch_moddown_sum<7>(c, l, ch.nu, ch.F, ch.wt, sp.perm_tab, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
-          case 8: launch_moddown_sum<8>(c, l, ch.nu, ch.F, ch.wt, sp.perm_tab, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
-          default: throw std::runtime_error("unsupported poly_modulus_degree for the window sums");
-          }
-        }
-      }
-      // exact fallback (more zero digit coefficients than k_hoist_fix handles): the unhoisted rotations, then the sums
-      GuardScope gs(c, reinterpret_cast<const uint32_t *>(flag.d));
-      for (size_t ci = 0; ci < chunks.size(); ci++) {
-        const Chunk &ch = chunks[ci];
-        if (c->tun.fb_persist) {
-          rot_fallback_launch(c, l, pairs.data() + ch.first, ch.np, nullptr, &ch.wt, ch.nu, ch.F, out_ps, flag.bar(ci));
-          continue;
-        }
-        Scratch rot(c, (size_t)ch.np * 2 * pps);
-        rot_chunk_plain(c, l, pairs.data() + ch.first, ch.np, rot.d);
-        const dim3 grid(c->N / 512, l, 2 * ch.nu);
-        if (ch.F == 1) EW_LAUNCH((k_window_sums<1>), grid, dim3(256), 0, c->stream, c->dev, ch.wt, rot.d, pps, out_ps);
-        else EW_LAUNCH((k_window_sums<2>), grid, dim3(256), 0, c->stream, c->dev, ch.wt, rot.d, pps, out_ps);
-        HIPCHK(hipGetLastError());
-      }
-    }
-  } catch (...) {
-    for (evah_ct *t : made) evah_ct_free(c, t);
-    throw;
-  }
-  for (uint32_t s = 0; s < n_sums; s++) outs[s] = made[s];
   API_END
 }
 

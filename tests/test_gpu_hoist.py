@@ -1,5 +1,5 @@
 """Hoisted rotations (several rotations of ONE ciphertext share the digit decomposition of c1;
-eva_amd/csrc/rotate.hip: k_hoist_mac) against the CPU oracle's rotate-then-switch-key, which
+eva_amd/csrc/rotation_sets.hip.h: k_hoist_mac) against the CPU oracle's rotate-then-switch-key, which
 follows SEAL's Evaluator::rotate_internal (/root/reference/eva/seal/seal_executor.h:181,188).
 The contexts are created with EVAH_HOIST_MIN_TILES=0, so every rotate_many of >= 2 steps takes
 the hoisted path; the zero-coefficient cases exercise the per-coefficient correction (k_hoist_fix)
