@@ -414,17 +414,21 @@ def test_window_sums_fused_path_is_the_one_that_runs():
         ctx_env.g.profile(False)
         return [o.download() for o in outs], prof
 
-    fused, pf = run(e)
-    old = os.environ.get("EVAH_WIN_FUSE")
-    os.environ["EVAH_WIN_FUSE"] = "0"
-    try:
-        e0 = Env(*cfg)
-    finally:
-        if old is None:
-            os.environ.pop("EVAH_WIN_FUSE", None)
-        else:
-            os.environ["EVAH_WIN_FUSE"] = old
-    unfused, pu = run(e0)
+    def with_env(settings):
+        saved = {k: os.environ.get(k) for k in settings}
+        os.environ.update(settings)
+        try:
+            return Env(*cfg)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    # both contexts pin the knobs they compare (the suite is also run with the knobs set globally)
+    fused, pf = run(with_env({"EVAH_WIN_FUSE": "1", "EVAH_FOLD_PA": "1", "EVAH_HOIST": "1", "EVAH_FB_PERSIST": "1"}))
+    unfused, pu = run(with_env({"EVAH_WIN_FUSE": "0", "EVAH_FOLD_PA": "1", "EVAH_HOIST": "1", "EVAH_FB_PERSIST": "1"}))
     for x, y in zip(fused, unfused):
         assert np.array_equal(x, y)
     # unfused: the weighted sums are elementwise launches of their own (the guarded fallback's launches are counted on
