@@ -284,7 +284,9 @@ int evah_decrypt_decode(evah_ctx *ctx, const evah_ct *ct, uint32_t n_out, double
  * independent rotations / rescales / relinearizations / ciphertext products of a level go out
  * through the batched entry points, a Relinearize read only by a Rescale is evaluated with it,
  * a Mul read only by such a Relinearize joins them (evah_multiply_relinearize_rescale_many),
- * and multiply_plain / add chains without other readers become one evah_weighted_sum. */
+ * multiply_plain / add chains without other readers become one evah_weighted_sum, and a Rotate whose
+ * readers are all such products (the taps of a convolution window) is not evaluated on its own: the
+ * sums that end at one level and share their rotations go out as one evah_rotate_weighted_sums. */
 enum { EVAH_VAL_NONE = 0, EVAH_VAL_CT = 1, EVAH_VAL_PT = 2 };
 enum { EVAH_OPF_FREE_SRC0 = 1, EVAH_OPF_FREE_SRC1 = 2 };
 typedef struct evah_val { uint32_t kind; void *h; } evah_val;
