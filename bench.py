@@ -1,32 +1,42 @@
 #!/usr/bin/env python
 """bench.py — BASELINE.json's metric on MI355X: homomorphic op-triples/s
-(multiply + relinearize + rescale) at N = 2^16, L = 10 data limbs (k = 11 key primes).
+(multiply + relinearize + rescale) at N = 2^16, L = 10 data limbs (k = 11 key primes), **execute() wall-time**.
 
-One "step" = one batch of --batch independent op-triples through the C-ABI of libeva_hip.so
-(per group of --group triples ONE evah_multiply_relinearize_rescale_many: multiply, relinearize and
-rescale_to_next evaluated together, the size-3 product never stored; --separate-multiply takes
-evah_multiply_many + evah_relinearize_rescale_many — all bit-identical to the three separate SEAL
-calls), groups alternating between --streams issue queues, inputs and the relinearization key already
-resident in HBM.  One process
-per GPU; ranks run independent batches (the path shards over independent ciphertexts — no data-path
-collective), `value` = triples of all ranks / max time over ranks.
+One "step" = --batch independent op-triples through `public_ctx.execute()` — the reference's
+SEALPublic::execute (/root/reference/eva/seal/seal.cpp:104-122, python binding wrapper.cpp:215): a compiled EVA
+program of --group products z_i = x_i * y_i (Mul -> Relinearize -> Rescale each, eager relinearization), one
+execute() call per group on that group's own encrypted valuation.  The valuations were left in HBM by encrypt()
+(a valuation "may hold device handles"), so inputs are resident when the timed region starts, the
+outputs stay resident, execute() is an asynchronous enqueue and consecutive calls alternate between the context's
+two issue queues.  Behind execute() the library scheduler runs each group as ONE
+evah_multiply_relinearize_rescale_many (bit-identical to the three separate SEAL calls).  One process per GPU;
+ranks run independent batches (the path shards over independent ciphertexts — no data-path collective), `value` =
+triples of all ranks / max time over ranks.
 
 `python bench.py --gpus N` with no torch.distributed environment launches the N ranks itself
-(python -m torch.distributed.run, 127.0.0.1); under torchrun it is one rank of the job.
+(python -m torch.distributed.run, 127.0.0.1); under torchrun it is one rank of the job.  EVA_BENCH_BACKEND=gloo
+runs the collectives around the data path over gloo, ranks sharing the visible GPUs (rank r on device r mod
+count) — how a 1-GPU box exercises every multi-rank branch of this file (tests/test_gpu_bench_ranks.py).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline     — SURVEY.md section 8(d) algorithmic bytes of the op-triple x value, over the 8 TB/s
-                 HBM peak (`frac`), plus the dominant kernel class by HIP-event time measured live
-                 inside the timed region on the launch stream
+  roofline     — SURVEY.md section 8(d) algorithmic bytes of the op-triple x value over the 8 TB/s HBM peak
+                 (`frac` = `hbm_frac`), the VALU-issue fraction from the committed SQ-counter pass (`valu_frac`; the
+                 path is integer-issue bound, `bound` says so), the compulsory bytes of one launch set with the key
+                 counted once, and the dominant kernel class by HIP-event time measured live inside the timed region
+                 on the launch streams
   verified     — after the timed region one output per group is downloaded and compared, word for
-                 word, with the CPU oracle's multiply+relinearize+rescale of the same operands
-  execute_path — the same op-triples as a compiled EVA program through public_ctx.execute()
-                 (upload + graph replay + download: the PCIe-inclusive figure, never `value`)
+                 word, with the CPU oracle's multiply+relinearize+rescale of the same operands; the same outputs are
+                 decrypted and compared with x * y
+  raw_cabi     — the same triples by direct C-ABI calls (evah_multiply_relinearize_rescale_many through ctypes),
+                 reported beside the headline, never as it
+  execute_path — host-valuation variants of the headline (pipelined host inputs, full host round trip: the
+                 PCIe-inclusive figures, never `value`)
   dag          — Harris corner detector, N = 2^15, L = 8 (BASELINE config 3): execute() ms and the
                  CPU walk of the same compiled DAG over the oracle (serial and all host cores),
                  north_star's ">= 10x the CPU on Harris" driver-timed
   cpu_baseline — the CPU oracle (kind "port"; "SEAL absent" unless a real SEAL is installed on the
-                 host) on one host core on a bounded sample, and on many cores
+                 host or a pin-kit result is present, tools/pin_with_seal.sh) on one host core on a bounded sample,
+                 and on many cores
 """
 import argparse
 import json
@@ -72,7 +82,8 @@ def self_launch(args):
     """--gpus N without a torch.distributed environment: start the N ranks here."""
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < args.gpus:
+    shared = os.environ.get("EVA_BENCH_BACKEND", "nccl") != "nccl"  # gloo: ranks share the visible GPUs (rank r on device r mod count)
+    if have < (1 if shared else args.gpus):
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -106,20 +117,11 @@ def host_cores():
         return max(1, os.cpu_count() or 1)
 
 
-def execute_leg(N, l, n_products, reps):
-    """The op-triples as a compiled program through public_ctx.execute(): z_i = x_i * y_i with eager
-    relinearization, so every product is Mul -> Relinearize -> Rescale on l limbs.  Three ways of
-    holding the valuations (the valuation "may hold device handles"):
-      resident        inputs left in HBM by encrypt(), outputs left in HBM for decrypt(): execute() is
-                      an asynchronous enqueue; timed as `reps` calls + one synchronize
-      pipelined_host  host inputs (pinned), resident outputs: each call blocks in its own uploads, which
-                      overlap the previous call's kernels on the other issue queue
-      host_roundtrip  host valuations in and out (EVA_RESIDENT=0 behaviour): upload, run, download, per call"""
-    import numpy as np
+def triple_program(n_products, N, l):
+    """z_i = x_i * y_i for i < n_products, compiled with eager relinearization: every product is
+    Mul -> Relinearize -> Rescale on l data limbs (k = l + 1 key primes, all 60-bit) -> (compiled, params, signature)"""
     from eva import EvaProgram, Input, Output
     from eva.ckks import CKKSCompiler
-    from eva.seal import generate_keys
-    from eva_amd.roofline import dag_bytes, roofline as rl
     prog = EvaProgram('op_triples', vec_size=1024)
     with prog:
         for i in range(n_products):
@@ -129,39 +131,30 @@ def execute_leg(N, l, n_products, reps):
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false', 'lazy_relinearize': 'false'}).compile(prog)
     params.poly_modulus_degree = N
     params.prime_bits = [60] * (l + 1)
-    pub, sec = generate_keys(params, 17)
-    rng = np.random.default_rng(5)
-    inputs = {}
-    for i in range(n_products):
-        inputs[f'x{i}'] = list(rng.uniform(-1, 1, 1024))
-        inputs[f'y{i}'] = list(rng.uniform(-1, 1, 1024))
-    enc = pub.encrypt(inputs, sig)              # resident: the ciphertexts stay in HBM
-    nbytes, _ = dag_bytes(compiled, sig, N, l + 1)
+    return compiled, params, sig
 
-    def timed(valuation, n):
-        for _ in range(2):                      # device context / key upload / pools; queue pair warm
-            out = pub.execute(compiled, valuation)
+
+def host_valuation_legs(pub, compiled, enc, n_products, l, N, reps, want):
+    """The headline's execute() with the valuations held on the HOST instead of in HBM (the PCIe-inclusive figures,
+    never `value`):
+      pipelined_host  host inputs (pinned), resident outputs: each call blocks in its own uploads, which
+                      overlap the previous call's kernels on the other issue queue
+      host_roundtrip  host valuations in and out (EVA_RESIDENT=0 behaviour): upload, run, download, per call
+    `want`: z0 of the resident run (the host paths must give the same words)."""
+    import numpy as np
+    enc.to_host(True)                           # host words only from here on (pinned pages)
+
+    def timed(n):
+        for _ in range(2):
+            out = pub.execute(compiled, enc)
         pub.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
-            out = pub.execute(compiled, valuation)
+            out = pub.execute(compiled, enc)
         pub.synchronize()
         return (time.perf_counter() - t0) / n, out
-
-    st0 = pub.transfer_stats()
-    t_res, out = timed(enc, reps)
-    st1 = pub.transfer_stats()
-    moved = {k: st1[k] - st0[k] for k in ("ct_uploads", "ct_downloads")}
-    # check the first and the last product against the oracle's op-triple on the same encrypted inputs and key
-    from oracle import pyoracle as po  # checker only
-    o = po.Oracle(N, list(pub.primes))
-    ok = True
-    for i in (0, n_products - 1):
-        want = o.op_triple(enc.get(f'x{i}')[4], enc.get(f'y{i}')[4], pub.relin_key())
-        ok = ok and bool(np.array_equal(out.get(f'z{i}')[4], want))
-    enc.to_host(True)                           # host words only from here on (pinned pages)
-    t_pipe, out2 = timed(enc, max(3, reps // 2))
-    ok = ok and bool(np.array_equal(out2.get('z0')[4], out.get('z0')[4]))
+    t_pipe, out2 = timed(max(3, reps // 2))
+    ok = bool(np.array_equal(out2.get('z0')[4], want))
     pub.resident = False
     ts, parts = [], []
     for _ in range(max(3, reps // 2) + 2):
@@ -169,24 +162,87 @@ def execute_leg(N, l, n_products, reps):
         out3 = pub.execute(compiled, enc)
         ts.append(time.perf_counter() - t0)
         parts.append(list(pub.last_timing))
+    pub.resident = True
     ts, parts = ts[2:], parts[2:]
     t_host = _median(ts)
-    ok = ok and bool(np.array_equal(out3.get('z0')[4], out.get('z0')[4]))
-    kinds = [str(d["op"]).split(".")[-1] for d in compiled._dump()]
-    pm = [_median([p[j] for p in parts]) for j in range(3)]
+    ok = ok and bool(np.array_equal(out3.get('z0')[4], want))
+    pm = [_median([p_[j] for p_ in parts]) for j in range(3)]
     in_mb = 2 * n_products * 2 * l * N * 8 / 1e6
-    return {"program": f"{n_products} independent products z_i = x_i * y_i (Mul -> Relinearize -> Rescale), N=2^{N.bit_length() - 1}, L={l}",
-            "ops": {kk: kinds.count(kk) for kk in ("Mul", "Relinearize", "Rescale")},
-            "triples_per_s": round(n_products / t_res, 1), "ms_per_execute": round(t_res * 1e3, 3),
-            "valuations": "device-resident (encrypt -> execute -> decrypt by handle; no PCIe, execute() does not wait for the GPU)",
-            "ciphertexts_moved_over_pcie": moved,
-            "roofline": rl(nbytes, t_res),
-            "pipelined_host_inputs": {"triples_per_s": round(n_products / t_pipe, 1), "ms_per_execute": round(t_pipe * 1e3, 3),
+    return {"pipelined_host_inputs": {"triples_per_s": round(n_products / t_pipe, 1), "ms_per_execute": round(t_pipe * 1e3, 3),
                                       "input_mb_per_execute": round(in_mb, 1), "pcie_gb_per_s": round(in_mb / 1e3 / t_pipe, 1),
                                       "note": "PCIe-bound: 21 MB of operands per triple; uploads overlap the previous call's kernels"},
             "host_roundtrip": {"triples_per_s": round(n_products / t_host, 1), "ms_per_execute": round(t_host * 1e3, 3),
                                "ms_upload_enqueue_drain": [round(x, 3) for x in pm],
                                "includes": "input upload (PCIe), run, output download (PCIe), synchronous"},
+            "same_words_as_resident": ok}
+
+
+def raw_cabi_leg(args, N, l, primes, device, steps, warmup):
+    """The same op-triples by direct C-ABI calls through ctypes (one evah_multiply_relinearize_rescale_many per group,
+    groups alternating between --streams issue queues, uniform random residues and key): what the library does without
+    the host side of execute() around it.  Reported beside the headline, never as it."""
+    import numpy as np
+    from eva_amd import backend
+    k = l + 1
+    g = backend.Context(N, primes, device=device)
+    queues = [g] + [g.fork() for _ in range(max(1, args.streams) - 1)]
+    rng = np.random.default_rng(0xE7A)
+
+    def rand(prefix, nl):
+        return np.stack([rng.integers(0, primes[i], size=prefix + (N,), dtype=np.uint64)
+                         for i in range(nl)], axis=len(prefix))
+    key_host = rand((l, 2), k)
+    g.upload_relin_key(key_host)
+    G = max(1, min(args.group, 64, args.batch))
+    pairs, host0 = [], None
+    for i in range(args.batch):
+        a, b = rand((2,), l), rand((2,), l)
+        pairs.append((g.upload_ct(a, 2.0 ** 40), g.upload_ct(b, 2.0 ** 40)))
+        if i == 0:
+            host0 = (a, b)
+
+    def step(keep=None):
+        for gi, i0 in enumerate(range(0, args.batch, G)):
+            q = queues[gi % len(queues)]
+            idx = range(i0, min(i0 + G, args.batch))
+            As, Bs = [pairs[i][0] for i in idx], [pairs[i][1] for i in idx]
+            if args.separate_multiply:
+                ms = q.multiply_many(As, Bs)
+                outs = q.relinearize_rescale_many(ms, 60)
+                hs = ms + outs
+            else:
+                outs = q.multiply_relinearize_rescale_many(As, Bs, 60)
+                hs = outs
+            if keep is not None and i0 == 0:
+                keep.append(outs[0].download())
+            for h in hs:
+                h.free()
+
+    def sync():
+        for q in queues:
+            q.sync()
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    got = []
+    step(keep=got)
+    sync()
+    from oracle import pyoracle as po  # checker only
+    ok = bool(np.array_equal(got[0], po.Oracle(N, primes).op_triple(host0[0], host0[1], key_host)))
+    for a, b in pairs:
+        a.free(); b.free()
+    for q in queues[1:]:
+        q.close()
+    g.close()
+    return {"triples_per_s": round(steps * args.batch / dt, 1), "ms_per_step": round(dt * 1e3 / steps, 4), "steps": steps,
+            "entry_point": "evah_multiply_relinearize_rescale_many" if not args.separate_multiply else
+                           "evah_multiply_many + evah_relinearize_rescale_many",
+            "streams": len(queues), "triples_per_call": G, "inputs": "uniform random residues and key (SURVEY.md 8(d))",
             "bit_exact_vs_oracle": ok}
 
 
@@ -344,7 +400,7 @@ def dag_sharded(args, dist):
     rank's groups over k contexts of its GPU with shard_mode = "dag").  One JSON line on rank 0: DAGs/s of the
     whole job and the achieved-HBM fraction per GPU."""
     import torch
-    world, local = dist.world, dist.local_rank
+    world, local = dist.world, dist.device_index
     dev_name = torch.cuda.get_device_name(local)
     rank_devices = [dev_name]
     if world > 1:
@@ -361,8 +417,10 @@ def dag_sharded(args, dist):
                 "ms_per_step": leg["ms_total"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "u64", "data": "synthetic",
                 "config": {"workload": leg["workload"], "batch": args.dag_batch, "parallelism": leg["partition"],
-                           "members_per_rank": leg["members_per_rank"], "rccl_ranks": world, "rank_devices": rank_devices,
-                           "collectives": "barrier + max-over-ranks of the wall time (torch.distributed nccl = RCCL); none in the data path"},
+                           "members_per_rank": leg["members_per_rank"], "ranks": world, "collectives_backend": dist.backend,
+                           "rccl_ranks": world if dist.backend == "nccl" else 0, "rank_devices": rank_devices,
+                           "collectives": "barrier + max-over-ranks of the wall time (torch.distributed "
+                                          + ("nccl = RCCL" if dist.backend == "nccl" else dist.backend) + "); none in the data path"},
                 "roofline": dict(leg["roofline"], bound="hbm", basis=leg["roofline_basis"]),
                 "verified": {"instances_checked_per_rank": leg["instances_checked_per_rank"], "bit_exact_vs_oracle": True},
                 "cpu_baseline": None, "dag_batch": leg}
@@ -370,27 +428,29 @@ def dag_sharded(args, dist):
     dist.close()
 
 
-def limb_execute_leg(N, l, dist, n_products=8, reps=5):
-    """z_i = x_i * y_i (Mul -> Relinearize -> Rescale each) through public_ctx.execute() with the RNS limbs dealt over
-    the ranks of the job: rank 0's ciphertexts on every rank, the C++ limb-shard evaluator behind execute(), collectives
-    at its exchange steps; rank 0 checks one product against the oracle's op-triple."""
+def limb_sharded(args, dist):
+    """--shard limb: every op-triple is computed by ALL GPUs together, the RNS limbs dealt over them (limb i on shard
+    i mod G; SURVEY.md 8(e) row 3, BASELINE config 5's mode): per key switch one all-gather of the coefficient-form
+    digits and one broadcast, per rescale one broadcast.  The timed region is public_ctx.execute() of the op-triple
+    program with shard_mode = "limb" — the C++ limb-shard evaluator (eva_amd/host/multi_device.h) is the only driver
+    of the protocol.  Under torchrun every rank is one shard and its exchange steps are collectives on the library's
+    device buffers (eva_amd.dist.attach_limb_dist: RCCL, or gloo staged through the host under EVA_BENCH_BACKEND=gloo);
+    with one process, --shards G runs G shards on the one GPU with one gather launch per receiving shard as the
+    exchange (what a 1-GPU box can measure: the cost of the phase structure, not xGMI)."""
     import numpy as np
     import torch.distributed as tdd
-    from eva import EvaProgram, Input, Output
-    from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys, SEALValuation
     from eva_amd.dist import attach_limb_dist
-    prog = EvaProgram('op_triples', vec_size=1024)
-    with prog:
-        for i in range(n_products):
-            Output(f'z{i}', Input(f'x{i}') * Input(f'y{i}'))
-    prog.set_input_scales(60)
-    prog.set_output_ranges(20)
-    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false', 'lazy_relinearize': 'false'}).compile(prog)
-    params.poly_modulus_degree = N
-    params.prime_bits = [60] * (l + 1)
-    pub, sec = generate_keys(params, 17)  # the same keys on every rank (seeded)
-    pub.device = dist.device_index
+    N, l = 1 << args.logn, args.limbs
+    world = dist.world
+    n_products = max(1, min(args.batch, 8))
+    compiled, params, sig = triple_program(n_products, N, l)
+    G = world if world > 1 else max(2, args.shards)
+    if world > 1:
+        pub, sec = generate_keys(params, 17)  # the same keys on every rank (seeded)
+        pub.device = dist.device_index
+    else:
+        pub, sec = generate_keys(params, 17, devices=[dist.device_index] * G, shard="limb")
     rng = np.random.default_rng(5)
     inputs = {}
     for i in range(n_products):
@@ -398,120 +458,57 @@ def limb_execute_leg(N, l, dist, n_products=8, reps=5):
         inputs[f'y{i}'] = list(rng.uniform(-1, 1, 1024))
     enc = pub.encrypt(inputs, sig)
     enc.to_host(True)
-    box = [{n: enc.get(n) for n in enc.names()} if dist.rank == 0 else None]
-    tdd.broadcast_object_list(box, src=0)  # encryption draws fresh randomness: every rank works on rank 0's ciphertexts
-    enc = SEALValuation()
-    for n, (kind, size, limbs, scale, data) in box[0].items():
-        enc._set_cipher(n, data, scale)
-    attach_limb_dist(pub, dist)
-    out = pub.execute(compiled, enc)
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    if world > 1:
+        box = [{n: enc.get(n) for n in enc.names()} if dist.rank == 0 else None]
+        tdd.broadcast_object_list(box, src=0)  # encryption draws fresh randomness: every rank works on rank 0's ciphertexts
+        enc = SEALValuation()
+        for n, (kind, size, limbs, scale, data) in box[0].items():
+            enc._set_cipher(n, data, scale)
+        attach_limb_dist(pub, dist)
+    for _ in range(max(1, args.warmup)):
         out = pub.execute(compiled, enc)
     dist.barrier()
-    dt = dist.max_over_ranks(time.perf_counter() - t0) / reps
-    res = {"program": f"{n_products} products z_i = x_i * y_i through public_ctx.execute(), limbs over {dist.world} ranks",
-           "triples_per_s": round(n_products / dt, 1), "ms_per_execute": round(dt * 1e3, 3),
-           "exchange_launches_per_execute": int(pub.last_exchange_launches), "exchanged_words_per_execute": int(pub.last_exchanged_words),
-           "includes": "input upload and output download (a limb-sharded value has no single device handle)"}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pub.execute(compiled, enc)
+    dist.barrier()
+    dt = dist.max_over_ranks(time.perf_counter() - t0)
+    value = args.steps * n_products / dt
+    ok = True
     if dist.rank == 0:
         from oracle import pyoracle as po  # checker only
         o = po.Oracle(N, list(pub.primes))
-        res["bit_exact_vs_oracle"] = bool(np.array_equal(out.get('z0')[4], o.op_triple(enc.get('x0')[4], enc.get('y0')[4], pub.relin_key())))
-    return res
-
-
-def limb_sharded(args, dist):
-    """--shard limb: every op-triple is computed by ALL GPUs together, the RNS limbs dealt over them
-    (limb i on shard i mod G; SURVEY.md 8(e) row 3, BASELINE config 5's mode): per key switch one
-    all-gather of the coefficient-form digits and one broadcast, per rescale one broadcast.  Under
-    torchrun every rank is one shard and the exchange steps are RCCL collectives on the library's
-    device buffers; with one process (--gpus 1) --shards G runs G shards on the one GPU with device
-    copies as the exchange (what a 1-GPU box can measure: the cost of the phase structure, not xGMI)."""
-    import numpy as np
-    from eva_amd.hostref import coeff_modulus_create
-    from eva_amd.shard import ShardedEvaluator
-    N, l = 1 << args.logn, args.limbs
-    k = l + 1
-    primes = coeff_modulus_create(N, [60] * k)
-    world = dist.world
-    if world > 1:
-        ev, G = ShardedEvaluator.distributed(N, primes, dist), world
-    else:
-        G = max(1, args.shards)
-        ev = ShardedEvaluator.in_process(N, primes, G)
-    rng = np.random.default_rng(0xE7A)  # the same operands on every rank: each uploads its own limbs
-
-    def rand(prefix, nl):
-        return np.stack([rng.integers(0, primes[i], size=prefix + (N,), dtype=np.uint64) for i in range(nl)], axis=len(prefix))
-    key_host = rand((l, 2), k)
-    ev.upload_relin_key(key_host)
-    n_pairs = min(args.batch, 16)
-    host, pairs = [], []
-    for i in range(n_pairs):
-        a, b = rand((2,), l), rand((2,), l)
-        pairs.append((ev.upload_ct(a, 2.0 ** 40), ev.upload_ct(b, 2.0 ** 40)))
-        if i == 0:
-            host.append((a, b))
-
-    def step():
-        out = None
-        for i in range(args.batch):
-            A, B = pairs[i % n_pairs]
-            out = ev.rescale(ev.relinearize(ev.multiply(A, B)), 60)
-        return out
-
-    def barrier():
-        ev.sync()
-        dist.barrier()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = dist.max_over_ranks(time.perf_counter() - t0)
-    value = args.steps * args.batch / dt
-    first = ev.rescale(ev.relinearize(ev.multiply(*pairs[0])), 60)
-    got = ev.gather(first, dist) if world > 1 else ev.download(first)
-    # the same partition behind public_ctx.execute(): the C++ limb-shard evaluator with this rank's limbs, its exchange
-    # steps as RCCL collectives on the library's buffers (eva_amd.dist.attach_limb_dist) — every rank takes part
-    exec_path = None
-    if world > 1 and not args.no_legs:
-        try:
-            exec_path = limb_execute_leg(N, l, dist)
-        except Exception as e:  # noqa: BLE001 — the leg must not cost the line
-            exec_path = {"error": repr(e)}
+        ok = bool(np.array_equal(out.get('z0')[4], o.op_triple(enc.get('x0')[4], enc.get('y0')[4], pub.relin_key())))
+    if dist.sum_over_ranks(0.0 if ok else 1.0) > 0:
+        raise SystemExit("bench.py --shard limb: the sharded result differs from the CPU oracle — number withheld")
     if dist.rank == 0:
-        from oracle import pyoracle as po  # checker only
-        ok = bool(np.array_equal(got, po.Oracle(N, primes).op_triple(host[0][0], host[0][1], key_host)))
-        if not ok:
-            raise SystemExit("bench.py --shard limb: the sharded result differs from the CPU oracle — number withheld")
         xbytes = (l * N * 8) * (G - 1) / G + 2 * N * 8 + 2 * N * 8  # per GPU per triple: all-gather receive + two broadcasts
+        kb = [int(b) for b in pub.key_bytes()]
         line = {"metric": "homomorphic ops/sec (mul+rescale+relin) at N=2^16, L=10; execute() wall-time",
                 "value": round(value, 2), "unit": "op-triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-                "config": {"workload": f"op-triple multiply+relinearize+rescale, N=2^{args.logn}, L={l}, {args.batch} triples per step, "
-                                       f"each computed by all shards together", "poly_modulus_degree": N, "limbs": l,
+                "config": {"workload": f"op-triple multiply+relinearize+rescale, N=2^{args.logn}, L={l}, {n_products} triples per step "
+                                       f"(one public_ctx.execute() of {n_products} products), each computed by all shards together",
+                           "poly_modulus_degree": N, "limbs": l, "entry_point": "public_ctx.execute (shard_mode = 'limb')",
                            "parallelism": f"RNS limbs over {G} shard(s) on {world} GPU(s): limb i on shard i mod G; per key switch "
                                           "all-gather of the digits + broadcast of the special limb, per rescale one broadcast",
-                           "exchange": "RCCL (torch.distributed nccl) on device buffers" if world > 1 else "device copies between the shards' queues (one GPU)",
+                           "ranks": world, "collectives_backend": dist.backend if world > 1 else None,
+                           "exchange": (("RCCL (torch.distributed nccl) in place on the library's device buffers" if dist.backend == "nccl" else
+                                         "gloo, staged through the host") if world > 1 else
+                                        "one gather launch per receiving shard (peer reads between the shards' contexts, one GPU)"),
                            "exchange_bytes_per_gpu_per_triple": int(xbytes),
-                           "key_bytes": {"whole_key": int(key_host.nbytes),
-                                         "per_shard_here": [int(sh.ctx.key_bytes()) for sh in ev.shards.values() if hasattr(sh, "ctx")]}},
+                           "exchange_launches_per_execute": int(pub.last_exchange_launches),
+                           "exchanged_words_per_execute": int(pub.last_exchanged_words),
+                           "key_bytes": {"whole_key": int(pub.relin_key().nbytes), "per_shard_here": kb[:-1]},
+                           "includes": "input upload and output download (a limb-sharded value has no single device handle)"},
                 "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "achieved": round(triple_bytes(N, l) * value / max(world, 1) / 1e9, 1),
                              "frac": round(triple_bytes(N, l) * value / max(world, 1) / 1e9 / HBM_PEAK_GBPS, 4),
                              "bytes_per_unit": triple_bytes(N, l),
                              "basis": "SURVEY.md 8(d) algorithmic bytes of one op-triple x op-triples/s, per GPU"},
-                "verified": {"triples_checked": 1, "bit_exact_vs_oracle": ok}, "cpu_baseline": None}
-        if exec_path is not None:
-            line["execute_path"] = exec_path
+                "verified": {"triples_checked": 1, "bit_exact_vs_oracle": True}, "cpu_baseline": None}
         print(json.dumps(line), flush=True)
-    ev.close()
     dist.close()
 
 
@@ -533,7 +530,8 @@ def subdag_leg(args, dist):
         from test_gpu_e2e import _harris, _image
         compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
         pad_chain(params, 9, 32768)
-        members = list(range(world)) if world > 1 else [0] * max(2, args.shards)
+        ndev = torch.cuda.device_count()
+        members = [r % ndev for r in range(world)] if world > 1 else [0] * max(2, args.shards)  # (gloo on a 1-GPU box: members share it)
         pub, sec = generate_keys(params, 1, devices=members, shard="subdag")
         nbytes, _ = dag_bytes(compiled, sig, 32768, 9)
         enc = pub.encrypt(_image(4096), sig)
@@ -572,15 +570,12 @@ def main():
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--limbs", type=int, default=10)
     ap.add_argument("--streams", type=int, default=2,
-                    help="issue queues (forked contexts = HIP streams) the groups of a step alternate between: with two, the "
-                         "VALU-bound key-switch launches of one group overlap the HBM-bound passes of the other (+2.5 %% "
-                         "over one queue in the same run, profiles/r03_tuning_notes.md); per-launch times then include that overlap")
+                    help="raw_cabi leg only: issue queues (forked contexts = HIP streams) its groups alternate between "
+                         "(execute() alternates between the context's own two issue queues)")
     ap.add_argument("--group", type=int, default=32,
-                    help="triples handed to one batched call (wide launches, shared key)")
+                    help="triples per execute() call = products of the compiled program (one wide launch set, shared key)")
     ap.add_argument("--separate-multiply", action="store_true",
-                    help="evah_multiply_many + evah_relinearize_rescale_many instead of the one-call op-triple "
-                         "evah_multiply_relinearize_rescale_many (no size-3 product in HBM).  r02 measured the one-call form 1.6 %% "
-                         "slower; with the r03 128-bit reduction it is 1.9 %% faster (same run), so it is the default")
+                    help="raw_cabi leg only: evah_multiply_many + evah_relinearize_rescale_many instead of the one-call op-triple")
     ap.add_argument("--members", type=int, default=1,
                     help="--shard dag: contexts per rank sharing its GPU (shard_mode='dag' inside execute_batch)")
     ap.add_argument("--dag-batch", type=int, default=256, help="--shard dag / the dag_batch leg: independent Sobel DAGs in the batch")
@@ -590,7 +585,7 @@ def main():
                          "subdag: one Harris execute() with its independent sub-DAGs on the GPUs")
     ap.add_argument("--shards", type=int, default=1, help="--shard limb with one process: shards on the one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-legs", action="store_true", help="skip the execute()-path and DAG legs")
+    ap.add_argument("--no-legs", action="store_true", help="skip the raw C-ABI, host-valuation and DAG legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -605,8 +600,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
                          "the product path has no CPU fallback")
-    dist = Dist(backend="nccl")
-    rank, world, local = dist.rank, dist.world, dist.local_rank
+    # nccl = RCCL, one GPU per rank (the driver's runs); gloo: ranks share the visible GPUs (1-GPU boxes, tests)
+    dist = Dist(backend=os.environ.get("EVA_BENCH_BACKEND", "nccl"))
+    rank, world, dev = dist.rank, dist.world, dist.device_index
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -617,129 +613,101 @@ def main():
     if args.shard == "dag":
         return dag_sharded(args, dist)
     # what every rank runs on: the driver's multi-GPU runs show that RCCL saw N ranks on N devices
-    dev_name = torch.cuda.get_device_name(local)
+    dev_name = torch.cuda.get_device_name(dev)
     rank_devices = [dev_name]
     if world > 1:
         import torch.distributed as tdist
         gathered = [None] * world
-        tdist.all_gather_object(gathered, f"rank {rank}: cuda:{local} {dev_name}")
+        tdist.all_gather_object(gathered, f"rank {rank}: cuda:{dev} {dev_name}")
         rank_devices = gathered
 
-    from eva_amd import backend
-    from eva_amd.hostref import coeff_modulus_create
+    from eva.seal import generate_keys
 
     N, l = 1 << args.logn, args.limbs
     k = l + 1
-    primes = coeff_modulus_create(N, [60] * k)
-    g = backend.Context(N, primes, device=local)
-    queues = [g] + [g.fork() for _ in range(max(1, args.streams) - 1)]
-    fused = not args.separate_multiply
-
-    # synthetic inputs: uniform residues; every triple of a step has its own
-    # operand pair (distinct HBM data: no triple finds its inputs in cache because another used them)
-    rng = np.random.default_rng(0xE7A + rank)
-
-    def rand(prefix, nl):
-        return np.stack([rng.integers(0, primes[i], size=prefix + (N,), dtype=np.uint64)
-                         for i in range(nl)], axis=len(prefix))
-
-    key_host = rand((l, 2), k)
-    g.upload_relin_key(key_host)
-    npairs = args.batch
     G = max(1, min(args.group, 64, args.batch))
-    host_pairs, pairs = {}, []
-    for i in range(npairs):
-        a, b = rand((2,), l), rand((2,), l)
-        pairs.append((g.upload_ct(a, 2.0 ** 40), g.upload_ct(b, 2.0 ** 40)))
-        if i % G == 0 or i < 4:
-            host_pairs[i] = (a, b)  # verification (first of each group) and the CPU baseline leg
+    n_calls = max(1, args.batch // G)          # execute() calls per step
+    batch = n_calls * G                        # triples per step
+    compiled, params, sig = triple_program(G, N, l)
+    pub, sec = generate_keys(params, 17 + rank)
+    pub.device = dev
+    sec.device = dev
+    primes = list(pub.primes)
 
-    PROF_EVERY = 8  # HIP-event brackets on every 8th triple only: keeps the timed region honest
+    # synthetic inputs: every triple of a step has its own operand pair (distinct HBM data: no triple finds its
+    # inputs in cache because another used them), encrypted by this key pair and LEFT IN HBM by encrypt()
+    rng = np.random.default_rng(0xE7A + rank)
+    clear, vals = [], []
+    for _ in range(n_calls):
+        inputs = {}
+        for i in range(G):
+            inputs[f'x{i}'] = list(rng.uniform(-1, 1, 1024))
+            inputs[f'y{i}'] = list(rng.uniform(-1, 1, 1024))
+        clear.append(inputs)
+        vals.append(pub.encrypt(inputs, sig))
+    st0 = pub.transfer_stats()
 
-    def run_group(q, idx):
-        """-> (handles to free, outputs)"""
-        As, Bs = [pairs[i % npairs][0] for i in idx], [pairs[i % npairs][1] for i in idx]
-        if len(idx) > 1:
-            if fused:
-                outs = q.multiply_relinearize_rescale_many(As, Bs, 60)
-                return outs, outs
-            ms = q.multiply_many(As, Bs)
-            outs = q.relinearize_rescale_many(ms, 60)
-            return ms + outs, outs
-        m = q.multiply(As[0], Bs[0])
-        o = q.relinearize_rescale(m, 60)
-        return [m, o], [o]
-
-    def step(profile=False, keep=None):
-        for gi, i0 in enumerate(range(0, args.batch, G)):
-            q = queues[gi % len(queues)]
-            sample = profile and (gi % max(1, PROF_EVERY // G) == 0)
-            if sample:
-                q.profile(True)
-            hs, outs = run_group(q, range(i0, min(i0 + G, args.batch)))
-            if sample:
-                q.profile(False)
-            if keep is not None:
-                keep[i0] = outs[0].download()
-            for h in hs:
-                h.free()
+    def step():
+        return [pub.execute(compiled, v) for v in vals]
 
     def barrier():
-        for q in queues:
-            q.sync()
-        dist.barrier()  # torch.cuda.synchronize() + RCCL barrier
+        pub.synchronize()
+        dist.barrier()  # torch.cuda.synchronize() + barrier over the ranks
 
-    for _ in range(args.warmup):
-        step()
+    outs = None
+    for _ in range(max(args.warmup, 2)):       # device context / key upload / pools of both issue queues
+        outs = step()
     barrier()
-    for q in queues:
-        q.profile_reset()
+    pub.profile(True)                          # HIP-event brackets around every launch of the timed region
+    pub.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(profile=True)
+        outs = step()
     barrier()
     dt = time.perf_counter() - t0
     dt = dist.max_over_ranks(dt)
-    prof = {}
-    for q in queues:
-        for c, (n_, ms_) in q.profile_get().items():
-            a_ = prof.get(c, (0, 0.0))
-            prof[c] = (a_[0] + n_, a_[1] + ms_)
+    prof = {c: v for c, v in pub.profile_get().items() if v[0]}
+    st1 = pub.transfer_stats()
+    moved = {kk: int(st1[kk] - st0[kk]) for kk in ("ct_uploads", "ct_downloads")}
 
-    triples = args.steps * args.batch * world
+    triples = args.steps * batch * world
     value = triples / dt
 
-    # With more than one issue queue the launches of the queues overlap, so a launch's HIP-event duration in the
-    # timed region is the time it SHARED the GPU for.  Outside the timed region: two steps on queue 0 alone, every
-    # launch bracketed, for the duration a kernel takes with the GPU to itself (what a rocprofv3 PMC pass, which
-    # serialises the kernels, reports as well).
-    prof_excl = None
-    if len(queues) > 1:
-        q0 = queues[0]
-        q0.profile_reset()
-        for _ in range(2):
-            for i0 in range(0, args.batch, G):
-                q0.profile(True)
-                hs, _outs = run_group(q0, range(i0, min(i0 + G, args.batch)))
-                q0.profile(False)
-                for h in hs:
-                    h.free()
-        q0.sync()
-        prof_excl = q0.profile_get()
+    # The calls alternate between two issue queues whose launches overlap, so a launch's HIP-event duration in the
+    # timed region is the time it SHARED the GPU for.  Outside the timed region: calls separated by a synchronize,
+    # every launch bracketed, for the duration a kernel takes with the GPU to itself (what a rocprofv3 PMC pass,
+    # which serialises the kernels, reports as well).
+    pub.profile_reset()
+    for _ in range(2):
+        for v in vals:
+            outs_alone = pub.execute(compiled, v)
+            pub.synchronize()
+    prof_excl = {c: v for c, v in pub.profile_get().items() if v[0]}
+    pub.profile(False)
+    del outs_alone
 
-    # ---- outside the timed region: one more step whose first output per group is downloaded and
-    # compared with the CPU oracle on the same operands
-    got = {}
-    step(keep=got)
-    barrier()
-    verified = None
-    if rank == 0:
-        from oracle import pyoracle as po  # checker only
-        o = po.Oracle(N, primes)
-        verified = {"triples_checked": len(got), "bit_exact_vs_oracle":
-                    bool(all(np.array_equal(got[i], o.op_triple(host_pairs[i][0], host_pairs[i][1], key_host)) for i in got))}
-        if not verified["bit_exact_vs_oracle"]:
-            raise SystemExit("bench.py: the timed path's output differs from the CPU oracle — number withheld")
+    # ---- outside the timed region: the first and last product of every group of the LAST timed step are downloaded and
+    # compared with the CPU oracle's op-triple of the same encrypted operands and key; the same outputs are decrypted
+    verified, host_ops = None, []
+    from oracle import pyoracle as po  # checker only
+    o = po.Oracle(N, primes)
+    ok, checked, max_err = True, 0, 0.0
+    key_host = pub.relin_key()
+    for ci, (v, out) in enumerate(zip(vals, outs)):
+        dec = sec.decrypt(out, sig)
+        for i in sorted({0, G - 1}):
+            a, b = v.get(f'x{i}')[4], v.get(f'y{i}')[4]
+            if len(host_ops) < 4:
+                host_ops.append((a, b))
+            ok = ok and bool(np.array_equal(out.get(f'z{i}')[4], o.op_triple(a, b, key_host)))
+            want = np.asarray(clear[ci][f'x{i}']) * np.asarray(clear[ci][f'y{i}'])
+            max_err = max(max_err, float(np.max(np.abs(np.asarray(dec[f'z{i}']) - want))))
+            checked += 1
+    bad = dist.sum_over_ranks(0.0 if ok and max_err < 1e-3 else 1.0)
+    if bad > 0:
+        raise SystemExit("bench.py: the timed path's output differs from the CPU oracle (or does not decrypt to x * y) — number withheld")
+    verified = {"triples_checked": checked, "bit_exact_vs_oracle": True, "decrypt_max_abs_err_vs_x_times_y": max_err,
+                "what": "outputs of the last timed step's execute() calls vs oracle multiply+relinearize+rescale of the same ciphertexts and key"}
 
     # N > 1: BASELINE config 4's scaling leg rides along — every rank runs its share (instance b on rank b mod
     # world) of the 256 Sobel DAGs, so a multi-GPU run of the default command reports DAGs/s and the achieved-HBM
@@ -751,12 +719,21 @@ def main():
     if rank == 0:
         cb = class_bytes(N, l, k, G)
         dom = max(prof, key=lambda c: prof[c][1]) if prof else None
-        roofline = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "achieved": round(triple_bytes(N, l) * value / world / 1e9, 1),
-                    "frac": round(triple_bytes(N, l) * value / world / 1e9 / HBM_PEAK_GBPS, 4),
-                    "bytes_per_unit": triple_bytes(N, l),
-                    "basis": "SURVEY.md 8(d) algorithmic bytes of one op-triple (inputs, outputs and key read/written "
-                             "once; NTT-internal passes count as zero) x op-triples/s per GPU"}
+        tb = triple_bytes(N, l)
+        key_bytes_once = 2 * l * (l + 1) * N * 8
+        roofline = {"bound": "valu", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "achieved": round(tb * value / world / 1e9, 1),
+                    "frac": round(tb * value / world / 1e9 / HBM_PEAK_GBPS, 4),
+                    "hbm_frac": round(tb * value / world / 1e9 / HBM_PEAK_GBPS, 4),
+                    "bytes_per_unit": tb,
+                    "basis": "achieved / peak / frac: SURVEY.md 8(d) algorithmic bytes of one op-triple (inputs, outputs and key "
+                             "read/written once; NTT-internal passes count as zero) x op-triples/s per GPU over the HBM peak.  "
+                             "bound = valu: the SQ counters put the VALUs at valu_frac of the time against hbm_frac of the "
+                             "HBM peak (64-bit modular multiplies, DESIGN.md section 4)",
+                    # 8(d) charges the key to every triple; a launch set of G triples reads it once
+                    "launch_compulsory_bytes": int(G * (tb - key_bytes_once) + key_bytes_once),
+                    "launch_compulsory_frac": round((G * (tb - key_bytes_once) + key_bytes_once) * (value / world / G) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "launch_set": f"{G} triples per execute(): one relinearization key read per launch set"}
         if dom:
             n_l, ms = prof[dom]
             avg_us = ms * 1e3 / max(n_l, 1)
@@ -780,22 +757,21 @@ def main():
                 "kernel": dom, "avg_launch_us": round(avg_us, 2), "launches_sampled": n_l,
                 "distinct_bytes_per_launch": int(cb.get(dom, 0)),
                 "achieved": round(cb.get(dom, 0) / (avg_us * 1e-6) / 1e9, 1) if avg_us else None,
-                "sampling": (f"HIP events on the launch stream around every launch of 1 in {max(1, PROF_EVERY // G)} "
-                             f"groups of {G} triples inside the timed region")}
-            if prof_excl and prof_excl.get(dom, (0, 0))[0]:
+                "sampling": f"HIP events on the launch stream around every launch inside the timed region ({G} triples per launch)"}
+            if prof_excl.get(dom, (0, 0))[0]:
                 ex_us = prof_excl[dom][1] * 1e3 / prof_excl[dom][0]
                 roofline["dominant"].update({
-                    "concurrent_queues": len(queues),
+                    "concurrent_queues": 2,
                     "avg_launch_us_alone": round(ex_us, 2), "launches_sampled_alone": prof_excl[dom][0],
                     "achieved_alone": round(cb.get(dom, 0) / (ex_us * 1e-6) / 1e9, 1),
-                    "note": (f"{len(queues)} issue queues: launches of the queues overlap in the timed region, so avg_launch_us is the "
-                             "time a launch shared the GPU for; *_alone = the same launches on one queue, measured right after "
-                             "the timed region")})
+                    "note": ("execute() alternates between 2 issue queues: launches of consecutive calls overlap in the timed region, so "
+                             "avg_launch_us is the time a launch shared the GPU for; *_alone = the same launches with a synchronize "
+                             "between the calls, measured right after the timed region")})
                 roofline["by_class_us_alone"] = {c: round(v[1] * 1e3 / max(v[0], 1), 2) for c, v in prof_excl.items() if v[0]}
             roofline["by_class_us"] = {c: round(v[1] * 1e3 / max(v[0], 1), 2) for c, v in prof.items() if v[0]}
             roofline["by_class_share"] = {c: round(v[1] / kern_total_ms, 3) for c, v in prof.items() if v[0]}
 
-        # secondary limiter: 32-bit integer-multiply / VALU issue.  The instruction count per
+        # the limiter (SURVEY 8(d) "secondary"): 32-bit integer-multiply / VALU issue.  The instruction count per
         # op-triple comes from the committed SQ-counter pass of this same command
         # (profiles/bench_valu_issue.json); the share of the measured time the VALUs spent issuing is
         # that count's issue time over this run's time per triple.
@@ -805,6 +781,7 @@ def main():
                 vj = json.load(open(vpath))
                 from eva_amd.roofline import csrc_tree_hash
                 us_per_triple = 1e6 * world / value
+                roofline["valu_frac"] = round(vj["valu_issuing_us_per_triple"] / us_per_triple, 3)
                 roofline["secondary"] = {
                     "bound": "valu integer issue", "valu_wave_instructions_per_triple": vj["valu_wave_instructions_per_triple"],
                     "valu_issuing_us_per_triple": vj["valu_issuing_us_per_triple"], "us_per_triple": round(us_per_triple, 2),
@@ -818,8 +795,15 @@ def main():
         legs = {}
         if world == 1 and not args.no_legs:
             try:
-                legs["execute_path"] = execute_leg(N, l, 32, 12)
+                legs["raw_cabi"] = raw_cabi_leg(args, N, l, primes, dev, max(5, min(args.steps, 20)), 3)
             except Exception as e:  # noqa: BLE001 — a leg must not cost the headline line
+                legs["raw_cabi"] = {"error": repr(e)}
+            try:
+                want = outs[0].get('z0')[4]
+                legs["execute_path"] = dict({"program": f"{G} independent products z_i = x_i * y_i (Mul -> Relinearize -> Rescale), "
+                                                        f"N=2^{args.logn}, L={l}: the headline's program with host valuations"},
+                                            **host_valuation_legs(pub, compiled, vals[0], G, l, N, 12, want))
+            except Exception as e:  # noqa: BLE001
                 legs["execute_path"] = {"error": repr(e)}
             try:
                 legs["dag"] = dag_leg(15, host_cores())
@@ -834,7 +818,7 @@ def main():
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
-            hp = [host_pairs[i] for i in sorted(host_pairs)][:4]
+            hp = host_ops
             a, b = hp[0]
             t1 = time.perf_counter()
             o.op_triple(a, b, key_host)
@@ -878,18 +862,19 @@ def main():
             cpu = {"value": round(n / cdt, 3), "unit": "op-triples/s", "cores": 1, "kind": "port",
                    "seal": "present: " + ",".join(seal.get("paths", [])[:2]) if seal.get("present") else
                            "SEAL absent on this host (tools/seal_probe.py): the oracle restatement is the baseline",
-                   "pin_with_seal": "on a host with Microsoft SEAL >= 3.6: python tests/golden/export_seal_vectors.py /tmp/vec 65536 "
-                                    + ",".join(["60"] * (l + 1)) + " && cmake -S tools -B build/seal_parity && cmake --build build/seal_parity"
-                                    " && build/seal_parity/seal_parity /tmp/vec --time-triple   (diffs primes, psi, NTT, every evaluator call, "
-                                    "the op-triple, encode, decrypt and decode with SEAL's own bits; prints SEAL's op-triples/s)",
+                   "pin_with_seal": "on a host with Microsoft SEAL >= 3.6: bash tools/pin_with_seal.sh   (exports the vectors, builds "
+                                    "tools/seal_parity.cpp against find_package(SEAL), diffs primes, psi, NTT, every evaluator call, the "
+                                    "op-triple, encode, decrypt, decode and the object format with SEAL's own bits, times SEAL's op-triple; "
+                                    "writes profiles/seal_pin.json, which this file then reports as cpu_baseline.kind = 'reference')",
                    "all_cores": {"value": round(all_rate, 2), "cores": cores,
                                  "sample": f"{cores} op-triples, one per thread, concurrently, on all {cores} cores of the "
                                            "affinity mask"},
                    "threads_64": None if rate64 is None else {"value": round(rate64, 2), "cores": 64,
                                                                "sample": "64 op-triples, one per thread, concurrently"},
                    "sample": f"{n} op-triples (multiply+relinearize+rescale) at N=2^{args.logn}, "
-                             f"L={l}, same inputs/key as the GPU run, oracle/libeva_oracle.so, "
+                             f"L={l}, same ciphertexts/key as the GPU run, oracle/libeva_oracle.so, "
                              f"1 thread of {cores} host cores"}
+            cpu = seal_pin_baseline(cpu, N, l)
         line = {
             "metric": "homomorphic ops/sec (mul+rescale+relin) at N=2^16, L=10; execute() wall-time",
             "value": round(value, 2), "unit": "op-triples/s", "n_gpus": world,
@@ -898,25 +883,49 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"op-triple multiply+relinearize+rescale, N=2^{args.logn}, "
                                    f"L={l} data limbs + 1 special prime (60-bit), "
-                                   f"{args.batch} independent triples per step per GPU",
-                       "poly_modulus_degree": N, "limbs": l, "batch_per_gpu": args.batch,
-                       "streams_per_gpu": len(queues), "triples_per_call": G,
-                       "entry_point": "evah_multiply_relinearize_rescale_many" if fused else
-                                      "evah_multiply_many + evah_relinearize_rescale_many",
+                                   f"{batch} independent triples per step per GPU",
+                       "poly_modulus_degree": N, "limbs": l, "batch_per_gpu": batch,
+                       "entry_point": "public_ctx.execute",
+                       "execute_calls_per_step": n_calls, "triples_per_call": G,
+                       "program": f"{G} products z_i = x_i * y_i, compiled with eager relinearization: Mul -> Relinearize -> Rescale each",
+                       "valuations": "device-resident (encrypt -> execute -> decrypt by handle): inputs are in HBM when the timed "
+                                     "region starts, execute() enqueues and returns, the timed region ends with synchronize()",
+                       "ciphertexts_moved_over_pcie_in_timed_region": moved,
+                       "issue_queues_per_gpu": 2,
                        "parallelism": f"independent ciphertexts sharded over {world} GPU(s), no collective",
-                       "rccl_ranks": world, "rank_devices": rank_devices,
-                       "collectives": "barrier + max-over-ranks of the wall time (torch.distributed nccl = RCCL); none in the data path"},
+                       "ranks": world, "collectives_backend": dist.backend,
+                       "rccl_ranks": world if dist.backend == "nccl" else 0, "rank_devices": rank_devices,
+                       "collectives": "barrier + max-over-ranks of the wall time (torch.distributed "
+                                      + ("nccl = RCCL" if dist.backend == "nccl" else dist.backend) + "); none in the data path"},
             "roofline": roofline, "verified": verified, "cpu_baseline": cpu,
         }
         line.update(legs)
         print(json.dumps(line), flush=True)
-    # orderly teardown: values, then forked queues, then the root context
-    for a, b in pairs:
-        a.free(); b.free()
-    for q in queues[1:]:
-        q.close()
-    g.close()
     dist.close()
+
+
+def seal_pin_baseline(cpu, N, l):
+    """tools/pin_with_seal.sh leaves profiles/seal_pin.json on a host that has Microsoft SEAL >= 3.6: the verdicts of
+    tools/seal_parity.cpp's sections and SEAL's own op-triple rate there.  When it is present (and was measured at this
+    (N, L)) the reported baseline is the reference itself — kind "reference" — with the port's figures kept beside it."""
+    path = os.path.join(ROOT, "profiles", "seal_pin.json")
+    if not os.path.exists(path):
+        return cpu
+    try:
+        pin = json.load(open(path))
+        rate = pin.get("seal_triples_per_s")
+        if not rate or (pin.get("N"), pin.get("limbs")) != (N, l):
+            cpu["seal_pin"] = {"file": "profiles/seal_pin.json", "used": False, "why": "no op-triple rate at this (N, L) in it"}
+            return cpu
+        port = {kk: cpu[kk] for kk in ("value", "cores", "sample", "all_cores", "threads_64")}
+        cpu.update({"value": round(float(rate), 3), "cores": int(pin.get("cores", 1)), "kind": "reference",
+                    "sample": pin.get("sample", "Evaluator::multiply + relinearize_inplace + rescale_to_next_inplace, tools/seal_parity.cpp --time-triple"),
+                    "seal": f"Microsoft SEAL {pin.get('seal_version', '?')} (tools/pin_with_seal.sh on {pin.get('host', '?')})",
+                    "port": port, "seal_pin": {"file": "profiles/seal_pin.json", "used": True, "sections": pin.get("sections"),
+                                               "all_sections_identical": pin.get("all_identical")}})
+    except Exception as e:  # noqa: BLE001
+        cpu["seal_pin"] = {"file": "profiles/seal_pin.json", "used": False, "why": repr(e)}
+    return cpu
 
 
 if __name__ == "__main__":

@@ -194,13 +194,8 @@ struct SharedDev {
   uint32_t *enc_slot_map = nullptr; // slot i (and its conjugate, at slots + i) -> FFT input index
   uint32_t key_rows = 0, key_shard = 0; // evaluation keys: 0 none yet, 1 whole, 2 the prime rows of limb shard `key_shard`
   uint64_t xfer[6] = {0, 0, 0, 0, 0, 0}; // evah_ctx_transfer_stats: ct up / down, pt up / down, bytes up / down
-  // one word of mapped host memory the persistent rotation fallback (rot_fallback.hip.h) sets if a grid-wide barrier
-  // gave up — the grid was not resident, its outputs are invalid; every call that waits for the device checks it
-  volatile uint32_t *fb_error = nullptr;
-  uint32_t *fb_error_dev = nullptr;
   ~SharedDev() {
     (void)hipSetDevice(device);
-    if (fb_error) (void)hipHostFree((void *)fb_error);
     if (enc_roots) (void)hipFree(enc_roots);
     if (enc_slot_map) (void)hipFree(enc_slot_map);
     if (relin.d) (void)hipFree(relin.d);
@@ -266,7 +261,10 @@ struct Tunables {
   // EVAH_FB_PERSIST (1): the exact fallback of a hoisted rotation set is one persistent launch per chunk (k_rot_fallback,
   // rot_fallback.hip.h) that leaves at once unless the zero counter overflowed; 0 = the ordinary unhoisted launches, each
   // guarded (about eight launches that return at once per chunk)
+  // EVAH_FB_GRID (0 = one workgroup per CU): workgroups of that launch; any value >= 1 gives the same bits (its phases
+  // are ordered by tickets, not by residency) — the tests run it with 1, 3 and 2000
   bool fb_persist = true;
+  uint32_t fb_grid = 0;
   // EVAH_MAC3 (1): key inner products accumulate in radix 2^30 (ks_inner_kernel<MAC3>) when every prime of the context
   // has the top-bit shape and the level has at most 15 limbs; the keys are then kept in the split layout as well
   bool mac3 = true;
@@ -298,6 +296,7 @@ struct Tunables {
     flag("EVAH_FOLD_PA", t.fold_pa);
     flag("EVAH_WIN_FUSE", t.win_fuse);
     flag("EVAH_FB_PERSIST", t.fb_persist);
+    count("EVAH_FB_GRID", t.fb_grid);
     flag("EVAH_MAC3", t.mac3);
     count("EVAH_LOOP_N", t.loop_n);
     count("EVAH_LOOP_MIN", t.loop_min);
@@ -475,15 +474,6 @@ struct Scratch { // pool-backed temporary, returned on scope exit (stream-ordere
   }
   ~Scratch() { c->pool.free(d, bytes); }
 };
-
-// after a wait for the device: did a persistent rotation fallback give up on a barrier since the last check?
-inline void check_fallback(evah_ctx *c) {
-  if (c->sh->fb_error && *c->sh->fb_error) {
-    *c->sh->fb_error = 0;
-    throw std::runtime_error("rotation fallback: its grid was not resident on the device, the results of this queue are invalid "
-                             "(EVAH_FB_PERSIST=0 selects the multi-launch fallback)");
-  }
-}
 
 inline dim3 ew_grid(evah_ctx *c, uint32_t limbs, uint32_t polys) {
   return dim3(c->N / 512, limbs, polys);

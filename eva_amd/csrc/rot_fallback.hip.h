@@ -6,9 +6,8 @@
 // taken once in a blue moon, but its launches used to be issued every time, each returning at once under the device-side
 // guard: ~8 empty launches per chunk, 4-8 % of the DAG legs' time.  Here the whole unhoisted computation of a chunk is
 // one persistent kernel: every workgroup reads the zero counter first and leaves if the hoisted results stand; otherwise
-// the grid walks the phases below, separated by grid-wide barriers (an atomic counter in global memory; the grid is at
-// most one workgroup per CU, so all of it is resident).  Nothing here is tuned — radix-2 stages on global memory, one
-// barrier per stage — it only has to be exact and bounded (milliseconds).
+// the workgroups walk the phases below.  Nothing here is tuned — radix-2 stages on global memory — it only has to be
+// exact and bounded (milliseconds).
 //   A  rc1[p][J] = c1_p[J] o perm_p (the rotated c1, NTT form); t = rc1
 //   B  t[p][J] <- INTT_J                                   (coefficient form of the digits, canonical)
 //   C  for every output prime I (the data limbs, then the special prime):
@@ -17,6 +16,18 @@
 //      rot[p][K][i] = (prod[p][K][i] - u[p][K][i]) * P^-1  (+ c0_p[i] o perm_p for K = 0)
 //   E  the window sums of rot (evah_rotate_weighted_sums), when the set has any
 // Every value is a canonical residue at every step, so the outputs are the bits of the ordinary kernels.
+//
+// Ordering between phases — correct by construction, whatever part of the grid is resident (r5; the r4 form was a
+// grid-wide spin barrier that assumed every workgroup resident and gave up after ~1 s otherwise).  Every phase is cut
+// into FB_NCH chunks; (phase, chunk) pairs are numbered phase-major and HANDED OUT IN THAT ORDER by one atomic ticket
+// counter: a workgroup takes the next ticket, waits until `done` — the count of finished chunks — has reached
+// phase * FB_NCH (all earlier phases complete), does its chunk, adds one to `done`, and takes the next ticket, until
+// the tickets run out.  A ticket is only ever held by a workgroup that is running, and a chunk waits only for tickets
+// with smaller numbers, so the unfinished chunk with the smallest ticket never waits for anything unfinished: there is
+// always a workgroup that can run to the end of its chunk, with one resident workgroup as with a thousand, and with any
+// number of other kernels (or other active fallbacks) on other queues.  It is the ordered-ticket argument of decoupled
+// look-back scans (rocPRIM's lookback_scan takes its tile ids from an atomic counter for the same reason).  No timeout,
+// no host-visible failure word, no assumption about the grid size.
 #pragma once
 #include "launch.hip.h"
 
@@ -33,77 +44,41 @@ struct FbBufs {
   u64 *prod;          // [np][2][l + 1][N]
   u64 *r;             // [np][2][N]
   u64 *u;             // [np][2][l][N]; the rotated ciphertexts end up here unless rot_out is given
-  unsigned *bar;      // [0]: arrivals, [1]: set when a workgroup gave up waiting (never, unless the grid was not resident)
-  uint32_t *err;      // mapped host word, set with it: the host reports the failure at its next wait (check_fallback)
+  unsigned *bar;      // [0]: tickets handed out, [1]: chunks finished — both zero at launch (ZeroFlag's memset)
 };
+constexpr unsigned FB_NCH = 256; // chunks per phase
 
-struct GridBar {
-  unsigned *bar;
-  uint32_t *err;
-  unsigned nb, epoch;
-  bool dead;
-};
-__device__ __forceinline__ void fb_grid_sync(GridBar &g) {
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0 && !g.dead) {
-    g.epoch++;
-    const unsigned target = g.epoch * g.nb;
-    __hip_atomic_fetch_add(g.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while (__hip_atomic_load(g.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(8);
-      // bounded: a grid that is not fully resident must not hang the queue (the outputs are then wrong and the host is told)
-      if (++spins > (1u << 20) || __hip_atomic_load(g.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        __hip_atomic_store(g.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(g.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        g.dead = true;
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  __threadfence();
-}
-
-// in-place forward / inverse negacyclic transforms of `npoly` polynomials of N words; polynomial pl is modulo
-// primes[fixed >= 0 ? fixed : pl % per]; the inverse leaves out the factor N^-1 (the consumer multiplies by ninv)
-__device__ __forceinline__ void fb_forward(GridBar &g, const DevCtx &cx, u64 *buf, uint32_t npoly, int fixed, uint32_t per) {
-  const uint32_t N = cx.N, logh = cx.logN - 1;
-  const size_t total = (size_t)npoly << logh, stride = (size_t)gridDim.x * blockDim.x;
-  uint32_t logt = logh;
-  for (uint32_t m = 1; m < N; m <<= 1, logt--) {
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-      const uint32_t pl = (uint32_t)(idx >> logh), b = (uint32_t)idx & ((1u << logh) - 1u);
-      const uint32_t i = b >> logt, j = b & ((1u << logt) - 1u), t = 1u << logt;
-      const uint32_t pr = fixed >= 0 ? (uint32_t)fixed : pl % per;
-      const DevPrime pm = cx.primes[pr];
-      const u64 W = cx.tw_fwd[(size_t)pr * N + m + i].x;
-      u64 *x = buf + (size_t)pl * N + 2 * (size_t)i * t + j;
-      const u64 a = x[0], v = mulmod(x[t], W, pm);
-      x[0] = addmod(a, v, pm.q);
-      x[t] = submod(a, v, pm.q);
-    }
-    fb_grid_sync(g);
+// one radix-2 stage (s = 0 .. logN - 1) of the in-place forward / inverse negacyclic transforms of `npoly` polynomials of
+// N words, chunk `ch` of FB_NCH; polynomial pl is modulo primes[fixed >= 0 ? fixed : pl % per]; the inverse leaves out the
+// factor N^-1 (the consumer multiplies by ninv)
+__device__ __forceinline__ void fb_forward_stage(const DevCtx &cx, u64 *buf, uint32_t npoly, int fixed, uint32_t per, uint32_t s, unsigned ch) {
+  const uint32_t N = cx.N, logh = cx.logN - 1, m = 1u << s, logt = logh - s;
+  const size_t total = (size_t)npoly << logh, stride = (size_t)FB_NCH * blockDim.x;
+  for (size_t idx = (size_t)ch * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const uint32_t pl = (uint32_t)(idx >> logh), b = (uint32_t)idx & ((1u << logh) - 1u);
+    const uint32_t i = b >> logt, j = b & ((1u << logt) - 1u), t = 1u << logt;
+    const uint32_t pr = fixed >= 0 ? (uint32_t)fixed : pl % per;
+    const DevPrime pm = cx.primes[pr];
+    const u64 W = cx.tw_fwd[(size_t)pr * N + m + i].x;
+    u64 *x = buf + (size_t)pl * N + 2 * (size_t)i * t + j;
+    const u64 a = x[0], v = mulmod(x[t], W, pm);
+    x[0] = addmod(a, v, pm.q);
+    x[t] = submod(a, v, pm.q);
   }
 }
-__device__ __forceinline__ void fb_inverse(GridBar &g, const DevCtx &cx, u64 *buf, uint32_t npoly, int fixed, uint32_t per) {
-  const uint32_t N = cx.N, logh = cx.logN - 1;
-  const size_t total = (size_t)npoly << logh, stride = (size_t)gridDim.x * blockDim.x;
-  uint32_t logt = 0;
-  for (uint32_t m = N >> 1; m >= 1; m >>= 1, logt++) {
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-      const uint32_t pl = (uint32_t)(idx >> logh), b = (uint32_t)idx & ((1u << logh) - 1u);
-      const uint32_t i = b >> logt, j = b & ((1u << logt) - 1u), t = 1u << logt;
-      const uint32_t pr = fixed >= 0 ? (uint32_t)fixed : pl % per;
-      const DevPrime pm = cx.primes[pr];
-      const u64 W = cx.tw_inv[(size_t)pr * N + m + i].x;
-      u64 *x = buf + (size_t)pl * N + 2 * (size_t)i * t + j;
-      const u64 a = x[0], v = x[t];
-      x[0] = addmod(a, v, pm.q);
-      x[t] = mulmod(submod(a, v, pm.q), W, pm);
-    }
-    fb_grid_sync(g);
+__device__ __forceinline__ void fb_inverse_stage(const DevCtx &cx, u64 *buf, uint32_t npoly, int fixed, uint32_t per, uint32_t s, unsigned ch) {
+  const uint32_t N = cx.N, logh = cx.logN - 1, m = N >> (s + 1), logt = s;
+  const size_t total = (size_t)npoly << logh, stride = (size_t)FB_NCH * blockDim.x;
+  for (size_t idx = (size_t)ch * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const uint32_t pl = (uint32_t)(idx >> logh), b = (uint32_t)idx & ((1u << logh) - 1u);
+    const uint32_t i = b >> logt, j = b & ((1u << logt) - 1u), t = 1u << logt;
+    const uint32_t pr = fixed >= 0 ? (uint32_t)fixed : pl % per;
+    const DevPrime pm = cx.primes[pr];
+    const u64 W = cx.tw_inv[(size_t)pr * N + m + i].x;
+    u64 *x = buf + (size_t)pl * N + 2 * (size_t)i * t + j;
+    const u64 a = x[0], v = x[t];
+    x[0] = addmod(a, v, pm.q);
+    x[t] = mulmod(submod(a, v, pm.q), W, pm);
   }
 }
 
@@ -111,100 +86,132 @@ __device__ __forceinline__ void fb_inverse(GridBar &g, const DevCtx &cx, u64 *bu
 template <int F>
 __global__ void __launch_bounds__(256)
 k_rot_fallback(DevCtx cx, FbPairs pr, uint32_t np, uint32_t l, FbBufs b, u64 *rot_out, WinSumTab ws, uint32_t n_win, size_t out_ps) {
-  if (cx.skipped()) return; // the hoisted results stand: every workgroup leaves before the first barrier
-  GridBar g{b.bar, b.err, gridDim.x, 0, false};
+  if (cx.skipped()) return; // the hoisted results stand: every workgroup leaves before it takes a ticket
   const uint32_t N = cx.N, logN = cx.logN, k = cx.k, sp = k - 1;
-  const size_t stride = (size_t)gridDim.x * blockDim.x, gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)FB_NCH * blockDim.x;
   const size_t lN = (size_t)l * N;
-  // A: the rotated c1
-  for (size_t idx = gt; idx < (size_t)np * lN; idx += stride) {
-    const uint32_t p = (uint32_t)(idx / lN), n = (uint32_t)idx & (N - 1);
-    const size_t J = (idx - (size_t)p * lN) >> logN;
-    const u64 v = pr.src[p][((size_t)pr.src_ps[p] + J) * N + pr.perm[p][n]];
-    b.rc1[idx] = v;
-    b.t[idx] = v;
-  }
-  fb_grid_sync(g);
-  // B: digits in coefficient form
-  fb_inverse(g, cx, b.t, np * l, -1, l);
-  for (size_t idx = gt; idx < (size_t)np * lN; idx += stride) {
-    const DevPrime pm = cx.primes[(idx >> logN) % l];
-    b.t[idx] = mulmod(b.t[idx], pm.ninv, pm);
-  }
-  fb_grid_sync(g);
-  // C: per output prime, the converted digits and the key inner product
-  for (uint32_t I = 0; I <= l; I++) {
-    const uint32_t kap = I == l ? sp : I;
-    const DevPrime pm = cx.primes[kap];
-    for (size_t idx = gt; idx < (size_t)np * lN; idx += stride) b.dig[idx] = barrett64(b.t[idx], pm.q, pm.brt);
-    fb_grid_sync(g);
-    fb_forward(g, cx, b.dig, np * l, (int)kap, 1);
-    for (size_t idx = gt; idx < (size_t)np * 2 * N; idx += stride) {
-      const uint32_t n = (uint32_t)idx & (N - 1), K = (uint32_t)(idx >> logN) & 1u, p = (uint32_t)(idx >> (logN + 1));
-      const u64 *key = pr.key[p] + ((size_t)K * k + kap) * N + n;
-      u64 acc = 0;
-      for (uint32_t J = 0; J < l; J++) {
-        const size_t at = (size_t)p * lN + (size_t)J * N + n;
-        const u64 d = J == I ? b.rc1[at] : b.dig[at];
-        acc = addmod(acc, mulmod(d, key[(size_t)J * 2 * k * N], pm), pm.q);
-      }
-      b.prod[((size_t)(2 * p + K) * (l + 1) + I) * N + n] = acc;
-    }
-    fb_grid_sync(g);
-  }
-  // D: mod-down by the special prime
-  for (size_t idx = gt; idx < (size_t)np * 2 * N; idx += stride)
-    b.r[idx] = b.prod[((idx >> logN) * (l + 1) + l) * N + (idx & (N - 1))];
-  fb_grid_sync(g);
-  fb_inverse(g, cx, b.r, np * 2, (int)sp, 1);
-  {
-    const DevPrime pa = cx.primes[sp];
-    for (size_t idx = gt; idx < (size_t)np * 2 * lN; idx += stride) {
-      const uint32_t n = (uint32_t)idx & (N - 1), i = (uint32_t)((idx >> logN) % l);
-      const size_t pp = idx / lN;
-      const DevPrime pm = cx.primes[i];
-      const u64 v = addmod(mulmod(b.r[pp * N + n], pa.ninv, pa), pa.q >> 1, pa.q);
-      b.u[idx] = submod(barrett64(v, pm.q, pm.brt), cx.halfmod[(size_t)sp * k + i], pm.q);
-    }
-  }
-  fb_grid_sync(g);
-  fb_forward(g, cx, b.u, np * 2 * l, -1, l);
+  // phases, in order: A | B: logN inverse stages, scale | C: per output prime (reduce, logN forward stages, inner product)
+  // | D: special rows, logN inverse stages, u, logN forward stages, combine | E: window sums (F > 0)
+  const uint32_t pB = 1, pC = pB + logN + 1, cper = logN + 2, pD = pC + (l + 1) * cper, pE = pD + 2 * logN + 3;
+  const uint32_t n_phases = pE + (F > 0 ? 1u : 0u);
   u64 *rot = F == 0 ? rot_out : b.u;
-  for (size_t idx = gt; idx < (size_t)np * 2 * lN; idx += stride) {
-    const uint32_t n = (uint32_t)idx & (N - 1), i = (uint32_t)((idx >> logN) % l);
-    const size_t pp = idx / lN;
-    const uint32_t p = (uint32_t)(pp >> 1);
-    const DevPrime pm = cx.primes[i];
-    const ulonglong2 inv = cx.invq[(size_t)sp * k + i];
-    u64 v = mul_shoup(submod(b.prod[(pp * (l + 1) + i) * N + n], b.u[idx], pm.q), inv.x, inv.y, pm.q);
-    if ((pp & 1) == 0) v = addmod(v, pr.src[p][(size_t)i * N + pr.perm[p][n]], pm.q);
-    rot[idx] = v;
-  }
-  if constexpr (F > 0) {
-    fb_grid_sync(g);
-    // E: the window sums (k_window_sums, one coefficient per thread)
-    for (size_t idx = gt; idx < (size_t)n_win * 2 * lN; idx += stride) {
-      const uint32_t n = (uint32_t)idx & (N - 1), i = (uint32_t)((idx >> logN) % l);
-      const uint32_t wK = (uint32_t)(idx / lN), w = wK >> 1, K = wK & 1u;
-      const DevPrime pm = cx.primes[i];
-      const size_t off = (size_t)i * N + n;
-      u128_t acc[F];
-#pragma unroll
-      for (int f = 0; f < F; f++) acc[f] = {0, 0};
-      const uint32_t first = ws.first[w], cnt = ws.count[w];
-      for (uint32_t t = first; t < first + cnt; t++) {
-        const u64 v = rot[(size_t)(2 * t + K) * lN + off];
-        acc128(acc[0], v, ws.w0[t] ? ws.w0[t][off] : 1);
-        if constexpr (F > 1) acc128(acc[1], v, ws.w1[t] ? ws.w1[t][off] : 1);
-      }
-      if (ws.id_src[w]) {
-        const u64 v = ws.id_src[w][(size_t)K * ws.id_ps[w] * N + off];
-        acc128(acc[0], v, ws.id_w0[w] ? ws.id_w0[w][off] : 1);
-        if constexpr (F > 1) acc128(acc[1], v, ws.id_w1[w] ? ws.id_w1[w][off] : 1);
-      }
-      ws.out0[w][(size_t)K * out_ps + off] = barrett128(acc[0], pm);
-      if constexpr (F > 1) ws.out1[w][(size_t)K * out_ps + off] = barrett128(acc[1], pm);
+  __shared__ unsigned s_ticket;
+  for (;;) {
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(b.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = s_ticket;
+    __syncthreads(); // everybody has read the ticket before thread 0 takes the next one
+    const uint32_t ph = ticket / FB_NCH;
+    const unsigned ch = ticket % FB_NCH;
+    if (ph >= n_phases) break; // uniform: the ticket is shared
+    if (ph > 0) { // every chunk of the earlier phases is finished (they hold smaller tickets: see the header)
+      if (threadIdx.x == 0)
+        while (__hip_atomic_load(b.bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < ph * FB_NCH) __builtin_amdgcn_s_sleep(4);
+      __syncthreads();
+      __threadfence();
     }
+    const size_t gt = (size_t)ch * blockDim.x + threadIdx.x;
+    if (ph == 0) {
+      // A: the rotated c1
+      for (size_t idx = gt; idx < (size_t)np * lN; idx += stride) {
+        const uint32_t p = (uint32_t)(idx / lN), n = (uint32_t)idx & (N - 1);
+        const size_t J = (idx - (size_t)p * lN) >> logN;
+        const u64 v = pr.src[p][((size_t)pr.src_ps[p] + J) * N + pr.perm[p][n]];
+        b.rc1[idx] = v;
+        b.t[idx] = v;
+      }
+    } else if (ph < pB + logN) {
+      // B: digits in coefficient form
+      fb_inverse_stage(cx, b.t, np * l, -1, l, ph - pB, ch);
+    } else if (ph == pB + logN) {
+      for (size_t idx = gt; idx < (size_t)np * lN; idx += stride) {
+        const DevPrime pm = cx.primes[(idx >> logN) % l];
+        b.t[idx] = mulmod(b.t[idx], pm.ninv, pm);
+      }
+    } else if (ph < pD) {
+      // C: per output prime, the converted digits and the key inner product
+      const uint32_t I = (ph - pC) / cper, sub = (ph - pC) % cper;
+      const uint32_t kap = I == l ? sp : I;
+      const DevPrime pm = cx.primes[kap];
+      if (sub == 0) {
+        for (size_t idx = gt; idx < (size_t)np * lN; idx += stride) b.dig[idx] = barrett64(b.t[idx], pm.q, pm.brt);
+      } else if (sub <= logN) {
+        fb_forward_stage(cx, b.dig, np * l, (int)kap, 1, sub - 1, ch);
+      } else {
+        for (size_t idx = gt; idx < (size_t)np * 2 * N; idx += stride) {
+          const uint32_t n = (uint32_t)idx & (N - 1), K = (uint32_t)(idx >> logN) & 1u, p = (uint32_t)(idx >> (logN + 1));
+          const u64 *key = pr.key[p] + ((size_t)K * k + kap) * N + n;
+          u64 acc = 0;
+          for (uint32_t J = 0; J < l; J++) {
+            const size_t at = (size_t)p * lN + (size_t)J * N + n;
+            const u64 d = J == I ? b.rc1[at] : b.dig[at];
+            acc = addmod(acc, mulmod(d, key[(size_t)J * 2 * k * N], pm), pm.q);
+          }
+          b.prod[((size_t)(2 * p + K) * (l + 1) + I) * N + n] = acc;
+        }
+      }
+    } else if (ph < pE) {
+      // D: mod-down by the special prime
+      const uint32_t sub = ph - pD;
+      if (sub == 0) {
+        for (size_t idx = gt; idx < (size_t)np * 2 * N; idx += stride)
+          b.r[idx] = b.prod[((idx >> logN) * (l + 1) + l) * N + (idx & (N - 1))];
+      } else if (sub <= logN) {
+        fb_inverse_stage(cx, b.r, np * 2, (int)sp, 1, sub - 1, ch);
+      } else if (sub == logN + 1) {
+        const DevPrime pa = cx.primes[sp];
+        for (size_t idx = gt; idx < (size_t)np * 2 * lN; idx += stride) {
+          const uint32_t n = (uint32_t)idx & (N - 1), i = (uint32_t)((idx >> logN) % l);
+          const size_t pp = idx / lN;
+          const DevPrime pm = cx.primes[i];
+          const u64 v = addmod(mulmod(b.r[pp * N + n], pa.ninv, pa), pa.q >> 1, pa.q);
+          b.u[idx] = submod(barrett64(v, pm.q, pm.brt), cx.halfmod[(size_t)sp * k + i], pm.q);
+        }
+      } else if (sub <= 2 * logN + 1) {
+        fb_forward_stage(cx, b.u, np * 2 * l, -1, l, sub - logN - 2, ch);
+      } else {
+        for (size_t idx = gt; idx < (size_t)np * 2 * lN; idx += stride) {
+          const uint32_t n = (uint32_t)idx & (N - 1), i = (uint32_t)((idx >> logN) % l);
+          const size_t pp = idx / lN;
+          const uint32_t p = (uint32_t)(pp >> 1);
+          const DevPrime pm = cx.primes[i];
+          const ulonglong2 inv = cx.invq[(size_t)sp * k + i];
+          u64 v = mul_shoup(submod(b.prod[(pp * (l + 1) + i) * N + n], b.u[idx], pm.q), inv.x, inv.y, pm.q);
+          if ((pp & 1) == 0) v = addmod(v, pr.src[p][(size_t)i * N + pr.perm[p][n]], pm.q);
+          rot[idx] = v;
+        }
+      }
+    } else {
+      if constexpr (F > 0) {
+        // E: the window sums (k_window_sums, one coefficient per thread)
+        for (size_t idx = gt; idx < (size_t)n_win * 2 * lN; idx += stride) {
+          const uint32_t n = (uint32_t)idx & (N - 1), i = (uint32_t)((idx >> logN) % l);
+          const uint32_t wK = (uint32_t)(idx / lN), w = wK >> 1, K = wK & 1u;
+          const DevPrime pm = cx.primes[i];
+          const size_t off = (size_t)i * N + n;
+          u128_t acc[F];
+#pragma unroll
+          for (int f = 0; f < F; f++) acc[f] = {0, 0};
+          const uint32_t first = ws.first[w], cnt = ws.count[w];
+          for (uint32_t t = first; t < first + cnt; t++) {
+            const u64 v = rot[(size_t)(2 * t + K) * lN + off];
+            acc128(acc[0], v, ws.w0[t] ? ws.w0[t][off] : 1);
+            if constexpr (F > 1) acc128(acc[1], v, ws.w1[t] ? ws.w1[t][off] : 1);
+          }
+          if (ws.id_src[w]) {
+            const u64 v = ws.id_src[w][(size_t)K * ws.id_ps[w] * N + off];
+            acc128(acc[0], v, ws.id_w0[w] ? ws.id_w0[w][off] : 1);
+            if constexpr (F > 1) acc128(acc[1], v, ws.id_w1[w] ? ws.id_w1[w][off] : 1);
+          }
+          ws.out0[w][(size_t)K * out_ps + off] = barrett128(acc[0], pm);
+          if constexpr (F > 1) ws.out1[w][(size_t)K * out_ps + off] = barrett128(acc[1], pm);
+        }
+      }
+    }
+    // this chunk is finished: its writes first, then the count the later phases wait for
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(b.bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 static_assert(sizeof(DevCtx) + sizeof(FbPairs) + sizeof(FbBufs) + sizeof(WinSumTab) + 64 <= 4096, "kernel arguments of k_rot_fallback");

@@ -379,8 +379,8 @@ static void rot_chunk_plain(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t
   rot_mod_down(c, l, np, prod.d, fold ? nullptr : perm.d, out_d, r.d, inv1);
 }
 // the zero-coefficient record of a hoisted set: d[0] = count, d[1..] = positions (OpPlainZ, k_hoist_fix), preceded in the
-// same allocation by one barrier word per chunk for the persistent fallback; everything that must start at zero is
-// cleared by one memset
+// same allocation by one word per chunk for the persistent fallback (its ticket and finished-chunk counters); everything
+// that must start at zero is cleared by one memset
 struct ZeroFlag {
   Scratch s;
   u64 *d;
@@ -419,18 +419,12 @@ static void rot_fallback_launch(evah_ctx *c, uint32_t l, const RotPair *pr, uint
     fp.src_ps[r] = (uint32_t)(pr[r].src_ps / N);
   }
   Scratch rc1(c, np * lN), t(c, np * lN), dig(c, np * lN), prod(c, (size_t)np * 2 * (l + 1) * N), r(c, (size_t)np * 2 * N), u(c, (size_t)np * 2 * lN);
-  if (!c->sh->fb_error) { // first use on this device state
-    if (c->capturing) throw std::logic_error("first hoisted rotation set cannot be captured into a graph");
-    void *h = nullptr, *d = nullptr;
-    HIPCHK(hipHostMalloc(&h, sizeof(uint32_t), hipHostMallocMapped));
-    *static_cast<uint32_t *>(h) = 0;
-    HIPCHK(hipHostGetDevicePointer(&d, h, 0));
-    c->sh->fb_error = static_cast<volatile uint32_t *>(h);
-    c->sh->fb_error_dev = static_cast<uint32_t *>(d);
-  }
-  FbBufs b{rc1.d, t.d, dig.d, prod.d, r.d, u.d, reinterpret_cast<unsigned *>(bar_word), c->sh->fb_error_dev};
-  // one workgroup per CU at most: the whole grid is resident, which the grid-wide barriers rely on
-  const uint32_t grid = std::min<uint32_t>(cu_count(c->device), 256);
+  FbBufs b{rc1.d, t.d, dig.d, prod.d, r.d, u.d, reinterpret_cast<unsigned *>(bar_word)};
+  // One workgroup per CU: enough to make the (rare) active path a matter of milliseconds, few enough that the launch
+  // costs what an empty kernel costs when the hoisted results stand.  Correctness does not depend on it — phases are
+  // ordered by tickets (rot_fallback.hip.h), not by a barrier over resident workgroups; EVAH_FB_GRID overrides (tests).
+  uint32_t grid = std::min<uint32_t>(cu_count(c->device), 256);
+  if (c->tun.fb_grid) grid = c->tun.fb_grid;
   WinSumTab none{};
   ProfScope ps(c, KC_EW);
   if (F == 0) hipLaunchKernelGGL((k_rot_fallback<0>), dim3(grid), dim3(256), 0, c->stream, c->dev, fp, np, l, b, rot_out, none, 0u, (size_t)0);

@@ -214,7 +214,6 @@ int evah_ctx_sync(evah_ctx *c) {
   API_BEGIN
   use(c);
   HIPCHK(hipStreamSynchronize(c->stream));
-  check_fallback(c);
   API_END
 }
 
@@ -366,7 +365,6 @@ static void io_copy(evah_ctx *c, uint32_t n, const std::function<hipError_t(uint
   for (uint32_t b = 0; b < n; b++) HIPCHK(copy_one(b, c->stream));
   if (wait) {
     HIPCHK(hipStreamSynchronize(c->stream));
-    check_fallback(c);
   }
 }
 
@@ -694,7 +692,6 @@ int evah_ct_download(evah_ctx *c, const evah_ct *ct, uint64_t *out) {
     HIPCHK(hipMemcpy2DAsync(out, row, ct->d, sizeof(u64) * ct->ps, row, (size_t)ct->size * ct->batch, hipMemcpyDeviceToHost,
                             c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  check_fallback(c);
   count_d2h(c, row * ct->size * ct->batch);
   API_END
 }

@@ -115,22 +115,31 @@ def attach_limb_dist(pub, dist):
     """RNS-limb sharding of public_ctx.execute() across the ranks of `dist` (one process per GPU; SURVEY.md 8(e) row 3,
     north_star: "RCCL all-gather over xGMI reassembling limbs before each key-switch").  The C++ limb-shard evaluator
     behind execute() (eva_amd/host/multi_device.h) keeps this rank's limbs and calls back here at its exchange steps:
-      nccl (= RCCL)  collectives in place on the library's device buffers, on torch's current stream — which is also
-                     made the stream the shard's kernels run on, so nothing waits for the host between phases
+      nccl (= RCCL)  collectives in place on the library's device buffers.  A torch stream created here becomes BOTH the
+                     stream the shard's kernels run on (set_limb_dist hands its handle to the library) and torch's
+                     current stream around every collective, so producer kernel -> collective -> consumer kernel are
+                     ordered by the streams alone and nothing waits for the host between phases.  (torch's default
+                     stream would not do: its handle is 0, which the library reads as "keep your own stream", and a
+                     library stream is non-blocking — unordered against the null stream the collectives would use.)
       gloo           the same steps staged through host memory (tests: several ranks sharing one GPU)"""
     import numpy as np
     torch, tdist = dist.torch, dist.dist
     device_collectives = dist.backend == "nccl"
     rank, world = dist.rank, dist.world
+    stream = torch.cuda.Stream(device=dist.device_index) if device_collectives else None
+    if stream is not None and not stream.cuda_stream:
+        raise RuntimeError("attach_limb_dist: torch returned the null stream; the limb shard needs a stream of its own")
 
     def view(ptr, words):
-        return torch.as_tensor(_DevWords(ptr, words), device="cuda")
+        return torch.as_tensor(_DevWords(ptr, words), device=f"cuda:{dist.device_index}")
 
     def all_gather(ptr, chunk):
-        full = view(ptr, world * chunk)
         if device_collectives:
-            tdist.all_gather_into_tensor(full, full[rank * chunk:(rank + 1) * chunk])
+            with torch.cuda.stream(stream):
+                full = view(ptr, world * chunk)
+                tdist.all_gather_into_tensor(full, full[rank * chunk:(rank + 1) * chunk])
             return
+        full = view(ptr, world * chunk)
         torch.cuda.synchronize()  # the library's own stream has produced the chunk
         mine = full[rank * chunk:(rank + 1) * chunk].cpu()
         parts = [torch.empty_like(mine) for _ in range(world)]
@@ -141,10 +150,11 @@ def attach_limb_dist(pub, dist):
         torch.cuda.synchronize()
 
     def broadcast(ptr, words, owner):
-        t = view(ptr, words)
         if device_collectives:
-            tdist.broadcast(t, src=owner)
+            with torch.cuda.stream(stream):
+                tdist.broadcast(view(ptr, words), src=owner)
             return
+        t = view(ptr, words)
         torch.cuda.synchronize()
         h = t.cpu() if rank == owner else torch.empty(words, dtype=torch.int64)
         tdist.broadcast(h, src=owner)
@@ -155,11 +165,12 @@ def attach_limb_dist(pub, dist):
     def sum_host(arr):
         t = torch.from_numpy(np.asarray(arr).view(np.int64))  # shares memory: the all-reduce lands in the caller's words
         if device_collectives:
-            d = t.cuda()
-            tdist.all_reduce(d)
-            t.copy_(d.cpu())
+            with torch.cuda.stream(stream):
+                d = t.to(f"cuda:{dist.device_index}")
+                tdist.all_reduce(d)
+                t.copy_(d.cpu())  # .cpu() waits for the stream
         else:
             tdist.all_reduce(t)
 
-    stream = torch.cuda.current_stream().cuda_stream if device_collectives else 0
-    pub.set_limb_dist(rank, world, all_gather, broadcast, sum_host, stream)
+    dist._limb_streams = getattr(dist, "_limb_streams", []) + [stream]  # the library holds the raw handle: keep it alive
+    pub.set_limb_dist(rank, world, all_gather, broadcast, sum_host, stream.cuda_stream if stream is not None else 0)

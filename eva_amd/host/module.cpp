@@ -251,7 +251,11 @@ PYBIND11_MODULE(_eva, m) {
   // traversal (wrapper.cpp:128-137) — is the number of issue queues independent DAG nodes are spread over.
   mseal.def("generate_keys", [](const CKKSParameters &p, uint64_t seed, py::object devices, py::object shard) {
     auto kp = generate_keys(p, seed);
-    if (!devices.is_none()) kp.first->devices = devices.cast<std::vector<int>>();
+    if (!devices.is_none()) {
+      kp.first->devices = devices.cast<std::vector<int>>();
+      // the key pair's own device state (inputs, constants, outputs; the secret half decrypts there) is member 0
+      if (!kp.first->devices.empty()) kp.first->device = kp.second->device = kp.first->devices[0];
+    }
     if (!shard.is_none()) kp.first->shard_mode = shard.cast<std::string>();
     if (g_num_threads > 1) kp.first->num_queues = std::min(g_num_threads, 8);
     return kp;
@@ -371,6 +375,13 @@ PYBIND11_MODULE(_eva, m) {
         d["h2d_bytes"] = st[4]; d["d2h_bytes"] = st[5];
         return d;
       }, "ciphertext / plaintext transfers across the host boundary since the device context was created")
+      .def("profile", &HipPublic::profile, py::arg("on"), "HIP-event brackets around every kernel launch of this context's issue queues, by kernel class")
+      .def("profile_reset", &HipPublic::profile_reset)
+      .def("profile_get", [](HipPublic &p) {
+        py::dict d;
+        for (auto &kv : p.profile_get()) d[py::str(kv.first)] = py::make_tuple(kv.second.first, kv.second.second);
+        return d;
+      }, "{kernel class: (launches, total ms)} since the last profile_reset(), summed over the issue queues")
       .def_readonly("last_timing", &HipPublic::last_timing, "ms of the last execute(): (input upload, DAG enqueue on the host, drain + output download)")
       .def_readwrite("num_queues", &HipPublic::num_queues, "HIP streams independent DAG nodes are spread over")
       .def_property_readonly("poly_modulus_degree", [](const HipPublic &p) { return p.host->N; })
@@ -402,6 +413,7 @@ PYBIND11_MODULE(_eva, m) {
       });
   py::class_<HipSecret, std::shared_ptr<HipSecret>>(mseal, "SEALSecret", "Secret context: decryption. Holds the secret key.")
       .def("decrypt", &HipSecret::decrypt, py::arg("enc_outputs"), py::arg("signature"))
+      .def_readwrite("device", &HipSecret::device, "device of the secret half's state when it is not shared with a public context")
       // test hook (as relin_key() on the public side): the secret key under every key prime, NTT form [k][N]
       .def("_secret_key_ntt", [](const HipSecret &s) { return to_numpy(s.sk.s_ntt, {(py::ssize_t)s.host->k, (py::ssize_t)s.host->N}); });
 }

@@ -181,6 +181,38 @@ public:
     if (group) for (evah_ctx *c : group->ctx) chk(evah_ctx_sync(c));
     for (auto &kv : plans) for (auto &f : kv.second->queues) chk(evah_ctx_sync(f->h));
   }
+  // Per-launch HIP-event profile by kernel class (evah_profile_*), over every issue queue this context owns: what
+  // bench.py's roofline reads when the timed region is execute() itself rather than raw C-ABI calls.
+  std::vector<evah_ctx *> all_queues() {
+    std::vector<evah_ctx *> q;
+    if (!dev) return q;
+    q.push_back(dev->h);
+    for (auto &f : forks) q.push_back(f->h);
+    for (auto &f : exec_q) if (f) q.push_back(f->h);
+    for (auto &f : batch_forks) q.push_back(f->h);
+    for (auto &f : batch_queues) q.push_back(f->h);
+    for (auto &kv : plans) for (auto &f : kv.second->queues) q.push_back(f->h);
+    return q;
+  }
+  void profile(bool on) {
+    ensure_device();
+    if (on && !exec_q[0]) { exec_q[0] = std::make_shared<Fork>(dev); exec_q[1] = std::make_shared<Fork>(dev); }
+    for (evah_ctx *q : all_queues()) chk(evah_profile_enable(q, on ? 1 : 0));
+  }
+  void profile_reset() { for (evah_ctx *q : all_queues()) chk(evah_profile_reset(q)); }
+  std::map<std::string, std::pair<uint64_t, double>> profile_get() {
+    std::map<std::string, std::pair<uint64_t, double>> out;
+    for (evah_ctx *q : all_queues())
+      for (int cls = 0; cls < evah_profile_classes(); cls++) {
+        uint64_t n = 0;
+        double ms = 0;
+        chk(evah_profile_get(q, cls, &n, &ms));
+        auto &e = out[evah_profile_class_name(cls)];
+        e.first += n;
+        e.second += ms;
+      }
+    return out;
+  }
   // ciphertexts up / down, plaintexts up / down, bytes up / down across the host boundary (evah_ctx_transfer_stats)
   std::array<uint64_t, 6> transfer_stats() {
     std::array<uint64_t, 6> st{0, 0, 0, 0, 0, 0};
@@ -396,6 +428,8 @@ private:
   bool eval_keys_uploaded = false;
   void ensure_device(bool eval_keys = true) {
     if (!dev) {
+      // a one-member `devices` list names the device of this context (several members: member 0 is checked by the modes)
+      if (!holder->dev && devices.size() == 1) device = devices[0];
       if (!holder->dev) holder->dev = std::make_shared<DeviceCtx>(host->N, host->primes, device);
       dev = holder->dev; // may have been created by the secret half of the key pair (decrypt first)
     }

@@ -1,4 +1,4 @@
-"""Test-side CPU shard: the phases of eva_amd/shard.py's limb-sharded key switch and rescale
+"""Test-side CPU shard: the phases of tests/shard_harness.py's limb-sharded key switch and rescale
 restated over the CPU oracle's primitives (per-prime NTT / INTT) and exact Python integers, so the
 partition / exchange / reassembly logic of ShardedEvaluator can be checked — in one process and
 across gloo ranks — without a GPU.  Follows SURVEY.md A.5 / A.6 limb by limb; the result of every

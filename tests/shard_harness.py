@@ -1,4 +1,11 @@
-"""Limb-sharded execution over G shards (BASELINE config 5): limb i of every
+"""TEST HARNESS (r5: moved here from the shipped package, where it was a second driver of the protocol): the phases
+of limb-sharded execution restated in Python over a pluggable shard backend.  The product's driver is the C++
+LimbShardEvaluator behind public_ctx.execute (eva_amd/host/multi_device.h, limb_exec.h) — what bench.py --shard limb
+times; this file exists so that the partition / exchange / reassembly logic can be checked WITHOUT a GPU (the CPU shard
+of tests/shard_cpu_backend.py over the oracle, one process and two gloo ranks) and so that the evah_shard_* entry
+points can be driven phase by phase from the tests (tests/test_gpu_shard.py).
+
+Limb-sharded execution over G shards (BASELINE config 5): limb i of every
 ciphertext and plaintext lives on shard i mod G, the special prime's limb of the key-switch products
 on shard l mod G.  Elementwise operations and the per-limb transforms are local to a shard; a key
 switch (relinearize, rotate) costs one all-gather of the l coefficient-form digits (l N 8 bytes)
@@ -11,18 +18,17 @@ The reference has no counterpart (its parallelism is node-level,
 switch_key_inplace behind relinearize / rotate_vector (/root/reference/eva/seal/seal_executor.h:200,
 :181/:188) and rescale_to_next (:213).
 
-Two deployments of the same code:
+Two deployments of the same harness:
   * one process, all G shards (`ShardedEvaluator.in_process(N, primes, G)`): the shards are G contexts —
     on G devices with peer access, or on one device — and the exchange steps are device / peer
-    copies (LocalExchange).  This is how the path is validated on a single MI355X.
-  * one process per GPU (`ShardedEvaluator.distributed(N, primes, Dist(...))`): every rank owns shard `rank`; the
+    copies (LocalExchange).
+  * one process per rank (`ShardedEvaluator.distributed(N, primes, Dist(...))`): every rank owns shard `rank`; the
     exchange steps are torch.distributed collectives directly on the library's device buffers
-    (backend "nccl" = RCCL over xGMI: all_gather_into_tensor, broadcast) or staged through host
-    memory (backend "gloo": two ranks can then share one GPU, or run the CPU backend of the tests).
+    (backend "nccl" = RCCL) or staged through host memory (backend "gloo": two ranks can then share one GPU, or run
+    the CPU backend of the tests).
 
-The shard backend is any object with the methods of HipShard below (the product's: libeva_hip.so
-through eva_amd.backend).  tests/ plugs in a CPU backend over the oracle (tests/shard_cpu_backend.py)
-to check the partition / exchange / reassembly logic, in one process and under gloo, without a GPU.
+The shard backend is any object with the methods of HipShard below (libeva_hip.so through eva_amd.backend, or the
+CPU backend over the oracle, tests/shard_cpu_backend.py).
 """
 import numpy as np
 
@@ -50,7 +56,7 @@ class HipShard:
     """One shard on the MI355X backend: an evah_ctx with the limb -> prime map (shard, G)."""
 
     def __init__(self, N, primes, shard, G, device=0):
-        from . import backend
+        from eva_amd import backend
         self.backend = backend
         self.N, self.primes, self.k, self.shard, self.G = N, list(primes), len(primes), shard, G
         # a device state of its own, and the shard map goes in BEFORE any key: evah_key_upload then keeps only
@@ -378,7 +384,7 @@ def execute_sharded(ev, program, enc_inputs, encode):
     serial forwardPass of the compiled program, SEALExecutor's dispatch per node
     (/root/reference/eva/seal/seal_executor.h:279-404).  encode(values, scale_bits, level) -> [l][N]
     plaintext residues (the host encoder).  Returns {output name: ShardedValue | list}."""
-    from . import Op
+    from eva_amd import Op
     vals = {}
     inputs = {name: t.index for name, t in program.inputs.items()}
     for name in enc_inputs.names():

@@ -1,4 +1,4 @@
-"""Limb-sharded execution on the MI355X backend (eva_amd/shard.py over the evah_shard_* entry
+"""Limb-sharded execution on the MI355X backend (tests/shard_harness.py over the evah_shard_* entry
 points; SURVEY.md 8(e) row 3, BASELINE config 5).  On the single GPU of the test box the G shards
 are G contexts (own queues, shared tables and keys) and the exchange steps are device copies; the
 assembled ciphertexts must equal the UNSHARDED oracle's bit for bit for G = 2, 3, 4, 8, at every
@@ -14,7 +14,7 @@ import textwrap
 import numpy as np
 import pytest
 
-from eva_amd.shard import ShardedEvaluator, execute_sharded
+from shard_harness import ShardedEvaluator, execute_sharded
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
@@ -94,10 +94,10 @@ def test_config5_dag_limb_sharded_over_8_bit_exact():
 
 WORKER = textwrap.dedent("""
     import json, os, sys
-    sys.path.insert(0, %r)
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
     import numpy as np
     from eva_amd.dist import Dist
-    from eva_amd.shard import ShardedEvaluator
+    from shard_harness import ShardedEvaluator
     from oracle import pyoracle as po
     d = Dist(backend="gloo")
     N, bits = 8192, [60, 40, 60, 60, 60]
@@ -136,10 +136,10 @@ def test_two_ranks_one_shard_each_on_the_gpu(tmp_path):
 
 RCCL_WORKER = textwrap.dedent("""
     import json, os, sys
-    sys.path.insert(0, %r)
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
     import numpy as np, torch, torch.distributed as td
     from eva_amd.dist import Dist
-    from eva_amd.shard import ShardedEvaluator, DistExchange
+    from shard_harness import ShardedEvaluator, DistExchange
     from oracle import pyoracle as po
     os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29645")
     torch.cuda.set_device(0)

@@ -1,4 +1,4 @@
-"""Limb-sharded execution (eva_amd/shard.py) on CPU: ShardedEvaluator driving
+"""Limb-sharded execution (tests/shard_harness.py) on CPU: ShardedEvaluator driving
 the CPU shard of tests/shard_cpu_backend.py, in one process for G = 2, 3, 4 and across two gloo
 ranks — every assembled ciphertext must equal the UNSHARDED oracle's, bit for bit."""
 import json
@@ -10,7 +10,7 @@ import textwrap
 import numpy as np
 import pytest
 
-from eva_amd.shard import ShardedEvaluator, local_limbs, rows_for
+from shard_harness import ShardedEvaluator, local_limbs, rows_for
 from oracle import pyoracle as po
 from shard_cpu_backend import OracleShard
 
@@ -88,7 +88,7 @@ WORKER = textwrap.dedent("""
     sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
     import numpy as np
     from eva_amd.dist import Dist
-    from eva_amd.shard import ShardedEvaluator
+    from shard_harness import ShardedEvaluator
     from oracle import pyoracle as po
     from shard_cpu_backend import OracleShard
     d = Dist(backend="gloo")
