@@ -43,6 +43,7 @@ _SIGS = {
     "evah_ctx_wait": [_vp, _vp],
     "evah_ctx_transfer_stats": [_vp, _u64p],
     "evah_ctx_key_bytes": [_vp, _u64p],
+    "evah_ctx_key_bytes_detail": [_vp, _u64p],
     "evah_pt_copy": [_vp, _vp, _vpp],
     "evah_pt_write": [_vp, _vp, _u64p],
     "evah_capture_begin": [_vp, _vpp, C.c_uint32],
@@ -70,6 +71,7 @@ _SIGS = {
     "evah_multiply_relinearize_rescale": [_vp, _vp, _vp, C.c_uint32, _vpp],
     "evah_multiply_relinearize_rescale_many": [_vp, _vpp, _vpp, C.c_uint32, C.c_uint32, _vpp],
     "evah_execute": [_vp, _vp, C.c_uint32, _vp, C.c_uint32],
+    "evah_elementwise_program": [_vp, _vp, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, _vpp],
     "evah_weighted_sum": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_rotate_pairs": [_vp, _vpp, C.POINTER(C.c_int32), C.c_uint32, _vpp],
     "evah_rotate_weighted_sums": [_vp, _vpp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, _vpp, _vpp],
@@ -135,6 +137,11 @@ class EvahOp(C.Structure):
     """include/eva_hip.h evah_op"""
     _fields_ = [("op", C.c_uint32), ("dst", C.c_uint32), ("src0", C.c_uint32), ("src1", C.c_uint32),
                 ("imm", C.c_int32), ("flags", C.c_uint32)]
+
+
+class EvahEwOp(C.Structure):
+    """include/eva_hip.h evah_ew_op"""
+    _fields_ = [("op", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32)]
 
 
 VAL_NONE, VAL_CT, VAL_PT = 0, 1, 2
@@ -459,6 +466,12 @@ class Context:
         _chk(_lib.evah_ctx_key_bytes(self.h, C.byref(out)))
         return int(out.value)
 
+    def key_bytes_detail(self):
+        """(key words as uploaded, radix-2^30 split copies, permuted copies used by hoisted rotation sets) in bytes"""
+        out = (C.c_uint64 * 3)()
+        _chk(_lib.evah_ctx_key_bytes_detail(self.h, out))
+        return tuple(int(x) for x in out)
+
     def mem_info(self):
         a, b = C.c_size_t(), C.c_size_t()
         _chk(_lib.evah_ctx_mem_info(self.h, C.byref(a), C.byref(b)))
@@ -632,6 +645,19 @@ class Context:
                 v.h = None
         _chk(rc)
         return out
+
+    def elementwise_program(self, inputs, ops, outs):
+        """evah_elementwise_program: inputs = [Ciphertext | Plaintext], ops = [(op, a, b)] with op in {10 Negate, 11 Add,
+        12 Sub, 13 Mul} over value indices (inputs first, then one value per op), outs = value indices -> [Ciphertext]"""
+        tab = (EvahVal * len(inputs))()
+        for i, v in enumerate(inputs):
+            tab[i].kind = VAL_CT if isinstance(v, Ciphertext) else VAL_PT
+            tab[i].h = v.h.value if isinstance(v.h, C.c_void_p) else v.h
+        arr = (EvahEwOp * max(len(ops), 1))(*[EvahEwOp(*o) for o in ops])
+        ov = (C.c_uint32 * len(outs))(*[int(x) for x in outs])
+        res = (C.c_void_p * len(outs))()
+        _chk(_lib.evah_elementwise_program(self.h, tab, len(inputs), arr, len(ops), ov, len(outs), res))
+        return [Ciphertext(self, C.c_void_p(res[i])) for i in range(len(outs))]
 
     def weighted_sum(self, cts, pts):
         """sum_j cts[j] (*) pts[j]; pts[j] may be None (the ciphertext itself)"""

@@ -29,7 +29,7 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm to build the gfx950 backend)")
 
 
-HIP_UNITS = ("runtime.hip", "elementwise.hip", "keyswitch.hip", "rotate.hip", "windows.hip", "shard.hip", "client.hip", "scheduler.hip")
+HIP_UNITS = ("runtime.hip", "elementwise.hip", "ewprogram.hip", "keyswitch.hip", "rotate.hip", "windows.hip", "shard.hip", "client.hip", "scheduler.hip")
 HIP_HEADERS = ("internal.hip.h", "launch.hip.h", "ntt.hip.h", "devmath.hip.h", "hostmath.h", "rotation_sets.hip.h", "rot_fallback.hip.h")
 
 

@@ -229,6 +229,9 @@ struct Tunables {
   // slower at N = 2^16 and kept it for N <= 8192; with the r03 128-bit reduction its on-the-fly products
   // are cheap enough that it wins at every size (op-triple 13 383 -> 13 635 /s)
   bool fuse_mul = true;
+  // EVAH_EW_FUSE (1): evah_execute defers elementwise ops (negate / add / sub / multiply, ciphertexts and plaintexts) on
+  // values nobody needs stored and runs each connected run of them as ONE evah_elementwise_program; 0 = one launch per op
+  bool ew_fuse = true;
   // EVAH_FUSE_SMALL (2048): launches of at most this many 2048-coefficient tiles are latency-bound — an
   // inverse transform followed by forward transforms of the result runs its two strided passes as one
   // launch (ntt_inv_fwd_kernel); 0 disables.  r03 sweep at the BASELINE sizes: Harris L=8 1.18 -> 1.15 ms,
@@ -244,6 +247,9 @@ struct Tunables {
   uint32_t hoist_min_tiles = 2048;
   // EVAH_HOIST_DEBUG (0): print the zero-coefficient count of every hoisted set (synchronises)
   bool hoist_debug = false;
+  // EVAH_HOIST_TABLE_FAIL (0): tests only — behave as if the device had no room for any NEW hoisting table (permuted
+  // key copies, per-(element, level) constants): the affected sets must run unhoisted with the same results
+  bool hoist_table_fail = false;
   // EVAH_FUSE_SPECIAL_INV (1): latency-bound key switches run the special row's first inverse pass
   // inside the key-switch kernel (ks_inner_kernel INVSP)
   bool fuse_special_inv = true;
@@ -286,12 +292,14 @@ struct Tunables {
     (void)N;
     flag("EVAH_FUSE_MAC", t.fuse_mac);
     flag("EVAH_FUSE_MUL", t.fuse_mul);
+    flag("EVAH_EW_FUSE", t.ew_fuse);
     count("EVAH_FUSE_SMALL", t.fuse_small_blocks);
     if (const char *e = std::getenv("EVAH_SMALL_LR")) t.small_lr = std::atoi(e) == 3 ? 3 : 2;
     count("EVAH_SMALL_LR_BLOCKS", t.small_lr_blocks);
     flag("EVAH_HOIST", t.hoist);
     count("EVAH_HOIST_MIN_TILES", t.hoist_min_tiles);
     flag("EVAH_HOIST_DEBUG", t.hoist_debug);
+    flag("EVAH_HOIST_TABLE_FAIL", t.hoist_table_fail);
     flag("EVAH_FUSE_SPECIAL_INV", t.fuse_special_inv);
     flag("EVAH_FOLD_PA", t.fold_pa);
     flag("EVAH_WIN_FUSE", t.win_fuse);

@@ -345,7 +345,7 @@ static void relin_rescale_core(evah_ctx *c, const evah_ct *const *as, uint32_t n
   std::vector<const KeyDev *> keys(n, &c->sh->relin);
   // r04: P * (the polynomials the key-switch result is added to) goes into the inner products themselves, so the
   // combine passes below read prod only (Tunables::fold_pa; the r03 forms stay for A/B runs)
-  const bool fold = c->tun.fold_pa;
+  const bool fold = c->tun.fold_pa && c->tun.fuse_mac; // EVAH_FUSE_MAC=0 (the unfused reference path): the OpRR / OpRRLast forms below
   switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2, mul, nullptr, fold, mul ? nullptr : &a_polys, /*lazy_out=*/fold);
   Scratch r(c, (size_t)n * 2 * N), t(c, (size_t)n * 2 * N);
   OpPlain::Params spp{prod.d + (size_t)l * N, r.d, pps, N, 1, sp, 1, {}};
@@ -380,6 +380,15 @@ static void mul_relin_rescale(evah_ctx *c, const evah_ct *const *as, const evah_
   const uint32_t l = as[0]->limbs;
   if (l < 2) throw std::invalid_argument("end of modulus switching chain reached");
   const size_t N = c->N, ops = (size_t)(l - 1) * N;
+  if (!c->tun.fuse_mac) { // the unfused reference path has no kernel that forms d2 on the fly: the three calls in turn
+    std::vector<evah_ct *> prods(n, nullptr);
+    if (evah_multiply_many(c, as, bs, n, prods.data())) throw std::runtime_error(g_err);
+    const int rc = evah_relinearize_rescale_many(c, prods.data(), n, divisor_bits, outs);
+    const std::string msg = g_err;
+    for (evah_ct *p : prods) evah_ct_free(c, p);
+    if (rc) throw std::runtime_error(msg);
+    return;
+  }
   MulTab tab{};
   std::vector<double> scales(n);
   for (uint32_t i = 0; i < n; i++) {

@@ -95,15 +95,17 @@ k_rot_fallback(DevCtx cx, FbPairs pr, uint32_t np, uint32_t l, FbBufs b, u64 *ro
   const uint32_t pB = 1, pC = pB + logN + 1, cper = logN + 2, pD = pC + (l + 1) * cper, pE = pD + 2 * logN + 3;
   const uint32_t n_phases = pE + (F > 0 ? 1u : 0u);
   u64 *rot = F == 0 ? rot_out : b.u;
+  // The ticket is made wave-uniform explicitly (readfirstlane): the loop condition and the phase dispatch are then scalar
+  // branches.  (As a per-lane value read from LDS, with "if (threadIdx.x == 0) atomic" at the loop's tail, the structurizer
+  // turned the loop into nested exec-mask loops in which the lanes other than lane 0 went round again — through the
+  // barrier and into the same chunk — before lane 0 had taken the next ticket.)
   __shared__ unsigned s_ticket;
-  for (;;) {
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(b.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned ticket = s_ticket;
-    __syncthreads(); // everybody has read the ticket before thread 0 takes the next one
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(b.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  unsigned ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+  while (ticket / FB_NCH < n_phases) {
     const uint32_t ph = ticket / FB_NCH;
     const unsigned ch = ticket % FB_NCH;
-    if (ph >= n_phases) break; // uniform: the ticket is shared
     if (ph > 0) { // every chunk of the earlier phases is finished (they hold smaller tickets: see the header)
       if (threadIdx.x == 0)
         while (__hip_atomic_load(b.bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < ph * FB_NCH) __builtin_amdgcn_s_sleep(4);
@@ -208,10 +210,15 @@ k_rot_fallback(DevCtx cx, FbPairs pr, uint32_t np, uint32_t l, FbBufs b, u64 *ro
         }
       }
     }
-    // this chunk is finished: its writes first, then the count the later phases wait for
+    // this chunk is finished: its writes first, then the count the later phases wait for; then the next ticket
     __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(b.bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(b.bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      s_ticket = __hip_atomic_fetch_add(b.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    ticket = __builtin_amdgcn_readfirstlane(s_ticket);
   }
 }
 static_assert(sizeof(DevCtx) + sizeof(FbPairs) + sizeof(FbBufs) + sizeof(WinSumTab) + 64 <= 4096, "kernel arguments of k_rot_fallback");

@@ -124,14 +124,17 @@ int evah_rotate_many(evah_ctx *c, const evah_ct *a, const int32_t *steps, uint32
   if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("rotate_many handles 1..64 rotations per call");
   const uint32_t l = a->limbs, B = a->batch;
   const size_t pps = (size_t)l * c->N;
-  const bool hoisted = hoist_wanted(c, l, n, B);
+  bool hoisted = hoist_wanted(c, l, n, B);
+  // the hoisting tables of every step first: if one does not fit the device, the whole set runs unhoisted
+  std::vector<RotPair> step_pair(n);
+  for (uint32_t j = 0; j < n; j++) step_pair[j] = rot_pair(c, a->d, a->ps, 0, steps[j], l, "rotate_many");
+  for (uint32_t j = 0; j < n && hoisted; j++) hoisted = hoist_prepare(c, step_pair[j], l);
   // (rotation j, instance b) pairs go out KS_BATCH_MAX at a time: m rotations x B instances per
   // launch set; pair index r = j * B + b, so rotation j's B outputs are one batched handle.
   std::vector<RotPair> pairs;
   pairs.reserve((size_t)n * B);
   for (uint32_t j = 0; j < n; j++) {
-    RotPair p = rot_pair(c, a->d, a->ps, 0, steps[j], l, "rotate_many");
-    if (hoisted) hoist_prepare(c, p, l);
+    RotPair p = step_pair[j];
     for (uint32_t b = 0; b < B; b++) {
       p.src = a->d + (size_t)b * 2 * a->ps;
       p.src_idx = b;
@@ -203,9 +206,8 @@ int evah_rotate_pairs(evah_ctx *c, const evah_ct *const *cts, const int32_t *ste
     pairs.push_back(rot_pair(c, a->d, a->ps, si, steps[r], l, "rotate_pairs"));
   }
   // worth hoisting when sources repeat and the digit transforms of the set are throughput-sized
-  const bool hoisted = srcs.size() < n && hoist_wanted(c, l, n, 1);
-  if (hoisted)
-    for (RotPair &p : pairs) hoist_prepare(c, p, l);
+  bool hoisted = srcs.size() < n && hoist_wanted(c, l, n, 1);
+  for (size_t i = 0; i < pairs.size() && hoisted; i++) hoisted = hoist_prepare(c, pairs[i], l); // no room for a table: unhoisted
   Buffer *ob = buf_new(c, (size_t)n * 2 * pps);
   try {
     rotation_set(c, l, pairs, {RotChunk{0, n, ob->d}}, srcs, src_ps, hoisted);

@@ -214,6 +214,17 @@ k_hoist_fix(DevCtx cx, const u64 *zeros, HoistFixTab tab, u64 *prod, size_t prod
   pr[(size_t)(l + 1) * N] = submod(pr[(size_t)(l + 1) * N], acc1, pm.q);
 }
 
+// The hoisting tables are an optimisation's working set (a permuted copy of every Galois key used in a hoisted set, a
+// constant per (element, level)): when the device has no room for one, the set runs unhoisted — SEAL's order, the
+// path that needs no tables — instead of failing.  null = no room (the runtime's error state is cleared).
+template <class T> static T *hoist_table_alloc(size_t bytes) {
+  void *d = nullptr;
+  if (hipMalloc(&d, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return static_cast<T *>(d);
+}
 // the inverse table: perm_inv[perm[n]] = n
 static const uint32_t *perm_inv_table(evah_ctx *c, uint32_t elt) {
   auto pit = c->sh->perms_inv.find(elt);
@@ -226,8 +237,8 @@ static const uint32_t *perm_inv_table(evah_ctx *c, uint32_t elt) {
     u64 raw = (((u64)elt * reversed) >> 1) & (u64)(N - 1);
     inv[bitrev((uint32_t)raw, c->logN)] = i;
   }
-  uint32_t *d = nullptr;
-  HIPCHK(hipMalloc(&d, sizeof(uint32_t) * N));
+  uint32_t *d = hoist_table_alloc<uint32_t>(sizeof(uint32_t) * N);
+  if (!d) return nullptr;
   HIPCHK(hipMemcpy(d, inv.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
   c->sh->perms_inv.emplace(elt, d);
   return d;
@@ -246,8 +257,8 @@ static const u64 *hoist_sign(evah_ctx *c, uint32_t elt) {
     if ((raw >> c->logN) & 1) s[raw & (N - 1)] = 1;
   }
   for (uint32_t p = 1; p < c->k; p++) std::copy_n(s.begin(), N, s.begin() + (size_t)p * N);
-  u64 *d = nullptr;
-  HIPCHK(hipMalloc(&d, sizeof(u64) * N * c->k));
+  u64 *d = hoist_table_alloc<u64>(sizeof(u64) * N * c->k);
+  if (!d) return nullptr;
   try {
     HIPCHK(hipMemcpyAsync(d, s.data(), sizeof(u64) * N * c->k, hipMemcpyHostToDevice, c->stream));
     OpPlain::Params p{d, d, 0, 0, c->k, 0, 0, {}};
@@ -266,8 +277,9 @@ static const u64 *hoist_corr(evah_ctx *c, uint32_t elt, uint32_t l, const KeyDev
   if (c->capturing) throw std::logic_error("first hoisted use of a Galois element cannot be captured into a graph");
   const u64 *sign = hoist_sign(c, elt);
   const uint32_t *pinv = perm_inv_table(c, elt);
-  u64 *d = nullptr;
-  HIPCHK(hipMalloc(&d, sizeof(u64) * 2 * (l + 1) * c->N));
+  if (!sign || !pinv) return nullptr;
+  u64 *d = hoist_table_alloc<u64>(sizeof(u64) * 2 * (l + 1) * c->N);
+  if (!d) return nullptr;
   hipLaunchKernelGGL(k_hoist_corr, dim3(c->N / 256, l + 1, 2), dim3(256), 0, c->stream, c->dev, sign, key.d, pinv, d, l);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -283,8 +295,9 @@ static const u64 *hoist_key(evah_ctx *c, uint32_t elt, KeyDev &key) {
   if (key.d_perm) return key.d_perm;
   if (c->capturing) throw std::logic_error("first hoisted use of a Galois key cannot be captured into a graph");
   const uint32_t *pinv = perm_inv_table(c, elt);
-  u64 *d = nullptr;
-  HIPCHK(hipMalloc(&d, key.bytes));
+  if (!pinv) return nullptr;
+  u64 *d = hoist_table_alloc<u64>(key.bytes);
+  if (!d) return nullptr;
   const uint32_t rows = (uint32_t)(key.bytes / (sizeof(u64) * c->N));
   hipLaunchKernelGGL(k_key_perm, dim3(c->N / 256, rows), dim3(256), 0, c->stream, key.d, pinv, d, (uint32_t)c->N);
   hipError_t e = hipGetLastError();
@@ -309,11 +322,15 @@ struct RotPair {
   const u64 *corr;  // hoisting constant of (elt, l) and the permuted key (hoist_prepare); null when the set is not hoisted
   const u64 *keyp;
 };
-// the tables a hoisted pair needs (first use of an element / level: not capturable, like perm_table)
-static void hoist_prepare(evah_ctx *c, RotPair &p, uint32_t l) {
+// the tables a hoisted pair needs (first use of an element / level: not capturable, like perm_table).
+// false: the device has no room for one of them — the caller runs its set unhoisted (rot_chunk_plain), as it would with
+// EVAH_HOIST=0; the tables that did fit stay for later sets.  EVAH_HOIST_TABLE_FAIL=1 (tests) refuses every NEW table.
+static bool hoist_prepare(evah_ctx *c, RotPair &p, uint32_t l) {
   KeyDev &key = c->sh->galois.at(p.elt);
+  if (c->tun.hoist_table_fail && (!key.d_perm || !c->sh->hoist_corr.count({p.elt, l}))) return false;
   p.corr = hoist_corr(c, p.elt, l, key);
-  p.keyp = hoist_key(c, p.elt, key);
+  p.keyp = p.corr ? hoist_key(c, p.elt, key) : nullptr;
+  return p.corr && p.keyp;
 }
 struct RotChunk {
   uint32_t first, count; // pairs [first, first + count)

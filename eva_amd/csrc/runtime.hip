@@ -110,7 +110,12 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
         uint32_t b = 0;
         while ((q >> b) != 0) b++;
         const u64 cc = (b < 64 ? ((u64)1 << b) : 0) - q;
-        const bool ok = b > 32 && cc < ((u64)1 << 32);
+        // top-bit reduction x -> (x mod 2^b) + (x >> b) c leaves x < q + 16 c for x < 16 q, and a pass then runs THREE
+        // lazy stages (+ 4 q each) before the next reduction: q + 16 c + 12 q < 16 q needs 16 c < 3 q.  Every
+        // CoeffModulus::Create prime has c < 2^(b-10); a caller's or a file's 33/34-bit prime far below 2^b may not
+        // (b = 33, q = 1.2 * 2^32: c = 0.8 * 2^32 passes "c < 2^32" and breaks the bound), so the shape also needs
+        // c < q / 16 — other primes take the compare-and-subtract butterflies
+        const bool ok = b > 32 && cc < ((u64)1 << 32) && cc < (q >> 4);
         d.tb_c = ok ? (uint32_t)cc : 0;
         d.tb_sh = ok ? b - 32 : 0;
         d.tb_mask = ok ? (uint32_t)(((u64)1 << (b - 32)) - 1) : 0;
@@ -571,6 +576,20 @@ int evah_ctx_key_bytes(evah_ctx *c, uint64_t *bytes) {
   uint64_t b = c->sh->relin.d ? c->sh->relin.bytes : 0;
   for (auto &kv : c->sh->galois) b += kv.second.bytes;
   *bytes = b;
+  API_END
+}
+
+int evah_ctx_key_bytes_detail(evah_ctx *c, uint64_t out[3]) {
+  API_BEGIN
+  out[0] = out[1] = out[2] = 0;
+  auto count = [&](const KeyDev &kd) {
+    if (!kd.d) return;
+    out[0] += kd.bytes;
+    if (kd.d_split) out[1] += kd.bytes;
+    if (kd.d_perm) out[2] += kd.bytes;
+  };
+  count(c->sh->relin);
+  for (auto &kv : c->sh->galois) count(kv.second);
   API_END
 }
 

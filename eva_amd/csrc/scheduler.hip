@@ -4,6 +4,7 @@
 // /root/reference/eva/seal/seal_executor.h:279-404) for the encrypted part of a program.  Host code
 // only: every device action goes through the entry points of the evaluator units / runtime.hip.
 #include "internal.hip.h"
+#include <set>
 
 extern "C" {
 
@@ -27,6 +28,25 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
   };
   constexpr uint32_t NONE_V = ~0u;
   struct DRot { evah_ct *src; int32_t step; }; // alias of the source
+  // An elementwise op (Negate / Add / Sub / Mul on ciphertexts and plaintexts) whose result nobody has needed as a stored
+  // ciphertext yet: operands are other such nodes, or aliases of handles.  When a consumer that is not elementwise (or
+  // the end of the walk) needs the value, every unevaluated node below it goes out as ONE evah_elementwise_program; only
+  // the nodes somebody outside that program reads are stored.
+  struct Expr {
+    evah_ctx *c;
+    uint32_t op, v;                    // Op code; the value slot this node defines
+    std::shared_ptr<Expr> ea, eb;      // operand nodes (null: the operand is a handle)
+    evah_ct *ca = nullptr, *cb = nullptr; // aliases owned here
+    evah_pt *pa = nullptr, *pb = nullptr;
+    bool same = false;                 // Mul(a, a): square
+    uint32_t size = 0, limbs = 0, batch = 1;
+    double scale = 0;
+    evah_ct *result = nullptr;         // alias, once the node has been evaluated and stored
+    ~Expr() {
+      for (evah_ct *h : {ca, cb, result}) if (h) evah_ct_free(c, h);
+      for (evah_pt *h : {pa, pb}) if (h) evah_pt_free(c, h);
+    }
+  };
   struct State {
     evah_ctx *c;
     std::map<uint32_t, LazySum> sums;
@@ -39,7 +59,10 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     std::map<uint32_t, DRot> drots;
     // rotations that sums outside one window share after all: evaluated once, kept until the end of the call
     std::map<uint32_t, evah_ct *> mat;
+    // value -> unevaluated elementwise expression (EVAH_EW_FUSE)
+    std::map<uint32_t, std::shared_ptr<Expr>> exprs;
     ~State() {
+      exprs.clear();
       for (auto &kv : drots) evah_ct_free(c, kv.second.src);
       for (auto &kv : mat) evah_ct_free(c, kv.second);
       for (auto &kv : sums) {
@@ -50,7 +73,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
       for (auto *m : {&prods, &prodrel})
         for (auto &kv : *m) { evah_ct_free(c, kv.second.first); evah_ct_free(c, kv.second.second); }
     }
-  } st{c, {}, {}, {}, {}, {}, {}};
+  } st{c, {}, {}, {}, {}, {}, {}, {}};
   auto chk = [&](int rc) {
     if (rc) throw std::runtime_error(g_err);
   };
@@ -195,7 +218,9 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     }
   };
   // a value as a device ciphertext: deferred forms are evaluated on first demand
+  std::function<void(const std::vector<uint32_t> &)> force_exprs; // defined below the analysis (needs readers[])
   auto ct_of = [&](uint32_t v) -> evah_ct * {
+    if (st.exprs.count(v)) force_exprs({v});
     if (st.sums.count(v)) eval_sums({v});
     auto dr = st.drots.find(v);
     if (dr != st.drots.end()) { // a deferred rotation somebody needs as a ciphertext after all
@@ -217,7 +242,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     if (x.kind != EVAH_VAL_CT || !x.h) throw std::invalid_argument("operand is not a ciphertext");
     return static_cast<evah_ct *>(x.h);
   };
-  auto is_ct = [&](uint32_t v) { return slot(v).kind == EVAH_VAL_CT || st.sums.count(v) || st.relins.count(v) || st.drots.count(v); };
+  auto is_ct = [&](uint32_t v) { return slot(v).kind == EVAH_VAL_CT || st.sums.count(v) || st.relins.count(v) || st.drots.count(v) || st.exprs.count(v); };
   auto is_plain_ct = [&](uint32_t v) { return tab[v].kind == EVAH_VAL_CT && !st.sums.count(v) && !st.relins.count(v); };
 
   API_BEGIN
@@ -276,7 +301,176 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
   auto shape = [&](uint32_t v, uint32_t &size, uint32_t &limbs, double &scale) {
     auto ls = st.sums.find(v);
     if (ls != st.sums.end()) { size = ls->second.size; limbs = ls->second.limbs; scale = ls->second.scale; return; }
+    auto ex = st.exprs.find(v);
+    if (ex != st.exprs.end()) { size = ex->second->size; limbs = ex->second->limbs; scale = ex->second->scale; return; }
     chk(evah_ct_info(ct_of(v), &size, &limbs, &scale));
+  };
+
+  // ---- elementwise expressions (Expr above; include/eva_hip.h evah_elementwise_program).
+  // Evaluate the unevaluated nodes below `roots`: one program per (level, batch size); a node is stored when it is a
+  // root or when an op outside the program reads it (a later level's op, elementwise or not).
+  force_exprs = [&](const std::vector<uint32_t> &roots) {
+    std::vector<std::shared_ptr<Expr>> order; // operands first
+    std::set<const Expr *> seen;
+    std::function<void(const std::shared_ptr<Expr> &)> visit = [&](const std::shared_ptr<Expr> &n) {
+      if (!n || n->result || seen.count(n.get())) return;
+      seen.insert(n.get());
+      visit(n->ea);
+      visit(n->eb);
+      order.push_back(n);
+    };
+    std::set<uint32_t> root_vals;
+    for (uint32_t v : roots) {
+      auto it = st.exprs.find(v);
+      if (it == st.exprs.end()) continue;
+      root_vals.insert(v);
+      visit(it->second);
+    }
+    if (order.empty()) return;
+    std::set<uint32_t> in_prog;
+    for (auto &n : order) in_prog.insert(n->v);
+    std::map<std::pair<uint32_t, uint32_t>, std::vector<std::shared_ptr<Expr>>> classes;
+    for (auto &n : order) classes[{n->limbs, n->batch}].push_back(n);
+    for (auto &kv : classes) {
+      const auto &nodes = kv.second;
+      std::vector<evah_val> in;
+      std::map<const void *, uint32_t> in_idx;
+      auto input = [&](uint32_t kind, void *h) {
+        auto it = in_idx.find(h);
+        if (it != in_idx.end()) return it->second;
+        in.push_back(evah_val{kind, h});
+        return in_idx[h] = (uint32_t)in.size() - 1;
+      };
+      // operand `which` of node n: an earlier node of this program (index into nodes, tagged), or an input
+      std::map<const Expr *, uint32_t> pos;
+      for (uint32_t j = 0; j < nodes.size(); j++) pos[nodes[j].get()] = j;
+      constexpr uint32_t NODE = 0x80000000u;
+      auto operand = [&](const Expr &n, int which) -> uint32_t {
+        const std::shared_ptr<Expr> &e = which ? n.eb : n.ea;
+        evah_ct *ch = which ? n.cb : n.ca;
+        evah_pt *ph = which ? n.pb : n.pa;
+        if (e) {
+          if (e->result) return input(EVAH_VAL_CT, e->result);
+          auto it = pos.find(e.get());
+          if (it == pos.end()) throw std::logic_error("elementwise expression: an operand was dropped before it was evaluated");
+          return NODE | it->second;
+        }
+        if (ch) return input(EVAH_VAL_CT, ch);
+        if (ph) return input(EVAH_VAL_PT, ph);
+        throw std::logic_error("elementwise expression without an operand");
+      };
+      std::vector<std::pair<uint32_t, uint32_t>> refs(nodes.size());
+      for (uint32_t j = 0; j < nodes.size(); j++) {
+        const Expr &n = *nodes[j];
+        refs[j].first = operand(n, 0);
+        refs[j].second = n.op == 10 ? refs[j].first : (n.same ? refs[j].first : operand(n, 1));
+      }
+      const uint32_t n_in = (uint32_t)in.size();
+      std::vector<evah_ew_op> eops(nodes.size());
+      auto idx = [&](uint32_t r) { return (r & NODE) ? n_in + (r & ~NODE) : r; };
+      for (uint32_t j = 0; j < nodes.size(); j++) eops[j] = evah_ew_op{nodes[j]->op, idx(refs[j].first), idx(refs[j].second)};
+      std::vector<uint32_t> out_vals, out_node;
+      for (uint32_t j = 0; j < nodes.size(); j++) {
+        const Expr &n = *nodes[j];
+        bool store = root_vals.count(n.v) != 0;
+        for (uint32_t ri : readers[n.v]) store = store || !in_prog.count(ops[ri].dst);
+        if (store) { out_vals.push_back(n_in + j); out_node.push_back(j); }
+      }
+      if (out_vals.empty()) continue; // (dead code: nobody reads any of it)
+      std::vector<evah_ct *> outs(out_vals.size(), nullptr);
+      chk(evah_elementwise_program(c, in.data(), n_in, eops.data(), (uint32_t)eops.size(), out_vals.data(), (uint32_t)out_vals.size(), outs.data()));
+      for (size_t k = 0; k < outs.size(); k++) {
+        Expr &n = *nodes[out_node[k]];
+        n.result = alias_ct(outs[k]);
+        if (reads[n.v] > 0 || !freeable[n.v]) put(n.v, outs[k]); // still has readers: the table owns it like any other value
+        else evah_ct_free(c, outs[k]);
+      }
+    }
+    for (auto &n : order) st.exprs.erase(n->v);
+  };
+  // Record op `o` as an unevaluated expression node instead of running it?  Only when its result is an intermediate of
+  // this walk (freeable, read by somebody), its operands are plain handles or expression nodes, and every check of the
+  // entry point it stands for passes — anything else takes the ordinary path, which reports the error.
+  auto try_defer_ew = [&](const evah_op &o) -> bool {
+    if (!c->tun.ew_fuse || !(o.op == 10 || o.op == 11 || o.op == 12 || o.op == 13)) return false;
+    if (!freeable[o.dst] || n_reads[o.dst] == 0) return false;
+    struct Opnd {
+      int kind = 0; // 1 ciphertext handle, 2 plaintext handle, 3 expression
+      evah_ct *ct = nullptr;
+      evah_pt *pt = nullptr;
+      std::shared_ptr<Expr> e;
+      uint32_t size = 1, limbs = 0, batch = 1;
+      double scale = 0;
+    };
+    auto operand = [&](uint32_t v, Opnd &x) {
+      if (v >= n_vals) return false;
+      auto it = st.exprs.find(v);
+      if (it != st.exprs.end()) {
+        x.kind = 3; x.e = it->second;
+        x.size = x.e->size; x.limbs = x.e->limbs; x.batch = x.e->batch; x.scale = x.e->scale;
+        return true;
+      }
+      if (st.sums.count(v) || st.relins.count(v) || st.drots.count(v) || st.prods.count(v) || st.prodrel.count(v)) return false;
+      if (tab[v].kind == EVAH_VAL_CT && tab[v].h) {
+        x.kind = 1; x.ct = static_cast<evah_ct *>(tab[v].h);
+        x.size = x.ct->size; x.limbs = x.ct->limbs; x.batch = x.ct->batch; x.scale = x.ct->scale;
+        return true;
+      }
+      if (tab[v].kind == EVAH_VAL_PT && tab[v].h) {
+        x.kind = 2; x.pt = static_cast<evah_pt *>(tab[v].h);
+        x.limbs = x.pt->limbs; x.scale = x.pt->scale;
+        return true;
+      }
+      return false;
+    };
+    Opnd a, b;
+    if (!operand(o.src0, a)) return false;
+    const bool unary = o.op == 10;
+    if (!unary && !operand(o.src1, b)) return false;
+    if (!unary && o.op != 12 && a.kind == 2) std::swap(a, b); // the ciphertext first (seal_executor.h:116-119, :155-158)
+    if (a.kind == 2) return false;
+    auto node = std::make_shared<Expr>();
+    node->c = c; node->op = o.op; node->v = o.dst;
+    node->limbs = a.limbs; node->batch = a.batch;
+    if (unary) {
+      node->size = a.size; node->scale = a.scale;
+    } else if (b.kind == 2) {
+      if (a.limbs != b.limbs) return false;
+      node->size = a.size;
+      if (o.op == 13) {
+        node->scale = a.scale * b.scale;
+        if (!(node->scale > 0) || (int)std::log2(node->scale) >= c->total_bits[a.limbs]) return false;
+      } else {
+        if (!same_scale(a.scale, b.scale)) return false;
+        node->scale = a.scale;
+      }
+    } else {
+      if (a.limbs != b.limbs || a.batch != b.batch) return false;
+      if (o.op == 13) {
+        if (a.size != 2 || b.size != 2) return false;
+        node->same = o.src0 == o.src1;
+        // Mul -> Relinearize -> Rescale without other readers is one fused key-switch call (below): not an expression
+        if (!node->same && c->tun.fuse_mac && c->tun.fuse_mul && feeds_only(o.dst, 20) && feeds_only(ops[only_reader[o.dst]].dst, 22) &&
+            a.limbs >= 2 && a.batch == 1)
+          return false;
+        node->size = 3;
+        node->scale = a.scale * b.scale;
+        if (!(node->scale > 0) || (int)std::log2(node->scale) >= c->total_bits[a.limbs]) return false;
+      } else {
+        if (!same_scale(a.scale, b.scale)) return false;
+        node->size = std::max(a.size, b.size);
+        node->scale = a.scale;
+      }
+    }
+    auto take = [&](Opnd &x, std::shared_ptr<Expr> &e, evah_ct *&ch, evah_pt *&ph) {
+      if (x.kind == 3) e = x.e;
+      else if (x.kind == 1) ch = alias_ct(x.ct);
+      else ph = alias_pt(x.pt);
+    };
+    take(a, node->ea, node->ca, node->pa);
+    if (!unary && !node->same) take(b, node->eb, node->cb, node->pb);
+    st.exprs[o.dst] = std::move(node);
+    return true;
   };
 
   for (auto &lvl : buckets) {
@@ -326,6 +520,15 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
       put(o.dst, out);
     };
     std::vector<uint32_t> ready; // sums whose chain of additions ends at this level
+    { // expressions that this level's key switches, rescales, rotations and outputs read: evaluated together, first
+      std::vector<uint32_t> need;
+      for (uint32_t i : lvl) {
+        const evah_op &o = ops[i];
+        if (o.op == 10 || o.op == 11 || o.op == 12 || o.op == 13) continue;
+        if (st.exprs.count(o.src0) && std::find(need.begin(), need.end(), o.src0) == need.end()) need.push_back(o.src0);
+      }
+      if (!need.empty()) force_exprs(need);
+    }
     // ---- classify
     for (uint32_t i : lvl) {
       const evah_op &o = ops[i];
@@ -351,6 +554,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         continue;
       }
       if (batched && (o.op == 22 || (o.op == 20 && !feeds_only(o.dst, 22)) || (o.op == 13 && o.src0 != o.src1 && is_ct(o.src0) && is_ct(o.src1)))) {
+        if (o.op == 13 && try_defer_ew(o)) continue; // a product of batched handles inside an elementwise expression
         if (o.op == 22 && st.relins.count(o.src0)) { // deferred relinearize + this rescale, on the batched handle
           evah_ct *out = nullptr;
           chk(evah_relinearize_rescale(c, st.relins[o.src0], (uint32_t)o.imm, &out));
@@ -383,6 +587,8 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
           shape(o.src0, size, limbs, scale);
           relins[limbs].push_back(i);
         }
+      } else if (o.op == 13 && is_ct(o.src0) && is_ct(o.src1) && try_defer_ew(o)) {
+        // ciphertext x ciphertext inside an elementwise expression (not a Mul -> Relinearize -> Rescale chain): nothing runs here
       } else if (o.op == 13 && is_ct(o.src0) && is_ct(o.src1) &&
                  (o.src0 != o.src1 || (!batched && ct_of(o.src0)->size == 2))) { // a square is the product (a, a): same residues
         // Mul read only by a Relinearize that is read only by a Rescale (the commonest CKKS
@@ -422,6 +628,8 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         ls.steps.push_back(0);
         ls.rv.push_back(NONE_V);
         st.sums[o.dst] = std::move(ls);
+      } else if (o.op == 13 && try_defer_ew(o)) {
+        // ciphertext x plaintext that is not a term of a sum: part of an elementwise expression
       } else if (o.op == 13 && !batched &&
                  ((is_plain_ct(o.src0) && slot(o.src1).kind == EVAH_VAL_PT) || (is_plain_ct(o.src1) && slot(o.src0).kind == EVAH_VAL_PT))) {
         // independent ciphertext x plaintext products of one shape at this level: one launch
@@ -457,6 +665,8 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         st.sums[o.dst] = std::move(ls);
         // the chain ends here: evaluated with the other sums that end at this level (windows share their rotations)
         if (!(feeds_only(o.dst, 11) && nterms < (size_t)KS_BATCH_MAX)) ready.push_back(o.dst);
+      } else if (try_defer_ew(o)) {
+        // add / sub / negate (and what is left of the products) on values nobody needs stored yet
       } else {
         single(o);
       }
@@ -593,6 +803,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
           if (dr != st.drots.end()) { evah_ct_free(c, dr->second.src); st.drots.erase(dr); } // its terms live in the sums now
           auto lr = st.relins.find(v);
           if (lr != st.relins.end()) { evah_ct_free(c, lr->second); st.relins.erase(lr); }
+          st.exprs.erase(v); // its readers hold the node (their operand) until they are evaluated
           if (tab[v].kind != EVAH_VAL_NONE) release(v);
         }
       }

@@ -116,6 +116,13 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
     }
   }
   fusable = fusable && distinct.size() * B <= (size_t)KS_BATCH_MAX && hoist_wanted(c, l, n_rot, B);
+  // the hoisting tables of every rotated term; when one does not fit the device the window takes the general form
+  std::vector<RotPair> term_pair(n_terms);
+  for (uint32_t t = 0; t < n_terms && fusable; t++) {
+    if (steps[t] == 0) continue;
+    term_pair[t] = rot_pair(c, cts[t]->d, cts[t]->ps, 0, steps[t], l, "rotate_weighted_sums");
+    fusable = hoist_prepare(c, term_pair[t], l);
+  }
   auto chk = [&](int rc) {
     if (rc) throw std::runtime_error(g_err);
   };
@@ -176,12 +183,6 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
       std::vector<uint32_t> pair_term; // pair -> its term (position among cts / steps)
       std::vector<Unit> units;
       {
-        std::vector<RotPair> term_pair(n_terms);
-        for (uint32_t t = 0; t < n_terms; t++) {
-          if (steps[t] == 0) continue;
-          term_pair[t] = rot_pair(c, cts[t]->d, cts[t]->ps, 0, steps[t], l, "rotate_weighted_sums");
-          hoist_prepare(c, term_pair[t], l);
-        }
         uint32_t t0 = 0, p0 = 0, s0 = 0;
         for (uint32_t w = 0; w < n_windows; w++) {
           const uint32_t nt = win_terms[w], ns = win_sums[w];

@@ -134,6 +134,12 @@ int evah_ctx_transfer_stats(evah_ctx *ctx, uint64_t out[6]);
  * evah_ctx_set_shard(ctx, s, G) an upload keeps only shard s's prime rows of a key (its data limbs and the
  * special prime): (ceil((k-1)/G) + 1) / k of the whole key. */
 int evah_ctx_key_bytes(evah_ctx *ctx, uint64_t *bytes);
+/* The same keys with the copies the library keeps beside them (the reference keeps one copy per key, seal.h:58-66):
+ * out[0] = the key words as uploaded (= evah_ctx_key_bytes), out[1] = the radix-2^30 split copies of whole keys on
+ * contexts whose primes all have the top-bit shape (ks_inner_kernel<MAC3>), out[2] = the permuted copies of Galois
+ * keys that hoisted rotation sets have used so far.  Up to 3x out[0]; a copy that does not fit the device is simply
+ * not made (the affected launches take the form that does not need it). */
+int evah_ctx_key_bytes_detail(evah_ctx *ctx, uint64_t out[3]);
 int evah_ct_info(const evah_ct *ct, uint32_t *size, uint32_t *limbs, double *scale);
 int evah_ct_download(evah_ctx *ctx, const evah_ct *ct, uint64_t *out /* [size][limbs][N] */);
 void evah_ct_free(evah_ctx *ctx, evah_ct *ct);
@@ -292,6 +298,21 @@ enum { EVAH_OPF_FREE_SRC0 = 1, EVAH_OPF_FREE_SRC1 = 2 };
 typedef struct evah_val { uint32_t kind; void *h; } evah_val;
 typedef struct evah_op { uint32_t op, dst, src0, src1; int32_t imm; uint32_t flags; } evah_op;
 int evah_execute(evah_ctx *ctx, const evah_op *ops, uint32_t n_ops, evah_val *table, uint32_t n_vals);
+
+/* ---- a straight-line program of elementwise evaluator calls in ONE launch (eva_amd/csrc/ewprogram.hip) ----------
+ * Replaces a run of SEALExecutor's elementwise dispatches — add / sub (+ plain) seal_executor.h:114-150, multiply /
+ * square / multiply_plain :152-175, negate :191-195 — on values nobody else reads: Harris' response
+ * det - k trace^2 is seven such calls, Sobel's magnitude and polynomial a dozen (examples/image_processing.py:39-100).
+ * Values 0 .. n_in-1 are the inputs (ciphertexts or plaintexts, as in evah_execute's table), value n_in + j is the
+ * result of ops[j]; `op` is the Op code of /root/reference/eva/ir/ops.h:11-25 (10 Negate, 11 Add, 12 Sub, 13 Mul) with
+ * SEALExecutor's dispatch rules: a plaintext first operand of Add / Mul goes behind the ciphertext, Mul(a, a) is
+ * square, Sub keeps its order (plain - cipher is "Unsupported operation encountered", as in the reference).  Checks,
+ * error messages and results are those of the separate entry points called in program order; intermediates that are not
+ * listed in out_vals never reach HBM.  All ciphertexts of a program are of one level and batch size.  A program beyond
+ * one launch's registers runs as the separate calls.  evah_execute builds these programs itself (EVAH_EW_FUSE). */
+typedef struct evah_ew_op { uint32_t op, a, b; } evah_ew_op;
+int evah_elementwise_program(evah_ctx *ctx, const evah_val *in, uint32_t n_in, const evah_ew_op *ops, uint32_t n_ops,
+                             const uint32_t *out_vals, uint32_t n_out, evah_ct **outs);
 
 /* ---- limb-sharded execution (BASELINE config 5) --------------------------
  * The RNS limbs of every value are dealt over G shards — limb i on shard i mod G — one shard per

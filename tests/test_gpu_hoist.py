@@ -486,3 +486,123 @@ def test_fallback_forms_agree():
         assert np.array_equal(u, v)
     for st, got in zip(steps[1:], res[0]):
         assert np.array_equal(got, e.o.rotate(a, st, e.keys[st]))
+
+
+def _env_with(cfg, **knobs):
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update({k: str(v) for k, v in knobs.items()})
+    try:
+        return Env(*cfg)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("grid", [1, 3, 2000])
+def test_fallback_is_independent_of_its_grid(grid):
+    """The persistent fallback orders its phases by tickets, not by a barrier over resident workgroups
+    (rot_fallback.hip.h): ONE workgroup walks every chunk of every phase alone, three share them, two thousand (far
+    more than fit the chip at once) compete for them — the same bits every time."""
+    cfg = CONFIGS[2]
+    e = env(cfg)
+    x = _env_with(cfg, EVAH_FB_GRID=grid)
+    l = e.k - 1
+    steps = [0, 1, 65, -3]
+    a = e.rand(2, l)
+    a[1] = 0
+    for st in steps[1:]:
+        x.g.upload_galois_key(x.g.galois_elt_from_step(st), e.key_for(st))
+    wts = [[_rand_pt(e, l) for _ in steps] for _ in range(2)]
+    A = x.g.upload_ct(a, 2.0 ** 20)
+    W = [[x.g.upload_pt(w, 2.0 ** 10) for w in row] for row in wts]
+    for st, o in zip(steps[1:], x.g.rotate_many(A, steps[1:])):
+        assert np.array_equal(o.download(), e.o.rotate(a, st, e.keys[st])), f"grid {grid}: step {st}"
+    sums = [o.download() for o in x.g.rotate_weighted_sums([([(A, st) for st in steps], W)])]
+    want = _window_oracle(e, [(a, st) for st in steps], wts)
+    for got, w in zip(sums, want):
+        assert np.array_equal(got, w), f"grid {grid}: window sums"
+
+
+def test_two_active_fallbacks_on_two_queues_under_load():
+    """Two ACTIVE fallbacks (transparent sources: every digit coefficient is zero) on two issue queues of one device
+    state while a third queue of the same GPU is kept full with the N = 2^16, L = 10 op-triple (32 triples per launch
+    set: kernels of ~1 ms that fill every CU).  The r4 fallback was a grid-wide spin barrier that relied on all of its
+    workgroups being resident, which co-running queues do not guarantee; the ticket-ordered form needs no such thing.
+    Everything is enqueued before anything is waited for; every result is compared with the oracle."""
+    cfg = CONFIGS[3]
+    e = env(cfg)
+    x = _env_with(cfg)
+    q = [x.g.fork(), x.g.fork()]
+    l = e.k - 1
+    steps = [1, 65, -3, 2]
+    for st in steps:
+        x.g.upload_galois_key(x.g.galois_elt_from_step(st), e.key_for(st))
+    srcs = []
+    for i in range(2):
+        a = e.rand(2, l)
+        a[1] = 0
+        srcs.append(a)
+    # the load: op-triples on a context of their own (another N), 3 launch sets of 32
+    N2, l2 = 65536, 10
+    primes2 = po.coeff_modulus_create(N2, [60] * (l2 + 1))
+    big = backend.Context(N2, primes2)
+    rng = np.random.default_rng(11)
+    rand2 = lambda prefix, nl: np.stack([rng.integers(0, primes2[i], size=prefix + (N2,), dtype=np.uint64)  # noqa: E731
+                                         for i in range(nl)], axis=len(prefix))
+    key2 = rand2((l2, 2), l2 + 1)
+    big.upload_relin_key(key2)
+    ha, hb = rand2((2,), l2), rand2((2,), l2)
+    As = [big.upload_ct(ha, 2.0 ** 40) for _ in range(32)]
+    Bs = [big.upload_ct(hb, 2.0 ** 40) for _ in range(32)]
+    handles = [qq.upload_ct(a, 2.0 ** 20) for qq, a in zip(q, srcs)]
+    for qq in q:
+        qq.sync()
+    big.sync()
+    rounds = []
+    for _ in range(3):
+        trip = big.multiply_relinearize_rescale_many(As, Bs, 60)
+        rot = [qq.rotate_many(h, steps) for qq, h in zip(q, handles)]
+        rounds.append((trip, rot))
+    for trip, rot in rounds:
+        for qi, outs in enumerate(rot):
+            for st, o in zip(steps, outs):
+                assert np.array_equal(o.download(), e.o.rotate(srcs[qi], st, e.keys[st])), f"queue {qi}: step {st}"
+    want = po.Oracle(N2, primes2).op_triple(ha, hb, key2)
+    for trip, _ in rounds:
+        assert np.array_equal(trip[0].download(), want) and np.array_equal(trip[31].download(), want)
+    for qq in q:
+        qq.close()
+    big.close()
+
+
+def test_hoisting_tables_that_do_not_fit_degrade_to_the_unhoisted_path():
+    """A hoisted set keeps a permuted copy of every Galois key it uses and a constant per (element, level); when the
+    device has no room for one (EVAH_HOIST_TABLE_FAIL=1 refuses every new table) the set — a rotation set, sibling
+    rotations of several sources, a convolution window — must run unhoisted with the same bits instead of failing,
+    and the copies that exist are accounted for (evah_ctx_key_bytes_detail)."""
+    cfg = CONFIGS[2]
+    e = env(cfg)
+    l = e.k - 1
+    steps = [1, 65, -3]
+    a, b = e.rand(2, l), e.rand(2, l)
+    wts = [[_rand_pt(e, l) for _ in [0] + steps]]
+    for fail in (1, 0):
+        x = _env_with(cfg, EVAH_HOIST_TABLE_FAIL=fail)
+        for st in steps:
+            x.g.upload_galois_key(x.g.galois_elt_from_step(st), e.key_for(st))
+        A, B = x.g.upload_ct(a, 2.0 ** 20), x.g.upload_ct(b, 2.0 ** 20)
+        for st, o in zip(steps, x.g.rotate_many(A, steps)):
+            assert np.array_equal(o.download(), e.o.rotate(a, st, e.keys[st])), f"fail={fail}: rotate_many step {st}"
+        outs = x.g.rotate_pairs([A, B, A, B], [1, 1, 65, -3])
+        for (src, st), o in zip([(a, 1), (b, 1), (a, 65), (b, -3)], outs):
+            assert np.array_equal(o.download(), e.o.rotate(src, st, e.keys[st])), f"fail={fail}: rotate_pairs step {st}"
+        W = [[x.g.upload_pt(w, 2.0 ** 10) for w in row] for row in wts]
+        sums = [o.download() for o in x.g.rotate_weighted_sums([([(A, st) for st in [0] + steps], W)])]
+        for got, w in zip(sums, _window_oracle(e, [(a, st) for st in [0] + steps], wts)):
+            assert np.array_equal(got, w), f"fail={fail}: window sums"
+        words, split, perm = x.g.key_bytes_detail()
+        assert words == x.g.key_bytes() == 3 * l * 2 * e.k * e.N * 8
+        assert perm == (0 if fail else words), (fail, words, split, perm)  # one permuted copy per key a hoisted set used

@@ -502,3 +502,74 @@ def test_multiply_plain_many_and_squares_as_products(cfg):
     assert np.array_equal(outs[0].download(), e.o.square(a))
     assert np.array_equal(outs[1].download(), e.o.multiply(a, b))
     assert np.array_equal(outs[2].download(), e.o.square(b))
+
+
+def _is_prime(n):
+    if n < 2:
+        return False
+    for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n % p == 0:
+            return n == p
+    d, s = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        s += 1
+    for a in (2, 325, 9375, 28178, 450775, 9780504, 1795265022):  # deterministic for n < 2^64
+        a %= n
+        if a == 0:
+            continue
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(s - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def _ntt_prime_below(bound, N):
+    q = bound - (bound % (2 * N)) + 1
+    while q >= bound or not _is_prime(q):
+        q -= 2 * N
+    return q
+
+
+def test_primes_of_top_bit_width_but_far_from_the_power_of_two():
+    """evah_ctx_create accepts a caller's primes, not only CoeffModulus::Create's.  A 33- or 34-bit prime far below 2^b
+    (q = 2^b - c with c close to 2^32) has c < 2^32 yet breaks the bound the top-bit butterflies rest on
+    (q + 16 c + 12 q < 16 q): such primes must take the compare-and-subtract path.  Transforms and a whole key switch
+    (relinearize, rescale, rotation) against the oracle, next to primes of the ordinary shape in the same chain."""
+    N = 2048
+    far33 = _ntt_prime_below(int(1.2 * 2 ** 32), N)   # 33 bits, c = 2^33 - q ~ 0.8 * 2^32
+    far34 = _ntt_prime_below(int(3.05 * 2 ** 32), N)  # 34 bits, c ~ 0.95 * 2^32
+    near = po.coeff_modulus_create(N, [60, 60])
+    primes = [far33, near[0], far34, near[1]]
+    assert far33.bit_length() == 33 and (1 << 33) - far33 < 2 ** 32 and far34.bit_length() == 34 and (1 << 34) - far34 < 2 ** 32
+    g = backend.Context(N, primes)
+    o = po.Oracle(N, primes)
+    rng = np.random.default_rng(99)
+    k, l = len(primes), len(primes) - 1
+    for i, q in enumerate(primes):
+        for a in (rng.integers(0, q, size=N, dtype=np.uint64), np.full(N, q - 1, dtype=np.uint64)):
+            f = g.test_ntt(i, a)
+            assert np.array_equal(f, o.ntt(i, a)), f"forward NTT, prime {i} ({q})"
+            assert np.array_equal(g.test_ntt(i, f, inverse=True), a), f"inverse NTT, prime {i} ({q})"
+    rand = lambda prefix, nl: np.stack([rng.integers(0, primes[i], size=prefix + (N,), dtype=np.uint64)  # noqa: E731
+                                        for i in range(nl)], axis=len(prefix))
+    rk, gk = rand((l, 2), k), rand((l, 2), k)
+    g.upload_relin_key(rk)
+    g.upload_galois_key(g.galois_elt_from_step(5), gk)
+    a, b = rand((2,), l), rand((2,), l)
+    A, B = g.upload_ct(a, 2.0 ** 20), g.upload_ct(b, 2.0 ** 20)
+    m = o.multiply(a, b)
+    assert np.array_equal(g.multiply(A, B).download(), m)
+    r = o.relinearize(m, rk)
+    R = g.relinearize(g.multiply(A, B))
+    assert np.array_equal(R.download(), r)
+    assert np.array_equal(g.rescale(R, 34).download(), o.rescale(r))
+    assert np.array_equal(g.rotate(A, 5).download(), o.rotate(a, 5, gk))
+    assert np.array_equal(g.multiply_relinearize_rescale_many([A, A], [B, B], 34)[1].download(), o.op_triple(a, b, rk))
+    g.close()
