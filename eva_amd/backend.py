@@ -443,6 +443,10 @@ class Context:
         _chk(_lib.evah_pt_copy(self.h, value.h, C.byref(h)))
         return Plaintext(self, h)
 
+    def enable_peer(self, other):
+        """peer access between this context's device and `other`'s, both directions (a refusal raises)"""
+        _chk(_lib.evah_ctx_enable_peer(self.h, other.h))
+
     # ---- plumbing
     def set_stream(self, stream_ptr):
         _chk(_lib.evah_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))

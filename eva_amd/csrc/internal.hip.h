@@ -247,6 +247,9 @@ struct Tunables {
   uint32_t hoist_min_tiles = 2048;
   // EVAH_HOIST_DEBUG (0): print the zero-coefficient count of every hoisted set (synchronises)
   bool hoist_debug = false;
+  // EVAH_PEER_SELF_CHECK (0): tests only — evah_ctx_enable_peer asks the runtime about the pair even when both contexts
+  // are on one device (where it answers "no"), so the refusal path can run on a 1-GPU box
+  bool peer_self_check = false;
   // EVAH_HOIST_TABLE_FAIL (0): tests only — behave as if the device had no room for any NEW hoisting table (permuted
   // key copies, per-(element, level) constants): the affected sets must run unhoisted with the same results
   bool hoist_table_fail = false;
@@ -300,6 +303,7 @@ struct Tunables {
     count("EVAH_HOIST_MIN_TILES", t.hoist_min_tiles);
     flag("EVAH_HOIST_DEBUG", t.hoist_debug);
     flag("EVAH_HOIST_TABLE_FAIL", t.hoist_table_fail);
+    flag("EVAH_PEER_SELF_CHECK", t.peer_self_check);
     flag("EVAH_FUSE_SPECIAL_INV", t.fuse_special_inv);
     flag("EVAH_FOLD_PA", t.fold_pa);
     flag("EVAH_WIN_FUSE", t.win_fuse);
@@ -414,6 +418,25 @@ inline hipEvent_t sync_event(evah_ctx *c) {
 // make `waiter`'s stream wait for everything enqueued so far on `signaller`'s stream
 inline void stream_wait(evah_ctx *waiter, evah_ctx *signaller) {
   if (waiter == signaller || waiter->stream == signaller->stream) return;
+  if (waiter->sh.get() != signaller->sh.get()) {
+    // Queues of two device states — two GPUs (sub-DAG members, limb shards), or two states on one GPU (how a 1-GPU box runs
+    // this branch: limb shards, "virtual device" members).  An event is recorded on a stream of the device it was created
+    // on, so it comes from the SIGNALLER's pool under the signaller's device; the wait is issued under the waiter's
+    // (hipStreamWaitEvent takes events of other devices).  r5: until now the event came from the waiter — on a real
+    // two-GPU box an event of device A recorded on a stream of device B, which no box had ever executed.
+    int cur = 0;
+    HIPCHK(hipGetDevice(&cur));
+    HIPCHK(hipSetDevice(signaller->device));
+    hipEvent_t e = sync_event(signaller);
+    hipError_t rc = hipEventRecord(e, signaller->stream);
+    (void)hipSetDevice(waiter->device);
+    if (rc == hipSuccess) rc = hipStreamWaitEvent(waiter->stream, e, 0);
+    (void)hipSetDevice(cur);
+    if (waiter->capturing || signaller->capturing) signaller->capture_events.push_back(e);
+    else signaller->sync_events.push_back(e);
+    HIPCHK(rc);
+    return;
+  }
   hipEvent_t e = sync_event(waiter);
   HIPCHK(hipEventRecord(e, signaller->stream));
   HIPCHK(hipStreamWaitEvent(waiter->stream, e, 0));

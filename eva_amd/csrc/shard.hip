@@ -149,7 +149,7 @@ int evah_buf_gather(evah_ctx *c, evah_buf *dst, uint32_t n, const evah_buf *cons
 // xGMI — so a refusal is an error here, not a silent fallback.  Contexts of one device: nothing to do.
 int evah_ctx_enable_peer(evah_ctx *a, evah_ctx *b) {
   API_BEGIN
-  if (a->device == b->device) return 0;
+  if (a->device == b->device && !a->tun.peer_self_check) return 0;
   for (int dir = 0; dir < 2; dir++) {
     const int from = dir ? b->device : a->device, to = dir ? a->device : b->device;
     int can = 0;

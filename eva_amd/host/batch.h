@@ -32,10 +32,25 @@ inline std::vector<HipValuation> HipPublic::execute_batch(Program &program, cons
   };
   size_t g = 0;
   const bool bounded = std::getenv("EVA_BATCH_BOUNDED") ? std::atoi(std::getenv("EVA_BATCH_BOUNDED")) != 0 : false;
+  // Group sizes.  The call includes the uploads of its first group and the downloads of its last, which nothing overlaps:
+  // with batch_ramp the first and the last batch_chunk instances go as a quarter-sized and a three-quarter-sized group
+  // (8, 24, 32, ..., 32, 24, 8 for 256 instances), so the pipeline fills and drains on a quarter of a group's copies.
+  std::vector<size_t> sizes;
+  {
+    const size_t n = inputs.size(), c = batch_chunk, q = c / 4;
+    if (batch_ramp && q >= 1 && n >= 4 * c) {
+      sizes = {q, c - q};
+      for (size_t left = n - 2 * c; left > 0; left -= std::min(left, c)) sizes.push_back(std::min(left, c));
+      sizes.push_back(c - q);
+      sizes.push_back(q);
+    } else {
+      for (size_t left = n; left > 0; left -= std::min(left, c)) sizes.push_back(std::min(left, c));
+    }
+  }
   const auto t_begin = std::chrono::steady_clock::now();
   try {
-    for (size_t i0 = 0; i0 < inputs.size(); i0 += batch_chunk, g++) {
-      const size_t n = std::min<size_t>(batch_chunk, inputs.size() - i0);
+    for (size_t i0 = 0; g < sizes.size(); i0 += sizes[g], g++) {
+      const size_t n = sizes[g];
       std::vector<const HipValuation *> chunk(inputs.begin() + i0, inputs.begin() + i0 + n);
       if (bounded && g >= Q) chk(evah_ctx_sync(qs[g % Q])); // group g-Q (same queue) has left the device
       HipExecutor ex(program, *host, std::vector<evah_ctx *>{qs[g % Q]}, dev.get());

@@ -254,7 +254,7 @@ PYBIND11_MODULE(_eva, m) {
     if (!devices.is_none()) {
       kp.first->devices = devices.cast<std::vector<int>>();
       // the key pair's own device state (inputs, constants, outputs; the secret half decrypts there) is member 0
-      if (!kp.first->devices.empty()) kp.first->device = kp.second->device = kp.first->devices[0];
+      if (!kp.first->devices.empty()) kp.first->device = kp.second->device = evahost::physical_device(kp.first->devices[0]);
     }
     if (!shard.is_none()) kp.first->shard_mode = shard.cast<std::string>();
     if (g_num_threads > 1) kp.first->num_queues = std::min(g_num_threads, 8);
@@ -337,6 +337,7 @@ PYBIND11_MODULE(_eva, m) {
            "execute() for a list of independent input valuations of one program; instances run batch_chunk at a time as batched device handles")
       .def_readwrite("library_scheduler", &HipPublic::library_scheduler, "run the encrypted part of a program as one evah_execute (default) instead of the node-by-node host walk")
       .def_readwrite("batch_chunk", &HipPublic::batch_chunk, "instances per batched device handle in execute_batch (1..64)")
+      .def_readwrite("batch_ramp", &HipPublic::batch_ramp, "execute_batch: quarter / three-quarter sized groups at both ends of the batch, so the pipeline fills and drains on small copies (EVA_BATCH_RAMP)")
       .def_readwrite("batch_depth", &HipPublic::batch_depth, "groups in flight in execute_batch = issue queues it rotates over (2..8; EVA_BATCH_DEPTH)")
       .def_readwrite("device", &HipPublic::device)
       .def_readwrite("free_eagerly", &HipPublic::free_eagerly)

@@ -31,6 +31,11 @@ struct DeviceGroup {
   size_t size() const { return ctx.size(); }
 };
 
+// A member id names a DEVICE STATE: ids below 256 are the HIP devices themselves; id = d + 256 v (v >= 1) is a further,
+// separate state — own tables, own keys, own queues — on device d ("virtual device").  With them a 1-GPU box runs every
+// branch that two GPUs take except the peer hardware itself: separate roots per member, key uploads per root, copies and
+// ordering between the queues of different states (evah_ct_copy / evah_pt_copy, stream_wait across states).
+inline int physical_device(int id) { return id & 0xff; }
 // peer access for every pair of members on different devices; a refusal throws (evah_last_error names the pair)
 inline void enable_peers(const DeviceGroup &g) {
   for (size_t a = 0; a < g.ctx.size(); a++)
@@ -51,7 +56,7 @@ inline DeviceGroup make_device_group(const std::vector<int> &ids, const std::sha
     const bool is_new = it == by_device.end();
     std::shared_ptr<DeviceCtx> root;
     if (is_new) {
-      root = std::make_shared<DeviceCtx>(host.N, host.primes, ids[m]);
+      root = std::make_shared<DeviceCtx>(host.N, host.primes, physical_device(ids[m]));
       upload_keys(root->h);
       by_device[ids[m]] = root;
     } else {
@@ -77,7 +82,7 @@ inline DeviceGroup make_limb_group(const std::vector<int> &ids, const HostContex
   g.ids = ids;
   const uint32_t G = (uint32_t)ids.size();
   for (uint32_t s = 0; s < G; s++) {
-    auto root = std::make_shared<DeviceCtx>(host.N, host.primes, ids[s]);
+    auto root = std::make_shared<DeviceCtx>(host.N, host.primes, physical_device(ids[s]));
     chk(evah_ctx_set_shard(root->h, s, G));
     upload_keys(root->h);
     g.roots.push_back(root);

@@ -245,6 +245,10 @@ public:
   // groups in flight in execute_batch: group g is enqueued on queue g mod batch_depth, so the copies of one group
   // overlap the kernels of the others; device memory = batch_depth groups' working sets
   uint32_t batch_depth = std::getenv("EVA_BATCH_DEPTH") ? (uint32_t)std::atoi(std::getenv("EVA_BATCH_DEPTH")) : 4;
+  // smaller groups at both ends of a batch (batch.h; EVA_BATCH_RAMP=1).  Off by default: measured on config 4
+  // (profiles/r05_tuning_notes.md) the shorter fill / drain is real — the best calls are the same 16.8 ms — but the odd
+  // group sizes make some calls 3-6 ms longer (pool misses), so the median is no better
+  bool batch_ramp = std::getenv("EVA_BATCH_RAMP") ? std::atoi(std::getenv("EVA_BATCH_RAMP")) != 0 : false;
   std::vector<HipValuation> execute_batch(Program &program, const std::vector<const HipValuation *> &inputs);
 
   // "dag" mode (BASELINE config 4): the groups of a batch are dealt over the members
@@ -297,7 +301,8 @@ private:
     int n = 0;
     chk(evah_device_count(&n));
     for (int d : devices)
-      if (d < 0 || d >= n) throw std::runtime_error("device " + std::to_string(d) + " requested, " + std::to_string(n) + " visible");
+      if (d < 0 || physical_device(d) >= n)
+        throw std::runtime_error("device " + std::to_string(physical_device(d)) + " requested, " + std::to_string(n) + " visible");
   }
   void ensure_group(bool) {
     if (group && group_ids == devices) return;
@@ -429,7 +434,7 @@ private:
   void ensure_device(bool eval_keys = true) {
     if (!dev) {
       // a one-member `devices` list names the device of this context (several members: member 0 is checked by the modes)
-      if (!holder->dev && devices.size() == 1) device = devices[0];
+      if (!holder->dev && devices.size() == 1) device = physical_device(devices[0]);
       if (!holder->dev) holder->dev = std::make_shared<DeviceCtx>(host->N, host->primes, device);
       dev = holder->dev; // may have been created by the secret half of the key pair (decrypt first)
     }

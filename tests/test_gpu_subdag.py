@@ -219,3 +219,64 @@ def test_two_real_devices():
     a = g0.upload_ct(data, 2.0 ** 30)
     assert np.array_equal(g1.copy_here(a).download(), data)
     g1.close(); g0.close()
+
+
+def test_members_with_device_states_of_their_own(monkeypatch):
+    """Member ids d + 256 v are further device STATES on device d (eva_amd/host/multi_device.h): own tables, own keys, own
+    queues.  [0, 256, 512] on the one GPU of this box takes what three GPUs take — a root per member with the keys
+    uploaded to each, evah_ct_copy / evah_pt_copy between the queues of different states at the cuts, the cross-state
+    ordering (events recorded under the signaller's device, waited for under the waiter's) — everything except the
+    peer hardware (test_two_real_devices, hardware-only)."""
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
+    params.poly_modulus_degree = 16384
+    pub, sec = generate_keys(params, 4)
+    enc = pub.encrypt(_image(4096), sig)
+    single = pub.execute(compiled, enc)
+    ref, _ = c_walk(pub, compiled, enc, threads=4)
+    pub.devices, pub.shard_mode = [0, 256, 512], "subdag"
+    for _ in range(2):
+        out = pub.execute(compiled, enc)
+        _same_as(out, ref, single)
+    assert sorted(m for m, _ in pub.last_subdag_plan[1:-1]) == [0, 1, 2]
+    res = sec.decrypt(out, sig)  # the outputs came back to member 0's state, where the secret half reads them
+    assert np.isfinite(np.array(res['image'])).all()
+    # limb shards on separate states of one device (each shard has a state of its own in any case) and of "two"
+    pub.devices, pub.shard_mode = [0, 256], "limb"
+    _same_as(pub.execute(compiled, enc), ref)
+    # dag mode: the groups of a batch dealt over two states
+    pub2, _ = generate_keys(params, 4, devices=[0, 256], shard="dag")
+    pub2.resident = False
+    pub2.batch_chunk = 2
+    encs = [pub2.encrypt(_image(4096), sig) for _ in range(5)]
+    outs = pub2.execute_batch(compiled, encs)
+    for e, o in zip(encs, outs):
+        r, _ = c_walk(pub2, compiled, e, threads=4)
+        _same_as(o, r)
+    # the raw C-ABI copy between two device states, both ways, and the release of a value through the other state's queue
+    g0 = backend.Context(pub.poly_modulus_degree, list(pub.primes), device=0)
+    g1 = backend.Context(pub.poly_modulus_degree, list(pub.primes), device=0)
+    data = enc.get('image')[4]
+    a = g0.upload_ct(data, 2.0 ** 30)
+    b = g1.copy_here(a)
+    c2 = g0.copy_here(g1.add(b, b))
+    assert np.array_equal(b.download(), data)
+    assert np.array_equal(c2.download(), g0.add(a, a).download())
+    g1.close(); g0.close()
+
+
+def test_peer_access_refusal_is_an_error(monkeypatch):
+    """evah_ctx_enable_peer: a pair the runtime refuses (hipDeviceCanAccessPeer says no) is an error naming the pair, never a
+    silent staging through host memory.  On one GPU the refusal is provoked by asking about the device itself
+    (EVAH_PEER_SELF_CHECK=1); the granting path (hipDeviceEnablePeerAccess) needs two GPUs."""
+    monkeypatch.setenv("EVAH_PEER_SELF_CHECK", "1")
+    compiled, params, sig = _conv_chain(1)
+    params.poly_modulus_degree = 4096
+    pub, sec = generate_keys(params, 6, devices=[0, 256], shard="subdag")
+    enc = pub.encrypt({'x': [0.5] * 1024}, sig)
+    with pytest.raises(RuntimeError, match="cannot access device 0 as a peer"):
+        pub.execute(compiled, enc)
+    g0 = backend.Context(4096, list(pub.primes), device=0)
+    g1 = backend.Context(4096, list(pub.primes), device=0)
+    with pytest.raises(backend.EvaHipError, match="as a peer"):
+        g0.enable_peer(g1)
+    g1.close(); g0.close()
