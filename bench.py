@@ -908,14 +908,15 @@ def seal_pin_baseline(cpu, N, l):
     """tools/pin_with_seal.sh leaves profiles/seal_pin.json on a host that has Microsoft SEAL >= 3.6: the verdicts of
     tools/seal_parity.cpp's sections and SEAL's own op-triple rate there.  When it is present (and was measured at this
     (N, L)) the reported baseline is the reference itself — kind "reference" — with the port's figures kept beside it."""
-    path = os.path.join(ROOT, "profiles", "seal_pin.json")
+    path = os.environ.get("EVA_SEAL_PIN_JSON") or os.path.join(ROOT, "profiles", "seal_pin.json")
     if not os.path.exists(path):
         return cpu
     try:
         pin = json.load(open(path))
         rate = pin.get("seal_triples_per_s")
-        if not rate or (pin.get("N"), pin.get("limbs")) != (N, l):
-            cpu["seal_pin"] = {"file": "profiles/seal_pin.json", "used": False, "why": "no op-triple rate at this (N, L) in it"}
+        if pin.get("dry_run") or not rate or (pin.get("N"), pin.get("limbs")) != (N, l):
+            cpu["seal_pin"] = {"file": "profiles/seal_pin.json", "used": False,
+                               "why": "a dry run: no SEAL took part" if pin.get("dry_run") else "no op-triple rate at this (N, L) in it"}
             return cpu
         port = {kk: cpu[kk] for kk in ("value", "cores", "sample", "all_cores", "threads_64")}
         cpu.update({"value": round(float(rate), 3), "cores": int(pin.get("cores", 1)), "kind": "reference",

@@ -81,3 +81,50 @@ def test_real_seal_reproduces_the_golden_vectors(tmp_path):
         pytest.skip("SEAL absent: " + res["reason"] + " — parity stays pinned to the oracle only")
     assert res.get("built"), res.get("log")
     assert res["ok"], res["failed"]
+
+
+def test_pin_kit_one_command(tmp_path, monkeypatch):
+    """tools/pin_with_seal.sh is the one command a SEAL-equipped host runs.  Here, without SEAL: its --dry-run (vector
+    export for a golden and a fresh set + the checker type-checked against the declarations) must work end to end and
+    say that it pinned nothing; its report step must turn seal_parity logs into the JSON bench.py ingests, and bench.py
+    must then report the reference as the baseline — and must NOT do so for a dry run or for another (N, L)."""
+    import json
+    import shutil
+    if not shutil.which("bash") or not shutil.which("g++"):
+        pytest.skip("no bash / g++")
+    script = os.path.join(ROOT, "tools", "pin_with_seal.sh")
+    assert subprocess.run(["bash", "-n", script]).returncode == 0
+    out = tmp_path / "pin.json"
+    env = dict(os.environ, PIN_CONFIGS="golden 2048:40,20,40,41", PIN_JSON=str(out), PYTHON=sys.executable)
+    r = subprocess.run(["bash", script, "--dry-run", str(tmp_path / "work")], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(out.read_text())
+    assert rep["dry_run"] is True and rep["sections"] is None and rep["all_identical"] is None and rep["seal_triples_per_s"] is None
+    assert [v["N"] for v in rep["vector_sets"]] == [1024, 2048]
+    # the report step on logs as tools/seal_parity.cpp prints them (report(): "PASS  <what>" / "FAIL  <what>", TIMING, SUMMARY)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import seal_pin_report
+    dirs = [str(tmp_path / "work" / "vec_golden"), str(tmp_path / "work" / "vec_2048")]
+    open(os.path.join(dirs[0], "seal_parity.log"), "w").write("PASS  CoeffModulus::Create\nPASS  psi\nSUMMARY 2 passed, 0 failed\n")
+    open(os.path.join(dirs[1], "seal_parity.log"), "w").write(
+        "PASS  multiply\nPASS  relinearize\nPASS  rescale_to_next\nTIMING op-triples/s 12.5 threads 1 N 65536 limbs 10\nSUMMARY 3 passed, 0 failed\n")
+    assert seal_pin_report.main(["--out", str(out)] + dirs) == 0
+    rep = json.loads(out.read_text())
+    assert rep["all_identical"] is True and rep["seal_triples_per_s"] == 12.5 and (rep["N"], rep["limbs"]) == (65536, 10)
+    assert rep["sections"]["1024:60,40,60"]["passed"] == 2 and rep["sections"]["2048:40,20,40,41"]["failed"] == []
+    # one FAIL line (or a log without its SUMMARY) is not "identical"
+    open(os.path.join(dirs[0], "seal_parity.log"), "w").write("PASS  psi\nFAIL  ntt_negacyclic_harvey\nSUMMARY 1 passed, 1 failed\n")
+    bad = tmp_path / "bad.json"
+    assert seal_pin_report.main(["--out", str(bad)] + dirs) == 1 and json.loads(bad.read_text())["all_identical"] is False
+    # bench.py: the reference becomes the reported baseline only for a real report at the bench's own (N, L)
+    sys.path.insert(0, ROOT)
+    import bench
+    port = {"value": 8.9, "unit": "op-triples/s", "cores": 1, "kind": "port", "sample": "oracle", "all_cores": {"value": 70.0}, "threads_64": None,
+            "seal": "SEAL absent"}
+    monkeypatch.setenv("EVA_SEAL_PIN_JSON", str(out))
+    got = bench.seal_pin_baseline(dict(port), 65536, 10)
+    assert got["kind"] == "reference" and got["value"] == 12.5 and got["port"]["value"] == 8.9 and got["seal_pin"]["all_sections_identical"] is True
+    assert bench.seal_pin_baseline(dict(port), 32768, 8)["kind"] == "port"
+    out.write_text(json.dumps({"dry_run": True, "sections": None, "seal_triples_per_s": None}))
+    again = bench.seal_pin_baseline(dict(port), 65536, 10)
+    assert again["kind"] == "port" and again["seal_pin"]["used"] is False
