@@ -26,6 +26,12 @@
 // offset are fused into the transforms instead of being separate HBM round trips; the ops work
 // on lazy values where the moduli allow it (no Barrett reduction on the way in or out).
 #pragma once
+// cache policy of the converted-digit stream into ks_inner_kernel<MAC3> (aux bits of global_load_lds: 1 = sc0, 2 = nt,
+// 16 = sc1).  0 measured best; 2 (non-temporal: the digits are read once and should not push the key out of the Infinity
+// Cache) was the r4 verdict's item 9 — profiles/r05_tuning_notes.md
+#ifndef EVAH_DIGIT_AUX
+#define EVAH_DIGIT_AUX 0
+#endif
 #include "devmath.hip.h"
 #include <type_traits>
 
@@ -943,7 +949,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads of `lin` issued so far have returned
 #pragma unroll
     for (int it = 0; it < NPAIR; it++)
-      __builtin_amdgcn_global_load_lds(src + 2 * (threadIdx.x + it * T), lin + 2 * it * T, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src + 2 * (threadIdx.x + it * T), lin + 2 * it * T, 16, 0, EVAH_DIGIT_AUX);
   };
   ulonglong2 dreg[MAC3 ? 1 : NPAIR];
   if constexpr (MAC3) dma_digits(0);

@@ -3,6 +3,7 @@
 // and the MI355X executor.  Submodules: _ckks (compiler), _seal (backend; the name is kept so
 // `from eva.seal import generate_keys` keeps working — the backend behind it is libeva_hip.so).
 #include <pybind11/numpy.h>
+#include <chrono>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -330,8 +331,12 @@ PYBIND11_MODULE(_eva, m) {
         return v;
       }, py::arg("program"), py::arg("inputs"))
       .def("execute_batch", [](HipPublic &p, Program &program, const std::vector<const HipValuation *> &inputs) {
+        const auto t0 = std::chrono::steady_clock::now();
         std::vector<HipValuation> out = p.execute_batch(program, inputs);
         for (HipValuation &v : out) v.params = p.host;
+        if (std::getenv("EVA_BATCH_TIMING"))
+          std::fprintf(stderr, "EVA: execute_batch binding: %.3f ms inside (before the results become Python objects)\n",
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         return out;
       }, py::arg("program"), py::arg("inputs"),
            "execute() for a list of independent input valuations of one program; instances run batch_chunk at a time as batched device handles")

@@ -6,7 +6,7 @@ R=$(cd $(dirname $0)/.. && pwd)
 name=$1; shift
 D=$R/eva_amd/lib/variants/$name; mkdir -p $D/obj
 pids=()
-for u in runtime elementwise keyswitch rotate windows shard client scheduler; do
+for u in runtime elementwise ewprogram keyswitch rotate windows shard client scheduler; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $R/eva_amd/csrc/$u.hip -o $D/obj/$u.o &
   pids+=($!)
 done
