@@ -21,10 +21,15 @@ inline std::vector<HipValuation> HipPublic::execute_batch(Program &program, cons
   std::vector<evah_ctx *> qs{dev->h};
   for (uint32_t i = 0; i + 1 < batch_depth; i++) qs.push_back(batch_forks[i]->h);
   const size_t Q = qs.size();
-  // constants (Constant / Encode nodes and raw arithmetic on them) are evaluated once, by the
-  // first group, and shared by all groups: their plaintexts stay resident for the whole call
-  std::vector<char> done;
-  std::vector<HipExecutor::RuntimeValue> consts;
+  // constants (Constant / Encode nodes and raw arithmetic on them) are evaluated once per PROGRAM — by the first group
+  // of the first call, or by an earlier execute() of the same program (const_cache) — and shared by all groups of all
+  // calls.  (r5: they used to be encoded by the first group of every call and released at its end: ~20 encodes in front
+  // of the first group's kernels and, at the release, an event wait per plaintext per reading queue — 0.5 ms of a 17 ms call)
+  ConstCache &cc = const_cache[&program];
+  const uint64_t prog_hash = program_hash(program);
+  bool fresh = cc.values.size() != program.size() || cc.hash != prog_hash;
+  std::vector<char> &done = cc.done;
+  std::vector<HipExecutor::RuntimeValue> &consts = cc.values;
   auto finish = [&]() {
     int rc = 0;
     for (evah_ctx *q : qs) rc |= evah_ctx_sync(q);
@@ -54,11 +59,13 @@ inline std::vector<HipValuation> HipPublic::execute_batch(Program &program, cons
       std::vector<const HipValuation *> chunk(inputs.begin() + i0, inputs.begin() + i0 + n);
       if (bounded && g >= Q) chk(evah_ctx_sync(qs[g % Q])); // group g-Q (same queue) has left the device
       HipExecutor ex(program, *host, std::vector<evah_ctx *>{qs[g % Q]}, dev.get());
-      if (g == 0) {
+      if (fresh) {
         done = ex.prepare_constants();
-        consts.resize(program.size());
+        consts.assign(program.size(), HipExecutor::RuntimeValue{});
         for (TermId t = 0; t < program.size(); t++)
           if (done[t]) consts[t] = ex.value(t);
+        cc.hash = prog_hash;
+        fresh = false;
       } else {
         for (TermId t = 0; t < program.size(); t++)
           if (done[t]) ex.set_value(t, consts[t]);
@@ -98,8 +105,12 @@ inline std::vector<HipValuation> HipPublic::execute_batch_multi(Program &program
       for (size_t k = 0; k < D; k++) batch_queues.push_back(std::make_shared<Fork>(group->roots[m]));
   }
   std::vector<HipValuation> all(inputs.size());
-  std::vector<std::vector<char>> done(G);
-  std::vector<std::vector<HipExecutor::RuntimeValue>> consts(G);
+  // per member: the program's constants, encoded once per program on that member's device state (as execute_batch does)
+  std::vector<ConstCache> &mc = multi_const_cache[&program];
+  const uint64_t prog_hash = program_hash(program);
+  if (mc.size() != G) mc.assign(G, ConstCache{});
+  for (ConstCache &c1 : mc)
+    if (c1.hash != prog_hash || c1.values.size() != program.size()) c1 = ConstCache{};
   std::vector<size_t> turn(G, 0);
   auto sync_all = [&]() {
     int rc = 0;
@@ -113,17 +124,19 @@ inline std::vector<HipValuation> HipPublic::execute_batch_multi(Program &program
       std::vector<const HipValuation *> chunk(inputs.begin() + i0, inputs.begin() + i0 + n);
       evah_ctx *q = batch_queues[D * m + (turn[m]++ % D)]->h;
       HipExecutor ex(program, *host, std::vector<evah_ctx *>{q}, group->roots[m].get());
-      if (done[m].empty()) { // the member's constants: encoded once, by its first group
-        done[m] = ex.prepare_constants();
-        consts[m].resize(program.size());
+      ConstCache &cm = mc[m];
+      if (cm.done.empty()) { // the member's constants: encoded once per program, by its first group
+        cm.done = ex.prepare_constants();
+        cm.values.assign(program.size(), HipExecutor::RuntimeValue{});
         for (TermId t = 0; t < program.size(); t++)
-          if (done[m][t]) consts[m][t] = ex.value(t);
+          if (cm.done[t]) cm.values[t] = ex.value(t);
+        cm.hash = prog_hash;
       } else {
         for (TermId t = 0; t < program.size(); t++)
-          if (done[m][t]) ex.set_value(t, consts[m][t]);
+          if (cm.done[t]) ex.set_value(t, cm.values[t]);
       }
       ex.set_inputs_batch(chunk, true);
-      ex.run_library(&done[m], true);
+      ex.run_library(&cm.done, true);
       ex.get_outputs_batch(all.data() + i0, n, true);
     }
   } catch (...) {

@@ -265,6 +265,7 @@ public:
 
   ~HipPublic() {
     const_cache.clear();
+    multi_const_cache.clear();
     plans.clear();
     batch_forks.clear();
     batch_queues.clear();
@@ -276,7 +277,7 @@ public:
     forks.clear(); // queues go before the root context (each fork also holds it)
     dev.reset();
   }
-  void drop_graphs() { plans.clear(); seen.clear(); no_graph.clear(); const_cache.clear(); }
+  void drop_graphs() { plans.clear(); seen.clear(); no_graph.clear(); const_cache.clear(); multi_const_cache.clear(); }
 
 private:
   std::shared_ptr<DeviceCtx> dev; // == holder->dev once a device is in use
@@ -307,6 +308,8 @@ private:
   void ensure_group(bool) {
     if (group && group_ids == devices) return;
     check_devices();
+    multi_const_cache.clear(); // constants of the old group's members
+    batch_queues.clear();
     group.reset();
     group = std::make_unique<DeviceGroup>(make_device_group(devices, dev, device, *host, [this](evah_ctx *c) { upload_eval_keys(c); }, true));
     group_ids = devices;
@@ -389,6 +392,7 @@ private:
     std::vector<HipExecutor::RuntimeValue> values;
   };
   std::unordered_map<const Program *, ConstCache> const_cache;
+  std::unordered_map<const Program *, std::vector<ConstCache>> multi_const_cache; // "dag" mode: per member of the device group
   std::unordered_map<const Program *, std::unique_ptr<GraphPlan>> plans;
   std::unordered_map<const Program *, int> seen;
   std::set<const Program *> no_graph; // programs whose capture failed once: always walked eagerly
