@@ -8,7 +8,7 @@
 // gradient magnitude and its polynomial square root a dozen (:39-63).  One launch each, every call reads its operands
 // from HBM and writes its result back: at N = 2^15 the seven launches of Harris are latency (5 us each for 3 MB), on a
 // 32-instance batched handle of config 4 they are bytes (a ciphertext is 42 MB).  Here the ciphertext-level calls are
-// lowered to instructions on POLYNOMIAL registers — one coefficient per thread, the registers in LDS (2 KB each per
+// lowered to instructions on POLYNOMIAL registers — two coefficients per thread, the registers in LDS (2-4 KB each per
 // workgroup, so an instruction's operands are addressed by register number) — and interpreted by one kernel: every input
 // word is read once, only the values that leave the program are written.  Every instruction produces the canonical
 // residue the corresponding kernel of elementwise.hip produces (add / sub / negate: compare-and-subtract; products:
@@ -20,7 +20,9 @@ namespace evah {
 
 constexpr int EW_MAX_INS = 160;  // polynomial instructions per launch
 constexpr int EW_MAX_PTR = 48;   // polynomials loaded or stored per launch
-constexpr int EW_MAX_REGS = 28;  // polynomial registers (2 KB of LDS each: at most 56 KB of dynamic LDS per workgroup)
+// polynomial registers: 8 or 16 bytes of LDS per thread each (one or two coefficients per thread).  With two, up to 14
+// registers a workgroup is 256 threads (4 KB per register), up to 28 it is 128 threads: at most 56 KB of dynamic LDS
+constexpr int EW_MAX_REGS = 28, EW_REGS_WIDE = 14;
 enum EwOp : uint32_t { EW_LOAD = 0, EW_STORE, EW_ADD, EW_SUB, EW_NEG, EW_MUL, EW_FMA2 };
 
 struct EwProg {
@@ -33,30 +35,66 @@ struct EwProg {
   uint32_t bstride[EW_MAX_PTR];  // distance between the instances of a batched handle, in units of N words (0: shared plaintext)
 };
 
+// V coefficients per thread.  V = 2 (throughput-sized launches): every interpreted instruction — the scalar fetch of its
+// words, the dispatch on its opcode — serves 128 coefficients of a wave instead of 64, global accesses are 16 bytes per lane
+// as in the dedicated elementwise kernels, and the two independent modular products of a MUL overlap in the VALU pipeline.
+// V = 1 (small launches, which are bound by the latency of ONE wave's instruction stream: Harris' response at N = 2^15 is
+// 34 instructions): half the work per instruction, twice the waves.  A thread touches only its own column of the register
+// file, so no barrier is needed anywhere.
+template <int V> struct EwVec;
+template <> struct EwVec<1> {
+  using T = u64;
+  static __device__ __forceinline__ T load(const u64 *p) { return *p; }
+  static __device__ __forceinline__ void store(u64 *p, T v) { *p = v; }
+  template <class F> static __device__ __forceinline__ T map1(T x, F f) { return f(x); }
+  template <class F> static __device__ __forceinline__ T map2(T x, T y, F f) { return f(x, y); }
+  template <class F> static __device__ __forceinline__ T map4(T x, T y, T z, T u, F f) { return f(x, y, z, u); }
+};
+template <> struct EwVec<2> {
+  using T = ulonglong2;
+  static __device__ __forceinline__ T load(const u64 *p) { return ld2(p); }
+  static __device__ __forceinline__ void store(u64 *p, T v) { st2(p, v); }
+  template <class F> static __device__ __forceinline__ T map1(T x, F f) { return make_ulonglong2(f(x.x), f(x.y)); }
+  template <class F> static __device__ __forceinline__ T map2(T x, T y, F f) { return make_ulonglong2(f(x.x, y.x), f(x.y, y.y)); }
+  template <class F> static __device__ __forceinline__ T map4(T x, T y, T z, T u, F f) {
+    return make_ulonglong2(f(x.x, y.x, z.x, u.x), f(x.y, y.y, z.y, u.y));
+  }
+};
+template <int V>
 __global__ void __launch_bounds__(256)
 k_ew_program(DevCtx cx, EwProg pg) {
-  extern __shared__ u64 ew_regs[]; // [register][thread]
-  const uint32_t i = blockIdx.y, inst = blockIdx.z, tid = threadIdx.x;
-  const size_t off = (size_t)i * cx.N + (size_t)blockIdx.x * blockDim.x + tid;
+  using VT = typename EwVec<V>::T;
+  extern __shared__ __attribute__((aligned(16))) u64 ew_lds[];
+  VT *ew_regs = reinterpret_cast<VT *>(ew_lds); // [register][thread]
+  const uint32_t i = blockIdx.y, inst = blockIdx.z, tid = threadIdx.x, T = blockDim.x;
+  const size_t off = (size_t)i * cx.N + V * ((size_t)blockIdx.x * T + tid);
   const DevPrime pm = cx.primes[cx.prime_of(i)];
+  uint32_t w0 = pg.w[0], w1 = pg.w[1];
   for (uint32_t pc = 0; pc < pg.n_ins; pc++) {
-    const uint32_t w0 = pg.w[2 * pc], w1 = pg.w[2 * pc + 1]; // wave-uniform: scalar loads from the kernel arguments
+    // wave-uniform: scalar loads from the kernel arguments; the next instruction's words are requested before this one runs
+    const uint32_t nx = pc + 1 < pg.n_ins ? pc + 1 : pc;
+    const uint32_t n0 = pg.w[2 * nx], n1 = pg.w[2 * nx + 1];
     const uint32_t op = w0 & 0xffu, dst = (w0 >> 8) & 0xffu, a = (w0 >> 16) & 0xffu, b = w0 >> 24;
-    u64 *rd = ew_regs + dst * 256 + tid;
+    VT *rd = ew_regs + dst * T + tid;
     switch (op) {
-    case EW_LOAD: *rd = pg.ptr[a][off + (size_t)inst * pg.bstride[a] * cx.N]; break;
-    case EW_STORE: pg.ptr[a][off + (size_t)inst * pg.bstride[a] * cx.N] = ew_regs[b * 256 + tid]; break;
-    case EW_ADD: *rd = addmod(ew_regs[a * 256 + tid], ew_regs[b * 256 + tid], pm.q); break;
-    case EW_SUB: *rd = submod(ew_regs[a * 256 + tid], ew_regs[b * 256 + tid], pm.q); break;
-    case EW_NEG: *rd = negmod(ew_regs[a * 256 + tid], pm.q); break;
-    case EW_MUL: *rd = mulmod(ew_regs[a * 256 + tid], ew_regs[b * 256 + tid], pm); break;
+    case EW_LOAD: *rd = EwVec<V>::load(pg.ptr[a] + off + (size_t)inst * pg.bstride[a] * cx.N); break;
+    case EW_STORE: EwVec<V>::store(pg.ptr[a] + off + (size_t)inst * pg.bstride[a] * cx.N, ew_regs[b * T + tid]); break;
+    case EW_ADD: *rd = EwVec<V>::map2(ew_regs[a * T + tid], ew_regs[b * T + tid], [&](u64 x, u64 y) { return addmod(x, y, pm.q); }); break;
+    case EW_SUB: *rd = EwVec<V>::map2(ew_regs[a * T + tid], ew_regs[b * T + tid], [&](u64 x, u64 y) { return submod(x, y, pm.q); }); break;
+    case EW_NEG: *rd = EwVec<V>::map1(ew_regs[a * T + tid], [&](u64 x) { return negmod(x, pm.q); }); break;
+    case EW_MUL: *rd = EwVec<V>::map2(ew_regs[a * T + tid], ew_regs[b * T + tid], [&](u64 x, u64 y) { return mulmod(x, y, pm); }); break;
     default: { // EW_FMA2
       const uint32_t cc = w1 & 0xffu, dd = (w1 >> 8) & 0xffu;
-      u128_t t = mul128(ew_regs[a * 256 + tid], ew_regs[b * 256 + tid]);
-      acc128(t, ew_regs[cc * 256 + tid], ew_regs[dd * 256 + tid]);
-      *rd = barrett128(t, pm);
+      *rd = EwVec<V>::map4(ew_regs[a * T + tid], ew_regs[b * T + tid], ew_regs[cc * T + tid], ew_regs[dd * T + tid],
+                           [&](u64 x, u64 y, u64 z, u64 u) {
+                             u128_t t = mul128(x, y);
+                             acc128(t, z, u);
+                             return barrett128(t, pm);
+                           });
     } break;
     }
+    w0 = n0;
+    w1 = n1;
   }
 }
 static_assert(sizeof(DevCtx) + sizeof(EwProg) + 64 <= 4096, "kernel arguments of k_ew_program");
@@ -305,8 +343,17 @@ int evah_elementwise_program(evah_ctx *c, const evah_val *in, uint32_t n_in, con
     } else {
       pg.n_ins = (uint32_t)live.size();
       for (size_t q = 0; q < ptr_used.size(); q++) { pg.ptr[q] = ptr_used[q].p; pg.bstride[q] = ptr_used[q].bstride; }
-      const size_t lds = (size_t)std::max(n_regs, 1) * 256 * sizeof(u64);
-      EW_LAUNCH(k_ew_program, dim3((unsigned)(N / 256), limbs, batch), dim3(256), lds, c->stream, c->dev, pg);
+      // throughput-sized launches: two coefficients per thread, 256 threads when the registers fit (else 128); small ones
+      // (bound by the latency of one wave's instruction stream): one coefficient per thread, 256 threads
+      const uint64_t coeffs = (uint64_t)N * limbs * batch;
+      if (coeffs >= ((uint64_t)1 << 21) && N >= 512) {
+        const uint32_t threads = n_regs <= EW_REGS_WIDE ? 256u : 128u;
+        const size_t lds = (size_t)std::max(n_regs, 1) * threads * sizeof(ulonglong2);
+        EW_LAUNCH(k_ew_program<2>, dim3((unsigned)(N / (2 * threads)), limbs, batch), dim3(threads), lds, c->stream, c->dev, pg);
+      } else {
+        const size_t lds = (size_t)std::max(n_regs, 1) * 256 * sizeof(u64);
+        EW_LAUNCH(k_ew_program<1>, dim3((unsigned)(N / 256), limbs, batch), dim3(256), lds, c->stream, c->dev, pg);
+      }
       HIPCHK(hipGetLastError());
       for (uint32_t k = 0; k < n_out; k++) outs[k] = made[k];
     }

@@ -311,6 +311,19 @@ template <class Op> struct HasRaw<Op, std::void_t<typename Op::Raw>> : std::true
 template <class Op, bool ON> struct RawOf { using type = NoPre; };
 template <class Op> struct RawOf<Op, true> { using type = typename Op::Raw; };
 
+// An op whose transform starts a launch set may have words to clear before the set's later kernels count into them (the
+// zero-coefficient record and the fallback's ticket words of a hoisted rotation set, OpPlainT<ZEROS>): the first workgroup
+// of the inverse transform's FIRST pass clears them — the recording happens in its second pass, a kernel boundary later —
+// so the set needs no memset launch of its own.
+template <class Op, class = void> struct ClearsWords : std::false_type {};
+template <class Op> struct ClearsWords<Op, std::void_t<decltype(Op::clears_words)>> : std::bool_constant<Op::clears_words> {};
+template <class Op> __device__ __forceinline__ void first_pass_clear(const typename Op::Params &prm) {
+  if constexpr (ClearsWords<Op>::value) {
+    if (prm.clear_words && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+      for (uint32_t w = threadIdx.x; w < prm.clear_words; w += blockDim.x) prm.clear_base[w] = 0;
+  }
+}
+
 template <int P, int LR, bool STRIDED, bool INVERSE, class Op, bool FULL>
 __global__ void __launch_bounds__(NTT_THREADS)
 ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC_rt, int log_tiles) {
@@ -319,6 +332,7 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC_rt, int log_tiles) 
   constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
   constexpr bool FIRST = (STRIDED != INVERSE);
   if (cx.skipped()) return;
+  if constexpr (INVERSE && !STRIDED) first_pass_clear<Op>(prm);
   const uint32_t tile_idx = blockIdx.x & ((1u << log_tiles) - 1u);
   typename Op::Job jb;
   if (!Op::setup(cx, prm, blockIdx.x >> log_tiles, blockIdx.y, blockIdx.z, jb)) return; // block-uniform
@@ -428,6 +442,7 @@ __global__ void __launch_bounds__(64)
 ntt_loop_kernel(DevCtx cx, typename Op::Params prm, int logC, int log_tiles, uint32_t nloop, uint32_t loop_count) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   if (cx.skipped()) return;
+  if constexpr (INVERSE) first_pass_clear<Op>(prm);
   constexpr int NTT_R = 1 << LR, NPAIR = NTT_R / 2;
   constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
   constexpr int AX = Op::loop_axis;
@@ -1224,7 +1239,11 @@ template <bool ZEROS, bool GATHER = false> struct OpPlainT { // ZEROS: the inver
     // word of zero_list[0] and the first HOIST_ZERO_CAP of them recorded as (poly << 48 | limb << 32 | index)
     u64 *zero_list = nullptr;
     std::conditional_t<GATHER, PermTab, NoGather> perm_tab{};
+    // ZEROS: words the first pass clears before the second pass counts into zero_list (first_pass_clear)
+    u64 *clear_base = nullptr;
+    uint32_t clear_words = 0;
   };
+  static constexpr bool clears_words = ZEROS;
   struct Job {
     uint32_t prime;
     const u64 *src;

@@ -68,12 +68,12 @@ static void rotation_set(evah_ctx *c, uint32_t l, const std::vector<RotPair> &pa
   const uint32_t n_src = (uint32_t)srcs.size();
   if (n_src > (uint32_t)KS_BATCH_MAX) throw std::logic_error("hoisted rotation set with too many sources");
   // one barrier word per chunk (k_rot_fallback), then the zero-coefficient count and the recorded positions: the words
-  // that must start at zero are adjacent (one memset)
+  // that must start at zero are adjacent (cleared by the first pass of hoist_digits)
   ZeroFlag flag(c, chunks.size());
   const size_t dg_bs = (size_t)(l + 1) * l * N;
   {
     Scratch t(c, (size_t)n_src * l * N), dg(c, n_src * dg_bs);
-    hoist_digits(c, l, srcs, src_ps, flag.d, t.d, dg.d);
+    hoist_digits(c, l, srcs, src_ps, flag, t.d, dg.d);
     for (const RotChunk &ch : chunks) {
       const RotPair *pr = pairs.data() + ch.first;
       const uint32_t np = ch.count;

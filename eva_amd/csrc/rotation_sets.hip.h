@@ -397,13 +397,14 @@ static void rot_chunk_plain(evah_ctx *c, uint32_t l, const RotPair *pr, uint32_t
 }
 // the zero-coefficient record of a hoisted set: d[0] = count, d[1..] = positions (OpPlainZ, k_hoist_fix), preceded in the
 // same allocation by one word per chunk for the persistent fallback (its ticket and finished-chunk counters); everything
-// that must start at zero is cleared by one memset
+// that must start at zero is adjacent
+// (r5: cleared by the first workgroup of the set's first kernel — the contiguous pass of hoist_digits' inverse transform,
+// ntt.hip.h first_pass_clear — instead of a memset launch per set)
 struct ZeroFlag {
   Scratch s;
   u64 *d;
-  ZeroFlag(evah_ctx *c, size_t chunks) : s(c, chunks + 1 + HOIST_ZERO_CAP), d(s.d + chunks) {
-    HIPCHK(hipMemsetAsync(s.d, 0, sizeof(u64) * (chunks + 1), c->stream));
-  }
+  uint32_t clear_words;
+  ZeroFlag(evah_ctx *c, size_t chunks) : s(c, chunks + 1 + HOIST_ZERO_CAP), d(s.d + chunks), clear_words((uint32_t)chunks + 1) {}
   u64 *bar(size_t chunk) const { return s.d + chunk; }
 };
 // launches issued while one of these lives return at once unless more than HOIST_ZERO_CAP zero digit coefficients were recorded
@@ -540,14 +541,16 @@ static void hoist_mac_launch(evah_ctx *c, HoistMacTab &mt, const HoistTiles &ht,
 }
 // digits of the unrotated c1 of every source, once: coefficient form (zeros recorded in flag_d), then the full
 // transforms under every output prime into dg_d[source][(l+1) l N]; t_d: n_src * l * N words of scratch
-static void hoist_digits(evah_ctx *c, uint32_t l, const std::vector<const u64 *> &srcs, const std::vector<size_t> &src_ps, u64 *flag_d,
+static void hoist_digits(evah_ctx *c, uint32_t l, const std::vector<const u64 *> &srcs, const std::vector<size_t> &src_ps, const ZeroFlag &flag,
                          u64 *t_d, u64 *dg_d) {
   const size_t N = c->N, dg_bs = (size_t)(l + 1) * l * N;
   const uint32_t n_src = (uint32_t)srcs.size();
   PtrTab c1{};
   for (uint32_t i = 0; i < n_src; i++) c1.p[i] = srcs[i] + src_ps[i];
   OpPlainZ::Params ip{nullptr, t_d, 0, (size_t)l * N, l, 0, 0, c1};
-  ip.zero_list = flag_d;
+  ip.zero_list = flag.d;
+  ip.clear_base = flag.s.d; // the fallback's ticket words and the zero count: cleared by this transform's first pass
+  ip.clear_words = flag.clear_words;
   ntt_inverse<OpPlainZ>(c, ip, n_src * l);
   OpKsDigit::Params dp{t_d, dg_d, l, (size_t)l * N, dg_bs, 0, l + 1};
   ntt_forward<OpKsDigit>(c, dp, n_src * (l + 1) * l);

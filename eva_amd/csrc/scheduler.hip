@@ -378,7 +378,22 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
       }
       if (out_vals.empty()) continue; // (dead code: nobody reads any of it)
       std::vector<evah_ct *> outs(out_vals.size(), nullptr);
-      chk(evah_elementwise_program(c, in.data(), n_in, eops.data(), (uint32_t)eops.size(), out_vals.data(), (uint32_t)out_vals.size(), outs.data()));
+      // nothing but independent ciphertext products of stored operands, all of them kept (the products of one level): the
+      // dedicated kernel does that in one launch already, at half the interpreter's latency
+      bool only_products = out_vals.size() == nodes.size() && nodes.size() <= (size_t)KS_BATCH_MAX && kv.first.second == 1;
+      for (auto &n : nodes) only_products = only_products && n->op == 13 && n->ca && (n->same || n->cb) && !n->ea && !n->eb;
+      if (only_products) {
+        std::vector<const evah_ct *> ia(nodes.size()), ib(nodes.size());
+        for (size_t j = 0; j < nodes.size(); j++) { ia[j] = nodes[j]->ca; ib[j] = nodes[j]->same ? nodes[j]->ca : nodes[j]->cb; }
+        if (nodes.size() == 1) {
+          if (nodes[0]->same) chk(evah_square(c, ia[0], &outs[0]));
+          else chk(evah_multiply(c, ia[0], ib[0], &outs[0]));
+        } else {
+          chk(evah_multiply_many(c, ia.data(), ib.data(), (uint32_t)nodes.size(), outs.data()));
+        }
+      } else {
+        chk(evah_elementwise_program(c, in.data(), n_in, eops.data(), (uint32_t)eops.size(), out_vals.data(), (uint32_t)out_vals.size(), outs.data()));
+      }
       for (size_t k = 0; k < outs.size(); k++) {
         Expr &n = *nodes[out_node[k]];
         n.result = alias_ct(outs[k]);

@@ -249,7 +249,7 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
       const size_t dg_bs = (size_t)(l + 1) * l * N;
       {
         Scratch t(c, srcs.size() * l * N), dg(c, srcs.size() * dg_bs);
-        hoist_digits(c, l, srcs, src_ps, flag.d, t.d, dg.d);
+        hoist_digits(c, l, srcs, src_ps, flag, t.d, dg.d);
         for (const Chunk &ch : chunks) {
           const RotPair *pr = pairs.data() + ch.first;
           const uint32_t np = ch.np;
