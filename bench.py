@@ -591,6 +591,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the raw C-ABI, host-valuation and DAG legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--raw-only", action="store_true",
+                    help="run only the raw C-ABI leg (uploaded operands, no encrypt / decrypt kernels in the trace) and print its "
+                         "dict: what scripts/collect_profiles.sh runs under the rocprofv3 counter passes — the launches per "
+                         "group are the ones execute() issues")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -610,6 +614,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    if args.raw_only:
+        from eva_amd.hostref import coeff_modulus_create
+        N, l = 1 << args.logn, args.limbs
+        print(json.dumps(raw_cabi_leg(args, N, l, coeff_modulus_create(N, [60] * (l + 1)), dev, args.steps, args.warmup)), flush=True)
+        return dist.close()
     if args.shard == "limb":
         return limb_sharded(args, dist)
     if args.shard == "subdag":

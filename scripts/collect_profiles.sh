@@ -1,10 +1,13 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun):  EVA_COMMIT=<short hash> bash scripts/collect_profiles.sh [round tag, default r04]
-# bench line (the driver's command) + rocprofv3 kernel trace + PMC traffic passes + SQ-counter pass of the same bench.py
-# command, summaries written under gpurun_out/prof_bench/ in the names they are committed under in profiles/.
+# Run on the GPU box (via gpurun):  EVA_COMMIT=<short hash> bash scripts/collect_profiles.sh [round tag, default r05]
+# bench line (the driver's command) + rocprofv3 kernel trace of the headline (public_ctx.execute(), --no-legs) + PMC traffic
+# passes + SQ-counter pass, summaries written under gpurun_out/prof_bench/ in the names they are committed under in
+# profiles/.  The counter passes run bench.py --raw-only: the same launch set per group of 32 triples as execute() issues
+# (same kernels, same grids — the trace of the headline shows them), without the encrypt / decrypt / verification kernels
+# of the headline in the counters' per-class averages.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$R/gpurun_out/prof_bench
 rm -rf $OUT; mkdir -p $OUT
 export PYTHONPATH=$R
@@ -13,12 +16,12 @@ ARGS="--steps 20 --warmup 3 --no-legs"
 timeout 600 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
 tail -c 400 $OUT/${TAG}_bench_line.json
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py $ARGS --no-cpu-baseline > $OUT/trace.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-legs > $OUT/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-legs > $OUT/pmc_write.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-legs > $OUT/pmc_sq.log 2>&1
-python $R/scripts/rocprof_summary.py $OUT/trace "$TAG bench.py $ARGS (N=2^16, L=10, 64 triples/step, fused op-triple, 2 queues x groups of 32; launches of the two queues overlap, so durations are while sharing the GPU): rocprofv3 --kernel-trace --stats" > $OUT/${TAG}_bench_kernel_trace.md
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --raw-only --steps 2 --warmup 1 > $OUT/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --raw-only --steps 2 --warmup 1 > $OUT/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --raw-only --steps 2 --warmup 1 > $OUT/pmc_sq.log 2>&1
+python $R/scripts/rocprof_summary.py $OUT/trace "$TAG bench.py $ARGS --no-cpu-baseline (the headline: public_ctx.execute() of 32-product programs, N=2^16, L=10, 64 triples/step on 2 issue queues whose launches overlap, so durations are while sharing the GPU; the k_enc_* / k_encrypt / k_dec_* rows are the set-up encryption and the verification decrypt outside the timed region): rocprofv3 --kernel-trace --stats" > $OUT/${TAG}_bench_kernel_trace.md
 cp $OUT/trace/*/*kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null
-python $R/scripts/pmc_sq_summary.py $OUT/pmc_sq "$TAG bench.py --steps 2 --warmup 1 --no-legs (a PMC pass serialises the kernels: durations are with the GPU to itself): SQ counters" > $OUT/${TAG}_bench_sq_counters.md
+python $R/scripts/pmc_sq_summary.py $OUT/pmc_sq "$TAG bench.py --raw-only --steps 2 --warmup 1 (the launch sets of the headline by direct C-ABI calls; a PMC pass serialises the kernels: durations are with the GPU to itself): SQ counters" > $OUT/${TAG}_bench_sq_counters.md
 python $R/scripts/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/bench_pmc_traffic.json > /dev/null
 python $R/scripts/valu_issue.py $OUT/pmc_sq 32 $OUT/bench_valu_issue.json > /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_batch -- python $R/scripts/prof_legs.py batch 2 > $OUT/trace_batch.log 2>&1
