@@ -37,6 +37,7 @@
 
 namespace evah {
 
+
 constexpr int NTT_THREADS = 256; // threads per workgroup (max); tile = NTT_THREADS << LR coefficients
 constexpr uint32_t HOIST_ZERO_CAP = 64; // zero digit coefficients a hoisted rotation set corrects individually
 
@@ -563,158 +564,6 @@ ntt_loop_kernel(DevCtx cx, typename Op::Params prm, int logC, int log_tiles, uin
   }
 }
 
-// ---- Window sums: the mod-down of a set of rotations fused with the plaintext-weighted sums that consume them
-// (the convolution pattern: out_f = sum_t w_ft (*) rotate(x, step_t); examples/image_processing.py convolutionXY).
-// Unfused, every rotated ciphertext is written by the mod-down's second pass and read back once by the weighted sum;
-// here the second pass of the mod-down walks the rotations of ONE window for its (limb, tile, polynomial), multiplies
-// each finished value by the window's weights and keeps the 128-bit partial sums of up to two sums in registers: the
-// rotated ciphertexts never exist in memory.  Same canonical residues as rotate -> multiply_plain -> add one by one.
-//   pair t of the chunk: polynomial pp = 2 t + K; mid[pp][i] = first (strided) pass of NTT_i(u) (OpModDown, dst = mid),
-//   prod[pp][i] = key inner product in the SOURCE's index space (k_hoist_mac), P * c0 already folded in: the pair's
-//   Galois permutation is applied when it is read, nothing is added here.
-//   value_t[n] = (prod[pp][i][perm_t[n]] - NTT_i(u)[n]) * P^-1 mod q_i;   out_f[K][i] = sum_t w_f[t][i] * value_t  (+ the unrotated term)
-#ifndef EVAH_KS_BATCH_MAX_DEFINED
-#define EVAH_KS_BATCH_MAX_DEFINED
-constexpr int KS_BATCH_MAX = 64; // as internal.hip.h (this header is also used alone)
-#endif
-// index tables of a launch's pairs (two polynomials each): data kept in a pair's source index space is read through them
-struct PermTab {
-  const uint32_t *p[KS_BATCH_MAX];
-};
-constexpr int WIN_MAX = 16; // windows per launch (the tables below travel as kernel arguments)
-struct WinSumTab {
-  uint8_t first[WIN_MAX], count[WIN_MAX];          // window w = pairs [first, first + count) of the chunk
-  const u64 *w0[KS_BATCH_MAX], *w1[KS_BATCH_MAX];  // per pair: weights (NTT form, [l][N]) in the window's sums; null = 1
-  const u64 *id_src[WIN_MAX];                      // per window: c0 of its unrotated term (null: none), c1 = + id_ps * N
-  const u64 *id_w0[WIN_MAX], *id_w1[WIN_MAX];
-  uint32_t id_ps[WIN_MAX];
-  u64 *out0[WIN_MAX], *out1[WIN_MAX];              // per window: c0 of the sums' outputs (c1 = + out_ps)
-};
-// grid = (N / 256, l, 2 * windows); one wave, 4 coefficients per thread (the shape of ntt_loop_kernel, whose
-// twiddle staging and tile pipeline this repeats)
-template <int P, int F>
-__global__ void __launch_bounds__(64)
-moddown_sum_kernel(DevCtx cx, WinSumTab ws, PermTab perms, const u64 *mid, size_t mid_ps, const u64 *prod, size_t prod_ps, size_t out_ps, int logC) {
-  extern __shared__ __attribute__((aligned(16))) u64 lds[];
-  if (cx.skipped()) return;
-  constexpr int LR = 2, NTT_R = 1 << LR, NPAIR = NTT_R / 2, T = 64;
-  constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
-  const uint32_t i = blockIdx.y, w = blockIdx.z >> 1, K = blockIdx.z & 1u;
-  const uint32_t first = ws.first[w], cnt = ws.count[w];
-  const int C = 1 << logC;
-  const uint32_t pre = cx.logN - P, sub0 = blockIdx.x << logC, gbase = sub0 << P;
-  const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
-  const uint32_t prime = cx.prime_of(i), a = cx.k - 1;
-  const DevPrime pm = cx.primes[prime];
-  const ulonglong2 inv = cx.invq[(size_t)a * cx.k + prime];
-  const ulonglong2 *tw = cx.tw_fwd + (size_t)prime * cx.N;
-  ulonglong2 *twl = reinterpret_cast<ulonglong2 *>(lds + ((C * SP + 1) & ~1));
-  for (int idx = threadIdx.x; idx < (C << P); idx += T) {
-    const int sb = idx >> P, n = idx & (S - 1);
-    if (n) {
-      const int d = 31 - __clz(n);
-      twl[idx] = tw[((size_t)((1u << pre) + sub0 + sb) << d) + (n - (1 << d))];
-    }
-  }
-  const size_t row = (size_t)i * cx.N + gbase + 2 * threadIdx.x; // + it * 2 T
-  auto load_tile = [&](uint32_t t, ulonglong2 *d) {
-    const u64 *src = mid + (size_t)(2 * t + K) * mid_ps + row;
-#pragma unroll
-    for (int it = 0; it < NPAIR; it++) d[it] = *reinterpret_cast<const ulonglong2 *>(src + it * 2 * T);
-  };
-  u128_t acc[F][NTT_R];
-#pragma unroll
-  for (int f = 0; f < F; f++)
-#pragma unroll
-    for (int e = 0; e < NTT_R; e++) acc[f][e] = {0, 0};
-  auto mac = [&](int f, int it, const ulonglong2 &v, const u64 *wt) { // wt: block-uniform; null stands for the weight 1
-    ulonglong2 x;
-    x.x = x.y = 1;
-    if (wt) x = *reinterpret_cast<const ulonglong2 *>(wt + row + it * 2 * T);
-    acc128(acc[f][2 * it], v.x, x.x);
-    acc128(acc[f][2 * it + 1], v.y, x.y);
-  };
-  ulonglong2 dreg[NPAIR];
-  uint2 pnext[NPAIR]; // the NEXT pair's gather indices (prod is indexed in the source's space): a pair ahead, so that the
-                      // gathers of a pair do not wait for an index load first
-  auto load_perm = [&](uint32_t t) {
-    const uint32_t *pi = perms.p[t] + gbase + 2 * threadIdx.x;
-#pragma unroll
-    for (int it = 0; it < NPAIR; it++) pnext[it] = *reinterpret_cast<const uint2 *>(pi + it * 2 * T);
-  };
-  if (cnt) {
-    load_tile(first, dreg);
-    load_perm(first);
-  }
-  for (uint32_t t = first; t < first + cnt; t++) {
-    uint2 at[NPAIR];
-#pragma unroll
-    for (int it = 0; it < NPAIR; it++) at[it] = pnext[it];
-    __syncthreads(); // the previous pair's LDS reads are done
-#pragma unroll
-    for (int it = 0; it < NPAIR; it++) {
-      const int idx = 2 * (threadIdx.x + it * T);
-      const int sb = idx >> P, e = idx & (S - 1);
-      lds[sb * SP + lds_pad<P>(e)] = dreg[it].x;
-      lds[sb * SP + lds_pad<P>(e + 1)] = dreg[it].y;
-    }
-    // the epilogue's operands, requested before the transform
-    const u64 *pr = prod + (size_t)(2 * t + K) * prod_ps + (size_t)i * cx.N;
-    const u64 *wt0 = ws.w0[t], *wt1 = F > 1 ? ws.w1[t] : nullptr;
-    ulonglong2 cp[NPAIR], x0[NPAIR], x1[NPAIR];
-#pragma unroll
-    for (int it = 0; it < NPAIR; it++) {
-      cp[it].x = pr[at[it].x];
-      cp[it].y = pr[at[it].y];
-      x0[it].x = x0[it].y = x1[it].x = x1[it].y = 1;
-      if (wt0) x0[it] = *reinterpret_cast<const ulonglong2 *>(wt0 + row + it * 2 * T);
-      if (F > 1 && wt1) x1[it] = *reinterpret_cast<const ulonglong2 *>(wt1 + row + it * 2 * T);
-    }
-    if (t + 1 < first + cnt) {
-      load_tile(t + 1, dreg);
-      load_perm(t + 1);
-    }
-    __syncthreads();
-    forward_rounds<P, LR, true, true>(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NPAIR; it++) {
-      const int idx = 2 * (threadIdx.x + it * T);
-      const int sb = idx >> P, e = idx & (S - 1);
-      u64 ux = lds[sb * SP + lds_pad<P>(e)], uy = lds[sb * SP + lds_pad<P>(e + 1)];
-      ux += (ux >= pm.q8 ? pm.nq8 : 0); // [0,16q) -> [0,8q)
-      uy += (uy >= pm.q8 ? pm.nq8 : 0);
-      const u64 vx = mul_shoup(cp[it].x + pm.q8 - ux, inv.x, inv.y, pm.q), vy = mul_shoup(cp[it].y + pm.q8 - uy, inv.x, inv.y, pm.q);
-      acc128(acc[0][2 * it], vx, x0[it].x);
-      acc128(acc[0][2 * it + 1], vy, x0[it].y);
-      if constexpr (F > 1) {
-        acc128(acc[1][2 * it], vx, x1[it].x);
-        acc128(acc[1][2 * it + 1], vy, x1[it].y);
-      }
-    }
-  }
-  if (ws.id_src[w]) { // the window's unrotated term: the source ciphertext itself
-    const u64 *src = ws.id_src[w] + (size_t)K * ws.id_ps[w] * cx.N + row;
-#pragma unroll
-    for (int it = 0; it < NPAIR; it++) {
-      const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + it * 2 * T);
-      mac(0, it, v, ws.id_w0[w]);
-      if constexpr (F > 1) mac(1, it, v, ws.id_w1[w]);
-    }
-  }
-#pragma unroll
-  for (int f = 0; f < F; f++) {
-    u64 *o = (f ? ws.out1[w] : ws.out0[w]) + (size_t)K * out_ps + row;
-#pragma unroll
-    for (int it = 0; it < NPAIR; it++) {
-      ulonglong2 r;
-      r.x = barrett128(acc[f][2 * it], pm);
-      r.y = barrett128(acc[f][2 * it + 1], pm);
-      *reinterpret_cast<ulonglong2 *>(o + it * 2 * T) = r;
-    }
-  }
-}
-
 // Inverse strided pass + forward strided pass in one launch, for the latency-bound (small) launches:
 // a mod-down / rescale / digit conversion starts from the inverse transform of ONE source limb and
 // continues with forward transforms of that polynomial under other primes.  The second (strided)
@@ -777,885 +626,9 @@ ntt_inv_fwd_kernel(DevCtx cx, typename Op::Params prm, int log_tiles) {
   for (int it = 0; it < NTT_R; it++) jb.dst[n0 + it * nstep] = lds[lds_at(it)]; // lazy intermediate of the forward transform
 }
 
-// Key-switch inner product fused with the second (contiguous) pass of the digit NTTs
-// (SURVEY.md A.6 step 2).  One workgroup owns output limb I = blockIdx.y and one tile of
-// coefficient positions; it walks the digits J, finishing NTT_kappa(t_J) for its tile in LDS
-// (or taking target[J] as is when I == J) and multiply-accumulating with key[J][0/1][kappa] into
-// 128-bit register accumulators.  The l^2 N converted digits are therefore never written back:
-// HBM sees the pass-1 intermediates once, the key once and prod[2][l+1][N] once.
-// Keys of a batch of key-switches issued as one launch (sibling rotations of one ciphertext).
-// KS_BATCH_MAX (instances per batched launch): internal.hip.h / defined below when this header is used alone
-#ifndef EVAH_KS_BATCH_MAX_DEFINED
-#define EVAH_KS_BATCH_MAX_DEFINED
-constexpr int KS_BATCH_MAX = 64;
-#endif
-struct KsKeys {
-  const u64 *key[KS_BATCH_MAX];
-  uint32_t rows; // 0: whole keys (k prime rows); else a limb shard's rows (KeyDev::rows), indexed by local limb
-};
-// Base pointers of a batch of separately allocated polynomials (2 per instance), passed by value.
-struct PtrTab {
-  const u64 *p[2 * KS_BATCH_MAX];
-};
-
-// Operands of a batch of ciphertext products (instance b = a[b] x b[b], both size 2), passed by
-// value.  With it the consumers of a product's polynomials d0 = a0 b0, d1 = a0 b1 + a1 b0,
-// d2 = a1 b1 evaluate the one they need from the operands where they would have
-// loaded it, so multiply -> relinearize -> rescale runs without the size-3 product ever being
-// written to or read back from HBM.  Every d_K is a canonical residue, so the result is the one
-// the separate evah_multiply call stores.
-struct MulTab {
-  const u64 *a[KS_BATCH_MAX], *b[KS_BATCH_MAX];
-  uint32_t a_ps[KS_BATCH_MAX], b_ps[KS_BATCH_MAX]; // poly strides in units of N coefficients
-};
-// One product's operands, resolved from a MulTab entry (block-uniform: scalar loads of the kernel argument)
-struct MulSrc {
-  const u64 *a, *b; // polynomial 0 of each operand
-  size_t sa, sb;    // poly strides in words
-};
-__device__ __forceinline__ MulSrc mul_src(const MulTab &t, uint32_t N, uint32_t inst) {
-  return MulSrc{t.a[inst], t.b[inst], (size_t)t.a_ps[inst] * N, (size_t)t.b_ps[inst] * N};
-}
-// d_K of a product at word `off` (= limb * N + n) of a polynomial, K in {0, 1, 2}
-__device__ __forceinline__ u64 product_poly(const MulSrc &m, uint32_t K, size_t off, const DevPrime &pm) {
-  const u64 *a0 = m.a + off, *b0 = m.b + off;
-  const size_t sa = m.sa, sb = m.sb;
-  if (K == 0) return mulmod(a0[0], b0[0], pm);
-  if (K == 2) return mulmod(a0[sa], b0[sb], pm);
-  u128_t s = mul128(a0[0], b0[sb]);
-  acc128(s, a0[sa], b0[0]);
-  return barrett128(s, pm);
-}
-
-struct NoMul {}; // placeholder for the operand table in the variants that read a stored product
-
-// Where the key-switch target and the polynomials the result is added to come from (MODE):
-//   KS_PLAIN   target from memory, nothing added
-//   KS_MUL     fused multiply, r03 form: the target d2 = a1 b1 of product `inst` is evaluated where the NTT-form
-//              digit is used as is (I == J); d0, d1 are left to the combine epilogue of the mod-down
-//   KS_FOLDMUL fused multiply, r04 form: the target is read from memory (OpMulIntt stores d2 next to its inverse
-//              transform) and P * d0, P * d1 (P = the special prime) are added to the inner products of the data
-//              limbs right here:  prod'[K][I] = prod[K][I] + P d_K[I]  mod q_I.  The mod-down computes
-//              (prod' - U) P^-1 = d_K + (prod - U) P^-1, the same canonical residue, without reading the operands
-//              again — its combine pass was waiting for those bytes (6 words per output word) while this
-//              kernel, which is bound by integer issue, has the memory slack to fetch them.  The products are
-//              128-bit MACs of a canonical operand with a lazy Shoup product (< 4q) of the other operand and P.
-//   KS_FOLDADD the same for stored polynomials (relinearize, relinearize + rescale of a size-3 ciphertext; a
-//              rotation's permuted c0): P * c_K is added, c_K = adds.p[2 inst + K] (limb 0; null = nothing to add),
-//              so the mod-down's combine pass no longer reads c_K.
-// (plain ints, not an unnamed enum: the enum's type would be mangled into the kernel's name as a local type and the
-// runtime could not find the symbol)
-constexpr int KS_PLAIN = 0, KS_MUL = 1, KS_FOLDMUL = 2, KS_FOLDADD = 3;
-// kernel-argument types per mode (a traits struct, so the kernel's mangled name carries no constant expression)
-template <int MODE> struct KsArgs { using Mul = NoMul; using Add = NoMul; };
-template <> struct KsArgs<KS_MUL> { using Mul = MulTab; using Add = NoMul; };
-template <> struct KsArgs<KS_FOLDMUL> { using Mul = MulTab; using Add = NoMul; };
-template <> struct KsArgs<KS_FOLDADD> { using Mul = NoMul; using Add = PtrTab; };
-template <int MODE> using KsMulArg = typename KsArgs<MODE>::Mul;
-template <int MODE> using KsAddArg = typename KsArgs<MODE>::Add;
-
-// INVSP (latency-bound launches): the workgroups of the special-prime row (I == l) go straight on
-// with the contiguous pass of that row's inverse transform — the first step of the mod-down that
-// always follows — on the tile they hold, and store its lazy intermediate to r_out[2 inst + K]
-// instead of the row itself: one launch fewer per key switch, same residues.
-// MAC3 (contexts whose primes all have the top-bit shape, whole keys in the split layout KeyDev::d_split): the inner
-// product accumulates in radix 2^30.  The transformed digit is brought to < 2^60 + 2^36 with the top-bit reduction and
-// cut at bit 30 (v0, v1), the key word arrives as (k0 | k1 << 32) with k0, k1 < 2^30, and the four partial products
-// — each < 2^60.1 — go into three 64-bit sums A0 += v0 k0, A1 += v0 k1 + v1 k0, A2 += v1 k1 with ONE v_mad_u64_u32
-// each and no carry handling: 13 VALU per coefficient and digit for both key polynomials (3 reduce + 2 split + 8 mad)
-// where the 128-bit accumulation takes 28.  A1 holds 7 digits (14 products < 16 x 2^60), so the sums are normalised
-// (carry words moved up) every 7 digits; after the loop they are recombined into the 128-bit accumulators the
-// epilogue works on.  6 registers per accumulator instead of 4.
-template <int P, int LR, int MAXT, int MODE, bool INVSP = false, bool MAC3 = false>
-__global__ void __launch_bounds__(MAXT)
-ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
-                size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, uint32_t i0,
-                int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets, KsMulArg<MODE> mul, uint32_t istep,
-                uint32_t nout, u64 *__restrict__ r_out, KsAddArg<MODE> adds, int lazy_out) {
-  constexpr bool MUL = MODE == KS_MUL;
-  extern __shared__ __attribute__((aligned(16))) u64 lds[];
-  if (cx.skipped()) return;
-  // grid.x carries (tile, instance): instances of one tile are placed 8 block ids apart, i.e. on
-  // the same XCD (blocks are dealt round-robin over the 8 XCDs) and close in dispatch order, so
-  // instances that share a key find its tile in that XCD's L2.  Speed only, never correctness.
-  uint32_t tile_idx, inst;
-  if ((n_tiles & 7u) == 0) {
-    const uint32_t x = blockIdx.x, lo = x & 7u, rest = x >> 3;
-    inst = rest % n_inst;
-    tile_idx = (rest / n_inst) * 8u + lo;
-  } else {
-    inst = blockIdx.x / n_tiles;
-    tile_idx = blockIdx.x % n_tiles;
-  }
-  // the divisions above go through the vector unit: make the results wave-uniform for the compiler, so that what is
-  // indexed by them (key, operand and product base pointers) lives in SGPRs
-  inst = __builtin_amdgcn_readfirstlane(inst);
-  tile_idx = __builtin_amdgcn_readfirstlane(tile_idx);
-  // MUL: the key-switch target is d2 = a1 b1 of product `inst`, evaluated where it is needed (I == J)
-  const u64 *__restrict__ target = MUL ? nullptr : (target_b ? target_b + inst * target_bs : targets.p[inst]);
-  const u64 *__restrict__ scratch = scratch_b + inst * scratch_bs;
-  const u64 *__restrict__ key = keys.key[inst];
-  u64 *__restrict__ prod = prod_b + inst * prod_bs;
-  constexpr int NTT_R = 1 << LR, NPAIR = NTT_R / 2;
-  constexpr int S = 1 << P, TPS = S / NTT_R, SP = lds_sub_stride<P>();
-  // output limb of this workgroup: I = i0 + blockIdx.y * istep.  istep == 1: the rows of scratch /
-  // prod / target are indexed by I itself (nout = l + 1); istep == G (a shard's limbs): by blockIdx.y
-  const uint32_t I = i0 + blockIdx.y * istep;
-  const uint32_t Irow = istep > 1 ? blockIdx.y : I;
-  const uint32_t kap = (I == l) ? cx.k - 1 : I;
-  const DevPrime pm = cx.primes[kap];
-  const ulonglong2 *tw = cx.tw_fwd + (size_t)kap * cx.N;
-  const int T = blockDim.x;
-  const uint32_t pre = cx.logN - P;
-  const uint32_t sub0 = tile_idx << logC, gbase = sub0 << P;
-  // key rows: by prime for a whole key; by local limb (last row: the special prime) for a shard's rows
-  const uint32_t krows = keys.rows ? keys.rows : cx.k;
-  const uint32_t krow = keys.rows ? (kap == cx.k - 1 ? krows - 1 : blockIdx.y) : kap;
-  const size_t N = cx.N, key_digit = (size_t)2 * krows * N;
-  const int sub = threadIdx.x / TPS, tid = threadIdx.x % TPS;
-
-  // The twiddles of this tile's sub-transforms are the same for every digit J: stage them in LDS
-  // once as per-sub local heaps (node n of sub s = global node ((2^pre + h_s) << depth(n)) + pos(n)),
-  // so the J loop touches global memory only for coefficients and key.
-  const int C = 1 << logC;
-  ulonglong2 *twl = reinterpret_cast<ulonglong2 *>(lds + ((C * SP + 1) & ~1));
-  for (int idx = threadIdx.x; idx < (C << P); idx += T) {
-    const int sb = idx >> P, n = idx & (S - 1);
-    if (n) {
-      const int d = 31 - __clz(n);
-      twl[idx] = tw[((size_t)((1u << pre) + sub0 + sb) << d) + (n - (1 << d))];
-    }
-  }
-
-  u128_t acc0[NTT_R], acc1[NTT_R];
-#pragma unroll
-  for (int i = 0; i < NTT_R; i++) { acc0[i] = {0, 0}; acc1[i] = {0, 0}; }
-  constexpr int NA = MAC3 ? NTT_R : 1;
-  u64 s0[2][NA], s1[2][NA], s2[2][NA]; // MAC3: radix-2^30 partial sums per key polynomial K
-#pragma unroll
-  for (int i = 0; i < NA; i++) { s0[0][i] = s1[0][i] = s2[0][i] = s0[1][i] = s1[1][i] = s2[1][i] = 0; }
-
-  // Software pipeline over the digits: the key words of digit J are requested before its
-  // transform starts and the coefficients of digit J+1 as soon as those of J sit in LDS, so both
-  // streams are in flight during the register rounds instead of being waited for at their use.
-  MulSrc msrc{nullptr, nullptr, 0, 0};
-  if constexpr (MUL || MODE == KS_FOLDMUL) msrc = mul_src(mul, cx.N, inst);
-  auto load_digits = [&](uint32_t J, ulonglong2 *d) {
-    if (MUL && I == J) { // block-uniform
-#pragma unroll
-      for (int it = 0; it < NPAIR; it++) {
-        const size_t off = (size_t)J * N + gbase + 2 * (threadIdx.x + it * T);
-        d[it].x = product_poly(msrc, 2, off, pm);
-        d[it].y = product_poly(msrc, 2, off + 1, pm);
-      }
-    } else {
-      const u64 *src = (I == J ? target + (size_t)Irow * N : scratch + ((size_t)Irow * l + J) * N) + gbase;
-#pragma unroll
-      for (int it = 0; it < NPAIR; it++) d[it] = *reinterpret_cast<const ulonglong2 *>(src + 2 * (threadIdx.x + it * T));
-    }
-  };
-  // MAC3: the digit tiles do not pass through registers.  An LDS-DMA load (global_load_lds_dwordx4: 16 bytes per lane,
-  // contiguous) puts tile J + 1 into an unpadded buffer `lin` while tile J is being transformed; the first register
-  // round reads its inputs from `lin`, and the load of the next tile is issued right after that round.  This frees
-  // the 8 prefetch registers (and the tile's ds_write) for the radix-2^30 sums.
-  u64 *lin = reinterpret_cast<u64 *>(twl + (C << P)); // [256] after the twiddle heaps
-  auto dma_digits = [&](uint32_t J) {
-    const u64 *src = (I == J ? target + (size_t)Irow * N : scratch + ((size_t)Irow * l + J) * N) + gbase;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads of `lin` issued so far have returned
-#pragma unroll
-    for (int it = 0; it < NPAIR; it++)
-      __builtin_amdgcn_global_load_lds(src + 2 * (threadIdx.x + it * T), lin + 2 * it * T, 16, 0, EVAH_DIGIT_AUX);
-  };
-  ulonglong2 dreg[MAC3 ? 1 : NPAIR];
-  if constexpr (MAC3) dma_digits(0);
-  else load_digits(0, dreg);
-  uint32_t since_fold = 0;
-  for (uint32_t J = 0; J < l; J++) {
-    ulonglong2 k0r[NPAIR], k1r[NPAIR];
-    if constexpr (!MAC3) {
-      const u64 *kp = key + J * key_digit + (size_t)krow * N + gbase;
-#pragma unroll
-      for (int it = 0; it < NPAIR; it++) {
-        const int idx = 2 * (threadIdx.x + it * T);
-        k0r[it] = *reinterpret_cast<const ulonglong2 *>(kp + idx);
-        k1r[it] = *reinterpret_cast<const ulonglong2 *>(kp + (size_t)krows * N + idx);
-      }
-    }
-    u64 val[NTT_R];
-    const uint32_t Jn = J + 1 < l ? J + 1 : J;
-    if constexpr (MAC3) {
-      using RS = Rounds<P, LR>;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // tile J has landed in `lin` (its load was issued a digit ago)
-      // the key words of this digit: requested now, used after the transform
-      const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<u64 *>(key + (size_t)krow * N + gbase), 0, 0x7fffffff, 0x00020000);
-      const uint32_t voff = 16u * threadIdx.x;
-      const uint32_t soff0 = (uint32_t)(J * key_digit * sizeof(u64)), soff1 = soff0 + (uint32_t)((size_t)krows * N * sizeof(u64));
-#pragma unroll
-      for (int it = 0; it < NPAIR; it++) {
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(krs, voff + 16u * (uint32_t)(it * T), soff0, 0);
-        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(krs, voff + 16u * (uint32_t)(it * T), soff1, 0);
-        k0r[it].x = ((u64)a.y << 32) | a.x;
-        k0r[it].y = ((u64)a.w << 32) | a.z;
-        k1r[it].x = ((u64)b.y << 32) | b.x;
-        k1r[it].y = ((u64)b.w << 32) | b.z;
-      }
-      if (I == J) { // NTT form already: the tile as it lies in `lin`
-#pragma unroll
-        for (int it = 0; it < NPAIR; it++) {
-          const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(lin + 2 * (threadIdx.x + it * T));
-          val[2 * it] = v.x;
-          val[2 * it + 1] = v.y;
-        }
-        if (J + 1 < l) dma_digits(J + 1);
-      } else {
-        __builtin_amdgcn_wave_barrier(); // (one wave: DS operations are in order; no s_barrier, no vmcnt drain)
-        // first round: from `lin` into the padded tile; then the next tile's load; then the remaining rounds
-        auto next_tile = [&]() { if (J + 1 < l) dma_digits(J + 1); }; // (waits for the round's reads of `lin` first)
-        ntt_round<P, LR, RS::bits(0), RS::lo(0), false, true, true, true, true>(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm,
-                                                                              lin + sub * S, next_tile);
-        if constexpr (RS::NR > 1) {
-          __builtin_amdgcn_wave_barrier();
-          RoundSeq<P, LR, 1, false, true, true, true, true, true>::run(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < NPAIR; it++) {
-          const int idx = 2 * (threadIdx.x + it * T);
-          const int sb = idx >> P, e = idx & (S - 1);
-          val[2 * it] = lds[sb * SP + lds_pad<P>(e)];
-          val[2 * it + 1] = lds[sb * SP + lds_pad<P>(e + 1)];
-        }
-      }
-    } else if (I == J) { // already in NTT form mod q_J: use the key-switch target directly
-#pragma unroll
-      for (int it = 0; it < NPAIR; it++) {
-        val[2 * it] = dreg[it].x;
-        val[2 * it + 1] = dreg[it].y;
-      }
-      load_digits(Jn, dreg);
-    } else {
-      __syncthreads(); // previous iteration's LDS reads are done
-#pragma unroll
-      for (int it = 0; it < NPAIR; it++) {
-        const int idx = 2 * (threadIdx.x + it * T);
-        const int sb = idx >> P, e = idx & (S - 1);
-        lds[sb * SP + lds_pad<P>(e)] = dreg[it].x;
-        lds[sb * SP + lds_pad<P>(e + 1)] = dreg[it].y;
-      }
-      load_digits(Jn, dreg);
-      __syncthreads();
-      // STRIDED=true selects local-heap node indexing, which is what the LDS copy uses
-      forward_rounds<P, LR, true, true>(lds + sub * SP, tid, 0, 0, twl + (sub << P), pm);
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < NPAIR; it++) {
-        const int idx = 2 * (threadIdx.x + it * T);
-        const int sb = idx >> P, e = idx & (S - 1);
-        val[2 * it] = lds[sb * SP + lds_pad<P>(e)];       // lazy [0,16q): fine for the 128-bit MAC (folded every 16 digits)
-        val[2 * it + 1] = lds[sb * SP + lds_pad<P>(e + 1)];
-      }
-    }
-    if constexpr (MAC3) {
-#pragma unroll
-      for (int i = 0; i < NTT_R; i++) {
-        const uint32_t hi = (uint32_t)(val[i] >> 32);
-        const u64 v = mad64(hi >> pm.tb_sh, pm.tb_c, ((u64)(hi & pm.tb_mask) << 32) | (uint32_t)val[i]); // < 2^60 + 2^36
-        const uint32_t v0 = (uint32_t)v & 0x3fffffffu, v1 = (uint32_t)(v >> 30);
-        const u64 kw0 = (i & 1) ? k0r[i >> 1].y : k0r[i >> 1].x, kw1 = (i & 1) ? k1r[i >> 1].y : k1r[i >> 1].x;
-        s0[0][i] = mad64(v0, (uint32_t)kw0, s0[0][i]);
-        s1[0][i] = mad64(v0, (uint32_t)(kw0 >> 32), s1[0][i]);
-        s1[0][i] = mad64(v1, (uint32_t)kw0, s1[0][i]);
-        s2[0][i] = mad64(v1, (uint32_t)(kw0 >> 32), s2[0][i]);
-        s0[1][i] = mad64(v0, (uint32_t)kw1, s0[1][i]);
-        s1[1][i] = mad64(v0, (uint32_t)(kw1 >> 32), s1[1][i]);
-        s1[1][i] = mad64(v1, (uint32_t)kw1, s1[1][i]);
-        s2[1][i] = mad64(v1, (uint32_t)(kw1 >> 32), s2[1][i]);
-      }
-      if (++since_fold == 7u && J + 1 < l) { // block-uniform: carry words up, 7 more digits fit
-        since_fold = 0;
-#pragma unroll
-        for (int K = 0; K < 2; K++)
-#pragma unroll
-          for (int i = 0; i < NTT_R; i++) {
-            s1[K][i] += s0[K][i] >> 30;
-            s0[K][i] &= 0x3fffffffull;
-            s2[K][i] += s1[K][i] >> 30;
-            s1[K][i] &= 0x3fffffffull;
-          }
-      }
-      continue;
-    }
-#pragma unroll
-    for (int it = 0; it < NPAIR; it++) {
-      acc128(acc0[2 * it], val[2 * it], k0r[it].x);
-      acc128(acc0[2 * it + 1], val[2 * it + 1], k0r[it].y);
-      acc128(acc1[2 * it], val[2 * it], k1r[it].x);
-      acc128(acc1[2 * it + 1], val[2 * it + 1], k1r[it].y);
-    }
-    // 16 lazy products (each < 16q * q < 2^124) fill the 128-bit accumulators, 15 of them and a folded word leave
-    // room for the P * d_K terms added after the loop (< 12 q^2 together): with more digits than that, fold the
-    // accumulators back to one word every 15 (block-uniform, only ever taken when l > 15)
-    if (++since_fold == 15u && J + 1 < l) {
-      since_fold = 0;
-#pragma unroll
-      for (int i = 0; i < NTT_R; i++) {
-        acc0[i] = {barrett128(acc0[i], pm), 0};
-        acc1[i] = {barrett128(acc1[i], pm), 0};
-      }
-    }
-  }
-  if constexpr (MAC3) { // S = s0 + s1 2^30 + s2 2^60 < 2^125: the 128-bit accumulators of the epilogue
-#pragma unroll
-    for (int i = 0; i < NTT_R; i++) {
-      unsigned __int128 a = s0[0][i], b = s0[1][i];
-      a += (unsigned __int128)s1[0][i] << 30;
-      a += (unsigned __int128)s2[0][i] << 60;
-      b += (unsigned __int128)s1[1][i] << 30;
-      b += (unsigned __int128)s2[1][i] << 60;
-      acc0[i] = {(u64)a, (u64)(a >> 64)};
-      acc1[i] = {(u64)b, (u64)(b >> 64)};
-    }
-  }
-  if constexpr (MODE == KS_FOLDMUL || MODE == KS_FOLDADD) {
-    { // after the digit loop, where its prefetch registers are free (as a prologue the block cost 32 VGPRs: 147, 3 waves
-      // per SIMD).  No branch: the special row multiplies by modq[P][P] = (0, 0) — P = 0 mod P — and reads a row that exists
-      const ulonglong2 Pm = cx.modq[(size_t)(cx.k - 1) * cx.k + kap]; // (P mod q_I, Shoup quotient)
-      const size_t off = (size_t)(Irow < l ? Irow : l - 1) * N + gbase;
-#pragma unroll
-      for (int it = 0; it < NPAIR; it++) {
-        const size_t o = off + 2 * (threadIdx.x + it * T);
-        if constexpr (MODE == KS_FOLDMUL) {
-          const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(msrc.a + o);
-          const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(msrc.a + msrc.sa + o);
-          const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(msrc.b + o);
-          const ulonglong2 b1 = *reinterpret_cast<const ulonglong2 *>(msrc.b + msrc.sb + o);
-          // a < q, lazy(b P) < 4q: each term < 2^122, three of them on top of 15 digit products still fit 128 bits
-          const u64 u0x = mul_tw_lazy5(b0.x, Pm.x, Pm.y, pm.nq), u0y = mul_tw_lazy5(b0.y, Pm.x, Pm.y, pm.nq);
-          const u64 u1x = mul_tw_lazy5(b1.x, Pm.x, Pm.y, pm.nq), u1y = mul_tw_lazy5(b1.y, Pm.x, Pm.y, pm.nq);
-          acc128(acc0[2 * it], a0.x, u0x);
-          acc128(acc0[2 * it + 1], a0.y, u0y);
-          acc128(acc1[2 * it], a0.x, u1x);
-          acc128(acc1[2 * it + 1], a0.y, u1y);
-          acc128(acc1[2 * it], a1.x, u0x);
-          acc128(acc1[2 * it + 1], a1.y, u0y);
-        } else {
-          // a null entry: nothing is added to that polynomial (a rotation adds the permuted c0 to K = 0 only)
-          const u64 *p0 = adds.p[2 * inst], *p1 = adds.p[2 * inst + 1]; // block-uniform
-          if (p0) {
-            const ulonglong2 c0 = *reinterpret_cast<const ulonglong2 *>(p0 + o);
-            acc128(acc0[2 * it], c0.x, Pm.x);
-            acc128(acc0[2 * it + 1], c0.y, Pm.x);
-          }
-          if (p1) {
-            const ulonglong2 c1 = *reinterpret_cast<const ulonglong2 *>(p1 + o);
-            acc128(acc1[2 * it], c1.x, Pm.x);
-            acc128(acc1[2 * it + 1], c1.y, Pm.x);
-          }
-        }
-      }
-    }
-  }
-  if constexpr (INVSP) {
-    if (I == l) { // block-uniform
-      const ulonglong2 *twi = cx.tw_inv + (size_t)kap * cx.N;
-#pragma unroll
-      for (int K = 0; K < 2; K++) {
-        __syncthreads(); // the tile in LDS has been consumed
-#pragma unroll
-        for (int it = 0; it < NPAIR; it++) {
-          const int idx = 2 * (threadIdx.x + it * T);
-          const int sb = idx >> P, e = idx & (S - 1);
-          lds[sb * SP + lds_pad<P>(e)] = barrett128(K ? acc1[2 * it] : acc0[2 * it], pm);
-          lds[sb * SP + lds_pad<P>(e + 1)] = barrett128(K ? acc1[2 * it + 1] : acc0[2 * it + 1], pm);
-        }
-        __syncthreads();
-        // as ntt_pass_kernel<P, LR, contiguous, inverse>: global twiddle heap of the row's prime
-        RoundSeq<P, LR, 0, true, false, true>::run(lds + sub * SP, tid, sub0 + sub, pre, twi, pm);
-        __syncthreads();
-        u64 *r = r_out + ((size_t)2 * inst + K) * N + gbase;
-#pragma unroll
-        for (int it = 0; it < NPAIR; it++) {
-          const int idx = 2 * (threadIdx.x + it * T);
-          const int sb = idx >> P, e = idx & (S - 1);
-          ulonglong2 v;
-          v.x = lds[sb * SP + lds_pad<P>(e)];
-          v.y = lds[sb * SP + lds_pad<P>(e + 1)];
-          *reinterpret_cast<ulonglong2 *>(r + idx) = v; // lazy intermediate of the inverse transform
-        }
-      }
-      return;
-    }
-  }
-  u64 *p0 = prod + (size_t)Irow * N + gbase, *p1 = prod + ((size_t)nout + Irow) * N + gbase;
-  // lazy_out: the data rows go to combine passes that take any 64-bit representative (OpRRT / OpRRLastT multiply prod by
-  // P^-1 first), so their last Barrett step is skipped; the special row feeds an inverse transform and stays canonical
-  if (lazy_out && I != l) { // block-uniform
-#pragma unroll
-    for (int it = 0; it < NPAIR; it++) {
-      const int idx = 2 * (threadIdx.x + it * T);
-      ulonglong2 r0, r1;
-      r0.x = reduce128_lazy(acc0[2 * it], pm);
-      r0.y = reduce128_lazy(acc0[2 * it + 1], pm);
-      r1.x = reduce128_lazy(acc1[2 * it], pm);
-      r1.y = reduce128_lazy(acc1[2 * it + 1], pm);
-      *reinterpret_cast<ulonglong2 *>(p0 + idx) = r0;
-      *reinterpret_cast<ulonglong2 *>(p1 + idx) = r1;
-    }
-    return;
-  }
-#pragma unroll
-  for (int it = 0; it < NPAIR; it++) {
-    const int idx = 2 * (threadIdx.x + it * T);
-    ulonglong2 r0, r1;
-    r0.x = barrett128(acc0[2 * it], pm);
-    r0.y = barrett128(acc0[2 * it + 1], pm);
-    r1.x = barrett128(acc1[2 * it], pm);
-    r1.y = barrett128(acc1[2 * it + 1], pm);
-    *reinterpret_cast<ulonglong2 *>(p0 + idx) = r0;
-    *reinterpret_cast<ulonglong2 *>(p1 + idx) = r1;
-  }
-}
-
-// ------------------------------------------------------------------ fused load/store ops
-
-// Plain batched transform over limbs.  job -> (poly p = job / jl, limb i = job % jl),
-// prime = prime0 + i.  addhalf: x <- x + floor(q/2) mod q on store (rounding offset of
-// rescale / key-switch mod-down).
-// GATHER: polynomial pp is read through an index table, x[n] = src[perm_tab.p[pp >> 1][n]] (the special rows of hoisted
-// key inner products, which rotation_sets.hip.h keeps in the source's index space: the Galois permutation is applied here)
-struct NoGather {};
-template <bool ZEROS, bool GATHER = false> struct OpPlainT { // ZEROS: the inverse transform also records zero coefficients
-  struct Params {
-    const u64 *src;
-    u64 *dst;
-    size_t src_ps, dst_ps; // poly strides (elements)
-    uint32_t jl, prime0;
-    int addhalf;
-    PtrTab src_tab; // used when src == nullptr: polynomial pp starts at src_tab.p[pp]
-    uint32_t pstep = 1; // limb i is modulo primes[prime0 + i * pstep] (limb-sharded values: the shard count)
-    // inverse transforms of hoisted rotations: coefficients that come out 0 are counted in the low
-    // word of zero_list[0] and the first HOIST_ZERO_CAP of them recorded as (poly << 48 | limb << 32 | index)
-    u64 *zero_list = nullptr;
-    std::conditional_t<GATHER, PermTab, NoGather> perm_tab{};
-    // ZEROS: words the first pass clears before the second pass counts into zero_list (first_pass_clear)
-    u64 *clear_base = nullptr;
-    uint32_t clear_words = 0;
-  };
-  static constexpr bool clears_words = ZEROS;
-  struct Job {
-    uint32_t prime;
-    const u64 *src;
-    u64 *dst;
-    int addhalf;
-    bool lazy;
-    u64 *zero_list;
-    uint32_t pp;
-    const uint32_t *perm;
-  };
-  // jobs = polys * jl: grid.y = limb i, grid.z = poly
-  static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
-  static constexpr int loop_axis = 2; // jobs that share a prime lie along grid.z (ntt_loop_kernel)
-  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i,
-                                               uint32_t pp, Job &j) {
-    j.prime = p.prime0 + i * p.pstep;
-    j.src = (p.src ? p.src + pp * p.src_ps : p.src_tab.p[pp]) + (size_t)i * cx.N;
-    j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
-    j.addhalf = p.addhalf;
-    j.lazy = false;
-    j.zero_list = p.zero_list;
-    j.pp = pp;
-    if constexpr (GATHER) j.perm = p.perm_tab.p[pp >> 1];
-    else j.perm = nullptr;
-    return true;
-  }
-  template <bool LZ>
-  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &, uint32_t n) {
-    if constexpr (GATHER) return j.src[j.perm[n]];
-    return j.src[n];
-  }
-  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm,
-                                               uint32_t n, u64 v) {
-    if constexpr (ZEROS) {
-      if (v == 0) {
-        const uint32_t at = atomicAdd(reinterpret_cast<uint32_t *>(j.zero_list), 1u);
-        if (at < HOIST_ZERO_CAP) j.zero_list[1 + at] = ((u64)j.pp << 48) | ((u64)j.prime << 32) | n;
-      }
-    }
-    if (j.addhalf) v = addmod(v, pm.q >> 1, pm.q);
-    j.dst[n] = v;
-  }
-  static __device__ __forceinline__ void store_fwd(const DevCtx &cx, const Job &j, const DevPrime &pm,
-                                                   uint32_t n, u64 v) {
-    store(cx, j, pm, n, barrett64(v, pm.q, pm.brt));
-  }
-};
-
-using OpPlain = OpPlainT<false>;
-using OpPlainZ = OpPlainT<true>;
-using OpPlainG = OpPlainT<false, true>;
-
-// Inverse transform of d2 = a1 b1 of a batch of products (the key-switch target of a fused
-// multiply -> relinearize): job -> (instance b = job / jl, limb i = job % jl); the product is
-// formed on load, so d2 itself never exists in memory.
-struct OpMulIntt {
-  struct Params {
-    MulTab mul;
-    u64 *dst;      // [batch][jl][N] coefficient-form digits
-    size_t dst_ps; // batch stride
-    uint32_t jl;
-    u64 *d2 = nullptr; // != nullptr: d2 itself (NTT form) is stored too, [batch][jl][N] at the same stride — the
-                       // key-switch kernel reads it where the digit is used as is (I == J) instead of forming it again
-  };
-  struct Job {
-    uint32_t prime;
-    size_t off;
-    MulSrc mul;
-    u64 *dst, *d2;
-    bool lazy;
-  };
-  static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
-  static constexpr int loop_axis = 2; // jobs that share a prime lie along grid.z (ntt_loop_kernel)
-  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i, uint32_t b, Job &j) {
-    j.prime = cx.prime_of(i);
-    j.off = (size_t)i * cx.N;
-    j.mul = mul_src(p.mul, cx.N, b);
-    j.dst = p.dst + b * p.dst_ps + (size_t)i * cx.N;
-    j.d2 = p.d2 ? p.d2 + b * p.dst_ps + (size_t)i * cx.N : nullptr;
-    j.lazy = false;
-    return true;
-  }
-  template <bool LZ>
-  static __device__ __forceinline__ u64 load(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n) {
-    const u64 v = product_poly(j.mul, 2, j.off + n, pm);
-    if (j.d2) j.d2[n] = v; // block-uniform
-    return v;
-  }
-  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &, uint32_t n, u64 v) {
-    j.dst[n] = v;
-  }
-  static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &, const DevPrime &, uint32_t, u64) {}
-  // ntt_loop_kernel: operands of the NEXT product requested before the current job's transform, multiplied after it
-  struct Raw { u64 a, b; };
-  static __device__ __forceinline__ Raw raw_load(const DevCtx &, const Job &j, const DevPrime &, uint32_t n) {
-    return Raw{j.mul.a[j.off + n + j.mul.sa], j.mul.b[j.off + n + j.mul.sb]};
-  }
-  static __device__ __forceinline__ u64 finish_load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, const Raw &r) {
-    const u64 v = mulmod(r.a, r.b, pm);
-    if (j.d2) j.d2[n] = v; // block-uniform
-    return v;
-  }
-};
-
-// Key-switch digit conversion: job -> (I = job / l, J = job % l);
-// scratch[I][J] = NTT_{kappa(I)}( t[J] mod q_kappa(I) ), I == J skipped (NTT form reused).
-struct OpKsDigit {
-  struct Params {
-    const u64 *t;   // [batch][l][N] coefficient-form digits
-    u64 *scratch;   // [batch][l+1][l][N]
-    uint32_t l;
-    size_t t_bs, scratch_bs; // batch strides
-    uint32_t i0, ni;         // output limbs handled by this launch: I = i0 + iy * istep, iy < ni (I == l: special prime)
-    uint32_t istep = 1;      // 1: a slice of all limbs; G: the limbs a shard of G owns (scratch rows are then local: iy)
-    uint32_t t_split = 1, t_rows = 0; // digit J sits at row (J % t_split) * t_rows + J / t_split of t (an all-gathered
-                                      // buffer is shard-major); t_split == 1: row J
-  };
-  struct Job {
-    uint32_t prime, digit;
-    const u64 *src;
-    u64 *dst;
-    bool lazy;
-  };
-  // jobs = batch * ni * l: grid.x carries the digit J, grid.y the output limb, grid.z the batch
-  static dim3 grid(const Params &p, uint32_t jobs) { return dim3(p.l, p.ni, jobs / (p.ni * p.l)); }
-  static constexpr int loop_axis = 0; // the digits J of one output limb share its prime (ntt_loop_kernel)
-  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t J, uint32_t iy,
-                                               uint32_t b, Job &j) {
-    const uint32_t I = p.i0 + iy * p.istep;
-    if (I == J) return false;
-    j.digit = J;
-    j.prime = (I == p.l) ? cx.k - 1 : I;
-    // t_J < q_J: when q_J <= 8 q_kappa the digit is already a valid lazy input (< 12 q_kappa)
-    j.lazy = cx.primes[J].q <= cx.primes[j.prime].q8;
-    const uint32_t row = p.t_split > 1 ? (J % p.t_split) * p.t_rows + J / p.t_split : J;
-    j.src = p.t + b * p.t_bs + (size_t)row * cx.N;
-    const uint32_t Irow = p.istep > 1 ? iy : I;
-    j.dst = p.scratch + b * p.scratch_bs + ((size_t)Irow * p.l + J) * cx.N;
-    return true;
-  }
-  template <bool LZ>
-  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
-    return conv<LZ>(j, pm, j.src[n]);
-  }
-  // hooks of ntt_inv_fwd_kernel: the source is digit J's contiguous-inverse-pass intermediate
-  static constexpr bool pre_addhalf = false;
-  static __device__ __forceinline__ uint32_t pre_prime(const Params &, const Job &j) { return j.digit; }
-  static __device__ __forceinline__ const u64 *pre_src(const Job &j) { return j.src; }
-  template <bool LZ> static __device__ __forceinline__ u64 conv(const Job &, const DevPrime &pm, u64 v) {
-    return LZ ? v : barrett64(v, pm.q, pm.brt);
-  }
-  static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &j, const DevPrime &pm,
-                                                   uint32_t n, u64 v) {
-    j.dst[n] = barrett64(v, pm.q, pm.brt);
-  }
-};
-
-// Divide-and-round by prime a (rescale: a = last data prime; key-switch: a = special prime).
-// job -> (p = job / jl, i = job % jl).  r[p] is INTT(limb a) + floor(q_a/2) in coefficient form.
-//   load : u = (r mod q_i) - (floor(q_a/2) mod q_i)
-//   store: v = (c[p][i] - NTT(u)) * q_a^-1 mod q_i ;  dst = add ? add + v : v
-// GATHER: c (the key inner products) is read through the pair's index table, c[perm_tab.p[pp >> 1][n]] (hoisted sets)
-template <bool GATHER> struct OpModDownT {
-  struct Params {
-    const u64 *r;
-    size_t r_ps;
-    const u64 *c;
-    size_t c_ps;
-    const u64 *add; // nullable; applies to polys p < add_polys (add_polys == ~0u: even p only)
-    size_t add_ps;
-    uint32_t add_polys;
-    u64 *dst;
-    size_t dst_ps;
-    uint32_t a, jl;
-    size_t add_bs = 0; // != 0: poly pp = 2b + K adds add[b * add_bs + K * add_ps] (batched relinearize)
-    // separately allocated operands (the *_many entry points): used when c == nullptr /
-    // use_add_tab; entry pp is limb 0 of polynomial pp, a null add entry means "nothing to add"
-    bool use_add_tab = false;
-    PtrTab c_tab{}, add_tab{};
-    std::conditional_t<GATHER, PermTab, NoGather> perm_tab{};
-  };
-  struct Job {
-    uint32_t prime;
-    const u64 *src, *c, *add;
-    u64 *dst;
-    u64 halfm;
-    ulonglong2 inv;
-    bool lazy;
-    const uint32_t *perm;
-  };
-  static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
-  static constexpr int loop_axis = 2; // jobs that share a prime lie along grid.z (ntt_loop_kernel)
-  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i,
-                                               uint32_t pp, Job &j) {
-    j.prime = cx.prime_of(i); // limb i of the values (c, add, dst) — the prime itself on an ordinary context
-    j.src = p.r + pp * p.r_ps;
-    j.c = (p.c ? p.c + pp * p.c_ps : p.c_tab.p[pp]) + (size_t)i * cx.N;
-    if (p.use_add_tab) {
-      j.add = p.add_tab.p[pp] ? p.add_tab.p[pp] + (size_t)i * cx.N : nullptr;
-    } else {
-      const bool use_add = p.add && (p.add_bs ? true : p.add_polys == ~0u ? (pp & 1u) == 0 : pp < p.add_polys);
-      const size_t add_off = p.add_bs ? (pp >> 1) * p.add_bs + (pp & 1u) * p.add_ps : pp * p.add_ps;
-      j.add = use_add ? p.add + add_off + (size_t)i * cx.N : nullptr;
-    }
-    j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
-    j.halfm = cx.halfmod[p.a * cx.k + j.prime];
-    j.inv = cx.invq[p.a * cx.k + j.prime];
-    j.lazy = cx.primes[p.a].q <= cx.primes[j.prime].q8; // r < q_a: r + (q_i - halfm) < 9 q_i
-    if constexpr (GATHER) j.perm = p.perm_tab.p[pp >> 1];
-    else j.perm = nullptr;
-    return true;
-  }
-  static __device__ __forceinline__ u64 c_at(const Job &j, uint32_t n) {
-    if constexpr (GATHER) return j.c[j.perm[n]];
-    return j.c[n];
-  }
-  template <bool LZ>
-  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
-    return conv<LZ>(j, pm, j.src[n]);
-  }
-  // hooks of ntt_inv_fwd_kernel: r holds the contiguous-inverse-pass intermediate of limb a
-  static constexpr bool pre_addhalf = true;
-  static __device__ __forceinline__ uint32_t pre_prime(const Params &p, const Job &) { return p.a; }
-  static __device__ __forceinline__ const u64 *pre_src(const Job &j) { return j.src; }
-  template <bool LZ> static __device__ __forceinline__ u64 conv(const Job &j, const DevPrime &pm, u64 v) {
-    if (LZ) return v + (pm.q - j.halfm);
-    return submod(barrett64(v, pm.q, pm.brt), j.halfm, pm.q);
-  }
-  static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &j, const DevPrime &pm,
-                                                   uint32_t n, u64 U) {
-    U += (U >= pm.q8 ? pm.nq8 : 0);                       // [0,16q) -> [0,8q)
-    u64 v = mul_shoup(c_at(j, n) + pm.q8 - U, j.inv.x, j.inv.y, pm.q); // exact for any 64-bit operand
-    if (j.add) v = addmod(j.add[n], v, pm.q);
-    j.dst[n] = v;
-  }
-  struct Pre { u64 c, add; };
-  static __device__ __forceinline__ Pre prefetch(const DevCtx &, const Job &j, const DevPrime &, uint32_t n) {
-    return Pre{c_at(j, n), j.add ? j.add[n] : 0};
-  }
-  static __device__ __forceinline__ void store_fwd_pre(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 U, const Pre &p) {
-    U += (U >= pm.q8 ? pm.nq8 : 0);
-    u64 v = mul_shoup(p.c + pm.q8 - U, j.inv.x, j.inv.y, pm.q);
-    if (j.add) v = addmod(p.add, v, pm.q);
-    j.dst[n] = v;
-  }
-};
-
-using OpModDown = OpModDownT<false>;
-using OpModDownG = OpModDownT<true>;
-
-// ---- relinearize followed by rescale, evaluated together (same canonical result as the two
-// SEAL calls in sequence, seal_executor.h:200 then :213).  With ct' = relinearize(a):
-//   ct'[K][i] = a[K][i] + (prod[K][i] - NTT_i(u_Ki)) * P^-1,  u_Ki = (r_K mod q_i) - floor(P/2) mod q_i
-//   out[K][i] = (ct'[K][i] - NTT_i(v_Ki)) * q_last^-1,        v_Ki = (t_K mod q_i) - floor(q_last/2) mod q_i
-// NTT is linear, so NTT_i(u)*P^-1 + NTT_i(v) = NTT_i(u*P^-1 + v): one forward transform per
-// (K,i) instead of two, and t_K = INTT(ct'[K][last]) + q_last/2 needs no NTT of u at all:
-//   t_K = INTT_last(a[K][last] + prod[K][last]*P^-1) - u_K,last*P^-1 + floor(q_last/2).
-
-// Where a[K] (the polynomials the key-switch result is added to) comes from (AM):
-//   RR_MEM    read from memory
-//   RR_MUL    d_K of a fused product, evaluated on load / in the epilogue (r03 form)
-//   RR_FOLDED nowhere: the key-switch kernel already added P * a[K] to prod (KS_FOLDMUL / KS_FOLDADD), so
-//             prod * P^-1 carries it
-constexpr int RR_MEM = 0, RR_MUL = 1, RR_FOLDED = 2;
-
-// inverse transform producing t_K; job = K, prime = last data prime
-template <int AM> struct OpRRLastT {
-  static constexpr bool MUL = AM == RR_MUL;
-  struct Params {
-    const u64 *a;     // a[0][last]
-    size_t a_ps;
-    const u64 *prod;  // prod[0][last]
-    size_t prod_ps;
-    const u64 *r;     // r_0 (INTT of the special limb + P/2)
-    size_t r_ps;
-    u64 *t;
-    size_t t_ps;
-    uint32_t last, sp;
-    PtrTab a_tab; // used when a == nullptr: a_tab.p[job] = poly K of instance b at limb `last` (job = 2b+K)
-    std::conditional_t<MUL, MulTab, NoMul> mul{}; // MUL: a[K] = d_K of product b = job / 2 (fused multiply), evaluated on load
-  };
-  struct Job {
-    uint32_t prime;
-    const u64 *a, *prod, *r;
-    u64 *dst;
-    u64 halfP;
-    ulonglong2 pinv;
-    bool lazy;
-    MulSrc mul;
-    uint32_t K;
-    size_t off;
-  };
-  static dim3 grid(const Params &, uint32_t jobs) { return dim3(1, jobs, 1); }
-  static constexpr int loop_axis = 1; // every job is modulo the last data prime (ntt_loop_kernel)
-  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t job, uint32_t,
-                                               Job &j) {
-    j.prime = p.last;
-    if constexpr (MUL) j.mul = mul_src(p.mul, cx.N, job >> 1);
-    j.K = job & 1u;
-    j.off = (size_t)p.last * cx.N;
-    j.a = AM != RR_MEM ? nullptr : (p.a ? p.a + job * p.a_ps : p.a_tab.p[job]);
-    j.prod = p.prod + job * p.prod_ps;
-    j.r = p.r + job * p.r_ps;
-    j.dst = p.t + job * p.t_ps;
-    j.halfP = cx.halfmod[p.sp * cx.k + p.last];
-    j.pinv = cx.invq[p.sp * cx.k + p.last];
-    j.lazy = false;
-    return true;
-  }
-  template <bool LZ>
-  static __device__ __forceinline__ u64 load(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n) {
-    const u64 pv = mul_shoup(j.prod[n], j.pinv.x, j.pinv.y, pm.q);
-    if constexpr (AM == RR_FOLDED) return pv;
-    const u64 av = MUL ? product_poly(j.mul, j.K, j.off + n, pm) : j.a[n];
-    return addmod(av, pv, pm.q);
-  }
-  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 x) {
-    const u64 u = submod(barrett64(j.r[n], pm.q, pm.brt), j.halfP, pm.q);
-    x = submod(x, mul_shoup(u, j.pinv.x, j.pinv.y, pm.q), pm.q);
-    j.dst[n] = addmod(x, pm.q >> 1, pm.q);
-  }
-};
-
-// forward transform of u*P^-1 + v with the combined epilogue; job -> (K = job / jl, i = job % jl)
-template <int AM> struct OpRRT {
-  static constexpr bool MUL = AM == RR_MUL;
-  struct Params {
-    const u64 *r;
-    size_t r_ps;
-    const u64 *t;
-    size_t t_ps;
-    const u64 *a;
-    size_t a_ps;
-    const u64 *prod;
-    size_t prod_ps;
-    u64 *dst;
-    size_t dst_ps;
-    uint32_t sp, last, jl;
-    PtrTab a_tab; // used when a == nullptr: a_tab.p[K] = poly K (limb 0), K = 2b + {0,1}
-    std::conditional_t<MUL, MulTab, NoMul> mul{}; // MUL: a[K] = d_(K&1) of product b = K / 2 (fused multiply), evaluated in the epilogue
-  };
-  struct Job {
-    uint32_t prime;
-    const u64 *r, *t, *a, *prod;
-    u64 *dst;
-    u64 halfP, halfL;
-    ulonglong2 pinv, linv;
-    bool lazy;
-    MulSrc mul;
-    uint32_t K;
-    size_t off;
-  };
-  static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
-  static constexpr int loop_axis = 2; // jobs that share a prime lie along grid.z (ntt_loop_kernel)
-  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i, uint32_t K,
-                                               Job &j) {
-    j.prime = i;
-    j.r = p.r + K * p.r_ps;
-    j.t = p.t + K * p.t_ps;
-    if constexpr (MUL) j.mul = mul_src(p.mul, cx.N, K >> 1);
-    j.K = K & 1u;
-    j.off = (size_t)i * cx.N;
-    j.a = AM != RR_MEM ? nullptr : (p.a ? p.a + K * p.a_ps : p.a_tab.p[K]) + (size_t)i * cx.N;
-    j.prod = p.prod + K * p.prod_ps + (size_t)i * cx.N;
-    j.dst = p.dst + K * p.dst_ps + (size_t)i * cx.N;
-    j.halfP = cx.halfmod[p.sp * cx.k + i];
-    j.halfL = cx.halfmod[p.last * cx.k + i];
-    j.pinv = cx.invq[p.sp * cx.k + i];
-    j.linv = cx.invq[p.last * cx.k + i];
-    // lazy input: lazy5(r + q_i - halfP) + t + q_i - halfL < 5q_i + q_last + q_i <= 10 q_i
-    j.lazy = cx.primes[p.last].q <= cx.primes[i].q4 && cx.primes[p.sp].q <= cx.primes[i].q8;
-    return true;
-  }
-  template <bool LZ>
-  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
-    if (LZ)
-      return mul_tw_lazy5(j.r[n] + (pm.q - j.halfP), j.pinv.x, j.pinv.y, pm.nq) + (j.t[n] + (pm.q - j.halfL));
-    const u64 u = submod(barrett64(j.r[n], pm.q, pm.brt), j.halfP, pm.q);
-    const u64 v = submod(barrett64(j.t[n], pm.q, pm.brt), j.halfL, pm.q);
-    return addmod(mul_shoup(u, j.pinv.x, j.pinv.y, pm.q), v, pm.q);
-  }
-  static __device__ __forceinline__ void store_fwd(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n, u64 W) {
-    W += (W >= pm.q8 ? pm.nq8 : 0);                                                  // [0,16q) -> [0,8q)
-    u64 av = 0;
-    if constexpr (AM != RR_FOLDED) av = MUL ? product_poly(j.mul, j.K, j.off + n, pm) : j.a[n];
-    const u64 x = av + mul_tw_lazy5(j.prod[n], j.pinv.x, j.pinv.y, pm.nq) + pm.q8 - W; // < 14q < 2^64
-    j.dst[n] = mul_shoup(x, j.linv.x, j.linv.y, pm.q);                               // exact for any 64-bit operand
-  }
-  // (no Pre here: requesting prod ahead of the tile measured 2 % slower on this pass — 372 against 364 us per
-  // 32-triple launch — its on-the-fly products already keep four loads per word in flight)
-  // ntt_loop_kernel (one wave walks the jobs: the epilogue's loads would be waited for once per job): prod, and a when
-  // it comes from memory, requested before the job's transform
-  struct LoopPre { u64 prod, a; };
-  static __device__ __forceinline__ LoopPre loop_prefetch(const DevCtx &, const Job &j, const DevPrime &, uint32_t n) {
-    return LoopPre{j.prod[n], AM == RR_MEM ? j.a[n] : 0};
-  }
-  static __device__ __forceinline__ void store_fwd_loop(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n, u64 W, const LoopPre &p) {
-    if constexpr (AM == RR_MUL) {
-      store_fwd(cx, j, pm, n, W);
-    } else {
-      W += (W >= pm.q8 ? pm.nq8 : 0);
-      const u64 x = p.a + mul_tw_lazy5(p.prod, j.pinv.x, j.pinv.y, pm.nq) + pm.q8 - W;
-      j.dst[n] = mul_shoup(x, j.linv.x, j.linv.y, pm.q);
-    }
-  }
-};
-
-using OpRRLast = OpRRLastT<RR_MEM>;
-using OpRRLastMul = OpRRLastT<RR_MUL>;
-using OpRRLastFolded = OpRRLastT<RR_FOLDED>;
-using OpRR = OpRRT<RR_MEM>;
-using OpRRMul = OpRRT<RR_MUL>;
-using OpRRFolded = OpRRT<RR_FOLDED>;
-
 } // namespace evah
+
+// the rest of what used to be this one file (r5: split by subject, same text, same order of definitions)
+#include "ntt_window_sum.hip.h" // moddown_sum_kernel: the mod-down's second pass with a convolution window's sums as its epilogue
+#include "ntt_ks_inner.hip.h"   // ks_inner_kernel: second pass of the digit transforms fused with the key inner product; operand tables
+#include "ntt_ops.hip.h"        // the fused load / store ops of the passes (OpPlainT, OpMulIntt, OpKsDigit, OpModDownT, OpRR*)
