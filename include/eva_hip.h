@@ -292,7 +292,11 @@ int evah_decrypt_decode(evah_ctx *ctx, const evah_ct *ct, uint32_t n_out, double
  * a Mul read only by such a Relinearize joins them (evah_multiply_relinearize_rescale_many),
  * multiply_plain / add chains without other readers become one evah_weighted_sum, and a Rotate whose
  * readers are all such products (the taps of a convolution window) is not evaluated on its own: the
- * sums that end at one level and share their rotations go out as one evah_rotate_weighted_sums. */
+ * sums that end at one level and share their rotations go out as one evah_rotate_weighted_sums.
+ * r5: what is left of the elementwise ops (Negate / Add / Sub / Mul on intermediates: freeable, read by somebody,
+ * every check of their entry point passing) is recorded, not run; when a rescale, key switch, rotation or output needs
+ * one of them, every unevaluated op below it goes out as one evah_elementwise_program per (level, batch size), storing
+ * only what an op outside the program reads (EVAH_EW_FUSE=0: one launch per op). */
 enum { EVAH_VAL_NONE = 0, EVAH_VAL_CT = 1, EVAH_VAL_PT = 2 };
 enum { EVAH_OPF_FREE_SRC0 = 1, EVAH_OPF_FREE_SRC1 = 2 };
 typedef struct evah_val { uint32_t kind; void *h; } evah_val;
