@@ -283,3 +283,27 @@ def test_the_scheduler_fuses_elementwise_runs_and_changes_no_bit(which):
     assert launches[1] < launches[0], launches
     if which == "harris":
         assert launches[0] - launches[1] >= 5, launches  # the seven calls of the response are one launch
+
+
+@pytest.mark.parametrize("live", [2, 6], ids=["wide_256_threads", "narrow_128_threads"])
+def test_throughput_sized_launches_two_coefficients_per_thread(live):
+    """>= 2^21 coefficients per launch: the interpreter runs two coefficients per thread — 256-thread workgroups while the
+    program needs at most 14 polynomial registers, 128-thread workgroups above (`live` products of 3 polynomials each alive
+    at once: 6 and 18 registers)."""
+    e = env((32768, [60, 60, 60]))
+    B = 32  # 32768 x 2 limbs x 32 instances = 2^21 coefficients
+    xs = [[e.ct(2) for _ in range(B)] for _ in range(live + 1)]
+    H = [e.g.upload_ct_batch(np.stack(x), 2.0 ** 20) for x in xs]
+    n_in = len(H)
+    ops = [(MUL, i, i + 1) for i in range(live)]          # values n_in .. n_in + live - 1, all alive until the sums below
+    acc = n_in
+    for j in range(1, live):
+        ops.append((ADD, acc, n_in + j))
+        acc = n_in + len(ops) - 1
+    ops.append((NEG, acc, acc))
+    out_v = n_in + len(ops) - 1
+    got = e.g.elementwise_program(H, ops, [out_v, n_in])
+    d_out, d_first = got[0].download(), got[1].download()
+    for b in (0, 13, B - 1):
+        ref = oracle_run(e, [("ct", xs[i][b], 2.0 ** 20) for i in range(n_in)], ops)
+        assert np.array_equal(d_out[b], ref[out_v][1]) and np.array_equal(d_first[b], ref[n_in][1]), b
