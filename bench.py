@@ -390,11 +390,11 @@ def _dag_batch_run(state, batch, reps, dist, members):
             "dags_per_s": round(batch / med, 1), "ms_total": round(med * 1e3, 2), "best_dags_per_s": round(batch / min(ts), 1),
             "ms_calls": [round(t * 1e3, 2) for t in ts],
             "timing": f"median of {reps} calls" + (", barrier + max over ranks per call" if world > 1 else ""),
-            "instances_per_device_handle": 32, "instances_per_rank": len(mine), "ranks": world,
+            "instances_per_device_handle": int(pub.batch_chunk), "instances_per_rank": len(mine), "ranks": world,
             "members_per_rank": members, "shard_mode": "dag" if members > 1 else "",
             "partition": "instance b on rank b mod world (SURVEY.md 8(e) row 1), no data-path collective" if world > 1 else "one rank",
             "roofline": rl(nbytes * batch / world, med), "roofline_basis": "algorithmic bytes of this rank's DAGs over the time, per GPU",
-            "includes": "input uploads, one DAG walk per 32 instances, output downloads",
+            "includes": f"input uploads, one DAG walk per {int(pub.batch_chunk)} instances, output downloads",
             "instances_checked_per_rank": len({1 % len(mine), max(0, len(mine) - 3)}), "bit_exact_vs_oracle": bad == 0.0}
 
 

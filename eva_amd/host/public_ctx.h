@@ -241,7 +241,11 @@ public:
   // valuation, bit for bit.  The reference has no counterpart: it loops SEALPublic::execute.
   // the encrypted part of a program as one evah_execute (EVA_LIBRARY_SCHEDULER=0: the host-side walks)
   bool library_scheduler = std::getenv("EVA_LIBRARY_SCHEDULER") ? std::atoi(std::getenv("EVA_LIBRARY_SCHEDULER")) != 0 : true;
-  uint32_t batch_chunk = 32;
+  // r5: 24 (EVA_BATCH_CHUNK).  Once a program's constants stayed resident, config 4 (256 Sobel DAGs, N = 2^14) measured
+  // 15.3 ms per call with groups of 32, 14.0 with 24, 14.6 with 16, 14.7 with 12, 17–20 with 8, 16.2 with 48, 18.3 with
+  // 64 (profiles/r05_tuning_notes.md section 9): smaller groups shorten the pipeline's fill and drain (the first group's
+  // uploads and the last group's downloads overlap nothing), larger ones launch wider kernels
+  uint32_t batch_chunk = std::getenv("EVA_BATCH_CHUNK") ? (uint32_t)std::atoi(std::getenv("EVA_BATCH_CHUNK")) : 24;
   // groups in flight in execute_batch: group g is enqueued on queue g mod batch_depth, so the copies of one group
   // overlap the kernels of the others; device memory = batch_depth groups' working sets
   uint32_t batch_depth = std::getenv("EVA_BATCH_DEPTH") ? (uint32_t)std::atoi(std::getenv("EVA_BATCH_DEPTH")) : 4;
