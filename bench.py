@@ -270,6 +270,16 @@ def dag_leg(reps, cpu_threads):
         pub.synchronize()
         ts.append(time.perf_counter() - t0)
     res_ms = _median(ts) * 1e3
+    # the same replays back to back (no wait in between): the GPU's own time per replay, and the host's per call
+    hs = []
+    t0 = time.perf_counter()
+    for _ in range(4 * reps):
+        h0 = time.perf_counter()
+        out = pub.execute(compiled, enc)
+        hs.append(time.perf_counter() - h0)
+    pub.synchronize()
+    b2b_ms = (time.perf_counter() - t0) / (4 * reps) * 1e3
+    host_us = _median(hs) * 1e6
     # host valuations: upload + replay + download, as the reference's execute() hands values over
     enc.to_host(True)
     pub.resident = False
@@ -293,6 +303,9 @@ def dag_leg(reps, cpu_threads):
             "relinearize": kinds.count("Relinearize"), "rescale": kinds.count("Rescale"),
             "gpu_execute_ms": round(gpu_ms, 3), "gpu_includes": "input upload, hipGraph replay, output download (host valuations)",
             "gpu_execute_resident_ms": round(res_ms, 3),
+            "resident_back_to_back_ms": round(b2b_ms, 3), "execute_returns_after_us": round(host_us, 1),
+            "resident_note": "gpu_execute_resident_ms = execute() + synchronize() per call (latency); back to back = the GPU's time per "
+                             "replay with the queue kept full; execute() itself returns to the host after execute_returns_after_us",
             "roofline": rl(nbytes, gpu_ms * 1e-3), "roofline_resident": rl(nbytes, res_ms * 1e-3),
             "cpu_walk_ms": dict({"1": round(t1 * 1e3, 1), str(cpu_threads): round(tn * 1e3, 1)},
                                 **({"64": round(t64 * 1e3, 1)} if t64 else {})),
