@@ -169,6 +169,11 @@ bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t targ
     // are still in L2 / Infinity Cache when the fused second pass consumes them.
     const int a = (c->logN + 1) / 2, b = c->logN / 2;
     const uint32_t groups = std::min<uint32_t>(std::max(1, c->tun.ks_groups), l + 1);
+    // r5: the digit transforms may be throughput-sized while the mod-down that follows is still a small launch
+    // (relinearize_many of Harris' three products: 3456 digit tiles, 768 mod-down tiles): the special rows' first inverse
+    // pass then rides the key-switch kernel here as well (one launch of ~6 us less)
+    const uint32_t max_tile = (uint32_t)c->tun.ks_threads << 2;
+    if (r_small && groups == 1 && c->tun.fuse_special_inv && (std::min<uint32_t>(c->N, max_tile) >> 2) <= 64) kb.r_out = r_small;
     for (uint32_t g = 0; g < groups; g++) {
       const uint32_t i0 = (uint32_t)((uint64_t)(l + 1) * g / groups), i1 = (uint32_t)((uint64_t)(l + 1) * (g + 1) / groups);
       if (i1 == i0) continue;
@@ -179,6 +184,7 @@ bool switch_key_products(evah_ctx *c, uint32_t l, const u64 *target, size_t targ
       // 2b. second (contiguous) pass fused with the inner product with the key
       launch_ks_inner(c, b, target, sc.d, kb, prod_d, l);
     }
+    return kb.r_out != nullptr;
   } else {
     // unfused reference path (EVAH_FUSE_MAC=0): full digit NTTs, then a separate MAC kernel
     ntt_forward<OpKsDigit>(c, dp, n * (l + 1) * l);
@@ -563,13 +569,14 @@ int evah_relinearize_many(evah_ctx *c, const evah_ct *const *cts, uint32_t n, ev
     Scratch prod(c, (size_t)n * 2 * pps);
     std::vector<const KeyDev *> keys(n, &c->sh->relin);
     const bool fold = c->tun.fold_pa && c->tun.fuse_mac;
-    switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2, nullptr, nullptr, fold, fold ? &c01 : nullptr);
     Scratch r(c, (size_t)n * 2 * N);
+    const bool inv1 = switch_key_products(c, l, nullptr, 0, keys.data(), n, prod.d, &c2, nullptr, fuse_small_launch(c, 2 * n * l) ? r.d : nullptr,
+                                          fold, fold ? &c01 : nullptr);
     OpPlain::Params sp{prod.d + (size_t)l * N, r.d, pps, N, 1, c->k - 1, 1, {}};
-        OpModDown::Params mp{r.d, N, prod.d, pps, nullptr, 0, 0, ob->d, ops, c->k - 1, l};
+    OpModDown::Params mp{r.d, N, prod.d, pps, nullptr, 0, 0, ob->d, ops, c->k - 1, l};
     mp.use_add_tab = !fold; // folded: P c_K is in prod already
     mp.add_tab = c01;
-    inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * n, mp, 2 * n * l);
+    inverse_then_forward<OpPlain, OpModDown>(c, sp, 2 * n, mp, 2 * n * l, inv1);
   } catch (...) {
     buf_unref(c, ob);
     throw;
