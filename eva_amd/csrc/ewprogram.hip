@@ -346,7 +346,7 @@ int evah_elementwise_program(evah_ctx *c, const evah_val *in, uint32_t n_in, con
       // throughput-sized launches: two coefficients per thread, 256 threads when the registers fit (else 128); small ones
       // (bound by the latency of one wave's instruction stream): one coefficient per thread, 256 threads
       const uint64_t coeffs = (uint64_t)N * limbs * batch;
-      if (coeffs >= ((uint64_t)1 << 21) && N >= 512) {
+      if (coeffs >= ((uint64_t)1 << 20) && N >= 512) { // (a 24-instance group of config 4 is 1.97 M coefficients)
         const uint32_t threads = n_regs <= EW_REGS_WIDE ? 256u : 128u;
         const size_t lds = (size_t)std::max(n_regs, 1) * threads * sizeof(ulonglong2);
         EW_LAUNCH(k_ew_program<2>, dim3((unsigned)(N / (2 * threads)), limbs, batch), dim3(threads), lds, c->stream, c->dev, pg);

@@ -287,7 +287,7 @@ def test_the_scheduler_fuses_elementwise_runs_and_changes_no_bit(which):
 
 @pytest.mark.parametrize("live", [2, 6], ids=["wide_256_threads", "narrow_128_threads"])
 def test_throughput_sized_launches_two_coefficients_per_thread(live):
-    """>= 2^21 coefficients per launch: the interpreter runs two coefficients per thread — 256-thread workgroups while the
+    """>= 2^20 coefficients per launch (here 2^21): the interpreter runs two coefficients per thread — 256-thread workgroups while the
     program needs at most 14 polynomial registers, 128-thread workgroups above (`live` products of 3 polynomials each alive
     at once: 6 and 18 registers)."""
     e = env((32768, [60, 60, 60]))
