@@ -97,11 +97,10 @@ def self_launch(args):
 
 
 def pad_chain(params, n_primes, N):
-    """force N and pad prime_bits with 60-bit primes (after the output prime) up to n_primes."""
-    params.poly_modulus_degree = N
-    pb = list(params.prime_bits)
-    if len(pb) < n_primes:
-        params.prime_bits = pb[:1] + [60] * (n_primes - len(pb)) + pb[1:]
+    """pad the prime chain to the stated L (eva_amd/workloads.py; imported late — torch must load its HIP
+    runtime before the library does)"""
+    from eva_amd.workloads import pad_chain as f
+    return f(params, n_primes, N)
 
 
 def _median(xs):
@@ -249,11 +248,10 @@ def raw_cabi_leg(args, N, l, primes, device, steps, warmup):
 def dag_leg(reps, cpu_threads):
     """BASELINE config 3 / north_star's target: Harris corner detector at N = 2^15, L = 8."""
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
     from eva_amd.roofline import dag_bytes, roofline as rl
-    from test_gpu_e2e import _harris, _image
+    from eva_amd.workloads import harris as _harris, image as _image
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
     pad_chain(params, 9, 32768)
     pub, sec = generate_keys(params, 1)
@@ -292,7 +290,7 @@ def dag_leg(reps, cpu_threads):
         ts.append(time.perf_counter() - t0)
     gpu_ms = _median(ts) * 1e3
     # CPU: the same compiled DAG walked in C over the oracle (checker / reported baseline only)
-    from oracle_executor import c_walk
+    from oracle.executor import c_walk
     ref, t1 = c_walk(pub, compiled, enc, threads=1)
     ok = all(np.array_equal(out_h.get(name)[4], ref[name]) and np.array_equal(out.get(name)[4], ref[name]) for name in ref)
     _, tn = c_walk(pub, compiled, enc, threads=cpu_threads)
@@ -323,11 +321,10 @@ def dag_batch_leg(batch, reps, dist=None, members=1):
     data-path collective), every rank checks one of its own instances, `dags_per_s` = batch / max-over-ranks
     time.  members > 1 (one process): shard_mode = "dag" over `members` contexts of this rank's GPU."""
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
     from eva_amd.roofline import dag_bytes, roofline as rl
-    from test_compiler import _sobel
+    from eva_amd.workloads import sobel as _sobel
     world = dist.world if dist else 1
     rank = dist.rank if dist else 0
     dev = dist.device_index if dist else 0
@@ -346,11 +343,10 @@ def dag_batch_leg(batch, reps, dist=None, members=1):
 
 def _dag_batch_setup(batch, rank, world, dev, members):
     import numpy as np  # noqa: F401
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
     from eva_amd.roofline import dag_bytes
-    from test_compiler import _sobel
+    from eva_amd.workloads import sobel as _sobel
     prog = _sobel(64, 64, 4096)
     prog.set_input_scales(25)
     prog.set_output_ranges(10)
@@ -393,7 +389,7 @@ def _dag_batch_run(state, batch, reps, dist, members):
         ts.append(dist.max_over_ranks(dt) if dist else dt)
     gc.enable()
     med = _median(ts)
-    from oracle_executor import c_walk
+    from oracle.executor import c_walk
     ok = True
     for i in sorted({1 % len(mine), max(0, len(mine) - 3)}):
         ref, _ = c_walk(pub, compiled, inputs[i], threads=1)
@@ -536,7 +532,6 @@ def subdag_leg(args, dist):
     0..world-1 and the other ranks of a torchrun job only take part in the barriers."""
     import numpy as np
     import torch
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
     from eva_amd.roofline import dag_bytes, roofline as rl
@@ -544,7 +539,7 @@ def subdag_leg(args, dist):
     names = [torch.cuda.get_device_name(i) for i in range(torch.cuda.device_count())]
     line = None
     if dist.rank == 0:
-        from test_gpu_e2e import _harris, _image
+        from eva_amd.workloads import harris as _harris, image as _image
         compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
         pad_chain(params, 9, 32768)
         ndev = torch.cuda.device_count()
@@ -560,7 +555,7 @@ def subdag_leg(args, dist):
             out = pub.execute(compiled, enc)
         pub.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
-        from oracle_executor import c_walk  # checker only
+        from oracle.executor import c_walk  # checker only
         ref, _ = c_walk(pub, compiled, enc, threads=8)
         ok = all(np.array_equal(out.get(n)[4], ref[n]) for n in ref)
         if not ok:

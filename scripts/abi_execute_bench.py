@@ -8,8 +8,8 @@ import numpy as np
 from eva.ckks import CKKSCompiler
 from eva.seal import generate_keys
 from eva_amd import backend as be
-from test_compiler import _sobel
-from test_gpu_e2e import _harris, _image
+from eva_amd.workloads import sobel as _sobel
+from eva_amd.workloads import harris as _harris, image as _image
 from test_gpu_execute_abi import _lower
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20

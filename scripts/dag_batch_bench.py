@@ -18,7 +18,7 @@ from eva_amd.dist import Dist
 d = Dist()
 from eva.ckks import CKKSCompiler
 from eva.seal import generate_keys
-from test_compiler import _sobel
+from eva_amd.workloads import sobel as _sobel
 
 prog = _sobel(64, 64, 4096); prog.set_input_scales(25); prog.set_output_ranges(10)
 compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)

@@ -13,8 +13,8 @@ from eva.ckks import CKKSCompiler
 from eva.seal import generate_keys
 from eva.metric import valuation_mse
 from eva import evaluate
-from test_compiler import _sobel
-from test_gpu_e2e import _harris, _image
+from eva_amd.workloads import sobel as _sobel
+from eva_amd.workloads import harris as _harris, image as _image
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
 no_cpu = "--cpu" not in sys.argv

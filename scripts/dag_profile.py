@@ -4,8 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from eva.ckks import CKKSCompiler
 from eva.seal import generate_keys
-from test_compiler import _sobel
-from test_gpu_e2e import _harris, _image
+from eva_amd.workloads import sobel as _sobel
+from eva_amd.workloads import harris as _harris, image as _image
 which = sys.argv[1] if len(sys.argv) > 1 else "sobel"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 if which == "sobel":

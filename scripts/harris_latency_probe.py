@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: F401
 from eva.ckks import CKKSCompiler
 from eva.seal import generate_keys
-from test_gpu_e2e import _harris, _image
+from eva_amd.workloads import harris as _harris, image as _image
 import bench
 compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
 bench.pad_chain(params, 9, 32768)

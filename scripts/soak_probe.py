@@ -7,7 +7,7 @@ import torch
 import numpy as np
 from eva.ckks import CKKSCompiler
 from eva.seal import generate_keys
-from test_gpu_e2e import _harris, _image
+from eva_amd.workloads import harris as _harris, image as _image
 import bench
 
 

@@ -47,28 +47,7 @@ def test_x1x1x2_scale60():
     compile_and_check(prog, executor=None)
 
 
-def _sobel(h, w, vec):
-    def convolutionXY(image, width, filt):
-        for i in range(3):
-            for j in range(3):
-                rotated = image << (i * width + j)
-                horizontal = rotated * filt[i][j]
-                vertical = rotated * filt[j][i]
-                if i == 0 and j == 0:
-                    Ix, Iy = horizontal, vertical
-                else:
-                    Ix += horizontal
-                    Iy += vertical
-        return Ix, Iy
-    sobel = EvaProgram('sobel', vec_size=vec)
-    with sobel:
-        image = Input('image')
-        f = [[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]]
-        a1, a2, a3 = 2.2137874823876622, -1.0984324107372518, 0.17254603006834726
-        ch, cv = convolutionXY(image, w, f)
-        x = ch ** 2 + cv ** 2
-        Output('image', x * a1 + x ** 2 * a2 + x ** 3 * a3)
-    return sobel
+from eva_amd.workloads import sobel as _sobel  # noqa: E402  (shared with bench.py and scripts/)
 
 
 @pytest.mark.parametrize("rescaler", ['lazy_waterline', 'eager_waterline', 'always'])

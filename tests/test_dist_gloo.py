@@ -15,7 +15,7 @@ WORKER = textwrap.dedent("""
     from eva_amd.dist import Dist, run_sharded
     from eva import evaluate
     from eva.ckks import CKKSCompiler
-    from test_compiler import _sobel
+    from eva_amd.workloads import sobel as _sobel
     d = Dist(backend="gloo")
     assert d.world == 2 and d.backend == "gloo"
     prog = _sobel(8, 8, 64); prog.set_input_scales(25); prog.set_output_ranges(10)
@@ -49,7 +49,7 @@ def test_two_rank_gloo_sharding(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eva import evaluate
     from eva.ckks import CKKSCompiler
-    from test_compiler import _sobel
+    from eva_amd.workloads import sobel as _sobel
     prog = _sobel(8, 8, 64)
     prog.set_input_scales(25)
     prog.set_output_ranges(10)

@@ -14,37 +14,9 @@ from eva.ckks import CKKSCompiler
 from eva.metric import valuation_mse
 from eva.seal import generate_keys
 from evatest import compile_and_check, oracle_execute
-from test_compiler import _sobel
-from test_gpu_e2e import _harris, _image
+from eva_amd.workloads import conv_depth8, harris as _harris, image as _image, pad_chain, sobel as _sobel
 
 pytestmark = pytest.mark.gpu
-
-
-def pad_chain(params, n_primes, N):
-    """force N and pad prime_bits with 60-bit primes (after the output prime) up to
-    n_primes = L + 1; legal because the reference builds its context with sec_level none
-    (/root/reference/eva/seal/seal.cpp:169)."""
-    params.poly_modulus_degree = N
-    pb = list(params.prime_bits)
-    if len(pb) < n_primes:
-        params.prime_bits = pb[:1] + [60] * (n_primes - len(pb)) + pb[1:]
-
-
-def conv_depth8():
-    deep = EvaProgram('conv+depth8', vec_size=4096)
-    with deep:
-        image = Input('image')
-        acc = None
-        for i in range(3):
-            for j in range(3):
-                t = (image << (i * 64 + j)) * (1.0 / 9.0)
-                acc = t if acc is None else acc + t
-        for _ in range(8):
-            acc = acc * acc
-        Output('y', acc)
-    deep.set_input_scales(30)
-    deep.set_output_ranges(20)
-    return deep
 
 
 def test_config5_conv_depth8_n65536_l12_bit_exact():

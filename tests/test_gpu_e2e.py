@@ -10,7 +10,7 @@ import pytest
 from eva import EvaProgram, Input, Output
 from eva.std.numeric import horizontal_sum
 from evatest import compile_and_check
-from test_compiler import _sobel
+from eva_amd.workloads import sobel as _sobel
 
 pytestmark = pytest.mark.gpu
 
@@ -135,8 +135,7 @@ def test_sobel_configs(rescaler, balance):
                       check_bit_exact=(rescaler == 'lazy_waterline' and balance == 'true'))
 
 
-def _image(n):
-    return {'image': [((37 * i) % 256) / 255.0 for i in range(n)]}
+from eva_amd.workloads import harris as _harris, image as _image  # noqa: E402  (shared with bench.py and scripts/)
 
 
 def test_sobel_example_n8192_bit_exact():
@@ -147,45 +146,6 @@ def test_sobel_example_n8192_bit_exact():
     def force(params):  # N forced to 2^13 (legal: seal.cpp:169 uses sec_level none)
         params.poly_modulus_degree = 8192
     compile_and_check(sobel, _image(4096), check_bit_exact=True, params_hook=force)
-
-
-def _harris():
-    h = w = 64
-
-    def convolution(image, width, filt):
-        for i in range(3):
-            for j in range(3):
-                partial = (image << i * width + j) * filt[i][j]
-                convolved = partial if (i == 0 and j == 0) else convolved + partial
-        return convolved
-
-    def convolutionXY(image, width, filt):
-        for i in range(3):
-            for j in range(3):
-                rotated = image << (i * width + j)
-                hz, vt = rotated * filt[i][j], rotated * filt[j][i]
-                if i == 0 and j == 0:
-                    Ix, Iy = hz, vt
-                else:
-                    Ix += hz
-                    Iy += vt
-        return Ix, Iy
-
-    harris = EvaProgram('harris', vec_size=h * w)
-    with harris:
-        image = Input('image')
-        sobel_filter = [[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]]
-        pool = [[1, 1, 1], [1, 1, 1], [1, 1, 1]]
-        c = 0.04
-        Ix, Iy = convolutionXY(image, w, sobel_filter)
-        Ixx, Iyy, Ixy = Ix ** 2, Iy ** 2, Ix * Iy
-        Sxx, Syy, Sxy = convolution(Ixx, w, pool), convolution(Iyy, w, pool), convolution(Ixy, w, pool)
-        det = Sxx * Syy - Sxy * Sxy
-        trace = Sxx + Syy
-        Output('image', det - trace ** 2 * c)
-    harris.set_input_scales(30)
-    harris.set_output_ranges(20)
-    return harris
 
 
 def test_harris_example():

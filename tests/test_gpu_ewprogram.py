@@ -250,8 +250,8 @@ def test_the_scheduler_fuses_elementwise_runs_and_changes_no_bit(which):
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
     from oracle_executor import c_walk
-    from test_compiler import _sobel
-    from test_gpu_e2e import _harris, _image
+    from eva_amd.workloads import sobel as _sobel
+    from eva_amd.workloads import harris as _harris, image as _image
     if which == "harris":
         prog, N = _harris(), 8192
     else:

@@ -9,7 +9,7 @@ from eva import EvaProgram, Input, Output, Op
 from eva.ckks import CKKSCompiler
 from eva.seal import generate_keys
 from eva_amd import backend as be
-from test_compiler import _sobel
+from eva_amd.workloads import sobel as _sobel
 
 pytestmark = pytest.mark.gpu
 
@@ -133,7 +133,7 @@ def test_execute_sobel_n8192():
 def test_execute_harris_level_batching():
     """BASELINE config 3's DAG (three independent convolution chains) through the one-call submit:
     its level scheduler batches them; results still equal the oracle walk."""
-    from test_gpu_e2e import _harris, _image
+    from eva_amd.workloads import harris as _harris, image as _image
     _check(_harris(), _image(4096), N=16384)
 
 

@@ -79,8 +79,8 @@ def test_config5_dag_limb_sharded_over_8_bit_exact():
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
     from oracle_executor import c_walk
-    from test_gpu_configs import conv_depth8, pad_chain
-    from test_gpu_e2e import _image
+    from eva_amd.workloads import conv_depth8, pad_chain
+    from eva_amd.workloads import image as _image
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(conv_depth8())
     pad_chain(params, 13, 65536)
     pub, sec = generate_keys(params, 21)

@@ -18,7 +18,7 @@ from eva.ckks import CKKSCompiler
 from eva.seal import generate_keys
 from eva_amd import backend
 from oracle_executor import c_walk
-from test_gpu_e2e import _harris, _image
+from eva_amd.workloads import harris as _harris, image as _image
 
 pytestmark = pytest.mark.gpu
 
@@ -151,7 +151,7 @@ def test_limb_sharded_context_never_uploads_the_whole_keys():
 
 
 def test_dag_mode_deals_a_batch_over_the_members():
-    from test_compiler import _sobel
+    from eva_amd.workloads import sobel as _sobel
     prog = _sobel(64, 64, 4096)
     prog.set_input_scales(25)
     prog.set_output_ranges(10)
@@ -175,7 +175,7 @@ def test_dag_mode_deals_a_batch_over_the_members():
 def test_groups_in_flight_do_not_change_a_batch(depth):
     """execute_batch rotates its groups over `batch_depth` issue queues (copies of one group against kernels of the
     others): any depth gives the ciphertexts of the one-by-one execute(), which equal the oracle walk"""
-    from test_compiler import _sobel
+    from eva_amd.workloads import sobel as _sobel
     prog = _sobel(64, 64, 4096)
     prog.set_input_scales(25)
     prog.set_output_ranges(10)

@@ -93,7 +93,7 @@ def test_threaded_oracle_walk_equals_serial_walk():
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
     from evatest import oracle_execute
-    from test_compiler import _sobel
+    from eva_amd.workloads import sobel as _sobel
     sob = _sobel(16, 16, 256)
     sob.set_input_scales(25)
     sob.set_output_ranges(10)
@@ -141,7 +141,7 @@ def test_c_dag_walk_equals_python_walk(threads):
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
     from oracle_executor import OracleExecutor, c_walk
-    from test_compiler import _sobel
+    from eva_amd.workloads import sobel as _sobel
     for prog, inputs in ((_sobel(16, 16, 256), {'image': [((37 * i) % 256) / 255.0 for i in range(256)]}),
                          (_constant_chain_program(), {'x': [i / 16.0 for i in range(16)]})):
         if prog.name != 'chain':
