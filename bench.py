@@ -250,12 +250,13 @@ def dag_leg(reps, cpu_threads):
     import numpy as np
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
-    from eva_amd.roofline import dag_bytes, roofline as rl
+    from eva_amd.roofline import dag_bytes, dag_compulsory_bytes, roofline as rl
     from eva_amd.workloads import harris as _harris, image as _image
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
     pad_chain(params, 9, 32768)
     pub, sec = generate_keys(params, 1)
     nbytes, by = dag_bytes(compiled, sig, 32768, 9)
+    comp = dag_compulsory_bytes(compiled, sig, 32768, 9)
     enc = pub.encrypt(_image(4096), sig)
     # resident valuations: enqueue + synchronize per call (the latency of one execute())
     for _ in range(3):
@@ -304,7 +305,7 @@ def dag_leg(reps, cpu_threads):
             "resident_back_to_back_ms": round(b2b_ms, 3), "execute_returns_after_us": round(host_us, 1),
             "resident_note": "gpu_execute_resident_ms = execute() + synchronize() per call (latency); back to back = the GPU's time per "
                              "replay with the queue kept full; execute() itself returns to the host after execute_returns_after_us",
-            "roofline": rl(nbytes, gpu_ms * 1e-3), "roofline_resident": rl(nbytes, res_ms * 1e-3),
+            "roofline": rl(nbytes, gpu_ms * 1e-3, compulsory=comp), "roofline_resident": rl(nbytes, res_ms * 1e-3, compulsory=comp),
             "cpu_walk_ms": dict({"1": round(t1 * 1e3, 1), str(cpu_threads): round(tn * 1e3, 1)},
                                 **({"64": round(t64 * 1e3, 1)} if t64 else {})),
             "cpu_cores": cpu_threads,
@@ -314,17 +315,21 @@ def dag_leg(reps, cpu_threads):
             "bit_exact_vs_oracle": bool(ok)}
 
 
-def dag_batch_leg(batch, reps, dist=None, members=1):
-    """BASELINE config 4: a batch of independent Sobel DAGs at N = 2^14, L = 5 through
-    execute_batch (uploads and downloads included); instances are checked against the C walk of the oracle.
-    dist with world > 1: instance b runs on rank b mod world (one process per GPU, no
-    data-path collective), every rank checks one of its own instances, `dags_per_s` = batch / max-over-ranks
-    time.  members > 1 (one process): shard_mode = "dag" over `members` contexts of this rank's GPU."""
-    import numpy as np
-    from eva.ckks import CKKSCompiler
-    from eva.seal import generate_keys
-    from eva_amd.roofline import dag_bytes, roofline as rl
-    from eva_amd.workloads import sobel as _sobel
+BATCH_WORKLOADS = {
+    # name -> (program builder, N, primes, what the line calls it, default instances per batched handle (None = the context's))
+    "sobel": ("sobel_example", 16384, 6, "independent Sobel DAGs (examples/image_processing.py:39-63), 64x64 images", None),
+    "harris": ("harris", 32768, 9, "independent Harris corner DAGs (examples/image_processing.py:65-100), 64x64 images", 16),
+}
+
+
+def dag_batch_leg(batch, reps, dist=None, members=1, workload="sobel", chunk=None, check=8):
+    """A batch of independent DAGs of one program through execute_batch (uploads and downloads included):
+      workload "sobel"   BASELINE config 4: Sobel at N = 2^14, L = 5
+      workload "harris"  north_star's target as THROUGHPUT: Harris corner detector at N = 2^15, L = 8 (config 3's DAG)
+    `check` instances per rank, spread over the groups and issue queues of the call, are compared word for word with
+    the C walk of the oracle.  dist with world > 1: instance b runs on rank b mod world (one
+    process per GPU, no data-path collective), `dags_per_s` = batch / max-over-ranks time.  members > 1 (one
+    process): shard_mode = "dag" over `members` contexts of this rank's GPU."""
     world = dist.world if dist else 1
     rank = dist.rank if dist else 0
     dev = dist.device_index if dist else 0
@@ -332,26 +337,23 @@ def dag_batch_leg(batch, reps, dist=None, members=1):
         # a rank that fails while the others wait in a barrier would stall the job: set up first, agree, then time
         err = None
         try:
-            state = _dag_batch_setup(batch, rank, world, dev, members)
+            state = _dag_batch_setup(batch, rank, world, dev, members, workload, chunk)
         except Exception as e:  # noqa: BLE001
             err, state = repr(e), None
         if dist.sum_over_ranks(0.0 if err is None else 1.0) > 0:
             return {"error": err or "set-up failed on another rank"}
-        return _dag_batch_run(state, batch, reps, dist, members)
-    return _dag_batch_run(_dag_batch_setup(batch, rank, world, dev, members), batch, reps, dist, members)
+        return _dag_batch_run(state, batch, reps, dist, members, workload, check)
+    return _dag_batch_run(_dag_batch_setup(batch, rank, world, dev, members, workload, chunk), batch, reps, dist, members, workload, check)
 
 
-def _dag_batch_setup(batch, rank, world, dev, members):
-    import numpy as np  # noqa: F401
+def _dag_batch_setup(batch, rank, world, dev, members, workload="sobel", chunk=None):
     from eva.ckks import CKKSCompiler
     from eva.seal import generate_keys
-    from eva_amd.roofline import dag_bytes
-    from eva_amd.workloads import sobel as _sobel
-    prog = _sobel(64, 64, 4096)
-    prog.set_input_scales(25)
-    prog.set_output_ranges(10)
-    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
-    pad_chain(params, 6, 16384)
+    from eva_amd import workloads
+    from eva_amd.roofline import dag_bytes, dag_compulsory_bytes
+    builder, N, n_primes, _, default_chunk = BATCH_WORKLOADS[workload]
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(getattr(workloads, builder)())
+    pad_chain(params, n_primes, N)
     if members > 1:
         pub, sec = generate_keys(params, 1, devices=[dev] * members, shard="dag")
     elif dev:
@@ -359,26 +361,36 @@ def _dag_batch_setup(batch, rank, world, dev, members):
     else:
         pub, sec = generate_keys(params, 1)
     pub.resident = False  # execute_batch assembles batched handles from host words and returns host words
-    nbytes, _ = dag_bytes(compiled, sig, 16384, len(params.prime_bits))
-    encs = [pub.encrypt({'image': [((37 * i + u) % 256) / 255.0 for i in range(4096)]}, sig) for u in range(8)]
+    if chunk or default_chunk:
+        pub.batch_chunk = int(chunk or default_chunk)
+    nbytes, _ = dag_bytes(compiled, sig, N, len(params.prime_bits))
+    comp = dag_compulsory_bytes(compiled, sig, N, len(params.prime_bits), instances=int(pub.batch_chunk))
+    encs = [pub.encrypt(workloads.image(4096, shift=u), sig) for u in range(8)]
     mine = list(range(rank, batch, world))  # instance b -> rank b mod world
     inputs = [encs[b % len(encs)] for b in mine]
     for _ in range(3):  # warm-up: tables, constants; the pools of the four issue queues reach their steady state in the second call
         pub.execute_batch(compiled, inputs)
-    return pub, sec, compiled, params, nbytes, inputs, mine
+    return pub, sec, compiled, params, (nbytes, comp), inputs, mine
 
 
-def _dag_batch_run(state, batch, reps, dist, members):
+def _spread(n, want):
+    """`want` instance indices out of n: both ends and evenly in between, offset so they fall in different groups / queues"""
+    if n <= want:
+        return list(range(n))
+    return sorted({0, n - 1} | {min(n - 1, (i * n) // (want - 1) + (i % 3)) for i in range(1, want - 1)})
+
+
+def _dag_batch_run(state, batch, reps, dist, members, workload="sobel", check=8):
     import numpy as np
     from eva_amd.roofline import roofline as rl
-    pub, sec, compiled, params, nbytes, inputs, mine = state
+    pub, sec, compiled, params, (nbytes, comp), inputs, mine = state
     world = dist.world if dist else 1
     ts, outs = [], None
     import gc
     gc.collect()
     gc.disable()  # (as timeit does: a generation-2 collection inside one call of ~17 ms is a visible outlier)
     for _ in range(reps):
-        outs = None  # the previous call's 256 output valuations go back to the pinned pool before the clock starts
+        outs = None  # the previous call's output valuations go back to the pinned pool before the clock starts
         if dist:
             dist.barrier()
         t0 = time.perf_counter()
@@ -389,22 +401,89 @@ def _dag_batch_run(state, batch, reps, dist, members):
         ts.append(dist.max_over_ranks(dt) if dist else dt)
     gc.enable()
     med = _median(ts)
-    from oracle.executor import c_walk
-    ok = True
-    for i in sorted({1 % len(mine), max(0, len(mine) - 3)}):
-        ref, _ = c_walk(pub, compiled, inputs[i], threads=1)
+    from oracle.executor import c_walk  # checker only
+    ok, picked, walked = True, _spread(len(mine), check), {}
+    for i in picked:
+        # (the batch cycles over 8 distinct encrypted images: one walk per distinct input, every picked instance compared)
+        if id(inputs[i]) not in walked:
+            walked[id(inputs[i])] = c_walk(pub, compiled, inputs[i], threads=min(host_cores(), 64))[0]
+        ref = walked[id(inputs[i])]
         ok = ok and all(np.array_equal(outs[i].get(name)[4], ref[name]) for name in ref)
     bad = dist.sum_over_ranks(0.0 if ok else 1.0) if dist else (0.0 if ok else 1.0)
-    return {"workload": f"{batch} independent Sobel DAGs (examples/image_processing.py), 64x64 images, N=2^14, primes={list(params.prime_bits)}",
+    chunk = int(pub.batch_chunk)
+    sets = -(-len(mine) // chunk) + (2 if pub.batch_ramp and chunk >= 4 and len(mine) >= 4 * chunk else 0)  # (batch.h: ramped first / last groups)
+    comp_rank = (comp[0] / chunk * len(mine) - comp[1]["key_bytes_once"] * (len(mine) / chunk - sets), dict(comp[1], launch_sets=sets))
+    return {"workload": f"{batch} {BATCH_WORKLOADS[workload][3]}, N=2^{int(np.log2(params.poly_modulus_degree))}, primes={list(params.prime_bits)}",
             "dags_per_s": round(batch / med, 1), "ms_total": round(med * 1e3, 2), "best_dags_per_s": round(batch / min(ts), 1),
             "ms_calls": [round(t * 1e3, 2) for t in ts],
             "timing": f"median of {reps} calls" + (", barrier + max over ranks per call" if world > 1 else ""),
-            "instances_per_device_handle": int(pub.batch_chunk), "instances_per_rank": len(mine), "ranks": world,
+            "instances_per_device_handle": chunk, "instances_per_rank": len(mine), "ranks": world,
             "members_per_rank": members, "shard_mode": "dag" if members > 1 else "",
             "partition": "instance b on rank b mod world (SURVEY.md 8(e) row 1), no data-path collective" if world > 1 else "one rank",
-            "roofline": rl(nbytes * batch / world, med), "roofline_basis": "algorithmic bytes of this rank's DAGs over the time, per GPU",
-            "includes": f"input uploads, one DAG walk per {int(pub.batch_chunk)} instances, output downloads",
-            "instances_checked_per_rank": len({1 % len(mine), max(0, len(mine) - 3)}), "bit_exact_vs_oracle": bad == 0.0}
+            "roofline": rl(nbytes * batch / world, med, compulsory=comp_rank),
+            "roofline_basis": "algorithmic bytes of this rank's DAGs over the time, per GPU; launch_compulsory: every evaluation key "
+                              f"charged once per group of {chunk} instances and scheduler level",
+            "includes": f"input uploads, one DAG walk per {chunk} instances, output downloads",
+            "instances_checked_per_rank": len(picked), "instances_checked": [int(mine[i]) for i in picked],
+            "bit_exact_vs_oracle": bad == 0.0}
+
+
+def dag_configs_leg(reps):
+    """"also report per-DAG execute() wall time for configs C1-C5".  C3 and C4 have legs of their own
+    (`dag`, `dag_batch`); here C1 (README polynomial), C2 (Sobel, N = 2^13) and C5 (3x3 convolution + 8 squarings,
+    N = 2^16, L = 12): execute() with host valuations (upload + run + download, as the reference hands values over) and
+    with resident valuations (enqueue + synchronize), each against the DAG's algorithmic bytes, outputs compared word
+    for word with the C walk of the oracle."""
+    import numpy as np
+    from eva.seal import generate_keys
+    from eva_amd import workloads
+    from eva_amd.roofline import dag_bytes, dag_compulsory_bytes, roofline as rl
+    from oracle.executor import c_walk  # checker only
+    out = {}
+    for name in ("c1", "c2", "c5"):
+        try:
+            compiled, params, sig, inputs = workloads.compile_config(name)
+            N, k = params.poly_modulus_degree, len(params.prime_bits)
+            pub, sec = generate_keys(params, 1)
+            enc = pub.encrypt(inputs, sig)
+            nbytes, _ = dag_bytes(compiled, sig, N, k)
+            comp = dag_compulsory_bytes(compiled, sig, N, k)
+            for _ in range(3):  # eager walk, hipGraph capture, first replay
+                res = pub.execute(compiled, enc)
+            pub.synchronize()
+            tr = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                res = pub.execute(compiled, enc)
+                pub.synchronize()
+                tr.append(time.perf_counter() - t0)
+            enc.to_host(True)
+            pub.resident = False
+            for _ in range(2):
+                hout = pub.execute(compiled, enc)
+            th = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                hout = pub.execute(compiled, enc)
+                th.append(time.perf_counter() - t0)
+            ref, t1 = c_walk(pub, compiled, enc, threads=1)
+            _, tn = c_walk(pub, compiled, enc, threads=min(host_cores(), 64))
+            ok = all(np.array_equal(hout.get(n)[4], ref[n]) and np.array_equal(res.get(n)[4], ref[n]) for n in ref)
+            kinds = [str(d["op"]).split(".")[-1] for d in compiled._dump()]
+            res_s, host_s = _median(tr), _median(th)
+            out[name] = {"workload": {"c1": "README polynomial 3x^2+5x-2, vec_size 1024", "c2": "Sobel 3x3 filter, 64x64 image",
+                                      "c5": "3x3 convolution + depth-8 squaring chain (tests/large_programs.py style)"}[name]
+                                     + f", N=2^{int(np.log2(N))}, primes={list(params.prime_bits)}",
+                         "terms": len(kinds), "rotations": kinds.count("RotateLeftConst") + kinds.count("RotateRightConst"),
+                         "relinearize": kinds.count("Relinearize"), "rescale": kinds.count("Rescale"),
+                         "host_ms": round(host_s * 1e3, 3), "resident_ms": round(res_s * 1e3, 3),
+                         "roofline": rl(nbytes, host_s, compulsory=comp), "roofline_resident": rl(nbytes, res_s, compulsory=comp),
+                         "cpu_walk_ms": {"1": round(t1 * 1e3, 1), str(min(host_cores(), 64)): round(tn * 1e3, 1)},
+                         "bit_exact_vs_oracle": bool(ok)}
+            res = hout = enc = pub = sec = None
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": repr(e)}
+    return out
 
 
 def dag_sharded(args, dist):
@@ -591,6 +670,9 @@ def main():
     ap.add_argument("--members", type=int, default=1,
                     help="--shard dag: contexts per rank sharing its GPU (shard_mode='dag' inside execute_batch)")
     ap.add_argument("--dag-batch", type=int, default=256, help="--shard dag / the dag_batch leg: independent Sobel DAGs in the batch")
+    ap.add_argument("--harris-batch", type=int, default=64, help="the dag_harris_batch leg: independent Harris DAGs (N=2^15, L=8) in the batch")
+    ap.add_argument("--harris-chunk", type=int, default=0, help="instances per batched device handle of the dag_harris_batch leg (0: the leg's default)")
+    ap.add_argument("--only-leg", default="", help="run only this leg (dag | dag_batch | dag_harris_batch | dag_configs) and print its dict")
     ap.add_argument("--shard", choices=["ciphertexts", "limb", "subdag", "dag"], default="ciphertexts",
                     help="ciphertexts: independent triples per GPU, no collective (default, weak scaling); "
                          "limb: every triple on all GPUs, RNS limbs dealt over them (strong scaling); "
@@ -626,6 +708,12 @@ def main():
         from eva_amd.hostref import coeff_modulus_create
         N, l = 1 << args.logn, args.limbs
         print(json.dumps(raw_cabi_leg(args, N, l, coeff_modulus_create(N, [60] * (l + 1)), dev, args.steps, args.warmup)), flush=True)
+        return dist.close()
+    if args.only_leg:
+        leg = {"dag": lambda: dag_leg(15, host_cores()), "dag_batch": lambda: dag_batch_leg(args.dag_batch, 7),
+               "dag_harris_batch": lambda: dag_batch_leg(args.harris_batch, 5, workload="harris", chunk=args.harris_chunk or None),
+               "dag_configs": lambda: dag_configs_leg(9)}[args.only_leg]()
+        print(json.dumps({args.only_leg: leg}), flush=True)
         return dist.close()
     if args.shard == "limb":
         return limb_sharded(args, dist)
@@ -835,9 +923,19 @@ def main():
             except Exception as e:  # noqa: BLE001
                 legs["dag"] = {"error": repr(e)}
             try:
+                legs["dag_harris_batch"] = dag_batch_leg(args.harris_batch, 5, workload="harris", chunk=args.harris_chunk or None)
+            except Exception as e:  # noqa: BLE001
+                legs["dag_harris_batch"] = {"error": repr(e)}
+            gc.collect()
+            try:
                 legs["dag_batch"] = dag_batch_leg(args.dag_batch, 7)
             except Exception as e:  # noqa: BLE001
                 legs["dag_batch"] = {"error": repr(e)}
+            gc.collect()
+            try:
+                legs["dag_configs"] = dag_configs_leg(9)
+            except Exception as e:  # noqa: BLE001
+                legs["dag_configs"] = {"error": repr(e)}
         if dag_batch_multi is not None:
             legs["dag_batch"] = dag_batch_multi
 

@@ -45,22 +45,17 @@ def op_bytes(kind, N, l, sa=2, sb=2):
     raise ValueError(kind)
 
 
-def dag_bytes(compiled, signature, N, n_primes):
-    """-> (total algorithmic bytes of one execute(), {op kind: (count, bytes)})"""
+def _walk(compiled, signature, N, n_primes):
+    """yields (kind, bytes, key) per ciphertext op of the compiled list; key = None or (level, which, l) naming the
+    evaluation key the op reads and the scheduler level it runs at (depth = longest path from the placed values, as
+    csrc/scheduler.hip buckets its op list): ops of one level that read one key form one launch set"""
     k = n_primes
     shape = {}   # term -> ("ct", size, limbs) | ("pt", limbs) | ("raw",)
-    by = {}
-    total = 0
-
-    def note(kind, b):
-        nonlocal total
-        c, s = by.get(kind, (0, 0))
-        by[kind] = (c + 1, s + b)
-        total += b
-
+    depth = {}
     in_ids = {t.index: name for name, t in compiled.inputs.items()}
     for d in compiled._dump():
         t, op, a = d["id"], d["op"], d["operands"]
+        depth[t] = 0
         if op == Op.Input:
             info = signature.inputs[in_ids[t]]
             kind = str(info.input_type).split(".")[-1]
@@ -78,6 +73,7 @@ def dag_bytes(compiled, signature, N, n_primes):
         if not cts:  # arithmetic on unencrypted values / their outputs: host work, no HBM traffic
             shape[t] = x[0] if op == Op.Output else ("raw",)
             continue
+        depth[t] = 1 + max(depth[i] for i in a)
         if op == Op.Output:
             shape[t] = x[0]
             continue
@@ -86,46 +82,92 @@ def dag_bytes(compiled, signature, N, n_primes):
         if op in (Op.Add, Op.Sub):
             name = "add" if op == Op.Add else "sub"
             if len(cts) == 2:
-                note(name, op_bytes(name, N, l, cts[0][1], cts[1][1]))
+                yield name, op_bytes(name, N, l, cts[0][1], cts[1][1]), None
                 shape[t] = ("ct", max(cts[0][1], cts[1][1]), l)
             else:
-                note(name + "_plain", op_bytes(name + "_plain", N, l, c0[1]))
+                yield name + "_plain", op_bytes(name + "_plain", N, l, c0[1]), None
                 shape[t] = c0
         elif op == Op.Mul:
             if len(cts) == 2:
                 same = a[0] == a[1]
-                note("square" if same else "multiply", op_bytes("square" if same else "multiply", N, l))
+                yield ("square" if same else "multiply"), op_bytes("square" if same else "multiply", N, l), None
                 shape[t] = ("ct", 3, l)
             else:
-                note("multiply_plain", op_bytes("multiply_plain", N, l, c0[1]))
+                yield "multiply_plain", op_bytes("multiply_plain", N, l, c0[1]), None
                 shape[t] = c0
         elif op == Op.Negate:
-            note("negate", op_bytes("negate", N, l, c0[1]))
+            yield "negate", op_bytes("negate", N, l, c0[1]), None
             shape[t] = c0
         elif op in (Op.RotateLeftConst, Op.RotateRightConst):
-            if d.get("rotation", 0):
-                note("rotate", op_bytes("rotate", N, l))
+            r = d.get("rotation", 0)
+            if r:
+                step = (r if op == Op.RotateLeftConst else -r) % (N // 2)
+                yield "rotate", op_bytes("rotate", N, l), (depth[t], ("galois", step), l)
             shape[t] = c0
         elif op == Op.Relinearize:
-            note("relinearize", op_bytes("relinearize", N, l))
+            yield "relinearize", op_bytes("relinearize", N, l), (depth[t], "relin", l)
             shape[t] = ("ct", 2, l)
         elif op == Op.Rescale:
-            note("rescale", op_bytes("rescale", N, l, c0[1]))
+            yield "rescale", op_bytes("rescale", N, l, c0[1]), None
             shape[t] = ("ct", c0[1], l - 1)
         elif op == Op.ModSwitch:
-            note("mod_switch", op_bytes("mod_switch", N, l, c0[1]))
+            yield "mod_switch", op_bytes("mod_switch", N, l, c0[1]), None
             shape[t] = ("ct", c0[1], l - 1)
         else:
             raise ValueError(f"unexpected op {op}")
+
+
+def key_bytes(N, l):
+    """one evaluation key as a key switch at l limbs reads it: l digits x 2 polynomials x (l + 1) primes"""
+    return 2 * l * (l + 1) * N * 8
+
+
+def dag_bytes(compiled, signature, N, n_primes):
+    """-> (total algorithmic bytes of one execute(), {op kind: (count, bytes)})"""
+    by = {}
+    total = 0
+    for kind, b, _ in _walk(compiled, signature, N, n_primes):
+        c, s = by.get(kind, (0, 0))
+        by[kind] = (c + 1, s + b)
+        total += b
     return total, by
 
 
-def roofline(total_bytes, seconds, peak_gbps=8000.0):
-    """the `roofline` object of a bench line for one unit of `total_bytes` done in `seconds`"""
+def dag_compulsory_bytes(compiled, signature, N, n_primes, instances=1):
+    """Bytes `instances` DAGs of ONE launch set must move: SURVEY.md 8(d) charges an evaluation key to every key
+    switch; here each distinct (scheduler level, key, limb count) is charged ONCE — the sibling rotations of a hoisted
+    set, the relinearizations of one level and the instances of a batched handle read one copy of their key.
+    -> (bytes of the whole set, {"keys_charged_8d": n, "keys_distinct": m, "key_bytes_8d": …, "key_bytes_once": …})"""
+    data = 0
+    charged, distinct = 0, {}
+    kb_all = 0
+    for kind, b, key in _walk(compiled, signature, N, n_primes):
+        if key is None:
+            data += b
+            continue
+        kb = key_bytes(N, key[2])
+        data += b - kb
+        kb_all += kb
+        charged += 1
+        distinct[key] = kb
+    once = sum(distinct.values())
+    return instances * data + once, {"keys_charged_8d": charged, "keys_distinct": len(distinct),
+                                     "key_bytes_8d": kb_all, "key_bytes_once": once, "instances": instances}
+
+
+def roofline(total_bytes, seconds, peak_gbps=8000.0, compulsory=None):
+    """the `roofline` object of a bench line for one unit of `total_bytes` done in `seconds`; `compulsory` =
+    (bytes, detail) of dag_compulsory_bytes for the SAME unit adds the fraction with every key charged once per launch set"""
     ach = total_bytes / seconds / 1e9
-    return {"bound": "hbm", "achieved": round(ach, 1), "peak": peak_gbps, "unit": "GB/s",
-            "frac": round(ach / peak_gbps, 4), "bytes_per_unit": int(total_bytes),
-            "basis": "SURVEY.md 8(d) algorithmic bytes summed over the compiled op list (eva_amd/roofline.py) / measured time"}
+    out = {"bound": "hbm", "achieved": round(ach, 1), "peak": peak_gbps, "unit": "GB/s",
+           "frac": round(ach / peak_gbps, 4), "bytes_per_unit": int(total_bytes),
+           "basis": "SURVEY.md 8(d) algorithmic bytes summed over the compiled op list (eva_amd/roofline.py) / measured time"}
+    if compulsory is not None:
+        cb, detail = compulsory
+        out.update({"launch_compulsory_bytes": int(cb), "launch_compulsory_frac": round(cb / seconds / 1e9 / peak_gbps, 4),
+                    "launch_compulsory": dict(detail, note="8(d) charges an evaluation key to every key switch; here each distinct "
+                                                            "(scheduler level, key, limbs) is read once per launch set")})
+    return out
 
 
 def csrc_tree_hash(root=None):

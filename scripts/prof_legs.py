@@ -1,4 +1,4 @@
-"""One bench leg under a profiler: python scripts/prof_legs.py batch|harris|execute [reps]
+"""One bench leg under a profiler: python scripts/prof_legs.py batch|harris|harris_batch|c1|c2|c5|execute [reps]
 (rocprofv3 --kernel-trace --stats -- python scripts/prof_legs.py batch 2)"""
 import json
 import os
@@ -15,5 +15,19 @@ if which == "batch":
     print(json.dumps(bench.dag_batch_leg(256, reps)))
 elif which == "harris":
     print(json.dumps(bench.dag_leg(reps, 8)))
+elif which == "harris_batch":
+    chunk = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    print(json.dumps(bench.dag_batch_leg(64, reps, workload="harris", chunk=chunk, check=2)))
+elif which in ("c1", "c2", "c5"):
+    # resident replays only (what the traces are read for): eager walk, capture, then `reps` replays
+    from eva.seal import generate_keys
+    from eva_amd import workloads
+    compiled, params, sig, inputs = workloads.compile_config(which)
+    pub, sec = generate_keys(params, 1)
+    enc = pub.encrypt(inputs, sig)
+    for _ in range(2 + reps):
+        out = pub.execute(compiled, enc)
+        pub.synchronize()
+    print(json.dumps({"config": which, "replays": reps}))
 else:
     print(json.dumps(bench.execute_leg(1 << 16, 10, 32, reps)))

@@ -31,7 +31,51 @@ def test_config3_harris_n32768_l8_bit_exact():
     assert params.poly_modulus_degree == 32768 and len(params.prime_bits) == 9 and len(params.rotations) == 9
 
 
-def test_config4_256_sobel_n16384_sampled_against_oracle():
+def _c_walk_valuation(pub, compiled, enc, threads=64):
+    from oracle_executor import c_walk
+    return c_walk(pub, compiled, enc, threads=threads)[0]
+
+
+def test_config3_harris_batch_n32768_l8_every_instance_bit_exact():
+    """north_star's target workload as a batch: independent Harris DAGs at N = 2^15, L = 8 through execute_batch
+    (what bench.py's dag_harris_batch leg times) — three groups over three issue queues, a last group that is not full,
+    EVERY instance against the oracle's walk of the same DAG on the same ciphertexts and keys"""
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
+    pad_chain(params, 9, 32768)
+    pub, sec = generate_keys(params, 5)
+    pub.batch_chunk = 4
+    imgs = [_image(4096, shift=11 * u, scale=255.0 if u % 2 else 300.0) for u in range(11)]
+    encs = [pub.encrypt(x, sig) for x in imgs]
+    outs = pub.execute_batch(compiled, encs)
+    assert len(outs) == 11
+    for u in range(11):
+        ref = _c_walk_valuation(pub, compiled, encs[u])
+        for name, words in ref.items():
+            assert np.array_equal(outs[u].get(name)[4], words), f"instance {u}, output {name}: execute_batch differs from the oracle walk"
+    for u in (0, 5, 10):
+        assert valuation_mse(sec.decrypt(outs[u], sig), evaluate(compiled, imgs[u])) < 0.01
+    # the same instances one execute() at a time give the same words (the batched handle changes nothing)
+    single = pub.execute(compiled, encs[6])
+    for name in single.names():
+        assert np.array_equal(single.get(name)[4], outs[6].get(name)[4])
+
+
+def test_config3_harris_batch_default_groups_bit_exact():
+    """the bench leg's own shape: groups of 16 instances (two full groups and a ragged one), sampled across them"""
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
+    pad_chain(params, 9, 32768)
+    pub, sec = generate_keys(params, 6)
+    pub.batch_chunk = 16
+    encs = [pub.encrypt(_image(4096, shift=u), sig) for u in range(4)]
+    inputs = [encs[b % 4] for b in range(37)]
+    outs = pub.execute_batch(compiled, inputs)
+    refs = [_c_walk_valuation(pub, compiled, e) for e in encs]
+    for u in range(37):
+        for name, words in refs[u % 4].items():
+            assert np.array_equal(outs[u].get(name)[4], words), f"instance {u}, output {name}"
+
+
+def test_config4_256_sobel_n16384_every_instance_against_oracle():
     sob = _sobel(64, 64, 4096)
     sob.set_input_scales(25)
     sob.set_output_ranges(10)
@@ -45,10 +89,14 @@ def test_config4_256_sobel_n16384_sampled_against_oracle():
     encs = [pub.encrypt(x, sig) for x in imgs]
     outs = pub.execute_batch(compiled, encs)
     assert len(outs) == 256
-    for u in (0, 1, 31, 32, 63, 64, 127, 200, 255):  # across batched handles and both issue queues
-        ref = oracle_execute(pub, compiled, encs[u])
-        for name in ref.names():
+    for u in range(256):  # every instance (r6; the C walk of the oracle on the host's cores does one in ~30 ms)
+        ref = _c_walk_valuation(pub, compiled, encs[u])
+        for name, words in ref.items():
+            assert np.array_equal(outs[u].get(name)[4], words), f"instance {u}, output {name}: execute_batch differs from the oracle walk"
+    for u in (0, 1, 31, 32, 63, 64, 127, 200, 255):  # shapes, scales and the decrypted values of a sample
+        ref = oracle_execute(pub, compiled, encs[u]) if u in (0, 255) else None
+        for name in (ref.names() if ref else ()):
             g, o = outs[u].get(name), ref.get(name)
             assert g[:4] == o[:4]
-            assert np.array_equal(g[4], o[4]), f"instance {u}, output {name}: execute_batch differs from the oracle walk"
+            assert np.array_equal(g[4], o[4])
         assert valuation_mse(sec.decrypt(outs[u], sig), evaluate(compiled, imgs[u])) < 0.01
