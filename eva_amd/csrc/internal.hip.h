@@ -284,6 +284,11 @@ struct Tunables {
   // EVAH_LOOP_MIN_WGS (2048): below this many workgroups (at two jobs per walk) the launch keeps ntt_pass_kernel
   // EVAH_LOOP_TARGET_WGS: the walk is shortened (down to 2 jobs) until the launch has this many one-wave workgroups
   uint32_t loop_n = 8, loop_min = 2, loop_min_wgs = 2048, loop_target_wgs = 8192;
+  // EVAH_HOIST_MAP (1): k_hoist_mac's workgroups in the order (xcd | tile | x_hi | I) — the tiles of one coefficient range
+  // run back to back on one XCD, so operand rows shared between tiles are read from HBM once; 0 = the r4 grid (x, I, tile)
+  // EVAH_HOIST_V (1): coefficients per thread of k_hoist_mac for tile shapes with <= 4 accumulator pairs (2 = 16-byte accesses)
+  bool hoist_map = true;
+  uint32_t hoist_v = 1;
   // EVAH_LDS_EXTRA (0): bytes of dynamic LDS added to every ntt_pass_kernel launch — an occupancy probe for the
   // tuning notes (fewer workgroups per CU), never set in production
   uint32_t lds_extra = 0;
@@ -315,6 +320,8 @@ struct Tunables {
     count("EVAH_LOOP_MIN_WGS", t.loop_min_wgs);
     count("EVAH_LOOP_TARGET_WGS", t.loop_target_wgs);
     count("EVAH_LDS_EXTRA", t.lds_extra);
+    flag("EVAH_HOIST_MAP", t.hoist_map);
+    count("EVAH_HOIST_V", t.hoist_v);
     if (const char *e = std::getenv("EVAH_KS_GROUPS")) t.ks_groups = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {
       const int n = std::atoi(e);

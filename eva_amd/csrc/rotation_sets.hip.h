@@ -108,13 +108,44 @@ k_key_perm(const u64 *key, const uint32_t *pinv, u64 *out, uint32_t N) {
   const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   out[(size_t)blockIdx.y * N + m] = key[(size_t)blockIdx.y * N + pinv[m]];
 }
-template <int TS, int TR>
+// r6 — which workgroups run together.  Tiles of a launch share operands: tiles with the same sources read the same digit
+// rows, tiles with the same elements the same key rows (8 instances x 8 rotations as 4 x 2 tiles: every key row is read by
+// 2 tiles, every digit row by 4).  With grid = (N/256, l+1, tiles) the workgroups that share a row are (N/256)(l+1)
+// dispatches apart — further than the L2s and the Infinity Cache reach at N = 2^15, l = 8 — so a 64-pair launch moved
+// 1.5 GB where 0.75 GB are distinct.  MAP = 1: a 1-D grid whose linear id is cut as (xcd | tile | x_hi | I): the dispatcher
+// places block b on XCD b mod 8 (MI355X_MICROARCH.md, workgroup dispatch), so the eight blocks of one round have eight
+// different coefficient ranges, and an XCD sees ALL tiles of its (x, I) back to back — the second reader of a row finds it
+// in that XCD's L2.  Placement only decides speed; the result does not depend on it.
+// V = coefficients per thread (2: 16-byte accesses, for the shapes with few accumulators).
+template <int V> struct HmVec { u64 v[V]; };
+template <int V> __device__ __forceinline__ HmVec<V> hm_ld(const u64 *p) {
+  HmVec<V> o;
+  if constexpr (V == 2) { const ulonglong2 t = ld2(p); o.v[0] = t.x; o.v[1] = t.y; }
+  else o.v[0] = p[0];
+  return o;
+}
+template <int V> __device__ __forceinline__ void hm_st(u64 *p, const HmVec<V> &x) {
+  if constexpr (V == 2) { ulonglong2 t; t.x = x.v[0]; t.y = x.v[1]; st2(p, t); }
+  else p[0] = x.v[0];
+}
+template <int TS, int TR, int V, bool MAP>
 __global__ void __launch_bounds__(256)
-k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistMacTab tab, uint32_t tile0, u64 *prod, size_t prod_bs, uint32_t l, bool fold_c0) {
-  const uint32_t I = blockIdx.y, kap = (I == l) ? cx.k - 1 : I;
-  const uint32_t *tw = tab.tile[tile0 + blockIdx.z]; // wave-uniform: scalar loads, the bytes are cut out with scalar shifts
+k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistMacTab tab, uint32_t n_tiles, u64 *prod, size_t prod_bs, uint32_t l, bool fold_c0) {
+  uint32_t xt, I, zt;
+  if constexpr (MAP) { // (host: N / (256 V) is a multiple of 8)
+    const uint32_t xh_log = cx.logN - (V == 2 ? 9 : 8) - 3;
+    uint32_t r = blockIdx.x >> 3;
+    zt = r % n_tiles;
+    r /= n_tiles;
+    xt = ((r & ((1u << xh_log) - 1u)) << 3) | (blockIdx.x & 7u);
+    I = r >> xh_log;
+  } else {
+    xt = blockIdx.x, I = blockIdx.y, zt = blockIdx.z;
+  }
+  const uint32_t kap = (I == l) ? cx.k - 1 : I;
+  const uint32_t *tw = tab.tile[zt]; // wave-uniform: scalar loads, the bytes are cut out with scalar shifts
   const u64 srcs = tw[0] | ((u64)tw[1] << 32), rots = tw[2] | ((u64)tw[3] << 32), outs = tw[4] | ((u64)tw[5] << 32);
-  const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t m = (size_t)V * ((size_t)xt * blockDim.x + threadIdx.x);
   const DevPrime pm = cx.primes[kap];
   const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
   const u64 *dgp[TS], *own[TS], *kp[TR];
@@ -126,52 +157,64 @@ k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistMacTab tab, uint32_
   }
 #pragma unroll
   for (int r = 0; r < TR; r++) kp[r] = tab.keyp[(uint32_t)(rots >> (8 * r)) & 0xffu] + (size_t)kap * N + m;
-  u128_t a0[TS][TR], a1[TS][TR];
+  u128_t a0[TS][TR][V], a1[TS][TR][V];
 #pragma unroll
   for (int s = 0; s < TS; s++)
 #pragma unroll
-    for (int r = 0; r < TR; r++) a0[s][r] = a1[s][r] = {0, 0};
+    for (int r = 0; r < TR; r++)
+#pragma unroll
+      for (int v = 0; v < V; v++) a0[s][r][v] = a1[s][r][v] = {0, 0};
   // operands are canonical (< q < 2^60): 256 products fit the 128-bit accumulators, l <= k - 1 < 64
 #pragma unroll 2
   for (uint32_t J = 0; J < l; J++) {
-    u64 d[TS], k0[TR], k1[TR];
+    HmVec<V> d[TS], k0[TR], k1[TR];
 #pragma unroll
-    for (int s = 0; s < TS; s++) d[s] = (I == J) ? own[s][(size_t)J * N] : dgp[s][(size_t)J * N];
+    for (int s = 0; s < TS; s++) d[s] = hm_ld<V>((I == J) ? own[s] + (size_t)J * N : dgp[s] + (size_t)J * N);
 #pragma unroll
     for (int r = 0; r < TR; r++) {
-      k0[r] = kp[r][J * key_digit];
-      k1[r] = kp[r][J * key_digit + (size_t)cx.k * N];
+      k0[r] = hm_ld<V>(kp[r] + J * key_digit);
+      k1[r] = hm_ld<V>(kp[r] + J * key_digit + (size_t)cx.k * N);
     }
     __builtin_amdgcn_sched_barrier(0); // all the loads of the step are issued before the first multiply waits for one
 #pragma unroll
     for (int r = 0; r < TR; r++)
 #pragma unroll
-      for (int s = 0; s < TS; s++) {
-        acc128(a0[s][r], d[s], k0[r]);
-        acc128(a1[s][r], d[s], k1[r]);
-      }
+      for (int s = 0; s < TS; s++)
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+          acc128(a0[s][r][v], d[s].v[v], k0[r].v[v]);
+          acc128(a1[s][r][v], d[s].v[v], k1[r].v[v]);
+        }
   }
   if (fold_c0 && I < l) { // block-uniform
     const u64 pmod = cx.modq[(size_t)(cx.k - 1) * cx.k + kap].x; // P mod q_I
 #pragma unroll
     for (int s = 0; s < TS; s++) {
       const uint32_t si = (uint32_t)(srcs >> (8 * s)) & 0xffu;
-      const u64 c0v = (own[s] - (size_t)tab.c1_ps[si] * N)[(size_t)I * N];
+      const HmVec<V> c0v = hm_ld<V>((own[s] - (size_t)tab.c1_ps[si] * N) + (size_t)I * N);
 #pragma unroll
-      for (int r = 0; r < TR; r++) acc128(a0[s][r], c0v, pmod);
+      for (int r = 0; r < TR; r++)
+#pragma unroll
+        for (int v = 0; v < V; v++) acc128(a0[s][r][v], c0v.v[v], pmod);
     }
   }
 #pragma unroll
   for (int r = 0; r < TR; r++) {
     const u64 *cr = tab.corrp[(uint32_t)(rots >> (8 * r)) & 0xffu] + (size_t)I * N + m;
-    const u64 c0 = cr[0], c1c = cr[(size_t)(l + 1) * N];
+    const HmVec<V> c0 = hm_ld<V>(cr), c1c = hm_ld<V>(cr + (size_t)(l + 1) * N);
 #pragma unroll
     for (int s = 0; s < TS; s++) {
       const uint32_t z = (uint32_t)(outs >> (8 * (s * TR + r))) & 0xffu;
       if (z == 0xffu) continue; // padding, or a (source, element) combination that is not a pair of the chunk
       u64 *pr = prod + z * prod_bs + (size_t)I * N + m;
-      pr[0] = addmod(barrett128(a0[s][r], pm), c0, pm.q);
-      pr[(size_t)(l + 1) * N] = addmod(barrett128(a1[s][r], pm), c1c, pm.q);
+      HmVec<V> o0, o1;
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        o0.v[v] = addmod(barrett128(a0[s][r][v], pm), c0.v[v], pm.q);
+        o1.v[v] = addmod(barrett128(a1[s][r][v], pm), c1c.v[v], pm.q);
+      }
+      hm_st<V>(pr, o0);
+      hm_st<V>(pr + (size_t)(l + 1) * N, o1);
     }
   }
 }
@@ -528,13 +571,23 @@ static void hoist_mac_launch(evah_ctx *c, HoistMacTab &mt, const HoistTiles &ht,
     const uint32_t n = std::min<uint32_t>(HT_TILES, ht.n_tiles - t0);
     for (uint32_t t = 0; t < n; t++)
       for (int i = 0; i < 6; i++) mt.tile[t][i] = ht.tiles[t0 + t][i];
-#define HM(S_, R_)                                                                                                                     \
-  if (ht.TS == S_ && ht.TR == R_) {                                                                                                    \
-    hipLaunchKernelGGL((k_hoist_mac<S_, R_>), dim3(c->N / 256, l + 1, n), dim3(256), 0, c->stream, c->dev, dg, dg_bs, mt, 0u, prod, prod_bs, l, fold); \
+    // V = 2 (16-byte accesses) for the shapes with at most four accumulator pairs; MAP needs N / (256 V) >= 8 tiles
+    const int V = (c->tun.hoist_v == 2 && ht.TS * ht.TR <= 4 && c->N >= 512) ? 2 : 1;
+    const uint32_t xt = c->N / (256 * V);
+    const bool map = c->tun.hoist_map && xt >= 8;
+#define HMV(S_, R_, V_)                                                                                                                \
+  if (ht.TS == S_ && ht.TR == R_ && V == V_) {                                                                                         \
+    if (map)                                                                                                                           \
+      hipLaunchKernelGGL((k_hoist_mac<S_, R_, V_, true>), dim3(xt * (l + 1) * n), dim3(256), 0, c->stream, c->dev, dg, dg_bs, mt, n, prod, prod_bs, l, fold); \
+    else                                                                                                                               \
+      hipLaunchKernelGGL((k_hoist_mac<S_, R_, V_, false>), dim3(xt, l + 1, n), dim3(256), 0, c->stream, c->dev, dg, dg_bs, mt, n, prod, prod_bs, l, fold); \
     HIPCHK(hipGetLastError());                                                                                                         \
     continue;                                                                                                                          \
   }
+#define HM(S_, R_) HMV(S_, R_, 1)
+    HMV(1, 1, 2) HMV(1, 2, 2) HMV(1, 4, 2) HMV(2, 1, 2) HMV(2, 2, 2) HMV(3, 1, 2) HMV(4, 1, 2)
     HM(1, 1) HM(1, 2) HM(1, 4) HM(2, 1) HM(2, 2) HM(2, 4) HM(3, 1) HM(3, 2) HM(4, 1) HM(4, 2)
+#undef HMV
 #undef HM
     throw std::logic_error("hoisted inner product: no kernel for this tile shape");
   }
