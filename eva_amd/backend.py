@@ -281,6 +281,12 @@ class Plaintext:
         _chk(_lib.evah_pt_download(self.ctx.h, self.h, _p(out)))
         return out
 
+    def write(self, data):
+        """replace the words of this handle (evah_pt_write; [limbs][N] NTT-form residues)"""
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        assert data.shape == (self.info()[0], self.ctx.N)
+        _chk(_lib.evah_pt_write(self.ctx.h, self.h, _p(data)))
+
     def free(self):
         if self.h:
             _lib.evah_pt_free(self.ctx.h, self.h)

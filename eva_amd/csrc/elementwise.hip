@@ -348,6 +348,7 @@ int evah_pt_uniform(evah_ctx *c, uint32_t limbs, double scale, const uint64_t *v
   for (uint32_t i = 0; i < limbs; i++) lv.v[i] = value[i];
   EW_LAUNCH(k_fill_limbs, ew_grid(c, limbs, 1), dim3(256), 0, c->stream, c->dev, lv, t->d);
   HIPCHK(hipGetLastError());
+  t->uniform = true;
   *out = t;
   API_END
 }

@@ -164,6 +164,10 @@ struct evah_pt {
   u64 *d;
   uint32_t limbs;
   double scale;
+  // every word of a limb's row is the same residue (evah_pt_uniform: the encoding of a uniform constant,
+  // Program::makeUniformConstant).  Multiplying by such a plaintext is multiplying by a scalar of Z_q, which commutes with
+  // the NTT: the convolution windows use it (ntt_window_lin.hip.h).  Cleared by anything that rewrites the words.
+  bool uniform = false;
 };
 struct evah_graph {
   hipGraph_t graph = nullptr;
@@ -267,6 +271,9 @@ struct Tunables {
   // EVAH_WIN_FUSE (1): evah_rotate_weighted_sums and the scheduler's convolution windows run the mod-down of the
   // window's rotations fused with the weighted sums (moddown_sum_kernel); 0 = rotation set, then evah_weighted_sum
   bool win_fuse = true;
+  // EVAH_WIN_LINEAR (1): a fused window all of whose rotated terms have uniform plaintexts (or 1) as weights runs the
+  // mod-down's forward transforms once per sum instead of once per rotation (ntt_window_lin.hip.h); 0 = moddown_sum_kernel
+  bool win_linear = true;
   // EVAH_FB_PERSIST (1): the exact fallback of a hoisted rotation set is one persistent launch per chunk (k_rot_fallback,
   // rot_fallback.hip.h) that leaves at once unless the zero counter overflowed; 0 = the ordinary unhoisted launches, each
   // guarded (about eight launches that return at once per chunk)
@@ -312,6 +319,7 @@ struct Tunables {
     flag("EVAH_FUSE_SPECIAL_INV", t.fuse_special_inv);
     flag("EVAH_FOLD_PA", t.fold_pa);
     flag("EVAH_WIN_FUSE", t.win_fuse);
+    flag("EVAH_WIN_LINEAR", t.win_linear);
     flag("EVAH_FB_PERSIST", t.fb_persist);
     count("EVAH_FB_GRID", t.fb_grid);
     flag("EVAH_MAC3", t.mac3);

@@ -117,15 +117,27 @@ k_key_perm(const u64 *key, const uint32_t *pinv, u64 *out, uint32_t N) {
 // different coefficient ranges, and an XCD sees ALL tiles of its (x, I) back to back — the second reader of a row finds it
 // in that XCD's L2.  Placement only decides speed; the result does not depend on it.
 // V = coefficients per thread (2: 16-byte accesses, for the shapes with few accumulators).
+#ifndef EVAH_HOIST_NT
+#define EVAH_HOIST_NT 0 // build-time experiment: 1 = the key stream with non-temporal loads, 2 = the products with non-temporal stores, 3 = both
+#endif
+#ifndef EVAH_HOIST_UNROLL
+#define EVAH_HOIST_UNROLL 2 // digit steps whose loads are in flight together
+#endif
 template <int V> struct HmVec { u64 v[V]; };
-template <int V> __device__ __forceinline__ HmVec<V> hm_ld(const u64 *p) {
+template <int V, bool NT = false> __device__ __forceinline__ HmVec<V> hm_ld(const u64 *p) {
   HmVec<V> o;
-  if constexpr (V == 2) { const ulonglong2 t = ld2(p); o.v[0] = t.x; o.v[1] = t.y; }
+  if constexpr (NT) {
+#pragma unroll
+    for (int v = 0; v < V; v++) o.v[v] = __builtin_nontemporal_load(p + v);
+  } else if constexpr (V == 2) { const ulonglong2 t = ld2(p); o.v[0] = t.x; o.v[1] = t.y; }
   else o.v[0] = p[0];
   return o;
 }
-template <int V> __device__ __forceinline__ void hm_st(u64 *p, const HmVec<V> &x) {
-  if constexpr (V == 2) { ulonglong2 t; t.x = x.v[0]; t.y = x.v[1]; st2(p, t); }
+template <int V, bool NT = false> __device__ __forceinline__ void hm_st(u64 *p, const HmVec<V> &x) {
+  if constexpr (NT) {
+#pragma unroll
+    for (int v = 0; v < V; v++) __builtin_nontemporal_store(x.v[v], p + v);
+  } else if constexpr (V == 2) { ulonglong2 t; t.x = x.v[0]; t.y = x.v[1]; st2(p, t); }
   else p[0] = x.v[0];
 }
 template <int TS, int TR, int V, bool MAP>
@@ -165,15 +177,15 @@ k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistMacTab tab, uint32_
 #pragma unroll
       for (int v = 0; v < V; v++) a0[s][r][v] = a1[s][r][v] = {0, 0};
   // operands are canonical (< q < 2^60): 256 products fit the 128-bit accumulators, l <= k - 1 < 64
-#pragma unroll 2
+#pragma unroll EVAH_HOIST_UNROLL
   for (uint32_t J = 0; J < l; J++) {
     HmVec<V> d[TS], k0[TR], k1[TR];
 #pragma unroll
     for (int s = 0; s < TS; s++) d[s] = hm_ld<V>((I == J) ? own[s] + (size_t)J * N : dgp[s] + (size_t)J * N);
 #pragma unroll
     for (int r = 0; r < TR; r++) {
-      k0[r] = hm_ld<V>(kp[r] + J * key_digit);
-      k1[r] = hm_ld<V>(kp[r] + J * key_digit + (size_t)cx.k * N);
+      k0[r] = hm_ld<V, (EVAH_HOIST_NT & 1) != 0>(kp[r] + J * key_digit);
+      k1[r] = hm_ld<V, (EVAH_HOIST_NT & 1) != 0>(kp[r] + J * key_digit + (size_t)cx.k * N);
     }
     __builtin_amdgcn_sched_barrier(0); // all the loads of the step are issued before the first multiply waits for one
 #pragma unroll
@@ -213,8 +225,8 @@ k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistMacTab tab, uint32_
         o0.v[v] = addmod(barrett128(a0[s][r][v], pm), c0.v[v], pm.q);
         o1.v[v] = addmod(barrett128(a1[s][r][v], pm), c1c.v[v], pm.q);
       }
-      hm_st<V>(pr, o0);
-      hm_st<V>(pr + (size_t)(l + 1) * N, o1);
+      hm_st<V, (EVAH_HOIST_NT & 2) != 0>(pr, o0);
+      hm_st<V, (EVAH_HOIST_NT & 2) != 0>(pr + (size_t)(l + 1) * N, o1);
     }
   }
 }
@@ -529,7 +541,9 @@ static HoistTiles hoist_tables(const RotPair *pr, uint32_t np, size_t N, HoistMa
   // (8 x 1 for the instances of a batched handle reads every key once but every digit row eight times: 14.3 k against
   // 14.5 k DAGs/s with 4 x 2 on config 4; 1 x 8 needs 159 VGPRs; a 64-VGPR ceiling for 8 waves per SIMD spills: 9.8 k)
   ht.TS = S >= 4 ? 4 : (int)S;
-  const int tr_max = ht.TS <= 2 ? 4 : 2; // (1 x 2 instead of 1 x 4: the same; 3 x 1 instead of 3 x 2: Harris +2.5 %)
+  if (const char *e = std::getenv("EVAH_HOIST_TS")) ht.TS = std::max(1, std::min(ht.TS, std::atoi(e))); // (experiments)
+  int tr_max = ht.TS <= 2 ? 4 : 2; // (1 x 2 instead of 1 x 4: the same; 3 x 1 instead of 3 x 2: Harris +2.5 %)
+  if (const char *e = std::getenv("EVAH_HOIST_TR")) tr_max = std::max(1, std::min(tr_max, std::atoi(e)));
   ht.TR = 1;
   while (ht.TR < tr_max && (size_t)ht.TR < R) ht.TR *= 2;
   // tiles: TR elements x TS sources, taken greedily in pair order (a rectangular set — every source with every element —

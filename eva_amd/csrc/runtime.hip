@@ -531,6 +531,7 @@ int evah_pt_copy(evah_ctx *c, const evah_pt *src, evah_pt **out) {
   acquire(c, src->buf);
   evah_pt *o = pt_new(c, src->limbs, src->scale);
   HIPCHK(hipMemcpyAsync(o->d, src->d, sizeof(u64) * (size_t)src->limbs * c->N, hipMemcpyDefault, c->stream));
+  o->uniform = src->uniform;
   *out = o;
   API_END
 }
@@ -611,6 +612,7 @@ int evah_pt_write(evah_ctx *c, evah_pt *pt, const uint64_t *data) {
   use(c);
   if (c->capturing) throw std::logic_error("evah_pt_write cannot be captured into a graph");
   acquire(c, pt->buf);
+  pt->uniform = false;
   HIPCHK(hipMemcpyAsync(pt->d, data, sizeof(u64) * (size_t)pt->limbs * c->N, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   count_h2d(c, sizeof(u64) * (size_t)pt->limbs * c->N, true);

@@ -2,6 +2,7 @@
 // (/root/reference/examples/image_processing.py:22-34: rotate_vector, multiply_plain and add of every tap;
 // seal_executor.h:181/188, :168, :124) as one launch set whose rotated ciphertexts are never written.
 #include "rotation_sets.hip.h"
+#include "ntt_window_lin.hip.h"
 
 namespace evah {
 // the guarded fallback's sums: the same outputs from rotated ciphertexts rot[pair][2][l N] (rot_chunk_plain)
@@ -80,6 +81,9 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
   // scales as evah_weighted_sum checks them; shape of every window
   std::vector<double> scales(n_sums);
   bool fusable = c->tun.win_fuse && c->tun.fold_pa;
+  // r6: every weight of a rotated term is a uniform plaintext (or 1): the window's mod-down runs ONE forward transform per
+  // (sum, polynomial, limb) — ntt_window_lin.hip.h; EVAH_WIN_LINEAR=0 keeps one per rotation
+  std::vector<char> win_lin(n_windows, c->tun.win_linear ? 1 : 0);
   uint32_t n_rot = 0;
   std::vector<const evah_ct *> distinct; // sources of rotated terms
   std::vector<uint32_t> src_of(n_terms, 0);
@@ -95,6 +99,7 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
           if (pt) {
             check_scale(c, sj, l);
             acquire(c, pt->buf);
+            if (steps[t0 + j] != 0 && !pt->uniform) win_lin[w] = 0;
           }
           if (j == 0) scales[s0 + s] = sj;
           else if (!same_scale(sj, scales[s0 + s])) throw std::invalid_argument("scale mismatch");
@@ -212,13 +217,14 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
           src_ps[si * B + b] = distinct[si]->ps;
         }
       // chunks: whole units, at most KS_BATCH_MAX pairs and WIN_MAX units, one number of sums per launch
-      struct Chunk { uint32_t u0, nu, first, np; int F; WinSumTab wt; };
+      struct Chunk { uint32_t u0, nu, first, np; int F; bool lin; WinSumTab wt; };
       std::vector<Chunk> chunks;
       for (uint32_t u = 0; u < units.size(); u++) {
         const int F = (int)win_sums[units[u].w];
-        if (chunks.empty() || chunks.back().F != F || chunks.back().nu == (uint32_t)WIN_MAX ||
+        const bool lin = win_lin[units[u].w] != 0;
+        if (chunks.empty() || chunks.back().F != F || chunks.back().lin != lin || chunks.back().nu == (uint32_t)WIN_MAX ||
             chunks.back().np + units[u].count > (uint32_t)KS_BATCH_MAX)
-          chunks.push_back(Chunk{u, 0, units[u].first, 0, F, WinSumTab{}});
+          chunks.push_back(Chunk{u, 0, units[u].first, 0, F, lin, WinSumTab{}});
         Chunk &ch = chunks.back();
         WinSumTab &wt = ch.wt;
         const Unit &un = units[u];
@@ -256,7 +262,7 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
           HoistMacTab mt{};
           HoistFixTab ft{};
           const HoistTiles tiles = hoist_tables(pr, np, N, mt, ft);
-          Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N), mid(c, (size_t)np * 2 * pps);
+          Scratch prod(c, np * prod_bs), r(c, (size_t)np * 2 * N), mid(c, (ch.lin ? (size_t)ch.nu * ch.F : (size_t)np) * 2 * pps);
           hoist_mac_launch(c, mt, tiles, dg.d, dg_bs, prod.d, prod_bs, l, true);
           {
             ProfScope ps(c, KC_KSMAC);
@@ -267,6 +273,19 @@ int evah_rotate_weighted_sums(evah_ctx *c, const evah_ct *const *cts, const int3
           // forward transforms into mid, then the second pass with the window's sums as its epilogue
           OpPlainG::Params sp{prod.d + (size_t)l * N, r.d, (size_t)(l + 1) * N, N, 1, c->k - 1, 1, {}};
           for (uint32_t q = 0; q < np; q++) sp.perm_tab.p[q] = pr[q].perm;
+          if (ch.lin) {
+            ntt_inverse<OpPlainG>(c, sp, 2 * np);
+            OpWinLin::Params wp{r.d, mid.d, c->k - 1, l, (uint32_t)ch.F, ch.wt};
+            launch_pass_p<true, false, OpWinLin>(c, (c->logN + 1) / 2, wp, l * ch.nu * ch.F * 2);
+            switch (c->logN / 2) {
+            case 5: launch_winlin_pass2<5>(c, l, ch.nu, ch.F, ch.wt, sp.perm_tab, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
+            case 6: launch_winlin_pass2<6>(c, l, ch.nu, ch.F, ch.wt, sp.perm_tab, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
+            case 7: launch_winlin_pass2<7>(c, l, ch.nu, ch.F, ch.wt, sp.perm_tab, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
+            case 8: launch_winlin_pass2<8>(c, l, ch.nu, ch.F, ch.wt, sp.perm_tab, mid.d, pps, prod.d, (size_t)(l + 1) * N, out_ps); break;
+            default: throw std::runtime_error("unsupported poly_modulus_degree for the window sums");
+            }
+            continue;
+          }
           OpModDown::Params mp{r.d, N, prod.d, (size_t)(l + 1) * N, nullptr, pps, ~0u, mid.d, pps, c->k - 1, l};
           if (fuse_small_launch(c, 2 * np * l)) {
             launch_pass_p<false, true, OpPlainG>(c, c->logN / 2, sp, 2 * np);

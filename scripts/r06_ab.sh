@@ -9,12 +9,17 @@ IFS='|' read -ra VARIANTS <<< "${3:-}"
 [ ${#VARIANTS[@]} -eq 0 ] && VARIANTS=("")
 export PYTHONPATH=$R
 cd $R
+BASE=$R/eva_amd/lib/libeva_hip.so
+cp $BASE /tmp/libeva_hip.base.so
+trap 'cp /tmp/libeva_hip.base.so $BASE' EXIT
 for vi in "${!VARIANTS[@]}"; do
   v="${VARIANTS[$vi]}"
+  # "ENV=.. ENV=..@name": the library variant eva_amd/lib/variants/<name>/libeva_hip.so (scripts/build_variant.sh)
+  if [[ "$v" == *@* ]]; then cp $R/eva_amd/lib/variants/${v##*@}/libeva_hip.so $BASE; vlabel="$v"; v="${v%@*}"; else cp /tmp/libeva_hip.base.so $BASE; vlabel="$v"; fi
   for leg in $LEGS; do
     f=$O/v${vi}_$leg.json
     env $v timeout 600 python bench.py --only-leg $leg ${EXTRA:-} > $f 2> $O/v${vi}_$leg.err || tail -5 $O/v${vi}_$leg.err
-    python - "$f" "$leg" "$v" <<'PY'
+    python - "$f" "$leg" "$vlabel" <<'PY'
 import json, sys
 f, leg, v = sys.argv[1:4]
 try:

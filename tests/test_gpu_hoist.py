@@ -324,6 +324,90 @@ def test_window_sums_bit_exact(cfg):
         assert np.array_equal(o.download(), r), f"sum {i}"
 
 
+def _uniform_pt(e, l):
+    """a uniform plaintext: one residue per limb in every slot (evah_pt_uniform, the encoding of a scalar constant)"""
+    vals = np.array([int(e.rng.integers(0, e.primes[i])) for i in range(l)], dtype=np.uint64)
+    return np.repeat(vals[:, None], e.N, axis=1), vals
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[0], CONFIGS[2], CONFIGS[3], CONFIGS[4], CONFIGS[5], CONFIGS[6], CONFIGS[7]],
+                         ids=lambda c: f"N{c[0]}_k{len(c[1])}")
+def test_window_sums_with_uniform_weights_bit_exact(cfg):
+    """r6: windows whose rotated terms are weighted by uniform plaintexts (EVA's scalar filter taps) run ONE forward transform
+    per sum in their mod-down (ntt_window_lin.hip.h).  Same words as rotate -> multiply_plain -> add one by one: two sums over
+    nine taps, one sum with the unrotated term in the middle and a general plaintext on it, weights of 1, two sources, and —
+    in the same call — a window with general weights (which keeps the per-rotation form)."""
+    e = env(cfg)
+    l = e.k - 1
+    steps9 = [0, 1, 2, 64, 65, 66, 128, 129, 130]
+    for st in steps9 + [-3]:
+        if st:
+            e.key_for(st)
+    img, x1, x2 = e.rand(2, l), e.rand(2, l), e.rand(2, l)
+    I, X1, X2 = (e.g.upload_ct(a, 2.0 ** 20) for a in (img, x1, x2))
+    uw = [[_uniform_pt(e, l) for _ in steps9] for _ in range(2)]
+    W = [[e.g.uniform_pt(v, 2.0 ** 10) for _, v in row] for row in uw]
+    wts = [[full for full, _ in row] for row in uw]
+    up = [_uniform_pt(e, l) for _ in range(4)]
+    P = [e.g.uniform_pt(v, 2.0 ** 10) for _, v in up]
+    pool = [full for full, _ in up]
+    gen = _rand_pt(e, l)  # a general plaintext on the UNROTATED term only
+    G = e.g.upload_pt(gen, 2.0 ** 10)
+    gw = [_rand_pt(e, l) for _ in range(2)]
+    GW = [e.g.upload_pt(w, 2.0 ** 10) for w in gw]
+    windows = [
+        ([(I, st) for st in steps9], W),
+        ([(X1, 1), (X1, 65), (X1, 0), (X1, -3)], [[P[0], P[1], G, P[3]]]),
+        ([(X2, 1), (X2, 2), (X2, 129)], [[P[1], P[2], P[3]]]),
+        ([(X1, 2), (X2, 64)], [[P[0], P[1]], [P[2], P[3]]]),
+        ([(X2, 66), (X2, 130)], [GW]),
+        ([(X2, 1), (X2, 2)], [[None, None]]),
+    ]
+    outs = e.g.rotate_weighted_sums(windows)
+    ref = (_window_oracle(e, [(img, st) for st in steps9], wts)
+           + _window_oracle(e, [(x1, 1), (x1, 65), (x1, 0), (x1, -3)], [[pool[0], pool[1], gen, pool[3]]])
+           + _window_oracle(e, [(x2, 1), (x2, 2), (x2, 129)], [[pool[1], pool[2], pool[3]]])
+           + _window_oracle(e, [(x1, 2), (x2, 64)], [[pool[0], pool[1]], [pool[2], pool[3]]])
+           + _window_oracle(e, [(x2, 66), (x2, 130)], [gw])
+           + _window_oracle(e, [(x2, 1), (x2, 2)], [[None, None]]))
+    assert len(outs) == len(ref) == 8
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        assert np.array_equal(o.download(), r), f"sum {i}"
+    # the same windows with the linear form switched off give the same words (A/B of the two forms)
+    os.environ["EVAH_WIN_LINEAR"] = "0"
+    try:
+        x = Env(*cfg)
+        for st in steps9 + [-3]:
+            if st:
+                x.g.upload_galois_key(x.g.galois_elt_from_step(st), e.keys[st])
+        Ix = x.g.upload_ct(img, 2.0 ** 20)
+        Wx = [[x.g.uniform_pt(v, 2.0 ** 10) for _, v in row] for row in uw]
+        outs0 = x.g.rotate_weighted_sums([([(Ix, st) for st in steps9], Wx)])
+        for o, r in zip(outs0, ref[:2]):
+            assert np.array_equal(o.download(), r)
+        x.g.close()
+    finally:
+        del os.environ["EVAH_WIN_LINEAR"]
+
+
+def test_a_rewritten_uniform_plaintext_is_not_treated_as_uniform():
+    """evah_pt_write replaces the words of a handle: the uniform mark must go with them"""
+    e = env(CONFIGS[2])
+    l = e.k - 1
+    for st in (1, 2):
+        e.key_for(st)
+    a = e.rand(2, l)
+    A = e.g.upload_ct(a, 2.0 ** 20)
+    _, v = _uniform_pt(e, l)
+    w = [e.g.uniform_pt(v, 2.0 ** 10) for _ in range(2)]
+    gen = _rand_pt(e, l)
+    w[1].write(gen)
+    outs = e.g.rotate_weighted_sums([([(A, 1), (A, 2)], [w])])
+    full = np.repeat(v[:, None], e.N, axis=1)
+    ref = _window_oracle(e, [(a, 1), (a, 2)], [[full, gen]])
+    assert np.array_equal(outs[0].download(), ref[0])
+
+
 def test_window_sums_general_shapes_take_the_unfused_path():
     """Three sums over one window and two unrotated terms are outside the fused kernel's tables: same results."""
     e = env(CONFIGS[2])
