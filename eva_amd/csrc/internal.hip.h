@@ -126,6 +126,10 @@ struct ProfRec {
   int cls;
 };
 
+// words of one block of a permuted key copy (KeyDev::d_perm): every digit and both polynomials of one prime row and 256
+// coefficients, plus one 2 KiB pad — with 8 digits a block would be exactly 32 KiB and the blocks of the eight workgroups
+// the dispatcher starts together would begin on the same memory channel (Harris' 3 x 2 tiles: 78 -> 94 us without the pad)
+__host__ __device__ inline size_t keyp_block_words(uint32_t nd) { return ((size_t)2 * nd + 1) * 256; }
 struct KeyDev {
   u64 *d = nullptr;
   uint32_t n_digits = 0;
@@ -140,7 +144,7 @@ struct KeyDev {
   // Galois keys used by hoisted rotation sets: the same words with every row read through the inverse of the element's
   // NTT-domain permutation — d_perm[..][m] = d[..][pi^-1(m)] — so that the hoisted inner product is elementwise in the
   // source's own index space (rotation_sets.hip.h, k_hoist_mac); built at the first hoisted use of the key
-  u64 *d_perm = nullptr;
+  u64 *d_perm = nullptr; // r6 layout: [prime row][N / 256][keyp_block_words(n_digits)], rotation_sets.hip.h k_key_perm
 };
 
 } // namespace evah

@@ -311,6 +311,11 @@ template <class Op, class = void> struct HasRaw : std::false_type {};
 template <class Op> struct HasRaw<Op, std::void_t<typename Op::Raw>> : std::true_type {};
 template <class Op, bool ON> struct RawOf { using type = NoPre; };
 template <class Op> struct RawOf<Op, true> { using type = typename Op::Raw; };
+// an op whose input transform reads SEVERAL words per element (OpWinLin: one per rotation of a window) fills the thread's
+// NTT_R elements itself — term-outer, so that the NTT_R loads of a term are in flight together instead of one element's
+// terms one after the other:  Op::fill_all<NTT_R>(cx, jb, pm, n0, nstep, out)
+template <class Op, class = void> struct HasFillAll : std::false_type {};
+template <class Op> struct HasFillAll<Op, std::void_t<decltype(Op::fills_all)>> : std::bool_constant<Op::fills_all> {};
 
 // An op whose transform starts a launch set may have words to clear before the set's later kernels count into them (the
 // zero-coefficient record and the fallback's ticket words of a hoisted rotation set, OpPlainT<ZEROS>): the first workgroup
@@ -379,10 +384,17 @@ ntt_pass_kernel(DevCtx cx, typename Op::Params prm, int logC_rt, int log_tiles) 
   // accept lazy values (< 12q forward), so no Barrett reduction is needed on the way in
   auto fill = [&](auto lazy_tag) {
     constexpr bool LZ = decltype(lazy_tag)::value;
+    if constexpr (FIRST && HasFillAll<Op>::value) {
+      u64 v[NTT_R];
+      Op::template fill_all<NTT_R>(cx, jb, pm, n0, nstep, v);
 #pragma unroll
-    for (int it = 0; it < NTT_R; it++) {
-      const uint32_t n = n0 + it * nstep;
-      lds[lds_at(it)] = FIRST ? Op::template load<LZ>(cx, jb, pm, n) : jb.dst[n];
+      for (int it = 0; it < NTT_R; it++) lds[lds_at(it)] = v[it];
+    } else {
+#pragma unroll
+      for (int it = 0; it < NTT_R; it++) {
+        const uint32_t n = n0 + it * nstep;
+        lds[lds_at(it)] = FIRST ? Op::template load<LZ>(cx, jb, pm, n) : jb.dst[n];
+      }
     }
   };
   // second forward pass: the epilogue's operands are requested before the tile, so they are in flight

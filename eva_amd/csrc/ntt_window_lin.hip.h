@@ -64,6 +64,43 @@ struct OpWinLin {
     }
     return barrett128(acc, pm);
   }
+  // the thread's R elements n0 + e * nstep, term-outer: two terms' loads (2 R words) in flight per step
+  static constexpr bool fills_all = true;
+  template <int R>
+  static __device__ __forceinline__ void fill_all(const DevCtx &cx, const Job &j, const DevPrime &pm, uint32_t n0, uint32_t nstep, u64 *out) {
+    u128_t acc[R];
+#pragma unroll
+    for (int e = 0; e < R; e++) acc[e] = {0, 0};
+    const u64 *rk = j.r + (size_t)j.K * cx.N + n0;
+    const size_t wofs = (size_t)j.i * cx.N;
+    uint32_t t = j.first;
+    const uint32_t end = j.first + j.cnt;
+    for (; t + 1 < end; t += 2) {
+      const u64 *wa = j.w[t], *wb = j.w[t + 1];                 // wave-uniform
+      const u64 Wa = wa ? wa[wofs] : 1, Wb = wb ? wb[wofs] : 1; // a uniform plaintext: any word of the limb
+      const u64 *ra = rk + (size_t)(2 * t) * cx.N, *rb = ra + 2 * (size_t)cx.N;
+      u64 va[R], vb[R];
+#pragma unroll
+      for (int e = 0; e < R; e++) {
+        va[e] = ra[e * nstep];
+        vb[e] = rb[e * nstep];
+      }
+#pragma unroll
+      for (int e = 0; e < R; e++) {
+        acc128(acc[e], va[e] + j.off, Wa);
+        acc128(acc[e], vb[e] + j.off, Wb);
+      }
+    }
+    if (t < end) {
+      const u64 *wa = j.w[t];
+      const u64 Wa = wa ? wa[wofs] : 1;
+      const u64 *ra = rk + (size_t)(2 * t) * cx.N;
+#pragma unroll
+      for (int e = 0; e < R; e++) acc128(acc[e], ra[e * nstep] + j.off, Wa);
+    }
+#pragma unroll
+    for (int e = 0; e < R; e++) out[e] = barrett128(acc[e], pm);
+  }
   static __device__ __forceinline__ void store(const DevCtx &, const Job &, const DevPrime &, uint32_t, u64) {}
   static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &, const DevPrime &, uint32_t, u64) {}
 };
@@ -96,6 +133,12 @@ winlin_pass2_kernel(DevCtx cx, WinSumTab ws, PermTab perms, const u64 *mid, size
     }
   }
   const size_t row = (size_t)i * cx.N + gbase + 2 * threadIdx.x; // + it * 2 T
+  // sum_t W_ft * prod_t[K][i][perm_t[n]]: prod is kept in each pair's source index space.  G terms per step: their G NTT_R
+  // gathers are in flight together, the next step's indices behind them.  (The Galois permutation maps an aligned
+  // 256-coefficient tile ONTO an aligned tile — the low bits of 2 br(n) + 1 pick the low bits of its product with the
+  // element — so a wave's gather stays inside one 2 KiB block of the row.)
+  constexpr int G = F > 1 ? 2 : 4;
+  const uint32_t end = first + cnt;
   for (uint32_t K = 0; K < 2; K++) {
     // the first sum's tile is requested before the gathers: it arrives while they are accumulated
     ulonglong2 dreg[NPAIR];
@@ -109,33 +152,42 @@ winlin_pass2_kernel(DevCtx cx, WinSumTab ws, PermTab perms, const u64 *mid, size
     for (int f = 0; f < F; f++)
 #pragma unroll
       for (int e = 0; e < NTT_R; e++) acc[f][e] = {0, 0};
-    // sum_t W_ft * prod_t[K][i][perm_t[n]]: prod is kept in each pair's source index space; indices a pair ahead
-    uint2 pnext[NPAIR];
-    auto load_perm = [&](uint32_t t) {
-      const uint32_t *pi = perms.p[t] + gbase + 2 * threadIdx.x;
+    uint2 pnext[G][NPAIR];
+    auto load_perms = [&](uint32_t t0) {
 #pragma unroll
-      for (int it = 0; it < NPAIR; it++) pnext[it] = *reinterpret_cast<const uint2 *>(pi + it * 2 * T);
+      for (int g = 0; g < G; g++) {
+        const uint32_t t = t0 + g < end ? t0 + g : end - 1; // (a short last group repeats its last term: loaded, weight 0)
+        const uint32_t *pi = perms.p[t] + gbase + 2 * threadIdx.x;
+#pragma unroll
+        for (int it = 0; it < NPAIR; it++) pnext[g][it] = *reinterpret_cast<const uint2 *>(pi + it * 2 * T);
+      }
     };
-    if (cnt) load_perm(first);
-    for (uint32_t t = first; t < first + cnt; t++) {
-      uint2 at[NPAIR];
+    if (cnt) load_perms(first);
+    for (uint32_t t0 = first; t0 < end; t0 += G) {
+      u64 pv[G][NTT_R];
+      u64 W[G][F];
 #pragma unroll
-      for (int it = 0; it < NPAIR; it++) at[it] = pnext[it];
-      if (t + 1 < first + cnt) load_perm(t + 1);
-      const u64 *pr = prod + (size_t)(2 * t + K) * prod_ps + (size_t)i * cx.N;
-      const u64 *wt0 = ws.w0[t], *wt1 = F > 1 ? ws.w1[t] : nullptr;
-      const u64 W0 = wt0 ? wt0[(size_t)i * cx.N] : 1, W1 = (F > 1 && wt1) ? wt1[(size_t)i * cx.N] : 1;
-      u64 pv[NTT_R];
+      for (int g = 0; g < G; g++) {
+        const bool live = t0 + g < end;
+        const uint32_t t = live ? t0 + g : end - 1;
+        const u64 *pr = prod + (size_t)(2 * t + K) * prod_ps + (size_t)i * cx.N;
 #pragma unroll
-      for (int it = 0; it < NPAIR; it++) {
-        pv[2 * it] = pr[at[it].x];
-        pv[2 * it + 1] = pr[at[it].y];
+        for (int it = 0; it < NPAIR; it++) {
+          pv[g][2 * it] = pr[pnext[g][it].x];
+          pv[g][2 * it + 1] = pr[pnext[g][it].y];
+        }
+        const u64 *wt0 = ws.w0[t], *wt1 = F > 1 ? ws.w1[t] : nullptr;
+        W[g][0] = !live ? 0 : wt0 ? wt0[(size_t)i * cx.N] : 1; // (a repeated term counts with the weight 0)
+        if constexpr (F > 1) W[g][1] = !live ? 0 : wt1 ? wt1[(size_t)i * cx.N] : 1;
       }
+      if (t0 + G < end) load_perms(t0 + G);
 #pragma unroll
-      for (int e = 0; e < NTT_R; e++) {
-        acc128(acc[0][e], pv[e], W0);
-        if constexpr (F > 1) acc128(acc[1][e], pv[e], W1);
-      }
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int e = 0; e < NTT_R; e++) {
+          acc128(acc[0][e], pv[g][e], W[g][0]);
+          if constexpr (F > 1) acc128(acc[1][e], pv[g][e], W[g][1]);
+        }
     }
 #pragma unroll
     for (int f = 0; f < F; f++) {

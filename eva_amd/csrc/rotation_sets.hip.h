@@ -78,6 +78,7 @@ struct HoistMacTab {
   uint32_t dg[KS_BATCH_MAX];      // index of the source among the set's transformed digits
   const u64 *keyp[KS_BATCH_MAX];  // per Galois element of the chunk: the permuted key, the permuted constant [2][l+1][N]
   const u64 *corrp[KS_BATCH_MAX];
+  uint32_t keyp_nd[KS_BATCH_MAX]; // digits of that key: a block of keyp is keyp_nd * 512 words
   // per tile, one byte per entry: sources [0..1], elements [2..3], pair (output slot) of combination s * TR + r [4..5]
   // (0xff: not a pair of the chunk)
   uint32_t tile[HT_TILES][6];
@@ -102,11 +103,17 @@ k_hoist_corr(DevCtx cx, const u64 *sign, const u64 *key, const uint32_t *pinv, u
   }
   corr[((size_t)K * (l + 1) + I) * N + m] = mulmod(sign[(size_t)kap * N + n], acc, pm);
 }
-// keyp[row][m] = key[row][pinv[m]] for every row of the key; grid = (N / 256, rows)
+// The permuted key copy, keyp[kap][x][J][K][256] = key[J][K][kap][pinv[256 x + .]]: every row of the key read through the
+// inverse permutation AND (r6) regrouped so that the words one workgroup of k_hoist_mac needs — prime row kap, 256
+// coefficients, every digit J, both polynomials K — are ONE contiguous block of n_digits * 4 KiB.  With the key's own
+// layout [J][K][kap][N] a workgroup took 2 KiB from each of 2 l rows megabytes apart, and the launch as a whole walked
+// several hundred DRAM streams at once (config 5's window: 1.3 GB of keys at 3.9 TB/s).  grid = (N / 256, rows of the key)
+// (keyp_block_words, internal.hip.h: one 2 KiB pad per block)
 static __global__ void __launch_bounds__(256)
-k_key_perm(const u64 *key, const uint32_t *pinv, u64 *out, uint32_t N) {
+k_key_perm(const u64 *key, const uint32_t *pinv, u64 *out, uint32_t N, uint32_t k, uint32_t nd) {
+  const uint32_t row = blockIdx.y, J = row / (2 * k), K = (row / k) & 1u, kap = row % k;
   const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-  out[(size_t)blockIdx.y * N + m] = key[(size_t)blockIdx.y * N + pinv[m]];
+  out[((size_t)kap * gridDim.x + blockIdx.x) * keyp_block_words(nd) + (J * 2 + K) * 256 + threadIdx.x] = key[(size_t)row * N + pinv[m]];
 }
 // r6 — which workgroups run together.  Tiles of a launch share operands: tiles with the same sources read the same digit
 // rows, tiles with the same elements the same key rows (8 instances x 8 rotations as 4 x 2 tiles: every key row is read by
@@ -118,7 +125,8 @@ k_key_perm(const u64 *key, const uint32_t *pinv, u64 *out, uint32_t N) {
 // in that XCD's L2.  Placement only decides speed; the result does not depend on it.
 // V = coefficients per thread (2: 16-byte accesses, for the shapes with few accumulators).
 #ifndef EVAH_HOIST_NT
-#define EVAH_HOIST_NT 0 // build-time experiment: 1 = the key stream with non-temporal loads, 2 = the products with non-temporal stores, 3 = both
+#define EVAH_HOIST_NT 1 // (r6 default: the key stream is read once — config 5 -3 %, Harris -4 %, the batches unchanged)
+// build-time experiment: 1 = the key stream with non-temporal loads, 2 = the products with non-temporal stores, 3 = both
 #endif
 #ifndef EVAH_HOIST_UNROLL
 #define EVAH_HOIST_UNROLL 2 // digit steps whose loads are in flight together
@@ -159,7 +167,7 @@ k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistMacTab tab, uint32_
   const u64 srcs = tw[0] | ((u64)tw[1] << 32), rots = tw[2] | ((u64)tw[3] << 32), outs = tw[4] | ((u64)tw[5] << 32);
   const size_t m = (size_t)V * ((size_t)xt * blockDim.x + threadIdx.x);
   const DevPrime pm = cx.primes[kap];
-  const size_t N = cx.N, key_digit = (size_t)2 * cx.k * N;
+  const size_t N = cx.N;
   const u64 *dgp[TS], *own[TS], *kp[TR];
 #pragma unroll
   for (int s = 0; s < TS; s++) {
@@ -167,8 +175,12 @@ k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistMacTab tab, uint32_
     dgp[s] = digits + tab.dg[si] * dg_bs + (size_t)I * l * N + m;
     own[s] = tab.c1[si] + m;
   }
+  static_assert(V == 1, "the blocked key copy is addressed by 256-coefficient blocks");
 #pragma unroll
-  for (int r = 0; r < TR; r++) kp[r] = tab.keyp[(uint32_t)(rots >> (8 * r)) & 0xffu] + (size_t)kap * N + m;
+  for (int r = 0; r < TR; r++) {
+    const uint32_t ei = (uint32_t)(rots >> (8 * r)) & 0xffu;
+    kp[r] = tab.keyp[ei] + ((size_t)kap * (N >> 8) + xt) * keyp_block_words(tab.keyp_nd[ei]) + threadIdx.x;
+  }
   u128_t a0[TS][TR][V], a1[TS][TR][V];
 #pragma unroll
   for (int s = 0; s < TS; s++)
@@ -184,8 +196,8 @@ k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistMacTab tab, uint32_
     for (int s = 0; s < TS; s++) d[s] = hm_ld<V>((I == J) ? own[s] + (size_t)J * N : dgp[s] + (size_t)J * N);
 #pragma unroll
     for (int r = 0; r < TR; r++) {
-      k0[r] = hm_ld<V, (EVAH_HOIST_NT & 1) != 0>(kp[r] + J * key_digit);
-      k1[r] = hm_ld<V, (EVAH_HOIST_NT & 1) != 0>(kp[r] + J * key_digit + (size_t)cx.k * N);
+      k0[r] = hm_ld<V, (EVAH_HOIST_NT & 1) != 0>(kp[r] + J * 512);
+      k1[r] = hm_ld<V, (EVAH_HOIST_NT & 1) != 0>(kp[r] + J * 512 + 256);
     }
     __builtin_amdgcn_sched_barrier(0); // all the loads of the step are issued before the first multiply waits for one
 #pragma unroll
@@ -351,10 +363,11 @@ static const u64 *hoist_key(evah_ctx *c, uint32_t elt, KeyDev &key) {
   if (c->capturing) throw std::logic_error("first hoisted use of a Galois key cannot be captured into a graph");
   const uint32_t *pinv = perm_inv_table(c, elt);
   if (!pinv) return nullptr;
-  u64 *d = hoist_table_alloc<u64>(key.bytes);
+  u64 *d = hoist_table_alloc<u64>(sizeof(u64) * keyp_block_words(key.n_digits) * (c->N / 256) * c->k);
   if (!d) return nullptr;
   const uint32_t rows = (uint32_t)(key.bytes / (sizeof(u64) * c->N));
-  hipLaunchKernelGGL(k_key_perm, dim3(c->N / 256, rows), dim3(256), 0, c->stream, key.d, pinv, d, (uint32_t)c->N);
+  if (key.rows != c->k || c->N < 256) { (void)hipFree(d); return nullptr; } // (a shard's partial key: never hoisted)
+  hipLaunchKernelGGL(k_key_perm, dim3(c->N / 256, rows), dim3(256), 0, c->stream, key.d, pinv, d, (uint32_t)c->N, c->k, key.n_digits);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream); // other queues may use the copy next
   if (e != hipSuccess) {
@@ -531,6 +544,7 @@ static HoistTiles hoist_tables(const RotPair *pr, uint32_t np, size_t N, HoistMa
       elts.push_back(pr[r].elt);
       mt.keyp[ei] = pr[r].keyp;
       mt.corrp[ei] = pr[r].corr;
+      mt.keyp_nd[ei] = pr[r].key->n_digits;
     }
     ps[r] = (uint32_t)si;
     pe[r] = (uint32_t)ei;
@@ -586,7 +600,7 @@ static void hoist_mac_launch(evah_ctx *c, HoistMacTab &mt, const HoistTiles &ht,
     for (uint32_t t = 0; t < n; t++)
       for (int i = 0; i < 6; i++) mt.tile[t][i] = ht.tiles[t0 + t][i];
     // V = 2 (16-byte accesses) for the shapes with at most four accumulator pairs; MAP needs N / (256 V) >= 8 tiles
-    const int V = (c->tun.hoist_v == 2 && ht.TS * ht.TR <= 4 && c->N >= 512) ? 2 : 1;
+    const int V = 1; // (r6: the 2-coefficient form was measured — config 5 1.67 -> 1.71 ms — and went with the blocked key copy)
     const uint32_t xt = c->N / (256 * V);
     const bool map = c->tun.hoist_map && xt >= 8;
 #define HMV(S_, R_, V_)                                                                                                                \
@@ -599,7 +613,6 @@ static void hoist_mac_launch(evah_ctx *c, HoistMacTab &mt, const HoistTiles &ht,
     continue;                                                                                                                          \
   }
 #define HM(S_, R_) HMV(S_, R_, 1)
-    HMV(1, 1, 2) HMV(1, 2, 2) HMV(1, 4, 2) HMV(2, 1, 2) HMV(2, 2, 2) HMV(3, 1, 2) HMV(4, 1, 2)
     HM(1, 1) HM(1, 2) HM(1, 4) HM(2, 1) HM(2, 2) HM(2, 4) HM(3, 1) HM(3, 2) HM(4, 1) HM(4, 2)
 #undef HMV
 #undef HM

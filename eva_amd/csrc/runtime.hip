@@ -587,7 +587,7 @@ int evah_ctx_key_bytes_detail(evah_ctx *c, uint64_t out[3]) {
     if (!kd.d) return;
     out[0] += kd.bytes;
     if (kd.d_split) out[1] += kd.bytes;
-    if (kd.d_perm) out[2] += kd.bytes;
+    if (kd.d_perm) out[2] += sizeof(u64) * keyp_block_words(kd.n_digits) * (c->N / 256) * kd.rows;
   };
   count(c->sh->relin);
   for (auto &kv : c->sh->galois) count(kv.second);

@@ -689,4 +689,5 @@ def test_hoisting_tables_that_do_not_fit_degrade_to_the_unhoisted_path():
             assert np.array_equal(got, w), f"fail={fail}: window sums"
         words, split, perm = x.g.key_bytes_detail()
         assert words == x.g.key_bytes() == 3 * l * 2 * e.k * e.N * 8
-        assert perm == (0 if fail else words), (fail, words, split, perm)  # one permuted copy per key a hoisted set used
+        # one permuted copy per key a hoisted set used; r6: in blocks of (2 digits + 1 pad) x 2 KiB per (prime row, 256 coefficients)
+        assert perm == (0 if fail else 3 * (2 * l + 1) * e.k * e.N * 8), (fail, words, split, perm)
