@@ -70,6 +70,8 @@ _SIGS = {
     "evah_multiply_many": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_multiply_relinearize_rescale": [_vp, _vp, _vp, C.c_uint32, _vpp],
     "evah_multiply_relinearize_rescale_many": [_vp, _vpp, _vpp, C.c_uint32, C.c_uint32, _vpp],
+    "evah_multiply_rescale_relinearize": [_vp, _vp, _vp, C.c_uint32, _vpp],
+    "evah_multiply_rescale_relinearize_many": [_vp, _vpp, _vpp, C.c_uint32, C.c_uint32, _vpp],
     "evah_execute": [_vp, _vp, C.c_uint32, _vp, C.c_uint32],
     "evah_elementwise_program": [_vp, _vp, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, _vpp],
     "evah_weighted_sum": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
@@ -711,6 +713,20 @@ class Context:
         ib = (C.c_void_p * n)(*[ct.h for ct in cts_b])
         outs = (C.c_void_p * n)()
         _chk(_lib.evah_multiply_relinearize_rescale_many(self.h, ia, ib, n, C.c_uint32(int(divisor_bits)), outs))
+        return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n)]
+
+    def multiply_rescale_relinearize(self, a, b, divisor_bits):
+        """multiply (a is b: square) -> rescale -> relinearize as one call (lazy relinearization's order)"""
+        out = C.c_void_p()
+        _chk(_lib.evah_multiply_rescale_relinearize(self.h, a.h, b.h, C.c_uint32(int(divisor_bits)), C.byref(out)))
+        return Ciphertext(self, out)
+
+    def multiply_rescale_relinearize_many(self, cts_a, cts_b, divisor_bits):
+        n = len(cts_a)
+        ia = (C.c_void_p * n)(*[ct.h for ct in cts_a])
+        ib = (C.c_void_p * n)(*[ct.h for ct in cts_b])
+        outs = (C.c_void_p * n)()
+        _chk(_lib.evah_multiply_rescale_relinearize_many(self.h, ia, ib, n, C.c_uint32(int(divisor_bits)), outs))
         return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n)]
 
     def rotate(self, a, steps):

@@ -237,6 +237,9 @@ struct Tunables {
   // slower at N = 2^16 and kept it for N <= 8192; with the r03 128-bit reduction its on-the-fly products
   // are cheap enough that it wins at every size (op-triple 13 383 -> 13 635 /s)
   bool fuse_mul = true;
+  // EVAH_FUSE_MUL2 (1): evah_execute runs Mul -> Rescale -> Relinearize chains (lazy relinearization's order) as ONE
+  // evah_multiply_rescale_relinearize_many (r6); 0 = the three calls
+  bool fuse_mul2 = true;
   // EVAH_EW_FUSE (1): evah_execute defers elementwise ops (negate / add / sub / multiply, ciphertexts and plaintexts) on
   // values nobody needs stored and runs each connected run of them as ONE evah_elementwise_program; 0 = one launch per op
   bool ew_fuse = true;
@@ -300,6 +303,10 @@ struct Tunables {
   // EVAH_HOIST_V (1): coefficients per thread of k_hoist_mac for tile shapes with <= 4 accumulator pairs (2 = 16-byte accesses)
   bool hoist_map = true;
   uint32_t hoist_v = 1;
+  // EVAH_SIDE_STREAM (0): evah_multiply_rescale_relinearize runs the rescale of d0 / d1 on the queue's side stream beside
+  // the key switch of d2.  Measured (r06_tuning_notes.md): eager walks gain (config 5 1.77 -> 1.70 ms), replayed hipGraphs
+  // do not — a fork / join inside a graph costs what the overlap returns — so the default is one stream
+  bool side_stream = false;
   // EVAH_LDS_EXTRA (0): bytes of dynamic LDS added to every ntt_pass_kernel launch — an occupancy probe for the
   // tuning notes (fewer workgroups per CU), never set in production
   uint32_t lds_extra = 0;
@@ -311,6 +318,7 @@ struct Tunables {
     (void)N;
     flag("EVAH_FUSE_MAC", t.fuse_mac);
     flag("EVAH_FUSE_MUL", t.fuse_mul);
+    flag("EVAH_FUSE_MUL2", t.fuse_mul2);
     flag("EVAH_EW_FUSE", t.ew_fuse);
     count("EVAH_FUSE_SMALL", t.fuse_small_blocks);
     if (const char *e = std::getenv("EVAH_SMALL_LR")) t.small_lr = std::atoi(e) == 3 ? 3 : 2;
@@ -333,6 +341,7 @@ struct Tunables {
     count("EVAH_LOOP_TARGET_WGS", t.loop_target_wgs);
     count("EVAH_LDS_EXTRA", t.lds_extra);
     flag("EVAH_HOIST_MAP", t.hoist_map);
+    flag("EVAH_SIDE_STREAM", t.side_stream);
     count("EVAH_HOIST_V", t.hoist_v);
     if (const char *e = std::getenv("EVAH_KS_GROUPS")) t.ks_groups = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {
@@ -351,6 +360,7 @@ struct evah_ctx {
   std::vector<int> total_bits; // total_bits[l] = bit length of prod primes[0..l)
   DevCtx dev{};
   hipStream_t own = nullptr, stream = nullptr;
+  hipStream_t side = nullptr; // second stream of this queue, created on first use (SideStream: independent halves of one fused call)
   Pool pool;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool capturing = false;              // inside evah_capture_begin/end: no syncs, no profiling events
@@ -465,6 +475,44 @@ inline void stream_wait(evah_ctx *waiter, evah_ctx *signaller) {
   if (waiter->capturing || signaller->capturing) waiter->capture_events.push_back(e);
   else waiter->sync_events.push_back(e);
 }
+// Two independent halves of ONE call on two streams of the same queue (r6; the rescale of a product's d0 / d1 beside the
+// key switch of its d2): fork() makes the side stream wait for everything enqueued on the queue so far and redirects the
+// queue's launches to it, back() returns to the queue's own stream, join() makes the queue wait for the side work.
+// Temporaries come from the queue's pool as always (they are returned after join(), in stream order).  Inside a graph
+// capture the side stream joins the capture through the fork's event and must be joined before the call returns.
+struct SideStream {
+  evah_ctx *c;
+  hipStream_t main;
+  bool forked = false, on_side = false;
+  explicit SideStream(evah_ctx *c_) : c(c_), main(c_->stream) {}
+  void link(hipStream_t from, hipStream_t to) {
+    hipEvent_t e = sync_event(c);
+    HIPCHK(hipEventRecord(e, from));
+    HIPCHK(hipStreamWaitEvent(to, e, 0));
+    if (c->capturing) c->capture_events.push_back(e);
+    else c->sync_events.push_back(e);
+  }
+  void fork() {
+    if (!c->side) HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    link(main, c->side);
+    c->stream = c->side;
+    forked = on_side = true;
+  }
+  void back() { c->stream = main; on_side = false; }
+  void join() {
+    back();
+    if (forked) link(c->side, main);
+    forked = false;
+  }
+  ~SideStream() { // (an exception between fork and join: the side work is still ordered before whatever follows)
+    c->stream = main;
+    if (forked) {
+      hipEvent_t e = sync_event(c);
+      if (hipEventRecord(e, c->side) == hipSuccess) (void)hipStreamWaitEvent(main, e, 0);
+      (c->capturing ? c->capture_events : c->sync_events).push_back(e);
+    }
+  }
+};
 // Called before queue `c` enqueues a read of `b`: orders the read after the producer and
 // remembers the reader so the buffer is not recycled under it.
 inline void acquire(evah_ctx *c, Buffer *b) {

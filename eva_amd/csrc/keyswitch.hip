@@ -500,6 +500,112 @@ int evah_multiply_relinearize_rescale(evah_ctx *c, const evah_ct *a, const evah_
   API_END
 }
 
+// multiply (size 2 x size 2; a == b: square) -> rescale_to_next -> relinearize for n (<= 64) independent pairs at one level:
+// the order lazy relinearization gives a product under the waterline rescalers (seal_executor.h:164 / :162, :213-214, :200).
+// The size-3 product is never written — its polynomials are formed where the rescale reads them (OpMulPolyIntt,
+// OpModDownMul).  Same ciphertext, bit for bit, as the three calls.
+static void mul_rescale_relin(evah_ctx *c, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n, uint32_t divisor_bits, evah_ct **outs) {
+  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("multiply_rescale_relinearize_many handles 1..64 products per call");
+  if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
+  const uint32_t l = as[0]->limbs;
+  if (l < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  const uint32_t lp = l - 1, last = l - 1, sp = c->k - 1;
+  const size_t N = c->N, ops = (size_t)lp * N, pps = (size_t)(lp + 1) * N;
+  MulTab tab{};
+  std::vector<double> scales(n);
+  for (uint32_t i = 0; i < n; i++) {
+    const evah_ct *a = as[i], *b = bs[i];
+    if (a->size != 2 || b->size != 2) throw std::invalid_argument("multiply supports size-2 operands only (relinearize first)");
+    if (a->batch != 1 || b->batch != 1) throw std::invalid_argument("multiply_rescale_relinearize_many takes single ciphertexts");
+    if (a->limbs != l || b->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+    scales[i] = a->scale * b->scale;
+    check_scale(c, scales[i], l);
+    acquire(c, a->buf);
+    acquire(c, b->buf);
+    tab.a[i] = a->d;
+    tab.b[i] = b->d;
+    tab.a_ps[i] = (uint32_t)(a->ps / N);
+    tab.b_ps[i] = (uint32_t)(b->ps / N);
+  }
+  Buffer *ob = buf_new(c, (size_t)n * 2 * ops);
+  try {
+    std::vector<const KeyDev *> keys(n, &c->sh->relin);
+    if (!c->tun.side_stream) {
+      // one stream (the default: inside a replayed hipGraph a fork / join costs more than the overlap returns — config 5
+      // 1.56 ms either way, r06_tuning_notes.md): the rescale of the three polynomials as one launch set, then the key
+      // switch of d2' with P * d0', P * d1' folded into its inner products, as evah_relinearize does on a stored ciphertext
+      Scratch dp(c, (size_t)n * 3 * ops), r3(c, (size_t)n * 3 * N);
+      OpMulPolyIntt::Params ip{tab, r3.d, 0, 3, last, 1};
+      OpModDownMul::Params mpr{r3.d, tab, dp.d, ops, 0, 3, last, lp};
+      inverse_then_forward<OpMulPolyIntt, OpModDownMul>(c, ip, 3 * n, mpr, 3 * n * lp);
+      Scratch prod(c, (size_t)n * 2 * pps), r(c, (size_t)n * 2 * N);
+      const bool fold = c->tun.fold_pa && c->tun.fuse_mac;
+      PtrTab adds{};
+      for (uint32_t b = 0; b < n && fold; b++)
+        for (uint32_t K = 0; K < 2; K++) adds.p[2 * b + K] = dp.d + (size_t)(3 * b + K) * ops;
+      const bool inv1 = switch_key_products(c, lp, dp.d + 2 * ops, 3 * ops, keys.data(), n, prod.d, nullptr, nullptr,
+                                            fuse_small_launch(c, 2 * n * lp) ? r.d : nullptr, fold, fold ? &adds : nullptr);
+      OpPlain::Params spp{prod.d + (size_t)lp * N, r.d, pps, N, 1, sp, 1, {}};
+      OpModDown::Params mp{r.d, N, prod.d, pps, fold ? nullptr : dp.d, ops, 2, ob->d, ops, sp, lp};
+      mp.add_bs = 3 * ops;
+      inverse_then_forward<OpPlain, OpModDown>(c, spp, 2 * n, mp, 2 * n * lp, inv1);
+    } else {
+    // two streams (EVAH_SIDE_STREAM=1; pays on eager walks: config 5 1.77 -> 1.70 ms): the rescale of d2 followed by its
+    // key switch on the queue's stream, the rescale of d0 and d1 beside them on the queue's side stream; the halves meet in
+    // the mod-down's combine, which adds d0' and d1'
+    Scratch dp2(c, (size_t)n * ops), dp01(c, (size_t)n * 2 * ops), r3(c, (size_t)n * 3 * N);
+    u64 *r01 = r3.d, *r2 = r3.d + (size_t)2 * n * N;
+    SideStream side(c);
+    // d2' = rescale(d2): what the key switch starts from
+    OpMulPolyIntt::Params ip2{tab, r2, 2, 1, last, 1};
+    OpModDownMul::Params mp2{r2, tab, dp2.d, ops, 2, 1, last, lp};
+    inverse_then_forward<OpMulPolyIntt, OpModDownMul>(c, ip2, n, mp2, n * lp);
+    // d0', d1' beside it
+    side.fork();
+    OpMulPolyIntt::Params ip01{tab, r01, 0, 2, last, 1};
+    OpModDownMul::Params mp01{r01, tab, dp01.d, ops, 0, 2, last, lp};
+    inverse_then_forward<OpMulPolyIntt, OpModDownMul>(c, ip01, 2 * n, mp01, 2 * n * lp);
+    side.back();
+    // key switch of d2' (the products only; d0', d1' join in the combine)
+    Scratch prod(c, (size_t)n * 2 * pps), r(c, (size_t)n * 2 * N);
+    const bool inv1 = switch_key_products(c, lp, dp2.d, ops, keys.data(), n, prod.d, nullptr, nullptr, fuse_small_launch(c, 2 * n * lp) ? r.d : nullptr);
+    side.join();
+    OpPlain::Params spp{prod.d + (size_t)lp * N, r.d, pps, N, 1, sp, 1, {}};
+    OpModDown::Params mp{r.d, N, prod.d, pps, dp01.d, ops, 2, ob->d, ops, sp, lp};
+    mp.add_bs = 2 * ops;
+    inverse_then_forward<OpPlain, OpModDown>(c, spp, 2 * n, mp, 2 * n * lp, inv1);
+    }
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)n;
+  for (uint32_t b = 0; b < n; b++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)b * 2 * ops;
+    t->size = 2;
+    t->limbs = lp;
+    t->ps = ops;
+    t->scale = scales[b] / std::pow(2.0, (double)divisor_bits);
+    outs[b] = t;
+  }
+}
+
+int evah_multiply_rescale_relinearize_many(evah_ctx *c, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n, uint32_t divisor_bits,
+                                           evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  mul_rescale_relin(c, as, bs, n, divisor_bits, outs);
+  API_END
+}
+int evah_multiply_rescale_relinearize(evah_ctx *c, const evah_ct *a, const evah_ct *b, uint32_t divisor_bits, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  mul_rescale_relin(c, &a, &b, 1, divisor_bits, out);
+  API_END
+}
+
 // n independent ciphertexts of one size and level rescaled in one launch set (n * size <= 128)
 int evah_rescale_many(evah_ctx *c, const evah_ct *const *cts, uint32_t n, uint32_t divisor_bits, evah_ct **outs) {
   API_BEGIN

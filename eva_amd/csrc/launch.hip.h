@@ -25,6 +25,8 @@ template <bool Z, bool G> struct OpClass<OpPlainT<Z, G>> { static constexpr int 
 template <> struct OpClass<OpMulIntt> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
 template <> struct OpClass<OpKsDigit> { static constexpr int fwd_a = KC_KSDIGIT_A, fwd_b = KC_KSDIGIT_B; };
 template <bool G> struct OpClass<OpModDownT<G>> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
+template <> struct OpClass<OpMulPolyIntt> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
+template <> struct OpClass<OpModDownMul> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 template <int M> struct OpClass<OpRRT<M>> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 template <int M> struct OpClass<OpRRLastT<M>> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 

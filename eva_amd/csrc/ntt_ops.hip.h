@@ -283,6 +283,98 @@ template <bool GATHER> struct OpModDownT {
 using OpModDown = OpModDownT<false>;
 using OpModDownG = OpModDownT<true>;
 
+// ---- a ciphertext product that is rescaled straight away (Mul -> Rescale, r6): the size-3 product is never written —
+// its polynomials d_K are formed where the rescale reads them (the last limb in the inverse transform's load, every other
+// limb in the combine epilogue).  Same canonical residues as evaluator.multiply / square then rescale_to_next.
+// Inverse transform of limb `last` of d_K; job = b * nK + (K - K0) for the polynomials K0 .. K0 + nK - 1 of product b
+struct OpMulPolyIntt {
+  struct Params {
+    MulTab mul;
+    u64 *dst;          // r[job][N]
+    uint32_t K0, nK, last;
+    int addhalf;
+  };
+  struct Job {
+    uint32_t prime, K;
+    size_t off;
+    MulSrc mul;
+    u64 *dst;
+    int addhalf;
+    bool lazy;
+  };
+  static dim3 grid(const Params &, uint32_t jobs) { return dim3(1, jobs, 1); }
+  static constexpr int loop_axis = 1; // every job is modulo the last data prime
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t job, uint32_t, Job &j) {
+    j.prime = cx.prime_of(p.last);
+    j.K = p.K0 + job % p.nK;
+    j.off = (size_t)p.last * cx.N;
+    j.mul = mul_src(p.mul, cx.N, job / p.nK);
+    j.dst = p.dst + (size_t)job * cx.N;
+    j.addhalf = p.addhalf;
+    j.lazy = false;
+    return true;
+  }
+  template <bool LZ>
+  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
+    return product_poly(j.mul, j.K, j.off + n, pm);
+  }
+  static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 v) {
+    if (j.addhalf) v = addmod(v, pm.q >> 1, pm.q);
+    j.dst[n] = v;
+  }
+  static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &, const DevPrime &, uint32_t, u64) {}
+};
+// Divide-and-round by the last data prime with c = d_K of a product formed in the epilogue; job -> (pp = job / jl, i = job % jl),
+// pp = b * nK + (K - K0); r[pp] = INTT(limb a of d_K) + floor(q_a/2) (OpMulPolyIntt)
+struct OpModDownMul {
+  struct Params {
+    const u64 *r;      // [pp][N]
+    MulTab mul;
+    u64 *dst;          // polynomial pp at dst + pp * dst_ps
+    size_t dst_ps;
+    uint32_t K0, nK, a, jl;
+  };
+  struct Job {
+    uint32_t prime, K;
+    const u64 *src;
+    size_t off;
+    MulSrc mul;
+    u64 *dst;
+    u64 halfm;
+    ulonglong2 inv;
+    bool lazy;
+  };
+  static dim3 grid(const Params &p, uint32_t jobs) { return dim3(1, p.jl, jobs / p.jl); }
+  static constexpr int loop_axis = 2;
+  static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t, uint32_t i, uint32_t pp, Job &j) {
+    j.prime = cx.prime_of(i);
+    j.K = p.K0 + pp % p.nK;
+    j.src = p.r + (size_t)pp * cx.N;
+    j.off = (size_t)i * cx.N;
+    j.mul = mul_src(p.mul, cx.N, pp / p.nK);
+    j.dst = p.dst + pp * p.dst_ps + (size_t)i * cx.N;
+    j.halfm = cx.halfmod[p.a * cx.k + j.prime];
+    j.inv = cx.invq[p.a * cx.k + j.prime];
+    j.lazy = cx.primes[p.a].q <= cx.primes[j.prime].q8;
+    return true;
+  }
+  template <bool LZ>
+  static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
+    return conv<LZ>(j, pm, j.src[n]);
+  }
+  static constexpr bool pre_addhalf = true;
+  static __device__ __forceinline__ uint32_t pre_prime(const Params &p, const Job &) { return p.a; }
+  static __device__ __forceinline__ const u64 *pre_src(const Job &j) { return j.src; }
+  template <bool LZ> static __device__ __forceinline__ u64 conv(const Job &j, const DevPrime &pm, u64 v) {
+    if (LZ) return v + (pm.q - j.halfm);
+    return submod(barrett64(v, pm.q, pm.brt), j.halfm, pm.q);
+  }
+  static __device__ __forceinline__ void store_fwd(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n, u64 U) {
+    U += (U >= pm.q8 ? pm.nq8 : 0); // [0,16q) -> [0,8q)
+    j.dst[n] = mul_shoup(product_poly(j.mul, j.K, j.off + n, pm) + pm.q8 - U, j.inv.x, j.inv.y, pm.q);
+  }
+};
+
 // ---- relinearize followed by rescale, evaluated together (same canonical result as the two
 // SEAL calls in sequence, seal_executor.h:200 then :213).  With ct' = relinearize(a):
 //   ct'[K][i] = a[K][i] + (prod[K][i] - NTT_i(u_Ki)) * P^-1,  u_Ki = (r_K mod q_i) - floor(P/2) mod q_i

@@ -195,6 +195,7 @@ void evah_ctx_destroy(evah_ctx *c) {
   ctx_unregister(c);
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); c->side = nullptr; }
   c->pool.release_cached();
   c->sh.reset(); // tables and keys go when the last fork goes
   for (auto &r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }

@@ -54,6 +54,11 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     // value -> aliases of the two operands of a deferred Mul (prods) / of a Relinearize of one (prodrel):
     // Mul -> Relinearize -> Rescale chains without other readers run as one fused call at the Rescale
     std::map<uint32_t, std::pair<evah_ct *, evah_ct *>> prods, prodrel;
+    // r6, the other order — Mul -> Rescale -> Relinearize, what lazy relinearization gives a product under the waterline
+    // rescalers: prods2 = the operands of a deferred Mul read only by such a Rescale, prodres = of that Rescale (with its
+    // divisor); the three run as one evah_multiply_rescale_relinearize_many at the Relinearize
+    std::map<uint32_t, std::pair<evah_ct *, evah_ct *>> prods2, prodres;
+    std::map<uint32_t, uint32_t> resdiv;
     // value -> deferred rotation: a Rotate whose readers are all ciphertext x plaintext products inside sums is not
     // evaluated; the sums carry (source, step) terms and go to evah_rotate_weighted_sums (the convolution window)
     std::map<uint32_t, DRot> drots;
@@ -70,10 +75,10 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         for (evah_pt *h : kv.second.pts) evah_pt_free(c, h);
       }
       for (auto &kv : relins) evah_ct_free(c, kv.second);
-      for (auto *m : {&prods, &prodrel})
+      for (auto *m : {&prods, &prodrel, &prods2, &prodres})
         for (auto &kv : *m) { evah_ct_free(c, kv.second.first); evah_ct_free(c, kv.second.second); }
     }
-  } st{c, {}, {}, {}, {}, {}, {}, {}};
+  } st{c, {}, {}, {}, {}, {}, {}, {}, {}, {}, {}};
   auto chk = [&](int rc) {
     if (rc) throw std::runtime_error(g_err);
   };
@@ -425,7 +430,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         x.size = x.e->size; x.limbs = x.e->limbs; x.batch = x.e->batch; x.scale = x.e->scale;
         return true;
       }
-      if (st.sums.count(v) || st.relins.count(v) || st.drots.count(v) || st.prods.count(v) || st.prodrel.count(v)) return false;
+      if (st.sums.count(v) || st.relins.count(v) || st.drots.count(v) || st.prods.count(v) || st.prodrel.count(v) || st.prods2.count(v) || st.prodres.count(v)) return false;
       if (tab[v].kind == EVAH_VAL_CT && tab[v].h) {
         x.kind = 1; x.ct = static_cast<evah_ct *>(tab[v].h);
         x.size = x.ct->size; x.limbs = x.ct->limbs; x.batch = x.ct->batch; x.scale = x.ct->scale;
@@ -492,7 +497,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     std::map<uint32_t, std::vector<uint32_t>> rots, relins, muls, batched_rots;
     std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> mulps; // ct x pt products by (size, limbs)
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<uint32_t>> rescales;
-    std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> fused, fused3;
+    std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> fused, fused3, fused3b;
     // ---- one op through the ordinary entry points (seal_executor.h:114-215)
     auto single = [&](const evah_op &o) {
       evah_ct *out = nullptr;
@@ -581,7 +586,13 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         }
         continue;
       }
-      if (o.op == 20 && st.prods.count(o.src0)) { // Relinearize of a deferred product: still deferred
+      if (o.op == 22 && st.prods2.count(o.src0)) { // Rescale of a deferred product that a Relinearize follows: still deferred
+        st.prodres[o.dst] = st.prods2[o.src0];
+        st.resdiv[o.dst] = (uint32_t)o.imm;
+        st.prods2.erase(o.src0);
+      } else if (o.op == 20 && st.prodres.count(o.src0)) {
+        fused3b[{st.prodres[o.src0].first->limbs, st.resdiv[o.src0]}].push_back(i);
+      } else if (o.op == 20 && st.prods.count(o.src0)) { // Relinearize of a deferred product: still deferred
         st.prodrel[o.dst] = st.prods[o.src0];
         st.prods.erase(o.src0);
       } else if (o.op == 22 && st.prodrel.count(o.src0)) {
@@ -602,6 +613,16 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
           shape(o.src0, size, limbs, scale);
           relins[limbs].push_back(i);
         }
+      } else if (o.op == 13 && is_ct(o.src0) && is_ct(o.src1) && !batched && c->tun.fuse_mac && c->tun.fuse_mul2 && c->sh->relin.d &&
+                 feeds_only(o.dst, 22) && feeds_only(ops[only_reader[o.dst]].dst, 20) && [&] {
+                   // Mul (or square) read only by a Rescale that is read only by a Relinearize — lazy relinearization's order:
+                   // nothing is computed here, the three run as one fused call at the Relinearize (r6)
+                   evah_ct *x = ct_of(o.src0), *y = ct_of(o.src1);
+                   if (!(x->size == 2 && y->size == 2 && x->limbs == y->limbs && x->limbs >= 2 && x->batch == 1 && y->batch == 1)) return false;
+                   check_scale(c, x->scale * y->scale, x->limbs);
+                   st.prods2[o.dst] = {alias_ct(x), alias_ct(y)};
+                   return true;
+                 }()) {
       } else if (o.op == 13 && is_ct(o.src0) && is_ct(o.src1) && try_defer_ew(o)) {
         // ciphertext x ciphertext inside an elementwise expression (not a Mul -> Relinearize -> Rescale chain): nothing runs here
       } else if (o.op == 13 && is_ct(o.src0) && is_ct(o.src1) &&
@@ -762,6 +783,25 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
           evah_ct_free(c, const_cast<evah_ct *>(ia[j]));
           evah_ct_free(c, const_cast<evah_ct *>(ib[j]));
           st.prodrel.erase(ops[is[j]].src0);
+        }
+        store(is, n, outs);
+      }
+    for (auto &kv : fused3b)
+      for (size_t i0 = 0; i0 < kv.second.size(); i0 += KS_BATCH_MAX) {
+        const uint32_t n = (uint32_t)std::min<size_t>(KS_BATCH_MAX, kv.second.size() - i0);
+        const uint32_t *is = kv.second.data() + i0;
+        std::vector<const evah_ct *> ia(n), ib(n);
+        std::vector<evah_ct *> outs(n, nullptr);
+        for (uint32_t j = 0; j < n; j++) {
+          ia[j] = st.prodres[ops[is[j]].src0].first;
+          ib[j] = st.prodres[ops[is[j]].src0].second;
+        }
+        chk(evah_multiply_rescale_relinearize_many(c, ia.data(), ib.data(), n, kv.first.second, outs.data()));
+        for (uint32_t j = 0; j < n; j++) {
+          evah_ct_free(c, const_cast<evah_ct *>(ia[j]));
+          evah_ct_free(c, const_cast<evah_ct *>(ib[j]));
+          st.prodres.erase(ops[is[j]].src0);
+          st.resdiv.erase(ops[is[j]].src0);
         }
         store(is, n, outs);
       }

@@ -164,6 +164,69 @@ def test_multiply_relinearize_rescale_fused_bit_exact(cfg):
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"N{c[0]}")
+@pytest.mark.parametrize("side", ["1", "0"])
+def test_multiply_rescale_relinearize_fused_bit_exact(cfg, side, monkeypatch):
+    """r6: evah_multiply_rescale_relinearize(_many) — the Mul -> Rescale -> Relinearize chain of lazy relinearization, the
+    size-3 product never in memory, the rescale of d0 / d1 on the queue's side stream beside the key switch of d2 — ==
+    the oracle's three separate calls; squares (a is b), a shared operand, a mod-switched view, with and without the side
+    stream, every level down to the last key switch (one limb left)."""
+    monkeypatch.setenv("EVAH_SIDE_STREAM", side)
+    e = Env(*cfg)
+    key = e.rand_key()
+    e.g.upload_relin_key(key)
+    for l in sorted({e.k - 1, max(2, e.k - 2), 2}):
+        hosts = [(e.rand(2, l), e.rand(2, l)) for _ in range(3)]
+        A = [e.g.upload_ct(a, 2.0 ** 25) for a, _ in hosts]
+        B = [e.g.upload_ct(b, 2.0 ** 25) for _, b in hosts]
+        want = [e.o.relinearize(e.o.rescale(e.o.multiply(a, b)), key) for a, b in hosts]
+        one = e.g.multiply_rescale_relinearize(A[0], B[0], 30)
+        assert one.info() == (2, l - 1, 2.0 ** 20)
+        assert np.array_equal(one.download(), want[0]), f"fused multiply+rescale+relinearize mismatch at l={l}"
+        sq = e.g.multiply_rescale_relinearize(A[1], A[1], 30)
+        assert np.array_equal(sq.download(), e.o.relinearize(e.o.rescale(e.o.square(hosts[1][0])), key)), f"square at l={l}"
+        outs = e.g.multiply_rescale_relinearize_many(A + [A[1], B[2]], B + [B[2], B[2]], 30)
+        for o, w in zip(outs, want):
+            assert np.array_equal(o.download(), w)
+        assert np.array_equal(outs[3].download(), e.o.relinearize(e.o.rescale(e.o.multiply(hosts[1][0], hosts[2][1])), key))
+        assert np.array_equal(outs[4].download(), e.o.relinearize(e.o.rescale(e.o.square(hosts[2][1])), key))
+        # the same words as the three separate calls of this library
+        sep = e.g.relinearize(e.g.rescale(e.g.multiply(A[0], B[0]), 30))
+        assert np.array_equal(sep.download(), want[0])
+        if l + 1 <= e.k - 1:  # operands that are mod-switched views of longer ciphertexts
+            big = e.rand(2, l + 1)
+            V = e.g.mod_switch(e.g.upload_ct(big, 2.0 ** 25))
+            got = e.g.multiply_rescale_relinearize(V, B[0], 30).download()
+            assert np.array_equal(got, e.o.relinearize(e.o.rescale(e.o.multiply(e.o.mod_switch(big), hosts[0][1])), key))
+    with pytest.raises(backend.EvaHipError, match="size-2"):
+        e.g.multiply_rescale_relinearize(e.g.upload_ct(e.rand(3, e.k - 1), 2.0 ** 20), e.g.upload_ct(e.rand(2, e.k - 1), 2.0 ** 20), 30)
+    with pytest.raises(backend.EvaHipError, match="end of modulus switching chain"):
+        e.g.multiply_rescale_relinearize(e.g.upload_ct(e.rand(2, 1), 2.0 ** 10), e.g.upload_ct(e.rand(2, 1), 2.0 ** 10), 10)
+    e.g.close()
+
+
+def test_multiply_rescale_relinearize_config5_shape_bit_exact():
+    """the shape it was built for: one square at N = 2^16, l = 12 of 13 primes (BASELINE config 5's chain step), eager and
+    from inside a captured graph replayed three times"""
+    N, bits = 65536, [60] * 13
+    e = Env(N, bits)
+    key = e.rand_key()
+    e.g.upload_relin_key(key)
+    a = e.rand(2, 12)
+    A = e.g.upload_ct(a, 2.0 ** 40)
+    want = e.o.relinearize(e.o.rescale(e.o.square(a)), key)
+    assert np.array_equal(e.g.multiply_rescale_relinearize(A, A, 60).download(), want)
+    e.g.capture_begin()
+    out = e.g.multiply_rescale_relinearize(A, A, 60)
+    graph = e.g.capture_end()
+    for _ in range(3):
+        e.g.graph_launch(graph)
+    e.g.sync()
+    assert np.array_equal(out.download(), want)
+    e.g.graph_free(graph)
+    e.g.close()
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"N{c[0]}")
 def test_rotate_bit_exact(cfg):
     e = env(cfg)
     l = e.k - 1
