@@ -323,7 +323,10 @@ BATCH_WORKLOADS = {
 
 
 def dag_batch_leg(batch, reps, dist=None, members=1, workload="sobel", chunk=None, check=8):
-    """A batch of independent DAGs of one program through execute_batch (uploads and downloads included):
+    """A batch of independent DAGs of one program through execute_batch.  r6: the valuations are device-resident — encrypt()
+    left the inputs in HBM, the outputs stay there (no ciphertext crosses PCIe in the timed calls: SURVEY.md 8(b), and the
+    rule that inputs are resident when the timed region starts); the same call with host valuations (uploads and downloads
+    included — what the leg timed through r5) is reported beside it as `host_valuations`.
       workload "sobel"   BASELINE config 4: Sobel at N = 2^14, L = 5
       workload "harris"  north_star's target as THROUGHPUT: Harris corner detector at N = 2^15, L = 8 (config 3's DAG)
     `check` instances per rank, spread over the groups and issue queues of the call, are compared word for word with
@@ -360,7 +363,7 @@ def _dag_batch_setup(batch, rank, world, dev, members, workload="sobel", chunk=N
         pub, sec = generate_keys(params, 1, devices=[dev])
     else:
         pub, sec = generate_keys(params, 1)
-    pub.resident = False  # execute_batch assembles batched handles from host words and returns host words
+    pub.resident = members == 1  # (shard_mode "dag" deals host valuations over its members)
     if chunk or default_chunk:
         pub.batch_chunk = int(chunk or default_chunk)
     nbytes, _ = dag_bytes(compiled, sig, N, len(params.prime_bits))
@@ -401,6 +404,29 @@ def _dag_batch_run(state, batch, reps, dist, members, workload="sobel", check=8)
         ts.append(dist.max_over_ranks(dt) if dist else dt)
     gc.enable()
     med = _median(ts)
+    # the same call with host valuations: inputs as host words (pinned), outputs downloaded — PCIe included
+    host_val = None
+    if pub.resident and not dist:
+        houts = None
+        try:
+            for e in {id(v): v for v in inputs}.values():
+                e.to_host(True)
+            pub.resident = False
+            hts = []
+            for _ in range(2 + max(3, reps // 2)):
+                houts = None
+                t0 = time.perf_counter()
+                houts = pub.execute_batch(compiled, inputs)
+                hts.append(time.perf_counter() - t0)
+            hmed = _median(hts[2:])
+            same = all(np.array_equal(houts[i].get(name)[4], outs[i].get(name)[4]) for i in (0, len(mine) - 1) for name in outs[i].names())
+            host_val = {"dags_per_s": round(batch / hmed, 1), "ms_total": round(hmed * 1e3, 2), "same_words_as_resident": bool(same),
+                        "includes": "input uploads and output downloads over PCIe (host valuations, as the reference hands values over)"}
+        except Exception as e:  # noqa: BLE001
+            host_val = {"error": repr(e)}
+        finally:
+            pub.resident = True
+            houts = None
     from oracle.executor import c_walk  # checker only
     ok, picked, walked = True, _spread(len(mine), check), {}
     for i in picked:
@@ -423,7 +449,10 @@ def _dag_batch_run(state, batch, reps, dist, members, workload="sobel", check=8)
             "roofline": rl(nbytes * batch / world, med, compulsory=comp_rank),
             "roofline_basis": "algorithmic bytes of this rank's DAGs over the time, per GPU; launch_compulsory: every evaluation key "
                               f"charged once per group of {chunk} instances and scheduler level",
-            "includes": f"input uploads, one DAG walk per {chunk} instances, output downloads",
+            "includes": (f"one DAG walk per {chunk} instances on device-resident valuations (inputs stacked device to device, outputs "
+                         "left in HBM); no ciphertext crosses PCIe" if pub.resident else
+                         f"input uploads, one DAG walk per {chunk} instances, output downloads"),
+            "valuations": "device-resident" if pub.resident else "host", "host_valuations": host_val,
             "instances_checked_per_rank": len(picked), "instances_checked": [int(mine[i]) for i in picked],
             "bit_exact_vs_oracle": bad == 0.0}
 

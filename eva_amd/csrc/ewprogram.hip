@@ -276,7 +276,7 @@ int evah_elementwise_program(evah_ctx *c, const evah_val *in, uint32_t n_in, con
     // pointer slots in use (loads of dropped instructions leave holes: renumber)
     std::vector<int> ptr_map(pptr.size(), -1);
     std::vector<PPtr> ptr_used;
-    bool fits = live.size() <= (size_t)EW_MAX_INS;
+    bool fits = live.size() <= (size_t)EW_MAX_INS && N >= 256; // (a launch is N / 256 workgroups of 256 threads: smaller rings take the separate calls)
     EwProg pg{};
     for (size_t q = 0; q < live.size() && fits; q++) {
       PIns pi = live[q];

@@ -40,6 +40,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     evah_pt *pa = nullptr, *pb = nullptr;
     bool same = false;                 // Mul(a, a): square
     uint32_t size = 0, limbs = 0, batch = 1;
+    uint32_t depth = 1;                // longest chain of unevaluated nodes ending here (bounded: EXPR_MAX_DEPTH)
     double scale = 0;
     evah_ct *result = nullptr;         // alias, once the node has been evaluated and stored
     ~Expr() {
@@ -411,7 +412,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
   // Record op `o` as an unevaluated expression node instead of running it?  Only when its result is an intermediate of
   // this walk (freeable, read by somebody), its operands are plain handles or expression nodes, and every check of the
   // entry point it stands for passes — anything else takes the ordinary path, which reports the error.
-  auto try_defer_ew = [&](const evah_op &o) -> bool {
+  std::function<bool(const evah_op &)> try_defer_ew = [&](const evah_op &o) -> bool {
     if (!c->tun.ew_fuse || !(o.op == 10 || o.op == 11 || o.op == 12 || o.op == 13)) return false;
     if (!freeable[o.dst] || n_reads[o.dst] == 0) return false;
     struct Opnd {
@@ -489,6 +490,20 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     };
     take(a, node->ea, node->ca, node->pa);
     if (!unary && !node->same) take(b, node->eb, node->cb, node->pb);
+    // r5 advisor: nothing bounded the depth of an expression graph — force_exprs' visit and the shared_ptr destructor
+    // chain recurse once per dependent node, and a program beyond EW_MAX_INS instructions runs as separate calls anyway.
+    // A chain this long is evaluated up to here; the node then starts a new expression on stored operands.
+    constexpr uint32_t EXPR_MAX_DEPTH = 48;
+    for (const auto &e : {node->ea, node->eb})
+      if (e && !e->result) node->depth = std::max(node->depth, e->depth + 1);
+    if (node->depth > EXPR_MAX_DEPTH) {
+      std::vector<uint32_t> below;
+      for (const auto &e : {node->ea, node->eb})
+        if (e && !e->result) below.push_back(e->v);
+      node.reset(); // (its aliases go; the operands' nodes stay in st.exprs until forced)
+      force_exprs(below);
+      return try_defer_ew(o); // operands are stored handles now: depth 1
+    }
     st.exprs[o.dst] = std::move(node);
     return true;
   };
@@ -557,7 +572,9 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
       // a batched handle already covers its instances in one launch set: the *_many forms take
       // single ciphertexts, so on batched operands only sibling rotations are grouped (rotate_many
       // accepts them) and the deferred forms below still apply
-      auto batched_val = [&](uint32_t v) {
+      auto batched_val = [&](uint32_t v) { // (r5 advisor: an operand that is still an unevaluated expression has a batch too)
+        auto ex = st.exprs.find(v);
+        if (ex != st.exprs.end()) return ex->second->batch > 1;
         return tab[v].kind == EVAH_VAL_CT && static_cast<evah_ct *>(tab[v].h)->batch > 1;
       };
       const bool batched = batched_val(o.src0) || ((o.op == 11 || o.op == 12 || o.op == 13) && batched_val(o.src1)) ||

@@ -73,7 +73,15 @@ inline std::vector<HipValuation> HipPublic::execute_batch(Program &program, cons
       ex.set_inputs_batch(chunk, true);
       if (library_scheduler) ex.run_library(&done, true);
       else run_counted(program, ex, &done);
-      ex.get_outputs_batch(all.data() + i0, n, true);
+      // r6: resident valuations (`resident`, the default) — inputs that encrypt() / execute() left in HBM were stacked device
+      // to device, and the outputs leave as handles (views of the group's batched output): no ciphertext crosses PCIe in
+      // the call.  Host valuations (resident = false, or inputs that hold host words only): uploads and downloads as before.
+      if (resident && ex.batch_inputs_resident) {
+        const DeviceResident res{dev, g % Q ? batch_forks[g % Q - 1] : nullptr, nullptr, host->N};
+        ex.get_outputs_batch(all.data() + i0, n, true, &res);
+      } else {
+        ex.get_outputs_batch(all.data() + i0, n, true);
+      }
     }
   } catch (...) {
     for (evah_ctx *q : qs) (void)evah_ctx_sync(q); // copies in flight still target `all` and the caller's inputs

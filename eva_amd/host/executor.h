@@ -144,10 +144,26 @@ public:
           check_shape(kv.first, c);
           if (c.size != c0->size || c.limbs != c0->limbs || c.scale != c0->scale)
             throw std::runtime_error("execute_batch: input " + kv.first + " differs in shape or scale across the batch");
-          ptrs[b] = (const uint64_t *)words(c).data(); // the batched handle is assembled from host words
+        }
+        // r6: instances that are already in HBM (valuations left there by encrypt() or an earlier execute()) are stacked
+        // device to device (evah_ct_stack: one strided copy per instance on this queue, ordered per buffer by the
+        // library) — no PCIe in the call; otherwise the batched handle is assembled from host words
+        std::vector<std::shared_ptr<CtHandle>> rh(B);
+        bool all_resident = true;
+        for (uint32_t b = 0; b < B && all_resident; b++) {
+          rh[b] = resident_handle(std::get<HostCipher>(batch[b]->values.at(kv.first)));
+          all_resident = rh[b] != nullptr;
         }
         evah_ct *h = nullptr;
-        chk((async ? evah_ct_upload_instances_async : evah_ct_upload_instances)(ctx, B, c0->size, c0->limbs, c0->scale, ptrs.data(), &h));
+        if (all_resident) {
+          std::vector<const evah_ct *> hs(B);
+          for (uint32_t b = 0; b < B; b++) hs[b] = rh[b]->h;
+          chk(evah_ct_stack(ctx, hs.data(), B, &h));
+          batch_inputs_resident = true;
+        } else {
+          for (uint32_t b = 0; b < B; b++) ptrs[b] = (const uint64_t *)words(std::get<HostCipher>(batch[b]->values.at(kv.first))).data();
+          chk((async ? evah_ct_upload_instances_async : evah_ct_upload_instances)(ctx, B, c0->size, c0->limbs, c0->scale, ptrs.data(), &h));
+        }
         objects[t] = std::make_shared<CtHandle>(ctx, h);
       } else if (auto *p = std::get_if<HostPlain>(&kv.second)) {
         check_shape(kv.first, *p);
@@ -172,7 +188,9 @@ public:
   }
   // outputs of a batched run, split back into one valuation per instance (outs[0..n)).  async: the
   // downloads are only enqueued; the words are valid after the queue is synchronised
-  void get_outputs_batch(HipValuation *outs, size_t n_outs, bool async = false) {
+  // res != nullptr (resident valuations): instance b of an output leaves as a handle — a view of the batched output
+  // (evah_ct_unstack: the instances share one allocation, freed with the last of them) — and nothing is downloaded
+  void get_outputs_batch(HipValuation *outs, size_t n_outs, bool async = false, const DeviceResident *res = nullptr) {
     for (auto &kv : program.outputs()) {
       auto &o = objects[kv.second];
       if (auto *c = std::get_if<std::shared_ptr<CtHandle>>(&o)) {
@@ -181,6 +199,16 @@ public:
         chk(evah_ct_info((*c)->h, &hc.size, &hc.limbs, &hc.scale));
         chk(evah_ct_batch((*c)->h, &B));
         if (B != n_outs) throw std::runtime_error("Output " + kv.first + " does not depend on an encrypted input of the batch");
+        if (res) {
+          for (uint32_t b = 0; b < B; b++) {
+            evah_ct *view = nullptr;
+            chk(evah_ct_unstack(ctx, (*c)->h, b, &view));
+            HostCipher one = hc;
+            one.dev = std::make_shared<DeviceResident>(DeviceResident{res->root, res->queue, std::make_shared<CtHandle>(ctx, view), host.N});
+            outs[b].values[kv.first] = std::move(one);
+          }
+          continue;
+        }
         const size_t each = (size_t)hc.size * hc.limbs * host.N;
         std::vector<uint64_t *> ptrs(B);
         for (uint32_t b = 0; b < B; b++) {
@@ -490,6 +518,9 @@ private:
   std::vector<std::pair<TermId, TermId>> deferred_free; // (lazy relin term, its source)
   const DeviceCtx *root = nullptr;
   std::vector<std::shared_ptr<DeviceResident>> resident_inputs;
+public:
+  bool batch_inputs_resident = false; // set_inputs_batch stacked at least one input from device handles
+private:
   bool batch_rotations = std::getenv("EVA_BATCH_ROTATIONS") ? std::atoi(std::getenv("EVA_BATCH_ROTATIONS")) != 0 : true;
   bool fuse_relin_rescale = std::getenv("EVA_FUSE_RELIN_RESCALE") ? std::atoi(std::getenv("EVA_FUSE_RELIN_RESCALE")) != 0 : true;
   bool device_encode = std::getenv("EVA_DEVICE_ENCODE") ? std::atoi(std::getenv("EVA_DEVICE_ENCODE")) != 0 : true;

@@ -58,6 +58,22 @@ def test_config3_harris_batch_n32768_l8_every_instance_bit_exact():
     single = pub.execute(compiled, encs[6])
     for name in single.names():
         assert np.array_equal(single.get(name)[4], outs[6].get(name)[4])
+    # r6: the call above ran on resident valuations (encrypt() leaves them in HBM, the outputs are views of the batched
+    # output: nothing crossed PCIe).  Host valuations — inputs as host words, outputs downloaded — give the same words
+    assert all(o.is_resident(n) for o in outs for n in o.names())
+    st0 = pub.transfer_stats()
+    again = pub.execute_batch(compiled, encs)
+    st1 = pub.transfer_stats()
+    assert st1["ct_uploads"] == st0["ct_uploads"] and st1["ct_downloads"] == st0["ct_downloads"], (st0, st1)
+    for e in encs:
+        e.to_host(True)
+    pub.resident = False
+    houts = pub.execute_batch(compiled, encs)
+    for u in range(11):
+        for name in houts[u].names():
+            assert not houts[u].is_resident(name)
+            assert np.array_equal(houts[u].get(name)[4], outs[u].get(name)[4])
+            assert np.array_equal(again[u].get(name)[4], outs[u].get(name)[4])
 
 
 def test_config3_harris_batch_default_groups_bit_exact():

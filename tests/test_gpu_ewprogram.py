@@ -285,6 +285,32 @@ def test_the_scheduler_fuses_elementwise_runs_and_changes_no_bit(which):
         assert launches[0] - launches[1] >= 5, launches  # the seven calls of the response are one launch
 
 
+def test_a_very_long_dependent_elementwise_chain_is_cut_not_recursed():
+    """r5 advisor: nothing bounded the depth of a deferred expression — 400 dependent negate / subtract ops used to build a
+    400-deep graph of nodes (recursive visit, recursive destructors).  The scheduler now evaluates a chain every 48 nodes;
+    the result is the oracle walk's, bit for bit."""
+    from eva import EvaProgram, Input, Output
+    from eva.ckks import CKKSCompiler
+    from eva.seal import generate_keys
+    from oracle_executor import c_walk
+    prog = EvaProgram('long_chain', vec_size=1024)
+    with prog:
+        x, y = Input('x'), Input('y')
+        acc = x
+        for i in range(400):
+            acc = (y - acc) if i % 2 else (-acc)
+        Output('z', acc * y)
+    prog.set_input_scales(30)
+    prog.set_output_ranges(20)
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(prog)
+    pub, sec = generate_keys(params, 3)
+    enc = pub.encrypt({'x': [i / 1024.0 for i in range(1024)], 'y': [1.0 - i / 2048.0 for i in range(1024)]}, sig)
+    out = pub.execute(compiled, enc)
+    ref, _ = c_walk(pub, compiled, enc, threads=4)
+    for name in ref:
+        assert np.array_equal(out.get(name)[4], ref[name])
+
+
 @pytest.mark.parametrize("live", [2, 6], ids=["wide_256_threads", "narrow_128_threads"])
 def test_throughput_sized_launches_two_coefficients_per_thread(live):
     """>= 2^20 coefficients per launch (here 2^21): the interpreter runs two coefficients per thread — 256-thread workgroups while the
