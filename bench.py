@@ -303,8 +303,10 @@ def dag_leg(reps, cpu_threads):
             "gpu_execute_ms": round(gpu_ms, 3), "gpu_includes": "input upload, hipGraph replay, output download (host valuations)",
             "gpu_execute_resident_ms": round(res_ms, 3),
             "resident_back_to_back_ms": round(b2b_ms, 3), "execute_returns_after_us": round(host_us, 1),
-            "resident_note": "gpu_execute_resident_ms = execute() + synchronize() per call (latency); back to back = the GPU's time per "
-                             "replay with the queue kept full; execute() itself returns to the host after execute_returns_after_us",
+            "resident_note": "gpu_execute_resident_ms = execute() + synchronize() per call (latency); back to back = time per call "
+                             "when the caller issues the next execute() while the previous replay runs (r6: the replays then "
+                             "alternate between the program's twin plans, two chains side by side); execute() itself returns "
+                             "to the host after execute_returns_after_us",
             "roofline": rl(nbytes, gpu_ms * 1e-3, compulsory=comp), "roofline_resident": rl(nbytes, res_ms * 1e-3, compulsory=comp),
             "cpu_walk_ms": dict({"1": round(t1 * 1e3, 1), str(cpu_threads): round(tn * 1e3, 1)},
                                 **({"64": round(t64 * 1e3, 1)} if t64 else {})),
@@ -486,6 +488,13 @@ def dag_configs_leg(reps):
                 res = pub.execute(compiled, enc)
                 pub.synchronize()
                 tr.append(time.perf_counter() - t0)
+            # the same replays with nothing waiting in between: the caller issues while the previous one runs, the replays
+            # alternate between the program's twin plans (public_ctx.h) — time per call with the queues kept full
+            t0 = time.perf_counter()
+            for _ in range(4 * reps):
+                res = pub.execute(compiled, enc)
+            pub.synchronize()
+            b2b_s = (time.perf_counter() - t0) / (4 * reps)
             enc.to_host(True)
             pub.resident = False
             for _ in range(2):
@@ -506,6 +515,7 @@ def dag_configs_leg(reps):
                          "terms": len(kinds), "rotations": kinds.count("RotateLeftConst") + kinds.count("RotateRightConst"),
                          "relinearize": kinds.count("Relinearize"), "rescale": kinds.count("Rescale"),
                          "host_ms": round(host_s * 1e3, 3), "resident_ms": round(res_s * 1e3, 3),
+                         "resident_back_to_back_ms": round(b2b_s * 1e3, 3),
                          "roofline": rl(nbytes, host_s, compulsory=comp), "roofline_resident": rl(nbytes, res_s, compulsory=comp),
                          "cpu_walk_ms": {"1": round(t1 * 1e3, 1), str(min(host_cores(), 64)): round(tn * 1e3, 1)},
                          "bit_exact_vs_oracle": bool(ok)}

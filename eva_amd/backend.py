@@ -72,6 +72,7 @@ _SIGS = {
     "evah_multiply_relinearize_rescale_many": [_vp, _vpp, _vpp, C.c_uint32, C.c_uint32, _vpp],
     "evah_multiply_rescale_relinearize": [_vp, _vp, _vp, C.c_uint32, _vpp],
     "evah_multiply_rescale_relinearize_many": [_vp, _vpp, _vpp, C.c_uint32, C.c_uint32, _vpp],
+    "evah_ctx_busy": [_vp, C.POINTER(C.c_int)],
     "evah_execute": [_vp, _vp, C.c_uint32, _vp, C.c_uint32],
     "evah_elementwise_program": [_vp, _vp, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, _vpp],
     "evah_weighted_sum": [_vp, _vpp, _vpp, C.c_uint32, _vpp],

@@ -216,6 +216,16 @@ int evah_ctx_set_stream(evah_ctx *c, void *s) {
   API_END
 }
 
+int evah_ctx_busy(evah_ctx *c, int *busy) {
+  API_BEGIN
+  use(c);
+  const hipError_t e = hipStreamQuery(c->stream);
+  if (e != hipSuccess && e != hipErrorNotReady) HIPCHK(e);
+  if (e == hipErrorNotReady) (void)hipGetLastError(); // (not an error: clear the runtime's sticky state)
+  *busy = e == hipErrorNotReady ? 1 : 0;
+  API_END
+}
+
 int evah_ctx_sync(evah_ctx *c) {
   API_BEGIN
   use(c);

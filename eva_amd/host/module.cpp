@@ -347,6 +347,8 @@ PYBIND11_MODULE(_eva, m) {
       .def_readwrite("device", &HipPublic::device)
       .def_readwrite("free_eagerly", &HipPublic::free_eagerly)
       .def_readwrite("use_graphs", &HipPublic::use_graphs, "replay repeated executions of one program from a captured hipGraph")
+      .def("_graph_plans", [](HipPublic &p) { return p.graph_plan_count(); }, "captured plans alive (a program found busy by the next call has two)")
+      .def_readwrite("twin_plans", &HipPublic::twin_plans, "a program whose replay is found busy by the next execute() gets a second captured plan on its own queue; calls then go to whichever is idle (EVA_GRAPH_TWIN)")
       .def("drop_graphs", &HipPublic::drop_graphs)
       .def_readwrite("devices", &HipPublic::devices, "device index per member of the multi-GPU modes (a repeated index = several contexts on one GPU)")
       .def_readwrite("shard_mode", &HipPublic::shard_mode, "'' (one device) | 'subdag' | 'limb' | 'dag' — how execute() / execute_batch() use `devices`")

@@ -53,6 +53,10 @@ void evah_ctx_destroy(evah_ctx *ctx);
 int evah_ctx_set_stream(evah_ctx *ctx, void *hip_stream);
 /* Block until all work issued on the context's stream has finished. */
 int evah_ctx_sync(evah_ctx *ctx);
+/* *busy = 1 while work enqueued on this queue has not finished (hipStreamQuery), without waiting: how the host side of
+ * execute() (seal.cpp:104-122) notices that the caller issued a call while the previous one is still running (r6: twin
+ * graph plans) */
+int evah_ctx_busy(evah_ctx *ctx, int *busy);
 /* Bytes currently held in the context's device pool (in use + cached). */
 int evah_ctx_mem_info(evah_ctx *ctx, size_t *in_use, size_t *cached);
 

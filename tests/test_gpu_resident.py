@@ -188,3 +188,36 @@ def test_unreduced_input_words_are_an_error_at_execute():
     v._set_cipher('x', words, good[3])
     out = pub.execute(compiled, v)
     _same(out, pub.execute(compiled, enc))
+
+
+def test_back_to_back_calls_use_twin_graph_plans_and_change_no_bit():
+    """r6: a caller that issues execute() while the previous replay of the program is still running gets a twin plan (the walk
+    captured a second time, own slots and buffers, own queue) and the calls go to whichever plan is idle.  Every result is
+    the oracle walk's of ITS input, whatever plan produced it; a caller that synchronises after every call never has two."""
+    from eva_amd.workloads import harris, image
+    from oracle_executor import c_walk
+    compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(harris())
+    params.poly_modulus_degree = 16384
+    pub, sec = generate_keys(params, 9)
+    encs = [pub.encrypt(image(4096, shift=7 * u), sig) for u in range(3)]
+    refs = [c_walk(pub, compiled, e, threads=8)[0] for e in encs]
+    for u in (0, 1, 2):  # eager walk, capture, first replay — each waited for: one plan
+        out = pub.execute(compiled, encs[u])
+        pub.synchronize()
+        for name, words in refs[u].items():
+            assert np.array_equal(out.get(name)[4], words)
+    n_plans = lambda: pub._graph_plans()
+    one = n_plans()
+    outs = [pub.execute(compiled, encs[i % 3]) for i in range(12)]  # nothing waits in between
+    pub.synchronize()
+    assert n_plans() == one + 1, "a busy plan did not get its twin"
+    for i, out in enumerate(outs):
+        for name, words in refs[i % 3].items():
+            assert np.array_equal(out.get(name)[4], words), f"call {i}"
+    # and with the twin switched off: the same words from the one plan
+    pub.twin_plans = False
+    outs = [pub.execute(compiled, encs[i % 3]) for i in range(6)]
+    pub.synchronize()
+    for i, out in enumerate(outs):
+        for name, words in refs[i % 3].items():
+            assert np.array_equal(out.get(name)[4], words)
