@@ -320,7 +320,7 @@ def dag_leg(reps, cpu_threads):
 BATCH_WORKLOADS = {
     # name -> (program builder, N, primes, what the line calls it, default instances per batched handle (None = the context's))
     "sobel": ("sobel_example", 16384, 6, "independent Sobel DAGs (examples/image_processing.py:39-63), 64x64 images", None),
-    "harris": ("harris", 32768, 9, "independent Harris corner DAGs (examples/image_processing.py:65-100), 64x64 images", 8),
+    "harris": ("harris", 32768, 9, "independent Harris corner DAGs (examples/image_processing.py:65-100), 64x64 images", 12),
 }
 
 

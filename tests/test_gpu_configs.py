@@ -77,11 +77,11 @@ def test_config3_harris_batch_n32768_l8_every_instance_bit_exact():
 
 
 def test_config3_harris_batch_default_groups_bit_exact():
-    """the bench leg's own shape: groups of 16 instances (two full groups and a ragged one), sampled across them"""
+    """the bench leg's own shape: groups of 12 instances (three full groups and a ragged one), every instance checked"""
     compiled, params, sig = CKKSCompiler(config={'warn_vec_size': 'false'}).compile(_harris())
     pad_chain(params, 9, 32768)
     pub, sec = generate_keys(params, 6)
-    pub.batch_chunk = 16
+    pub.batch_chunk = 12
     encs = [pub.encrypt(_image(4096, shift=u), sig) for u in range(4)]
     inputs = [encs[b % 4] for b in range(37)]
     outs = pub.execute_batch(compiled, inputs)
