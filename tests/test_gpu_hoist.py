@@ -427,6 +427,47 @@ def test_window_sums_general_shapes_take_the_unfused_path():
         e.g.rotate_weighted_sums([([(A, 1), (A, 65)], [[W[0][0], None]])])
 
 
+@pytest.mark.parametrize("sums", [1, 2])
+@pytest.mark.parametrize("case", ["transparent", "several_zeros"])
+@pytest.mark.parametrize("cfg", [CONFIGS[2], CONFIGS[4]], ids=lambda c: f"N{c[0]}")
+def test_uniform_weight_window_sums_with_zero_digit_coefficients(cfg, case, sums):
+    """r6: the same two cases through the linear mod-down (uniform weights): k_hoist_fix's corrections land in the products
+    the weighted sums are formed from, the guarded fallback recomputes a transparent source; also as a batched handle of
+    three instances with zeros in two of them"""
+    e = env(cfg)
+    l = e.k - 1
+    steps = [0, 1, 65, -3]
+    for st in steps[1:]:
+        e.key_for(st)
+    insts = []
+    for b in range(3):
+        a = e.rand(2, l)
+        if b != 1:
+            if case == "transparent":
+                a[1] = 0
+            else:
+                for limb, count in ((0, 5), (min(2, l - 1), 3), (l - 1, 1)):
+                    x = e.rng.integers(1, e.primes[limb], size=e.N, dtype=np.uint64)
+                    x[e.rng.choice(e.N, size=count, replace=False)] = 0
+                    a[1][limb] = e.o.ntt(limb, x)
+        insts.append(a)
+    uw = [[_uniform_pt(e, l) for _ in steps] for _ in range(sums)]
+    W = [[e.g.uniform_pt(v, 2.0 ** 10) for _, v in row] for row in uw]
+    wts = [[full for full, _ in row] for row in uw]
+    # one instance
+    A = e.g.upload_ct(insts[0], 2.0 ** 20)
+    outs = e.g.rotate_weighted_sums([([(A, st) for st in steps], W)])
+    for o, r in zip(outs, _window_oracle(e, [(insts[0], st) for st in steps], wts)):
+        assert np.array_equal(o.download(), r), case
+    # a batched handle of the three
+    H = e.g.stack([e.g.upload_ct(a, 2.0 ** 20) for a in insts])
+    outs = e.g.rotate_weighted_sums([([(H, st) for st in steps], W)])
+    for f, o in enumerate(outs):
+        for b in range(3):
+            want = _window_oracle(e, [(insts[b], st) for st in steps], wts)[f]
+            assert np.array_equal(o.unstack(b).download(), want), (case, f, b)
+
+
 @pytest.mark.parametrize("case", ["transparent", "several_zeros"])
 def test_window_sums_with_zero_digit_coefficients(case):
     """k_hoist_fix's correction and, beyond its capacity, the guarded fallback (unhoisted rotations + k_window_sums)"""
