@@ -76,10 +76,30 @@ def test_random_parameters(seed):
         assert all(np.array_equal(m.download(), e.o.rescale(relin)) for m in many)
         outs = e.g.rescale_many([A2, B2], 3)
         assert np.array_equal(outs[0].download(), e.o.rescale(a2)) and np.array_equal(outs[1].download(), e.o.rescale(b2))
+        # r6: Mul -> Rescale -> Relinearize as one call (product formed where the rescale reads it), also as a square
+        mrr = e.o.relinearize(e.o.rescale(e.o.multiply(a2, b2)), key)
+        assert np.array_equal(e.g.multiply_rescale_relinearize(A2, B2, 3).download(), mrr)
+        sq = e.g.multiply_rescale_relinearize_many([A2, B2], [A2, B2], 3)
+        assert np.array_equal(sq[0].download(), e.o.relinearize(e.o.rescale(e.o.square(a2)), key))
+        assert np.array_equal(sq[1].download(), e.o.relinearize(e.o.rescale(e.o.square(b2)), key))
     outs = e.g.relinearize_many([A3, up(a3f)])
     assert all(np.array_equal(m.download(), relin) for m in outs)
     outs = e.g.rotate_pairs([A2, B2], [steps, steps])
     assert np.array_equal(outs[0].download(), rot) and np.array_equal(outs[1].download(), e.o.rotate(b2, steps, gk))
+    # r6: a window with uniform (scalar) weights — the linear mod-down — and the same window with a general weight
+    steps2 = next(st for st in (-steps, 1, 2, 5) if abs(st) < N // 2 and e.g.galois_elt_from_step(st) != e.g.galois_elt_from_step(steps))
+    gk2 = e.rand_key()  # (a second key for the same element would replace the first)
+    e.g.upload_galois_key(e.g.galois_elt_from_step(steps2), gk2)
+    uv = np.array([int(np_rng.integers(0, e.primes[i])) for i in range(l)], dtype=np.uint64)
+    ufull = np.repeat(uv[:, None], N, axis=1)
+    U = e.g.uniform_pt(uv, 2.0 ** 8)
+    rot2 = e.o.rotate(a2, steps2, gk2)
+    want = e.o.add(e.o.add(e.o.multiply_plain(rot, ufull), e.o.multiply_plain(rot2, ufull)), e.o.multiply_plain(a2, pt))
+    got = e.g.rotate_weighted_sums([([(A2, steps), (A2, steps2), (A2, 0)], [[U, U, PT]])])[0]
+    assert np.array_equal(got.download(), want)
+    want_g = e.o.add(e.o.multiply_plain(rot, pt), e.o.multiply_plain(rot2, ufull))
+    got_g = e.g.rotate_weighted_sums([([(A2, steps), (A2, steps2)], [[PT, U]])])[0]
+    assert np.array_equal(got_g.download(), want_g)
     batch = e.g.stack([e.g.upload_ct(a3, 2.0 ** 8), e.g.upload_ct(a3, 2.0 ** 8)]) if drop == 0 else None
     if batch is not None:
         d = e.g.relinearize(batch).download()
