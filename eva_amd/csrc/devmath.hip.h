@@ -43,6 +43,7 @@ struct DevCtx {
   const ulonglong2 *invq;      // [k][k]  invq[a*k+b] = (q_a^-1 mod q_b, Shoup quotient)
   const u64 *halfmod;          // [k][k]  (q_a >> 1) mod q_b
   const ulonglong2 *modq;      // [k][k]  modq[a*k+b] = (q_a mod q_b, Shoup quotient); (0, 0) on the diagonal
+  const ulonglong2 *plinv;     // [k][k]  plinv[a*k+b] = (P q_a^-1 mod q_b, Shoup quotient), P = primes[k-1]; (0, 0) for b == a, b == k-1
   uint32_t N, logN, k;
   // Limb -> prime map of the context's values: limb j of a ciphertext / plaintext is modulo
   // primes[p0 + j * pstep].  An ordinary context has (0, 1).  A limb-sharded context (shard s of G,

@@ -307,6 +307,13 @@ struct Tunables {
   // the key switch of d2.  Measured (r06_tuning_notes.md): eager walks gain (config 5 1.77 -> 1.70 ms), replayed hipGraphs
   // do not — a fork / join inside a graph costs what the overlap returns — so the default is one stream
   bool side_stream = false;
+  // EVAH_CHAIN_STEP (1): evah_multiply_rescale_relinearize(_many) as the six-launch chain step of ntt_chain.hip.h (the rescaled d2
+  // formed in coefficient form, the rescale of d0 / d1 sharing the mod-down's forward transform); 0 = the r6 launch set
+  // (rescale of the three polynomials, then the key switch: nine or ten launches)
+  // EVAH_CHAIN_FUSE_BLOCKS (2048): digit launches of at most this many 2048-coefficient tiles recompute t_J per output limb
+  // inside the digit conversion's launch (one launch less); above it t is stored once and OpKsDigit reads it
+  bool chain_step = true;
+  uint32_t chain_fuse_blocks = 2048;
   // EVAH_LDS_EXTRA (0): bytes of dynamic LDS added to every ntt_pass_kernel launch — an occupancy probe for the
   // tuning notes (fewer workgroups per CU), never set in production
   uint32_t lds_extra = 0;
@@ -342,6 +349,8 @@ struct Tunables {
     count("EVAH_LDS_EXTRA", t.lds_extra);
     flag("EVAH_HOIST_MAP", t.hoist_map);
     flag("EVAH_SIDE_STREAM", t.side_stream);
+    flag("EVAH_CHAIN_STEP", t.chain_step);
+    count("EVAH_CHAIN_FUSE_BLOCKS", t.chain_fuse_blocks);
     count("EVAH_HOIST_V", t.hoist_v);
     if (const char *e = std::getenv("EVAH_KS_GROUPS")) t.ks_groups = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("EVAH_KS_THREADS")) {

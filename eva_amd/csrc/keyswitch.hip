@@ -53,7 +53,7 @@ static void launch_ks_inner_plr(evah_ctx *c, const u64 *target, const u64 *scrat
   auto go = [&](auto kernel, const auto &mt, const auto &at) {
     hipLaunchKernelGGL(kernel, dim3(n_tiles * kb.n, kb.ni), dim3(tile >> LR), lds, c->stream, c->dev, target, kb.target_bs, scratch,
                        kb.scratch_bs, kb.keys, prod, kb.prod_bs, l, kb.i0, logC, n_tiles, kb.n, kb.targets, mt, kb.istep,
-                       kb.nout ? kb.nout : l + 1, kb.r_out, at, kb.lazy_out ? 1 : 0);
+                       kb.nout ? kb.nout : l + 1, kb.r_out, at, (kb.lazy_out ? 1 : 0) | (kb.diag ? 2 : 0), kb.fold_row);
   };
   if (kb.r_out && ((tile >> LR) > 64 || kb.istep != 1)) throw std::logic_error("fused special-row inverse pass needs the one-wave key-switch kernel");
   if (kb.fold && kb.istep != 1) throw std::logic_error("the folded key-switch forms are not used on limb shards");
@@ -504,6 +504,77 @@ int evah_multiply_relinearize_rescale(evah_ctx *c, const evah_ct *a, const evah_
 // the order lazy relinearization gives a product under the waterline rescalers (seal_executor.h:164 / :162, :213-214, :200).
 // The size-3 product is never written — its polynomials are formed where the rescale reads them (OpMulPolyIntt,
 // OpModDownMul).  Same ciphertext, bit for bit, as the three calls.
+// The chain step in six launches (ntt_chain.hip.h: the rescaled d2 formed in coefficient form where the digit decomposition
+// wants it; the rescale of d0 / d1 and the mod-down sharing one forward transform through (P L^-1) d_K folded into the inner
+// products).  For ordinary contexts with whole keys and full transform tiles; anything else keeps the forms below.
+static bool chain_step_applies(evah_ctx *c, uint32_t lp, uint32_t n) {
+  (void)lp;
+  (void)n;
+  return c->tun.chain_step && c->tun.fuse_mac && c->tun.fold_pa && std::max(1, c->tun.ks_groups) == 1 && c->dev.pstep == 1 &&
+         c->dev.p0 == 0 && !c->dev.guard && c->N >= ((uint32_t)NTT_THREADS << 3) && c->sh->relin.rows == c->k;
+}
+static void chain_step(evah_ctx *c, const MulTab &tab, uint32_t n, uint32_t l, u64 *out_d) {
+  const uint32_t lp = l - 1, last = l - 1, sp = c->k - 1;
+  const size_t N = c->N, ops = (size_t)lp * N, pps = (size_t)(lp + 1) * N;
+  const KeyDev &key = c->sh->relin;
+  if (key.n_digits < lp) throw std::runtime_error("key switching key has too few digits");
+  Scratch t2(c, (size_t)n * l * N), r01(c, (size_t)n * 2 * N);
+  // 1. products + contiguous inverse pass: every limb of d2, limb L of d0 and d1
+  OpChainIntt::Params ip{tab, t2.d, r01.d, l};
+  launch_pass_p<false, true, OpChainIntt>(c, c->logN / 2, ip, n * (l + 2));
+  // 2. t_J = rescaled d2 in coefficient form, digit conversion, strided forward pass
+  KsBatch kb;
+  kb.n = n;
+  kb.scratch_bs = (size_t)(lp + 1) * lp * N;
+  kb.prod_bs = (size_t)2 * (lp + 1) * N;
+  const uint32_t ks_tile = std::min<uint32_t>(c->N, (uint32_t)c->tun.ks_threads << 2);
+  kb.mac3 = c->tun.mac3 && c->all_tb && lp <= 15 && (ks_tile >> 2) <= 64 && key.d_split;
+  for (uint32_t b = 0; b < n; b++) kb.keys.key[b] = kb.mac3 ? key.d_split : key.d;
+  kb.mul = &tab;
+  kb.fold = true;
+  kb.fold_row = last;
+  kb.diag = true;
+  kb.i0 = 0;
+  kb.ni = lp + 1;
+  Scratch sc(c, n * kb.scratch_bs);
+  const uint32_t dig_jobs = n * (lp + 1) * lp;
+  if (fuse_small_launch(c, dig_jobs) && (uint64_t)dig_jobs * (c->N >> 11) <= c->tun.chain_fuse_blocks) {
+    OpChainDigit::Params dp{t2.d, sc.d, l, kb.scratch_bs};
+    launch_inv2<OpChainDigit, true>(c, dp, dig_jobs);
+  } else {
+    Scratch t(c, (size_t)n * lp * N);
+    OpChainT::Params tp{t2.d, t.d, l};
+    launch_inv2<OpChainT, false>(c, tp, n * lp);
+    OpKsDigit::Params dp{t.d, sc.d, lp, (size_t)lp * N, kb.scratch_bs, 0, lp + 1};
+    dp.diag = true;
+    launch_pass_p<true, false, OpKsDigit>(c, (c->logN + 1) / 2, dp, dig_jobs);
+    // (t is released in stream order: the digit pass above is enqueued before anything that could reuse it)
+  }
+  // 3. contiguous forward pass + key inner product + (P L^-1) d_K; the special limb's contiguous inverse pass when the
+  //    mod-down is a small launch
+  Scratch prod(c, (size_t)n * 2 * pps), r(c, (size_t)n * 2 * N);
+  const bool small_md = fuse_small_launch(c, 2 * n * lp);
+  if (small_md && c->tun.fuse_special_inv && (ks_tile >> 2) <= 64) kb.r_out = r.d;
+  launch_ks_inner(c, c->logN / 2, nullptr, sc.d, kb, prod.d, lp);
+  // 4. / 5. one forward transform per (K, i) for the rescale of d_K and the mod-down of prod_K
+  OpRsMd::Params fp{r01.d, r.d, out_d, ops, last, sp, lp};
+  OpModDown::Params mp{r.d, N, prod.d, pps, nullptr, 0, 0, out_d, ops, sp, lp};
+  if (small_md) {
+    if (!kb.r_out) {
+      OpPlain::Params spp{prod.d + (size_t)lp * N, r.d, pps, N, 1, sp, 1, {}};
+      launch_pass_p<false, true, OpPlain>(c, c->logN / 2, spp, 2 * n);
+    }
+    launch_inv2<OpRsMd, true>(c, fp, 2 * n * lp);
+  } else {
+    OpPlain::Params spp{prod.d + (size_t)lp * N, r.d, pps, N, 1, sp, 1, {}};
+    ntt_inverse<OpPlain>(c, spp, 2 * n);
+    OpPlain::Params lpp{r01.d, r01.d, N, N, 1, last, 1, {}}; // second (strided) pass of limb L of d0 / d1, in place
+    launch_pass_p<true, true, OpPlain>(c, (c->logN + 1) / 2, lpp, 2 * n);
+    launch_pass_p<true, false, OpRsMd>(c, (c->logN + 1) / 2, fp, 2 * n * lp);
+  }
+  launch_pass_p<false, false, OpModDown>(c, c->logN / 2, mp, 2 * n * lp);
+}
+
 static void mul_rescale_relin(evah_ctx *c, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n, uint32_t divisor_bits, evah_ct **outs) {
   if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("multiply_rescale_relinearize_many handles 1..64 products per call");
   if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
@@ -530,7 +601,9 @@ static void mul_rescale_relin(evah_ctx *c, const evah_ct *const *as, const evah_
   Buffer *ob = buf_new(c, (size_t)n * 2 * ops);
   try {
     std::vector<const KeyDev *> keys(n, &c->sh->relin);
-    if (!c->tun.side_stream) {
+    if (chain_step_applies(c, lp, n)) {
+      chain_step(c, tab, n, l, ob->d);
+    } else if (!c->tun.side_stream) {
       // one stream (the default: inside a replayed hipGraph a fork / join costs more than the overlap returns — config 5
       // 1.56 ms either way, r06_tuning_notes.md): the rescale of the three polynomials as one launch set, then the key
       // switch of d2' with P * d0', P * d1' folded into its inner products, as evah_relinearize does on a stored ciphertext

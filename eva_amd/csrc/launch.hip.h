@@ -29,6 +29,10 @@ template <> struct OpClass<OpMulPolyIntt> { static constexpr int fwd_a = KC_NTT_
 template <> struct OpClass<OpModDownMul> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 template <int M> struct OpClass<OpRRT<M>> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 template <int M> struct OpClass<OpRRLastT<M>> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
+template <> struct OpClass<OpChainIntt> { static constexpr int fwd_a = KC_NTT_A, fwd_b = KC_NTT_B; };
+template <> struct OpClass<OpChainT> { static constexpr int fwd_a = KC_INTT_B, fwd_b = KC_INTT_B; };
+template <> struct OpClass<OpChainDigit> { static constexpr int fwd_a = KC_KSDIGIT_A, fwd_b = KC_KSDIGIT_B; };
+template <> struct OpClass<OpRsMd> { static constexpr int fwd_a = KC_MODDOWN_A, fwd_b = KC_MODDOWN_B; };
 
 template <int P, int LR, bool STRIDED, bool INVERSE, class Op>
 static void launch_pass(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
@@ -138,7 +142,10 @@ struct KsBatch { // one launch worth of key-switches: regular strides, irregular
   bool lazy_out = false;       // the data rows of prod may be any 64-bit representative (consumer: the relinearize + rescale combine)
   uint32_t istep = 1, nout = 0; // output limbs I = i0 + y * istep; nout = rows per polynomial of prod (0: l + 1)
   u64 *r_out = nullptr; // != nullptr: the special row leaves as the first inverse pass of the mod-down (INVSP)
-};// second (contiguous) pass of the digit transforms fused with the key inner product (keyswitch.hip)
+  bool diag = false;    // the diagonal digit comes from scratch too (no NTT-form target: the chain step, ntt_chain.hip.h)
+  uint32_t fold_row = ~0u; // KS_FOLDMUL: != ~0u adds (P q_a^-1) d_K, a = fold_row, instead of P d_K
+};
+// second (contiguous) pass of the digit transforms fused with the key inner product (keyswitch.hip)
 void launch_ks_inner(evah_ctx *c, int P, const u64 *target, const u64 *scratch, const KsBatch &key, u64 *prod, uint32_t l);
 
 template <class Op> static void ntt_forward(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
@@ -179,6 +186,31 @@ template <class Op> static void launch_inv_fwd(evah_ctx *c, const typename Op::P
   case 7: launch_inv_fwd_p<7, Op>(c, prm, jobs); break;
   case 8: launch_inv_fwd_p<8, Op>(c, prm, jobs); break;
   case 9: launch_inv_fwd_p<9, Op>(c, prm, jobs); break;
+  default: throw std::runtime_error("unsupported poly_modulus_degree for the fused inverse/forward pass");
+  }
+}
+// two strided inverse passes + combine (+ strided forward pass): ntt_inv2_kernel (ntt_chain.hip.h)
+template <int P, class Op, bool FWD, int LR> static void launch_inv2_plr(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  ProfScope ps(c, OpClass<Op>::fwd_a);
+  const uint32_t tile = (uint32_t)NTT_THREADS << LR, n_tiles = c->N / tile;
+  const int logC = (int)ilog2(tile) - P;
+  const size_t lds = ((((size_t)1 << logC) * lds_sub_stride<P>() + 1) & ~(size_t)1) * sizeof(u64) + 2 * ((size_t)1 << P) * sizeof(ulonglong2);
+  dim3 grid = Op::grid(prm, jobs);
+  grid.x *= n_tiles;
+  hipLaunchKernelGGL((ntt_inv2_kernel<P, LR, Op, FWD>), grid, dim3(NTT_THREADS), lds, c->stream, c->dev, prm, (int)ilog2(n_tiles));
+  HIPCHK(hipGetLastError());
+}
+template <class Op, bool FWD> static void launch_inv2(evah_ctx *c, const typename Op::Params &prm, uint32_t jobs) {
+  auto go = [&](auto ptag) {
+    constexpr int P = decltype(ptag)::value;
+    if (c->tun.small_lr == 2) launch_inv2_plr<P, Op, FWD, 2>(c, prm, jobs);
+    else launch_inv2_plr<P, Op, FWD, 3>(c, prm, jobs);
+  };
+  switch ((c->logN + 1) / 2) {
+  case 6: go(std::integral_constant<int, 6>{}); break;
+  case 7: go(std::integral_constant<int, 7>{}); break;
+  case 8: go(std::integral_constant<int, 8>{}); break;
+  case 9: go(std::integral_constant<int, 9>{}); break;
   default: throw std::runtime_error("unsupported poly_modulus_degree for the fused inverse/forward pass");
   }
 }

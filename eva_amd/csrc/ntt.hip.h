@@ -644,3 +644,4 @@ ntt_inv_fwd_kernel(DevCtx cx, typename Op::Params prm, int log_tiles) {
 #include "ntt_window_sum.hip.h" // moddown_sum_kernel: the mod-down's second pass with a convolution window's sums as its epilogue
 #include "ntt_ks_inner.hip.h"   // ks_inner_kernel: second pass of the digit transforms fused with the key inner product; operand tables
 #include "ntt_ops.hip.h"        // the fused load / store ops of the passes (OpPlainT, OpMulIntt, OpKsDigit, OpModDownT, OpRR*)
+#include "ntt_chain.hip.h"      // the chain step Mul -> Rescale -> Relinearize in six launches: ntt_inv2_kernel and its ops

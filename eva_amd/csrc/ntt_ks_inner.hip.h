@@ -99,7 +99,11 @@ __global__ void __launch_bounds__(MAXT)
 ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, const u64 *__restrict__ scratch_b,
                 size_t scratch_bs, KsKeys keys, u64 *__restrict__ prod_b, size_t prod_bs, uint32_t l, uint32_t i0,
                 int logC, uint32_t n_tiles, uint32_t n_inst, PtrTab targets, KsMulArg<MODE> mul, uint32_t istep,
-                uint32_t nout, u64 *__restrict__ r_out, KsAddArg<MODE> adds, int lazy_out) {
+                uint32_t nout, u64 *__restrict__ r_out, KsAddArg<MODE> adds, int flags, uint32_t fold_row) {
+  // flags: bit 0 = lazy_out; bit 1 = diag — the diagonal digit I == J comes from scratch like every other (first-pass
+  // intermediate of its forward transform) instead of an NTT-form target (the chain step, ntt_chain.hip.h).
+  // fold_row (KS_FOLDMUL): ~0u adds P d_K; a = fold_row adds (P q_a^-1) d_K (DevCtx::plinv — the chain step's folded rescale)
+  const bool lazy_out = flags & 1, diag = flags & 2;
   constexpr bool MUL = MODE == KS_MUL;
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   if (cx.skipped()) return;
@@ -177,7 +181,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
         d[it].y = product_poly(msrc, 2, off + 1, pm);
       }
     } else {
-      const u64 *src = (I == J ? target + (size_t)Irow * N : scratch + ((size_t)Irow * l + J) * N) + gbase;
+      const u64 *src = (I == J && !diag ? target + (size_t)Irow * N : scratch + ((size_t)Irow * l + J) * N) + gbase;
 #pragma unroll
       for (int it = 0; it < NPAIR; it++) d[it] = *reinterpret_cast<const ulonglong2 *>(src + 2 * (threadIdx.x + it * T));
     }
@@ -188,7 +192,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   // the 8 prefetch registers (and the tile's ds_write) for the radix-2^30 sums.
   u64 *lin = reinterpret_cast<u64 *>(twl + (C << P)); // [256] after the twiddle heaps
   auto dma_digits = [&](uint32_t J) {
-    const u64 *src = (I == J ? target + (size_t)Irow * N : scratch + ((size_t)Irow * l + J) * N) + gbase;
+    const u64 *src = (I == J && !diag ? target + (size_t)Irow * N : scratch + ((size_t)Irow * l + J) * N) + gbase;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads of `lin` issued so far have returned
 #pragma unroll
     for (int it = 0; it < NPAIR; it++)
@@ -229,7 +233,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
         k1r[it].x = ((u64)b.y << 32) | b.x;
         k1r[it].y = ((u64)b.w << 32) | b.z;
       }
-      if (I == J) { // NTT form already: the tile as it lies in `lin`
+      if (I == J && !diag) { // NTT form already: the tile as it lies in `lin`
 #pragma unroll
         for (int it = 0; it < NPAIR; it++) {
           const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(lin + 2 * (threadIdx.x + it * T));
@@ -256,7 +260,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
           val[2 * it + 1] = lds[sb * SP + lds_pad<P>(e + 1)];
         }
       }
-    } else if (I == J) { // already in NTT form mod q_J: use the key-switch target directly
+    } else if (I == J && !diag) { // already in NTT form mod q_J: use the key-switch target directly
 #pragma unroll
       for (int it = 0; it < NPAIR; it++) {
         val[2 * it] = dreg[it].x;
@@ -349,7 +353,8 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   if constexpr (MODE == KS_FOLDMUL || MODE == KS_FOLDADD) {
     { // after the digit loop, where its prefetch registers are free (as a prologue the block cost 32 VGPRs: 147, 3 waves
       // per SIMD).  No branch: the special row multiplies by modq[P][P] = (0, 0) — P = 0 mod P — and reads a row that exists
-      const ulonglong2 Pm = cx.modq[(size_t)(cx.k - 1) * cx.k + kap]; // (P mod q_I, Shoup quotient)
+      const ulonglong2 Pm = (MODE == KS_FOLDMUL && fold_row != ~0u) ? cx.plinv[(size_t)fold_row * cx.k + kap]
+                                                                     : cx.modq[(size_t)(cx.k - 1) * cx.k + kap]; // (P mod q_I, Shoup quotient)
       const size_t off = (size_t)(Irow < l ? Irow : l - 1) * N + gbase;
 #pragma unroll
       for (int it = 0; it < NPAIR; it++) {

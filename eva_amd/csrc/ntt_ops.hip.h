@@ -149,6 +149,7 @@ struct OpKsDigit {
     uint32_t istep = 1;      // 1: a slice of all limbs; G: the limbs a shard of G owns (scratch rows are then local: iy)
     uint32_t t_split = 1, t_rows = 0; // digit J sits at row (J % t_split) * t_rows + J / t_split of t (an all-gathered
                                       // buffer is shard-major); t_split == 1: row J
+    bool diag = false; // the diagonal I == J is transformed as well (no NTT-form target exists: the chain step, ntt_chain.hip.h)
   };
   struct Job {
     uint32_t prime, digit;
@@ -162,7 +163,7 @@ struct OpKsDigit {
   static __device__ __forceinline__ bool setup(const DevCtx &cx, const Params &p, uint32_t J, uint32_t iy,
                                                uint32_t b, Job &j) {
     const uint32_t I = p.i0 + iy * p.istep;
-    if (I == J) return false;
+    if (I == J && !p.diag) return false;
     j.digit = J;
     j.prime = (I == p.l) ? cx.k - 1 : I;
     // t_J < q_J: when q_J <= 8 q_kappa the digit is already a valid lazy input (< 12 q_kappa)

@@ -69,17 +69,18 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     c->stream = c->own;
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
-    // ---- tables: [primes k][tw_fwd k*N][tw_inv k*N][invq k*k][modq k*k][halfmod k*k]
+    // ---- tables: [primes k][tw_fwd k*N][tw_inv k*N][invq k*k][modq k*k][plinv k*k][halfmod k*k]
     const size_t sz_pr = sizeof(DevPrime) * k, sz_tw = sizeof(ulonglong2) * (size_t)k * N,
                  sz_iq = sizeof(ulonglong2) * (size_t)k * k, sz_hm = sizeof(u64) * (size_t)k * k;
-    const size_t total = sz_pr + 2 * sz_tw + 2 * sz_iq + sz_hm;
+    const size_t total = sz_pr + 2 * sz_tw + 3 * sz_iq + sz_hm;
     std::vector<unsigned char> host(total);
     auto *hp = reinterpret_cast<DevPrime *>(host.data());
     auto *hf = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr);
     auto *hi = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr + sz_tw);
     auto *hq = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr + 2 * sz_tw);
     auto *hm = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr + 2 * sz_tw + sz_iq);
-    auto *hh = reinterpret_cast<u64 *>(host.data() + sz_pr + 2 * sz_tw + 2 * sz_iq);
+    auto *hl = reinterpret_cast<ulonglong2 *>(host.data() + sz_pr + 2 * sz_tw + 2 * sz_iq);
+    auto *hh = reinterpret_cast<u64 *>(host.data() + sz_pr + 2 * sz_tw + 3 * sz_iq);
     for (uint32_t i = 0; i < k; i++) {
       const u64 q = c->primes[i];
       const u64 psi = minimal_primitive_root(N, q), psi_inv = invmod(psi, q);
@@ -126,9 +127,13 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
         if (a == i) {
           hq[a * k + i] = make_ulonglong2(0, 0);
           hm[a * k + i] = make_ulonglong2(0, 0);
+          hl[a * k + i] = make_ulonglong2(0, 0);
           hh[a * k + i] = 0;
         } else {
           u64 inv = invmod(qa % q, q);
+          // P q_a^-1 mod q_i (P = the special prime; 0 under P itself): the chain step's folded rescale (DevCtx::plinv)
+          const u64 pl = mulmod(c->primes[k - 1] % q, inv, q);
+          hl[a * k + i] = make_ulonglong2(pl, shoup(pl, q));
           hq[a * k + i] = make_ulonglong2(inv, shoup(inv, q));
           hm[a * k + i] = make_ulonglong2(qa % q, shoup(qa % q, q));
           hh[a * k + i] = (qa >> 1) % q;
@@ -147,7 +152,8 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     c->dev.tw_inv = reinterpret_cast<const ulonglong2 *>(base + sz_pr + sz_tw);
     c->dev.invq = reinterpret_cast<const ulonglong2 *>(base + sz_pr + 2 * sz_tw);
     c->dev.modq = reinterpret_cast<const ulonglong2 *>(base + sz_pr + 2 * sz_tw + sz_iq);
-    c->dev.halfmod = reinterpret_cast<const u64 *>(base + sz_pr + 2 * sz_tw + 2 * sz_iq);
+    c->dev.plinv = reinterpret_cast<const ulonglong2 *>(base + sz_pr + 2 * sz_tw + 2 * sz_iq);
+    c->dev.halfmod = reinterpret_cast<const u64 *>(base + sz_pr + 2 * sz_tw + 3 * sz_iq);
     c->dev.N = N;
     c->dev.logN = c->logN;
     c->dev.k = k;

@@ -163,14 +163,24 @@ def test_multiply_relinearize_rescale_fused_bit_exact(cfg):
         e.g.multiply_relinearize_rescale(e.g.upload_ct(e.rand(3, e.k - 1), 2.0 ** 20), e.g.upload_ct(e.rand(2, e.k - 1), 2.0 ** 20), 30)
 
 
+# (EVAH_SIDE_STREAM, EVAH_CHAIN_STEP, EVAH_CHAIN_FUSE_BLOCKS): the r6 launch set with / without the side stream, and the
+# six-launch chain step (ntt_chain.hip.h) with t_J recomputed per output limb (default) and stored once (0)
+CHAIN_MODES = [("1", "0", None), ("0", "0", None), ("0", "1", None), ("0", "1", "0")]
+
+
 @pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"N{c[0]}")
-@pytest.mark.parametrize("side", ["1", "0"])
-def test_multiply_rescale_relinearize_fused_bit_exact(cfg, side, monkeypatch):
+@pytest.mark.parametrize("mode", CHAIN_MODES, ids=lambda m: f"side{m[0]}-chain{m[1]}-fuse{m[2]}")
+def test_multiply_rescale_relinearize_fused_bit_exact(cfg, mode, monkeypatch):
     """r6: evah_multiply_rescale_relinearize(_many) — the Mul -> Rescale -> Relinearize chain of lazy relinearization, the
-    size-3 product never in memory, the rescale of d0 / d1 on the queue's side stream beside the key switch of d2 — ==
-    the oracle's three separate calls; squares (a is b), a shared operand, a mod-switched view, with and without the side
-    stream, every level down to the last key switch (one limb left)."""
+    size-3 product never in memory — == the oracle's three separate calls; squares (a is b), a shared operand, a
+    mod-switched view, every level down to the last key switch (one limb left).  Launch forms: the rescale of d0 / d1 on
+    the queue's side stream beside the key switch of d2, the same on one stream, and the six-launch chain step (the
+    rescaled d2 formed in coefficient form, d0 / d1 rescaled by the mod-down's forward transform) in both of its shapes."""
+    side, chain, fuse = mode
     monkeypatch.setenv("EVAH_SIDE_STREAM", side)
+    monkeypatch.setenv("EVAH_CHAIN_STEP", chain)
+    if fuse is not None:
+        monkeypatch.setenv("EVAH_CHAIN_FUSE_BLOCKS", fuse)
     e = Env(*cfg)
     key = e.rand_key()
     e.g.upload_relin_key(key)
@@ -204,9 +214,12 @@ def test_multiply_rescale_relinearize_fused_bit_exact(cfg, side, monkeypatch):
     e.g.close()
 
 
-def test_multiply_rescale_relinearize_config5_shape_bit_exact():
+@pytest.mark.parametrize("chain", ["1", "0"])
+def test_multiply_rescale_relinearize_config5_shape_bit_exact(chain, monkeypatch):
     """the shape it was built for: one square at N = 2^16, l = 12 of 13 primes (BASELINE config 5's chain step), eager and
-    from inside a captured graph replayed three times"""
+    from inside a captured graph replayed three times; then four products in one call (the chain step's launches are no
+    longer latency-sized: stored t, separate inverse passes before the shared forward transform)"""
+    monkeypatch.setenv("EVAH_CHAIN_STEP", chain)
     N, bits = 65536, [60] * 13
     e = Env(N, bits)
     key = e.rand_key()
@@ -223,6 +236,14 @@ def test_multiply_rescale_relinearize_config5_shape_bit_exact():
     e.g.sync()
     assert np.array_equal(out.download(), want)
     e.g.graph_free(graph)
+    b = e.rand(2, 12)
+    B = e.g.upload_ct(b, 2.0 ** 40)
+    outs = e.g.multiply_rescale_relinearize_many([A, A, B, B], [A, B, B, A], 60)
+    ab = e.o.relinearize(e.o.rescale(e.o.multiply(a, b)), key)
+    assert np.array_equal(outs[0].download(), want)
+    assert np.array_equal(outs[1].download(), ab)
+    assert np.array_equal(outs[2].download(), e.o.relinearize(e.o.rescale(e.o.square(b)), key))
+    assert np.array_equal(outs[3].download(), e.o.relinearize(e.o.rescale(e.o.multiply(b, a)), key))
     e.g.close()
 
 
