@@ -310,10 +310,12 @@ struct Tunables {
   // EVAH_CHAIN_STEP (1): evah_multiply_rescale_relinearize(_many) as the six-launch chain step of ntt_chain.hip.h (the rescaled d2
   // formed in coefficient form, the rescale of d0 / d1 sharing the mod-down's forward transform); 0 = the r6 launch set
   // (rescale of the three polynomials, then the key switch: nine or ten launches)
-  // EVAH_CHAIN_FUSE_BLOCKS (2048): digit launches of at most this many 2048-coefficient tiles recompute t_J per output limb
+  // EVAH_CHAIN_FUSE_BLOCKS (256): digit launches of at most this many 2048-coefficient tiles recompute t_J per output limb
   // inside the digit conversion's launch (one launch less); above it t is stored once and OpKsDigit reads it
-  bool chain_step = true;
-  uint32_t chain_fuse_blocks = 2048;
+  // EVAH_CHAIN_BATCHED (1): evah_execute defers Mul -> Rescale -> Relinearize chains on batched handles as well (the instances of
+  // a handle become entries of the fused call's launch set); 0 = the three batched calls
+  bool chain_step = true, chain_batched = true;
+  uint32_t chain_fuse_blocks = 256;
   // EVAH_LDS_EXTRA (0): bytes of dynamic LDS added to every ntt_pass_kernel launch — an occupancy probe for the
   // tuning notes (fewer workgroups per CU), never set in production
   uint32_t lds_extra = 0;
@@ -350,6 +352,7 @@ struct Tunables {
     flag("EVAH_HOIST_MAP", t.hoist_map);
     flag("EVAH_SIDE_STREAM", t.side_stream);
     flag("EVAH_CHAIN_STEP", t.chain_step);
+    flag("EVAH_CHAIN_BATCHED", t.chain_batched);
     count("EVAH_CHAIN_FUSE_BLOCKS", t.chain_fuse_blocks);
     count("EVAH_HOIST_V", t.hoist_v);
     if (const char *e = std::getenv("EVAH_KS_GROUPS")) t.ks_groups = std::max(1, std::atoi(e));
@@ -376,7 +379,7 @@ struct evah_ctx {
   std::vector<hipEvent_t> capture_events; // events consumed by the capture in progress
   std::vector<hipEvent_t> sync_events; // recycled events for cross-queue ordering
   Tunables tun; // launch-shape decisions, read from the environment once when the context is created
-  bool all_tb = false; // every prime is 2^b - c with b > 32, c < 2^32 (DevPrime::tb_c != 0)
+  bool all_tb = false; // every prime is 2^b - c with b > 32, c < 2^32 (DevPrime::tb_c != 0) or below 2^54: ks_inner_kernel<MAC3> applies
   // per-launch profile
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;

@@ -576,27 +576,34 @@ static void chain_step(evah_ctx *c, const MulTab &tab, uint32_t n, uint32_t l, u
 }
 
 static void mul_rescale_relin(evah_ctx *c, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n, uint32_t divisor_bits, evah_ct **outs) {
-  if (n < 1 || n > (uint32_t)KS_BATCH_MAX) throw std::invalid_argument("multiply_rescale_relinearize_many handles 1..64 products per call");
+  // batched handles (r6): every operand holds B instances; product i of instance b is entry i * B + b of the launch set, so the
+  // outputs of one pair are contiguous — a batched handle again.  pairs * B <= 64 per call.
+  const uint32_t pairs = n, B = pairs ? as[0]->batch : 0;
+  if (pairs < 1 || B < 1 || (uint64_t)pairs * B > (uint64_t)KS_BATCH_MAX)
+    throw std::invalid_argument("multiply_rescale_relinearize_many handles 1..64 products per call (pairs x instances of a batched handle)");
+  n = pairs * B;
   if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
   const uint32_t l = as[0]->limbs;
   if (l < 2) throw std::invalid_argument("end of modulus switching chain reached");
   const uint32_t lp = l - 1, last = l - 1, sp = c->k - 1;
   const size_t N = c->N, ops = (size_t)lp * N, pps = (size_t)(lp + 1) * N;
   MulTab tab{};
-  std::vector<double> scales(n);
-  for (uint32_t i = 0; i < n; i++) {
+  std::vector<double> scales(pairs);
+  for (uint32_t i = 0; i < pairs; i++) {
     const evah_ct *a = as[i], *b = bs[i];
     if (a->size != 2 || b->size != 2) throw std::invalid_argument("multiply supports size-2 operands only (relinearize first)");
-    if (a->batch != 1 || b->batch != 1) throw std::invalid_argument("multiply_rescale_relinearize_many takes single ciphertexts");
+    if (a->batch != B || b->batch != B) throw std::invalid_argument("multiply_rescale_relinearize_many: operands of one call hold the same number of instances");
     if (a->limbs != l || b->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
     scales[i] = a->scale * b->scale;
     check_scale(c, scales[i], l);
     acquire(c, a->buf);
     acquire(c, b->buf);
-    tab.a[i] = a->d;
-    tab.b[i] = b->d;
-    tab.a_ps[i] = (uint32_t)(a->ps / N);
-    tab.b_ps[i] = (uint32_t)(b->ps / N);
+    for (uint32_t x = 0; x < B; x++) {
+      tab.a[i * B + x] = a->d + (size_t)x * 2 * a->ps;
+      tab.b[i * B + x] = b->d + (size_t)x * 2 * b->ps;
+      tab.a_ps[i * B + x] = (uint32_t)(a->ps / N);
+      tab.b_ps[i * B + x] = (uint32_t)(b->ps / N);
+    }
   }
   Buffer *ob = buf_new(c, (size_t)n * 2 * ops);
   try {
@@ -652,15 +659,16 @@ static void mul_rescale_relin(evah_ctx *c, const evah_ct *const *as, const evah_
     buf_unref(c, ob);
     throw;
   }
-  ob->refs = (int)n;
-  for (uint32_t b = 0; b < n; b++) {
+  ob->refs = (int)pairs;
+  for (uint32_t b = 0; b < pairs; b++) {
     evah_ct *t = new evah_ct;
     t->buf = ob;
-    t->d = ob->d + (size_t)b * 2 * ops;
+    t->d = ob->d + (size_t)b * B * 2 * ops;
     t->size = 2;
     t->limbs = lp;
     t->ps = ops;
     t->scale = scales[b] / std::pow(2.0, (double)divisor_bits);
+    t->batch = B;
     outs[b] = t;
   }
 }

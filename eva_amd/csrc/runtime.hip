@@ -119,7 +119,12 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
         const bool ok = b > 32 && cc < ((u64)1 << 32) && cc < (q >> 4);
         d.tb_c = ok ? (uint32_t)cc : 0;
         d.tb_sh = ok ? b - 32 : 0;
-        d.tb_mask = ok ? (uint32_t)(((u64)1 << (b - 32)) - 1) : 0;
+        // a prime of another shape: (c, shift, mask) = (0, 0, ~0) makes the top-bit reduction the identity.  The ordinary
+        // passes never use it (tb_c == 0 selects the compare-and-subtract butterflies); ks_inner_kernel<MAC3>, whose rounds
+        // are compiled with the top-bit form only, then runs such a row without any reduction — correct while the 8-stage
+        // lazy growth (9 q in, + 4 q per stage: < 41 q) stays below the 2^60 the radix-2^30 split needs, i.e. q < 2^54
+        // (mac3_ok below): the 20..50-bit scale primes of EVA's chains
+        d.tb_mask = ok ? (uint32_t)(((u64)1 << (b - 32)) - 1) : 0xffffffffu;
         d.tb_pad = 0;
       }
       for (uint32_t a = 0; a < k; a++) {
@@ -141,7 +146,7 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
       }
     }
     c->all_tb = true;
-    for (uint32_t i = 0; i < k; i++) c->all_tb = c->all_tb && hp[i].tb_c != 0;
+    for (uint32_t i = 0; i < k; i++) c->all_tb = c->all_tb && (hp[i].tb_c != 0 || hp[i].q < ((u64)1 << 54));
     c->sh = std::make_shared<SharedDev>();
     c->sh->device = device;
     HIPCHK(hipMalloc(&c->sh->d_tables, total));

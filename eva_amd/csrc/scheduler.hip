@@ -512,7 +512,8 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     std::map<uint32_t, std::vector<uint32_t>> rots, relins, muls, batched_rots;
     std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> mulps; // ct x pt products by (size, limbs)
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<uint32_t>> rescales;
-    std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> fused, fused3, fused3b;
+    std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> fused, fused3;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<uint32_t>> fused3b; // (limbs, divisor, instances per handle)
     // ---- one op through the ordinary entry points (seal_executor.h:114-215)
     auto single = [&](const evah_op &o) {
       evah_ct *out = nullptr;
@@ -590,6 +591,21 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         batched_rots[o.src0].push_back(i);
         continue;
       }
+      // Mul (or square) read only by a Rescale that is read only by a Relinearize — lazy relinearization's order: nothing is
+      // computed here, the three run as one fused call at the Relinearize (r6; batched handles too: the instances of a handle
+      // are entries of the same launch set)
+      auto defer_chain2 = [&]() {
+        if (!(o.op == 13 && is_ct(o.src0) && is_ct(o.src1) && c->tun.fuse_mac && c->tun.fuse_mul2 && c->sh->relin.d &&
+              feeds_only(o.dst, 22) && feeds_only(ops[only_reader[o.dst]].dst, 20)))
+          return false;
+        evah_ct *x = ct_of(o.src0), *y = ct_of(o.src1);
+        if (!(x->size == 2 && y->size == 2 && x->limbs == y->limbs && x->limbs >= 2 && x->batch == y->batch && x->batch <= (uint32_t)KS_BATCH_MAX)) return false;
+        if (x->batch > 1 && !c->tun.chain_batched) return false;
+        check_scale(c, x->scale * y->scale, x->limbs);
+        st.prods2[o.dst] = {alias_ct(x), alias_ct(y)};
+        return true;
+      };
+      if (batched && defer_chain2()) continue;
       if (batched && (o.op == 22 || (o.op == 20 && !feeds_only(o.dst, 22)) || (o.op == 13 && o.src0 != o.src1 && is_ct(o.src0) && is_ct(o.src1)))) {
         if (o.op == 13 && try_defer_ew(o)) continue; // a product of batched handles inside an elementwise expression
         if (o.op == 22 && st.relins.count(o.src0)) { // deferred relinearize + this rescale, on the batched handle
@@ -608,7 +624,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         st.resdiv[o.dst] = (uint32_t)o.imm;
         st.prods2.erase(o.src0);
       } else if (o.op == 20 && st.prodres.count(o.src0)) {
-        fused3b[{st.prodres[o.src0].first->limbs, st.resdiv[o.src0]}].push_back(i);
+        fused3b[{st.prodres[o.src0].first->limbs, st.resdiv[o.src0], st.prodres[o.src0].first->batch}].push_back(i);
       } else if (o.op == 20 && st.prods.count(o.src0)) { // Relinearize of a deferred product: still deferred
         st.prodrel[o.dst] = st.prods[o.src0];
         st.prods.erase(o.src0);
@@ -630,16 +646,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
           shape(o.src0, size, limbs, scale);
           relins[limbs].push_back(i);
         }
-      } else if (o.op == 13 && is_ct(o.src0) && is_ct(o.src1) && !batched && c->tun.fuse_mac && c->tun.fuse_mul2 && c->sh->relin.d &&
-                 feeds_only(o.dst, 22) && feeds_only(ops[only_reader[o.dst]].dst, 20) && [&] {
-                   // Mul (or square) read only by a Rescale that is read only by a Relinearize — lazy relinearization's order:
-                   // nothing is computed here, the three run as one fused call at the Relinearize (r6)
-                   evah_ct *x = ct_of(o.src0), *y = ct_of(o.src1);
-                   if (!(x->size == 2 && y->size == 2 && x->limbs == y->limbs && x->limbs >= 2 && x->batch == 1 && y->batch == 1)) return false;
-                   check_scale(c, x->scale * y->scale, x->limbs);
-                   st.prods2[o.dst] = {alias_ct(x), alias_ct(y)};
-                   return true;
-                 }()) {
+      } else if (!batched && defer_chain2()) {
       } else if (o.op == 13 && is_ct(o.src0) && is_ct(o.src1) && try_defer_ew(o)) {
         // ciphertext x ciphertext inside an elementwise expression (not a Mul -> Relinearize -> Rescale chain): nothing runs here
       } else if (o.op == 13 && is_ct(o.src0) && is_ct(o.src1) &&
@@ -803,9 +810,10 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         }
         store(is, n, outs);
       }
-    for (auto &kv : fused3b)
-      for (size_t i0 = 0; i0 < kv.second.size(); i0 += KS_BATCH_MAX) {
-        const uint32_t n = (uint32_t)std::min<size_t>(KS_BATCH_MAX, kv.second.size() - i0);
+    for (auto &kv : fused3b) {
+      const size_t per_call = std::max<size_t>(1, (size_t)KS_BATCH_MAX / std::max<uint32_t>(1, std::get<2>(kv.first)));
+      for (size_t i0 = 0; i0 < kv.second.size(); i0 += per_call) {
+        const uint32_t n = (uint32_t)std::min<size_t>(per_call, kv.second.size() - i0);
         const uint32_t *is = kv.second.data() + i0;
         std::vector<const evah_ct *> ia(n), ib(n);
         std::vector<evah_ct *> outs(n, nullptr);
@@ -813,7 +821,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
           ia[j] = st.prodres[ops[is[j]].src0].first;
           ib[j] = st.prodres[ops[is[j]].src0].second;
         }
-        chk(evah_multiply_rescale_relinearize_many(c, ia.data(), ib.data(), n, kv.first.second, outs.data()));
+        chk(evah_multiply_rescale_relinearize_many(c, ia.data(), ib.data(), n, std::get<1>(kv.first), outs.data()));
         for (uint32_t j = 0; j < n; j++) {
           evah_ct_free(c, const_cast<evah_ct *>(ia[j]));
           evah_ct_free(c, const_cast<evah_ct *>(ib[j]));
@@ -822,6 +830,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         }
         store(is, n, outs);
       }
+    }
     for (auto &kv : rescales)
       each_chunk(kv.second, (2 * KS_BATCH_MAX) / std::get<0>(kv.first), [&](const uint32_t *is, uint32_t n) {
         std::vector<const evah_ct *> in(n);

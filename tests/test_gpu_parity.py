@@ -214,6 +214,34 @@ def test_multiply_rescale_relinearize_fused_bit_exact(cfg, mode, monkeypatch):
     e.g.close()
 
 
+@pytest.mark.parametrize("cfg", [c for c in CONFIGS if c[0] >= 4096], ids=lambda c: f"N{c[0]}")
+@pytest.mark.parametrize("chain", ["1", "0"])
+def test_multiply_rescale_relinearize_batched_handles_bit_exact(cfg, chain, monkeypatch):
+    """r6: batched handles through evah_multiply_rescale_relinearize(_many) — every operand holds B instances, the outputs are
+    batched handles again (instance b of pair i == the oracle's three calls on instance b of its operands); a square and a
+    pair sharing an operand in one call; unequal instance counts are an error"""
+    monkeypatch.setenv("EVAH_CHAIN_STEP", chain)
+    e = Env(*cfg)
+    key = e.rand_key()
+    e.g.upload_relin_key(key)
+    B, l = 3, e.k - 1
+    xs = [np.stack([e.rand(2, l) for _ in range(B)]) for _ in range(3)]
+    X = [e.g.upload_ct_batch(x, 2.0 ** 25) for x in xs]
+    outs = e.g.multiply_rescale_relinearize_many([X[0], X[1], X[2]], [X[1], X[1], X[0]], 30)
+    pairs = [(0, 1), (1, 1), (2, 0)]
+    for o, (i, j) in zip(outs, pairs):
+        assert o.batch == B and o.info() == (2, l - 1, 2.0 ** 20)
+        got = o.download()
+        for b in range(B):
+            prod = e.o.square(xs[i][b]) if i == j else e.o.multiply(xs[i][b], xs[j][b])
+            assert np.array_equal(got[b], e.o.relinearize(e.o.rescale(prod), key)), f"pair {i}x{j} instance {b}"
+    one = e.g.multiply_rescale_relinearize(X[0], X[2], 30)
+    assert np.array_equal(one.download()[B - 1], e.o.relinearize(e.o.rescale(e.o.multiply(xs[0][B - 1], xs[2][B - 1])), key))
+    with pytest.raises(backend.EvaHipError, match="same number of instances"):
+        e.g.multiply_rescale_relinearize(X[0], e.g.upload_ct(e.rand(2, l), 2.0 ** 25), 30)
+    e.g.close()
+
+
 @pytest.mark.parametrize("chain", ["1", "0"])
 def test_multiply_rescale_relinearize_config5_shape_bit_exact(chain, monkeypatch):
     """the shape it was built for: one square at N = 2^16, l = 12 of 13 primes (BASELINE config 5's chain step), eager and
