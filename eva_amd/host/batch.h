@@ -10,7 +10,7 @@ inline std::vector<HipValuation> HipPublic::execute_batch(Program &program, cons
   ensure_device();
   if (batch_chunk < 1 || batch_chunk > 64) throw std::runtime_error("batch_chunk must be 1..64");
   std::vector<HipValuation> all(inputs.size());
-  // Groups rotate over batch_depth issue queues (default four: +6 % over two on config 4) and nothing waits in between: each group's uploads,
+  // Groups rotate over batch_depth issue queues (default three, r6: +9 % over four and +11 % over two on config 4) and nothing waits in between: each group's uploads,
   // launches and downloads are enqueued in queue order (evah_ct_*_instances_async), so the copies
   // of one group overlap the kernels of the other and the host never idles the device.  Device
   // memory stays at two groups' working sets (the pools recycle in queue order); the inputs belong
