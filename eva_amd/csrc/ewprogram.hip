@@ -23,14 +23,21 @@ constexpr int EW_MAX_PTR = 48;   // polynomials loaded or stored per launch
 // polynomial registers: 8 or 16 bytes of LDS per thread each (one or two coefficients per thread).  With two, up to 14
 // registers a workgroup is 256 threads (4 KB per register), up to 28 it is 128 threads: at most 56 KB of dynamic LDS
 constexpr int EW_MAX_REGS = 28, EW_REGS_WIDE = 14;
-enum EwOp : uint32_t { EW_LOAD = 0, EW_STORE, EW_ADD, EW_SUB, EW_NEG, EW_MUL, EW_FMA2 };
+constexpr int EW_MAX_SC = 16;    // uniform plaintexts (scalars of Z_q per limb) multiplied by per launch
+enum EwOp : uint32_t { EW_LOAD = 0, EW_STORE, EW_ADD, EW_SUB, EW_NEG, EW_MUL, EW_FMA2, EW_MULU };
 
 struct EwProg {
   uint32_t n_ins;
   // instruction j: w[2j] = op | dst << 8 | a << 16 | b << 24, w[2j + 1] = c | d << 8
   //   LOAD  dst <- ptr[a]          STORE ptr[a] <- reg b
   //   ADD / SUB dst <- a (+/-) b   NEG dst <- -a      MUL dst <- a b      FMA2 dst <- a b + c d
+  //   MULU dst <- a * scalar b     (r6: a uniform plaintext — evah_pt_uniform, every word of limb i the same residue W_i — is a
+  //                                 scalar of Z_{q_i}: its polynomial is never loaded, the product is a Shoup product with the
+  //                                 quotient floor(W_i 2^64 / q_i) the workgroup computes once; same canonical residue as MUL)
   uint32_t w[2 * EW_MAX_INS];
+  uint32_t n_sc;                 // scalars: sc_ptr[s] = pointer slot of the uniform plaintext (word 0 of limb i is W_i)
+  uint32_t sc_reg0;              // the scalar table starts where register sc_reg0 would (behind the register file in LDS)
+  uint8_t sc_ptr[EW_MAX_SC];
   u64 *ptr[EW_MAX_PTR];          // polynomial bases (instance 0, limb 0)
   uint32_t bstride[EW_MAX_PTR];  // distance between the instances of a batched handle, in units of N words (0: shared plaintext)
 };
@@ -69,6 +76,19 @@ k_ew_program(DevCtx cx, EwProg pg) {
   const uint32_t i = blockIdx.y, inst = blockIdx.z, tid = threadIdx.x, T = blockDim.x;
   const size_t off = (size_t)i * cx.N + V * ((size_t)blockIdx.x * T + tid);
   const DevPrime pm = cx.primes[cx.prime_of(i)];
+  // the launch's scalars with their Shoup quotients, behind the register file: (W, floor(W 2^64 / q)) — the quotient from
+  // floor(2^128 / q) (DevPrime::r0, r1: at most 2 below), corrected with the remainder
+  ulonglong2 *ew_sc = reinterpret_cast<ulonglong2 *>(ew_regs + (size_t)pg.sc_reg0 * T);
+  if (pg.n_sc) { // block-uniform; the index into the kernel arguments stays wave-uniform (scalar loads)
+    for (uint32_t sI = 0; sI < pg.n_sc; sI++) {
+      const u64 w = pg.ptr[pg.sc_ptr[sI]][(size_t)i * cx.N];
+      u64 e = w * pm.r1 + __umul64hi(w, pm.r0); // floor(W floor(2^128 / q) / 2^64): the quotient or one below
+      u64 rem = 0ull - e * pm.q;                // W 2^64 - e q  (mod 2^64; the true value is below 2 q)
+      while (rem >= pm.q) { rem -= pm.q; e++; }
+      if (tid == 0) ew_sc[sI] = make_ulonglong2(w, e);
+    }
+    __syncthreads();
+  }
   uint32_t w0 = pg.w[0], w1 = pg.w[1];
   for (uint32_t pc = 0; pc < pg.n_ins; pc++) {
     // wave-uniform: scalar loads from the kernel arguments; the next instruction's words are requested before this one runs
@@ -83,6 +103,10 @@ k_ew_program(DevCtx cx, EwProg pg) {
     case EW_SUB: *rd = EwVec<V>::map2(ew_regs[a * T + tid], ew_regs[b * T + tid], [&](u64 x, u64 y) { return submod(x, y, pm.q); }); break;
     case EW_NEG: *rd = EwVec<V>::map1(ew_regs[a * T + tid], [&](u64 x) { return negmod(x, pm.q); }); break;
     case EW_MUL: *rd = EwVec<V>::map2(ew_regs[a * T + tid], ew_regs[b * T + tid], [&](u64 x, u64 y) { return mulmod(x, y, pm); }); break;
+    case EW_MULU: {
+      const ulonglong2 sc = ew_sc[b];
+      *rd = EwVec<V>::map1(ew_regs[a * T + tid], [&](u64 x) { return mul_shoup(x, sc.x, sc.y, pm.q); });
+    } break;
     default: { // EW_FMA2
       const uint32_t cc = w1 & 0xffu, dd = (w1 >> 8) & 0xffu;
       *rd = EwVec<V>::map4(ew_regs[a * T + tid], ew_regs[b * T + tid], ew_regs[cc * T + tid], ew_regs[dd * T + tid],
@@ -206,8 +230,14 @@ int evah_elementwise_program(evah_ctx *c, const evah_val *in, uint32_t n_in, con
         if (o.op == 13) {
           r.scale = a.scale * b.scale;
           check_scale(c, r.scale, a.limbs);
-          const int w = poly(ib, 0);
-          for (uint32_t p = 0; p < a.size; p++) r.preg[p] = emit(EW_MUL, poly(ia, p), w);
+          if (b.pt->uniform && c->tun.ew_uniform) { // a scalar per limb: no load of the plaintext, Shoup products
+            pptr.push_back({b.pt->d, 0u});
+            const int ps = (int)pptr.size() - 1;
+            for (uint32_t p = 0; p < a.size; p++) r.preg[p] = emit(EW_MULU, poly(ia, p), 0, ps);
+          } else {
+            const int w = poly(ib, 0);
+            for (uint32_t p = 0; p < a.size; p++) r.preg[p] = emit(EW_MUL, poly(ia, p), w);
+          }
         } else {
           if (!same_scale(a.scale, b.scale)) throw std::invalid_argument("scale mismatch");
           r.scale = a.scale;
@@ -261,7 +291,7 @@ int evah_elementwise_program(evah_ctx *c, const evah_val *in, uint32_t n_in, con
       if (pi.op == EW_STORE) out[n++] = pi.b;
       else if (pi.op != EW_LOAD) {
         out[n++] = pi.a;
-        if (pi.op != EW_NEG) out[n++] = pi.b;
+        if (pi.op != EW_NEG && pi.op != EW_MULU) out[n++] = pi.b;
         if (pi.op == EW_FMA2) { out[n++] = pi.cc; out[n++] = pi.dd; }
       }
       return n;
@@ -296,16 +326,29 @@ int evah_elementwise_program(evah_ctx *c, const evah_val *in, uint32_t n_in, con
       if (pi.op == EW_LOAD || pi.op == EW_STORE) {
         if (ptr_map[pi.a] < 0) { ptr_map[pi.a] = (int)ptr_used.size(); ptr_used.push_back(pptr[pi.a]); }
       }
+      int sc_idx = 0;
+      if (pi.op == EW_MULU) { // the scalar's slot: one per distinct plaintext
+        int slot = -1;
+        for (size_t t = 0; t < ptr_used.size(); t++) if (ptr_used[t].p == pptr[pi.cc].p && ptr_used[t].bstride == 0) slot = (int)t;
+        if (slot < 0) { slot = (int)ptr_used.size(); ptr_used.push_back(pptr[pi.cc]); }
+        for (uint32_t t = 0; t < pg.n_sc; t++) if (pg.sc_ptr[t] == slot) sc_idx = (int)t + 1;
+        if (!sc_idx) {
+          if (pg.n_sc < (uint32_t)EW_MAX_SC) { pg.sc_ptr[pg.n_sc++] = (uint8_t)slot; sc_idx = (int)pg.n_sc; }
+          else { fits = false; break; }
+        }
+        sc_idx--;
+      }
       uint32_t w0 = pi.op, w1 = 0;
       if (pi.op == EW_LOAD) w0 |= (uint32_t)pd << 8 | (uint32_t)ptr_map[pi.a] << 16;
       else if (pi.op == EW_STORE) w0 |= (uint32_t)ptr_map[pi.a] << 16 | (uint32_t)pu[0] << 24;
+      else if (pi.op == EW_MULU) w0 |= (uint32_t)pd << 8 | (uint32_t)pu[0] << 16 | (uint32_t)sc_idx << 24;
       else {
         w0 |= (uint32_t)pd << 8 | (uint32_t)pu[0] << 16 | (uint32_t)(pi.op == EW_NEG ? 0 : pu[1]) << 24;
         if (pi.op == EW_FMA2) w1 = (uint32_t)pu[2] | (uint32_t)pu[3] << 8;
       }
       pg.w[2 * q] = w0;
       pg.w[2 * q + 1] = w1;
-      fits = n_regs <= EW_MAX_REGS && ptr_used.size() <= (size_t)EW_MAX_PTR;
+      fits = fits && n_regs <= EW_MAX_REGS && ptr_used.size() <= (size_t)EW_MAX_PTR;
     }
     if (!fits) {
       // a program beyond one launch's registers / instructions / pointers: the separate entry points, call by call
@@ -348,10 +391,12 @@ int evah_elementwise_program(evah_ctx *c, const evah_val *in, uint32_t n_in, con
       const uint64_t coeffs = (uint64_t)N * limbs * batch;
       if (coeffs >= ((uint64_t)1 << 20) && N >= 512) { // (a 24-instance group of config 4 is 1.97 M coefficients)
         const uint32_t threads = n_regs <= EW_REGS_WIDE ? 256u : 128u;
-        const size_t lds = (size_t)std::max(n_regs, 1) * threads * sizeof(ulonglong2);
+        pg.sc_reg0 = (uint32_t)std::max(n_regs, 1);
+        const size_t lds = (size_t)std::max(n_regs, 1) * threads * sizeof(ulonglong2) + EW_MAX_SC * sizeof(ulonglong2);
         EW_LAUNCH(k_ew_program<2>, dim3((unsigned)(N / (2 * threads)), limbs, batch), dim3(threads), lds, c->stream, c->dev, pg);
       } else {
-        const size_t lds = (size_t)std::max(n_regs, 1) * 256 * sizeof(u64);
+        pg.sc_reg0 = (uint32_t)std::max(n_regs, 1);
+        const size_t lds = (size_t)std::max(n_regs, 1) * 256 * sizeof(u64) + EW_MAX_SC * sizeof(ulonglong2);
         EW_LAUNCH(k_ew_program<1>, dim3((unsigned)(N / 256), limbs, batch), dim3(256), lds, c->stream, c->dev, pg);
       }
       HIPCHK(hipGetLastError());

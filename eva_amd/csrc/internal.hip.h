@@ -243,6 +243,9 @@ struct Tunables {
   // EVAH_EW_FUSE (1): evah_execute defers elementwise ops (negate / add / sub / multiply, ciphertexts and plaintexts) on
   // values nobody needs stored and runs each connected run of them as ONE evah_elementwise_program; 0 = one launch per op
   bool ew_fuse = true;
+  // EVAH_EW_UNIFORM (1): an elementwise program multiplies by a uniform plaintext (evah_pt_uniform) as by a scalar per limb —
+  // Shoup products, the plaintext's polynomial never loaded (EW_MULU); 0 = the general product
+  bool ew_uniform = true;
   // EVAH_FUSE_SMALL (2048): launches of at most this many 2048-coefficient tiles are latency-bound — an
   // inverse transform followed by forward transforms of the result runs its two strided passes as one
   // launch (ntt_inv_fwd_kernel); 0 disables.  r03 sweep at the BASELINE sizes: Harris L=8 1.18 -> 1.15 ms,
@@ -329,6 +332,7 @@ struct Tunables {
     flag("EVAH_FUSE_MUL", t.fuse_mul);
     flag("EVAH_FUSE_MUL2", t.fuse_mul2);
     flag("EVAH_EW_FUSE", t.ew_fuse);
+    flag("EVAH_EW_UNIFORM", t.ew_uniform);
     count("EVAH_FUSE_SMALL", t.fuse_small_blocks);
     if (const char *e = std::getenv("EVAH_SMALL_LR")) t.small_lr = std::atoi(e) == 3 ? 3 : 2;
     count("EVAH_SMALL_LR_BLOCKS", t.small_lr_blocks);

@@ -99,6 +99,68 @@ def upload(e, inputs, g=None):
     return [g.upload_ct(w, s) if k == "ct" else g.upload_pt(w, s) for k, w, s in inputs]
 
 
+def uniform_input(e, scale, l=None):
+    """a uniform plaintext (evah_pt_uniform: one residue per limb in every slot) -> (oracle-side input, per-limb values)"""
+    l = l or e.l
+    uv = np.array([int(e.rng.integers(0, e.primes[i])) for i in range(l)], dtype=np.uint64)
+    return ("pt", np.repeat(uv[:, None], e.N, axis=1), scale), uv
+
+
+@pytest.mark.parametrize("on", ["1", "0"])
+def test_uniform_plaintexts_multiply_as_scalars(on, monkeypatch):
+    """r6: a product with a uniform plaintext (EVA's scalar constants) is a Shoup product with a per-limb scalar inside the
+    interpreter (EW_MULU: the plaintext's polynomial is never loaded) — the same canonical residues as multiply_plain;
+    mixed with general plaintexts, a mod-switched uniform plaintext (fewer limbs), zero and q - 1 as scalars, batched
+    handles, the throughput-sized two-coefficient launch, and more distinct scalars than one launch holds (separate calls)"""
+    monkeypatch.setenv("EVAH_EW_UNIFORM", on)
+    for cfg, batch in (((4096, [60, 20, 60, 60]), 1), ((8192, [60, 30, 60, 60, 60]), 3), ((32768, [60] * 5), 8)):
+        e = Env(*cfg)
+        l = e.l
+        us = [uniform_input(e, 2.0 ** 10) for _ in range(3)]
+        us[1][1][0] = 0                      # the scalar 0
+        us[2][1][:] = np.array(e.primes[:l], dtype=np.uint64) - 1  # q - 1 in every limb
+        for (k, w, sc), uv in us:
+            w[:] = np.repeat(uv[:, None], e.N, axis=1)
+        inputs = [("ct", e.ct(2), 2.0 ** 10), ("ct", e.ct(3), 2.0 ** 10), ("pt", e.pt(), 2.0 ** 10)] + [u[0] for u in us]
+        #       6: a*u0   7: b*u1   8: a*pt   9: 6+8     10: 9*u2   11: 7*u0   12: u1*a (plaintext first)  13: 12 - 6
+        ops = [(MUL, 0, 3), (MUL, 1, 4), (MUL, 0, 2), (ADD, 6, 8), (MUL, 9, 5), (MUL, 7, 3), (MUL, 4, 0), (SUB, 12, 6)]
+        ref = oracle_run(e, inputs, ops)
+
+        def handles(b):
+            hs = []
+            for j, (k, w, sc) in enumerate(inputs):
+                if k == "ct":
+                    hs.append(e.g.upload_ct(w, sc) if b == 1 else e.g.upload_ct_batch(np.stack([w] * b), sc))
+                elif j >= 3:
+                    hs.append(e.g.uniform_pt(us[j - 3][1], sc))
+                else:
+                    hs.append(e.g.upload_pt(w, sc))
+            return hs
+        outs = [10, 11, 13]
+        got = e.g.elementwise_program(handles(batch), ops, outs)
+        for v, h in zip(outs, got):
+            d = h.download()
+            for b in range(batch):
+                assert np.array_equal(d[b] if batch > 1 else d, ref[v][1]), f"N={cfg[0]} value {v} instance {b}"
+        # more distinct uniform plaintexts than one launch's scalar table (16): the separate entry points, same words
+        many = [uniform_input(e, 2.0 ** 2) for _ in range(18)]
+        inputs2 = [("ct", e.ct(2), 2.0 ** 2)] + [m[0] for m in many]
+        ops2 = [(MUL, 0 if j == 0 else 19 + j - 1, 1 + j) for j in range(18)]
+        ref2 = oracle_run(e, inputs2, ops2)
+        h2 = [e.g.upload_ct(inputs2[0][1], inputs2[0][2])] + [e.g.uniform_pt(m[1], 2.0 ** 2) for m in many]
+        got2 = e.g.elementwise_program(h2, ops2, [19 + 17])[0]
+        assert np.array_equal(got2.download(), ref2[-1][1])
+        # a uniform plaintext of fewer limbs on a mod-switched view
+        if l >= 3:
+            (k, w, sc), uv = uniform_input(e, 2.0 ** 10, l - 1)
+            big = e.ct(2)
+            V = e.g.mod_switch(e.g.upload_ct(big, 2.0 ** 10))
+            got3 = e.g.elementwise_program([V, e.g.uniform_pt(uv, sc)], [(MUL, 0, 1), (ADD, 2, 2)], [3])[0]
+            want = e.o.multiply_plain(e.o.mod_switch(big), w)
+            assert np.array_equal(got3.download(), e.o.add(want, want))
+        e.g.close()
+
+
 @pytest.mark.parametrize("cfg", [(1024, [30, 30, 31]), (4096, [60, 20, 60, 60]), (8192, [60, 60, 60, 60, 60]), (32768, [60, 60, 60])],
                          ids=lambda c: f"N{c[0]}_k{len(c[1])}")
 def test_random_programs_bit_exact(cfg):
