@@ -4,7 +4,10 @@
 // seal_executor.h:264-277, 420-435) — see include/eva_hip.h for the per-entry-point mapping.
 // gfx950 only; no CPU fallback: every entry point needs a HIP device and fails otherwise.
 #include "internal.hip.h"
-namespace evah { void key_split_launch(evah_ctx *c, const u64 *src, u64 *dst, size_t words); } // elementwise.hip
+namespace evah {
+void key_split_launch(evah_ctx *c, const u64 *src, u64 *dst, size_t words); // elementwise.hip
+void ct_stack_launch(evah_ctx *c, const evah_ct *const *cts, uint32_t n, evah_ct *o); // elementwise.hip
+}
 
 namespace evah {
 
@@ -511,10 +514,12 @@ int evah_ct_stack(evah_ctx *c, const evah_ct *const *cts, uint32_t n, evah_ct **
     acquire(c, cts[i]->buf);
   }
   evah_ct *o = ct_new(c, f->size, f->limbs, f->scale, n);
-  const size_t row = sizeof(u64) * (size_t)f->limbs * c->N;
-  for (uint32_t i = 0; i < n; i++)
-    HIPCHK(hipMemcpy2DAsync(o->d + (size_t)i * o->size * o->ps, sizeof(u64) * o->ps, cts[i]->d, sizeof(u64) * cts[i]->ps, row,
-                            f->size, hipMemcpyDeviceToDevice, c->stream));
+  try {
+    ct_stack_launch(c, cts, n, o); // one gather launch (r6; a 2-D copy per instance before)
+  } catch (...) {
+    evah_ct_free(c, o);
+    throw;
+  }
   *out = o;
   API_END
 }

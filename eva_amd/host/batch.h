@@ -25,6 +25,9 @@ inline std::vector<HipValuation> HipPublic::execute_batch(Program &program, cons
   // of the first call, or by an earlier execute() of the same program (const_cache) — and shared by all groups of all
   // calls.  (r5: they used to be encoded by the first group of every call and released at its end: ~20 encodes in front
   // of the first group's kernels and, at the release, an event wait per plaintext per reading queue — 0.5 ms of a 17 ms call)
+  // (the cached plaintexts were encoded on the queue of whichever group ran first and are read from every batch queue in
+  // later calls: nothing waits explicitly at the lookup — each library call acquires the buffers it reads, Buffer::owner /
+  // readers in csrc/internal.hip.h, which is what orders a reading queue behind the encoding one)
   ConstCache &cc = const_cache[&program];
   const uint64_t prog_hash = program_hash(program);
   bool fresh = cc.values.size() != program.size() || cc.hash != prog_hash;

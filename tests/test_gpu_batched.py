@@ -57,6 +57,11 @@ def test_batched_elementwise_and_rescale(cfg):
     singles = [e.g.upload_ct(a2[b], s) for b in range(B)]
     st = e.g.stack(singles)
     assert st.batch == B and np.array_equal(st.download(), a2)
+    if l >= 2:  # r6 (one gather launch): sources with their own polynomial stride — mod-switched views next to plain ones
+        mixed = [e.g.mod_switch(singles[0]), e.g.upload_ct(a2[1][:, :l - 1], s), e.g.mod_switch(e.g.upload_ct(b3[2][:2], s))]
+        sm = e.g.stack(mixed)
+        assert sm.batch == 3 and sm.info()[:2] == (2, l - 1)
+        assert np.array_equal(sm.download(), np.stack([a2[0][:, :l - 1], a2[1][:, :l - 1], b3[2][:2, :l - 1]]))
     u = A2.unstack(1)
     assert u.batch == 1 and np.array_equal(u.download(), a2[1])
     assert np.array_equal(e.g.add(u, singles[0]).download(), e.o.add(a2[1], a2[0]))

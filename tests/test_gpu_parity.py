@@ -580,6 +580,10 @@ def test_more_than_16_limbs():
     # and one level down, where l = 17 still exceeds 16
     ms = e.g.mod_switch(A3)
     assert np.array_equal(e.g.relinearize(ms).download(), e.o.relinearize(e.o.mod_switch(a3), key))
+    # the chain step (Mul -> Rescale -> Relinearize) with 17 digits: the 128-bit sums fold once, then take (P L^-1) d_K
+    b2 = e.rand(2, l)
+    got = e.g.multiply_rescale_relinearize(e.g.upload_ct(a2, 2.0 ** 10), e.g.upload_ct(b2, 2.0 ** 10), 10)
+    assert np.array_equal(got.download(), e.o.relinearize(e.o.rescale(e.o.multiply(a2, b2)), key))
 
 
 @pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[3], CONFIGS[5]], ids=lambda c: f"N{c[0]}")
@@ -684,4 +688,19 @@ def test_primes_of_top_bit_width_but_far_from_the_power_of_two():
     assert np.array_equal(g.rescale(R, 34).download(), o.rescale(r))
     assert np.array_equal(g.rotate(A, 5).download(), o.rotate(a, 5, gk))
     assert np.array_equal(g.multiply_relinearize_rescale_many([A, A], [B, B], 34)[1].download(), o.op_triple(a, b, rk))
+    assert np.array_equal(g.multiply_rescale_relinearize(A, B, 34).download(), o.relinearize(o.rescale(m), rk))
+    g.close()
+    # a 60-bit prime far below 2^60 (c >= 2^32: no top-bit shape, too large for reduction-free radix-2^30 rows): the whole
+    # context takes the 128-bit inner products, the chain step included
+    far60 = _ntt_prime_below(int(0.7 * 2 ** 60), N)
+    primes = [near[0], far60, _ntt_prime_below(near[0] - 1, N), near[1]]
+    g, o = backend.Context(N, primes), po.Oracle(N, primes)
+    k, l = len(primes), len(primes) - 1
+    rk = rand((l, 2), k)
+    g.upload_relin_key(rk)
+    for lv in (l, l - 1):
+        a, b = rand((2,), lv), rand((2,), lv)
+        A, B = g.upload_ct(a, 2.0 ** 20), g.upload_ct(b, 2.0 ** 20)
+        assert np.array_equal(g.multiply_rescale_relinearize(A, B, 60).download(), o.relinearize(o.rescale(o.multiply(a, b)), rk))
+        assert np.array_equal(g.multiply_relinearize_rescale(A, B, 60).download(), o.op_triple(a, b, rk))
     g.close()
