@@ -81,6 +81,8 @@ _SIGS = {
     "evah_multiply_plain_many": [_vp, _vpp, _vpp, C.c_uint32, _vpp],
     "evah_rescale_many": [_vp, _vpp, C.c_uint32, C.c_uint32, _vpp],
     "evah_relinearize_many": [_vp, _vpp, C.c_uint32, _vpp],
+    "evah_rescale_relinearize": [_vp, _vp, C.c_uint32, _vpp],
+    "evah_rescale_relinearize_many": [_vp, _vpp, C.c_uint32, C.c_uint32, _vpp],
     "evah_pt_encode": [_vp, C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_double, _vpp],
     "evah_ct_upload_batch": [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, _u64p, _vpp],
     "evah_ct_upload_instances": [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(_u64p), _vpp],
@@ -721,6 +723,19 @@ class Context:
         out = C.c_void_p()
         _chk(_lib.evah_multiply_rescale_relinearize(self.h, a.h, b.h, C.c_uint32(int(divisor_bits)), C.byref(out)))
         return Ciphertext(self, out)
+
+    def rescale_relinearize(self, a, divisor_bits):
+        """rescale_to_next of a size-3 ciphertext -> relinearize as one call"""
+        out = C.c_void_p()
+        _chk(_lib.evah_rescale_relinearize(self.h, a.h, C.c_uint32(int(divisor_bits)), C.byref(out)))
+        return Ciphertext(self, out)
+
+    def rescale_relinearize_many(self, cts, divisor_bits):
+        n = len(cts)
+        ins = (C.c_void_p * n)(*[ct.h for ct in cts])
+        outs = (C.c_void_p * n)()
+        _chk(_lib.evah_rescale_relinearize_many(self.h, ins, n, C.c_uint32(int(divisor_bits)), outs))
+        return [Ciphertext(self, C.c_void_p(outs[i])) for i in range(n)]
 
     def multiply_rescale_relinearize_many(self, cts_a, cts_b, divisor_bits):
         n = len(cts_a)

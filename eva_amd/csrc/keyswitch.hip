@@ -513,7 +513,9 @@ static bool chain_step_applies(evah_ctx *c, uint32_t lp, uint32_t n) {
   return c->tun.chain_step && c->tun.fuse_mac && c->tun.fold_pa && std::max(1, c->tun.ks_groups) == 1 && c->dev.pstep == 1 &&
          c->dev.p0 == 0 && !c->dev.guard && c->N >= ((uint32_t)NTT_THREADS << 3) && c->sh->relin.rows == c->k;
 }
-static void chain_step(evah_ctx *c, const MulTab &tab, uint32_t n, uint32_t l, u64 *out_d) {
+// stored: instance b is a STORED size-3 ciphertext at tab.a[b] (polynomial stride tab.a_ps[b], tab.b[b] == nullptr) instead of
+// the product tab.a[b] x tab.b[b] — Rescale -> Relinearize of a sum of products (evah_rescale_relinearize)
+static void chain_step(evah_ctx *c, const MulTab &tab, uint32_t n, uint32_t l, u64 *out_d, bool stored = false) {
   const uint32_t lp = l - 1, last = l - 1, sp = c->k - 1;
   const size_t N = c->N, ops = (size_t)lp * N, pps = (size_t)(lp + 1) * N;
   const KeyDev &key = c->sh->relin;
@@ -530,7 +532,14 @@ static void chain_step(evah_ctx *c, const MulTab &tab, uint32_t n, uint32_t l, u
   const uint32_t ks_tile = std::min<uint32_t>(c->N, (uint32_t)c->tun.ks_threads << 2);
   kb.mac3 = c->tun.mac3 && c->all_tb && lp <= 15 && (ks_tile >> 2) <= 64 && key.d_split;
   for (uint32_t b = 0; b < n; b++) kb.keys.key[b] = kb.mac3 ? key.d_split : key.d;
-  kb.mul = &tab;
+  PtrTab adds{};
+  if (stored) { // (P L^-1) c_K from memory: KS_FOLDADD
+    for (uint32_t b = 0; b < n; b++)
+      for (uint32_t K = 0; K < 2; K++) adds.p[2 * b + K] = tab.a[b] + (size_t)K * tab.a_ps[b] * N;
+    kb.adds = &adds;
+  } else {
+    kb.mul = &tab;
+  }
   kb.fold = true;
   kb.fold_row = last;
   kb.diag = true;
@@ -684,6 +693,78 @@ int evah_multiply_rescale_relinearize(evah_ctx *c, const evah_ct *a, const evah_
   API_BEGIN
   use(c);
   mul_rescale_relin(c, &a, &b, 1, divisor_bits, out);
+  API_END
+}
+
+// rescale_to_next of a size-3 ciphertext followed by relinearize (seal_executor.h:213-214, :200) — what lazy relinearization
+// leaves after a SUM of products (Sobel's Ix^2 + Iy^2, Harris' response) — as the chain step on stored polynomials: n handles
+// of B instances each, n * B <= 64.  Same ciphertext as the two calls.
+static void rescale_relin(evah_ctx *c, const evah_ct *const *as, uint32_t pairs, uint32_t divisor_bits, evah_ct **outs) {
+  const uint32_t B = pairs ? as[0]->batch : 0;
+  if (pairs < 1 || B < 1 || (uint64_t)pairs * B > (uint64_t)KS_BATCH_MAX)
+    throw std::invalid_argument("rescale_relinearize_many handles 1..64 ciphertexts per call (handles x instances of a batched handle)");
+  if (!c->sh->relin.d) throw std::invalid_argument("relinearization key not present");
+  const uint32_t l = as[0]->limbs, n = pairs * B;
+  if (l < 2) throw std::invalid_argument("end of modulus switching chain reached");
+  const uint32_t lp = l - 1;
+  const size_t N = c->N, ops = (size_t)lp * N;
+  for (uint32_t i = 0; i < pairs; i++) {
+    if (as[i]->size != 3) throw std::invalid_argument("relinearize expects a size-3 ciphertext");
+    if (as[i]->batch != B) throw std::invalid_argument("rescale_relinearize_many: the handles of one call hold the same number of instances");
+    if (as[i]->limbs != l) throw std::invalid_argument("encrypted parameter mismatch in batch");
+  }
+  if (!chain_step_applies(c, lp, n)) { // the two calls
+    for (uint32_t i = 0; i < pairs; i++) {
+      evah_ct *r = nullptr;
+      if (evah_rescale(c, as[i], divisor_bits, &r)) throw std::runtime_error(g_err);
+      const int rc = evah_relinearize(c, r, &outs[i]);
+      const std::string msg = g_err;
+      evah_ct_free(c, r);
+      if (rc) {
+        for (uint32_t j = 0; j < i; j++) evah_ct_free(c, outs[j]);
+        throw std::runtime_error(msg);
+      }
+    }
+    return;
+  }
+  MulTab tab{};
+  for (uint32_t i = 0; i < pairs; i++) {
+    acquire(c, as[i]->buf);
+    for (uint32_t x = 0; x < B; x++) {
+      tab.a[i * B + x] = as[i]->d + (size_t)x * 3 * as[i]->ps;
+      tab.a_ps[i * B + x] = (uint32_t)(as[i]->ps / N);
+    }
+  }
+  Buffer *ob = buf_new(c, (size_t)n * 2 * ops);
+  try {
+    chain_step(c, tab, n, l, ob->d, /*stored=*/true);
+  } catch (...) {
+    buf_unref(c, ob);
+    throw;
+  }
+  ob->refs = (int)pairs;
+  for (uint32_t b = 0; b < pairs; b++) {
+    evah_ct *t = new evah_ct;
+    t->buf = ob;
+    t->d = ob->d + (size_t)b * B * 2 * ops;
+    t->size = 2;
+    t->limbs = lp;
+    t->ps = ops;
+    t->scale = as[b]->scale / std::pow(2.0, (double)divisor_bits);
+    t->batch = B;
+    outs[b] = t;
+  }
+}
+int evah_rescale_relinearize_many(evah_ctx *c, const evah_ct *const *as, uint32_t n, uint32_t divisor_bits, evah_ct **outs) {
+  API_BEGIN
+  use(c);
+  rescale_relin(c, as, n, divisor_bits, outs);
+  API_END
+}
+int evah_rescale_relinearize(evah_ctx *c, const evah_ct *a, uint32_t divisor_bits, evah_ct **out) {
+  API_BEGIN
+  use(c);
+  rescale_relin(c, &a, 1, divisor_bits, out);
   API_END
 }
 

@@ -129,8 +129,11 @@ struct OpChainIntt {
     j.lazy = false;
     return true;
   }
+  // (mul.b == nullptr, block-uniform: a STORED size-3 ciphertext — evah_rescale_relinearize — whose polynomial K lies
+  // at mul.a + K * mul.sa)
   template <bool LZ>
   static __device__ __forceinline__ u64 load(const DevCtx &, const Job &j, const DevPrime &pm, uint32_t n) {
+    if (!j.mul.b) return j.mul.a[j.K * j.mul.sa + j.off + n];
     return product_poly(j.mul, j.K, j.off + n, pm);
   }
   static __device__ __forceinline__ void store(const DevCtx &, const Job &j, const DevPrime &, uint32_t n, u64 v) { j.dst[n] = v; }

@@ -102,7 +102,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
                 uint32_t nout, u64 *__restrict__ r_out, KsAddArg<MODE> adds, int flags, uint32_t fold_row) {
   // flags: bit 0 = lazy_out; bit 1 = diag — the diagonal digit I == J comes from scratch like every other (first-pass
   // intermediate of its forward transform) instead of an NTT-form target (the chain step, ntt_chain.hip.h).
-  // fold_row (KS_FOLDMUL): ~0u adds P d_K; a = fold_row adds (P q_a^-1) d_K (DevCtx::plinv — the chain step's folded rescale)
+  // fold_row (KS_FOLDMUL / KS_FOLDADD): ~0u adds P d_K; a = fold_row adds (P q_a^-1) d_K (DevCtx::plinv — the chain step's folded rescale)
   const bool lazy_out = flags & 1, diag = flags & 2;
   constexpr bool MUL = MODE == KS_MUL;
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
@@ -353,7 +353,7 @@ ks_inner_kernel(DevCtx cx, const u64 *__restrict__ target_b, size_t target_bs, c
   if constexpr (MODE == KS_FOLDMUL || MODE == KS_FOLDADD) {
     { // after the digit loop, where its prefetch registers are free (as a prologue the block cost 32 VGPRs: 147, 3 waves
       // per SIMD).  No branch: the special row multiplies by modq[P][P] = (0, 0) — P = 0 mod P — and reads a row that exists
-      const ulonglong2 Pm = (MODE == KS_FOLDMUL && fold_row != ~0u) ? cx.plinv[(size_t)fold_row * cx.k + kap]
+      const ulonglong2 Pm = (fold_row != ~0u) ? cx.plinv[(size_t)fold_row * cx.k + kap]
                                                                      : cx.modq[(size_t)(cx.k - 1) * cx.k + kap]; // (P mod q_I, Shoup quotient)
       const size_t off = (size_t)(Irow < l ? Irow : l - 1) * N + gbase;
 #pragma unroll

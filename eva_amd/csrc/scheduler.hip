@@ -60,6 +60,9 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     // divisor); the three run as one evah_multiply_rescale_relinearize_many at the Relinearize
     std::map<uint32_t, std::pair<evah_ct *, evah_ct *>> prods2, prodres;
     std::map<uint32_t, uint32_t> resdiv;
+    // value -> alias of the size-3 operand of a deferred Rescale that only a Relinearize reads (a SUM of products under lazy
+    // relinearization): the two run as one evah_rescale_relinearize_many at the Relinearize (r6)
+    std::map<uint32_t, evah_ct *> resrel;
     // value -> deferred rotation: a Rotate whose readers are all ciphertext x plaintext products inside sums is not
     // evaluated; the sums carry (source, step) terms and go to evah_rotate_weighted_sums (the convolution window)
     std::map<uint32_t, DRot> drots;
@@ -76,10 +79,11 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         for (evah_pt *h : kv.second.pts) evah_pt_free(c, h);
       }
       for (auto &kv : relins) evah_ct_free(c, kv.second);
+      for (auto &kv : resrel) evah_ct_free(c, kv.second);
       for (auto *m : {&prods, &prodrel, &prods2, &prodres})
         for (auto &kv : *m) { evah_ct_free(c, kv.second.first); evah_ct_free(c, kv.second.second); }
     }
-  } st{c, {}, {}, {}, {}, {}, {}, {}, {}, {}, {}};
+  } st{c, {}, {}, {}, {}, {}, {}, {}, {}, {}, {}, {}};
   auto chk = [&](int rc) {
     if (rc) throw std::runtime_error(g_err);
   };
@@ -431,7 +435,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         x.size = x.e->size; x.limbs = x.e->limbs; x.batch = x.e->batch; x.scale = x.e->scale;
         return true;
       }
-      if (st.sums.count(v) || st.relins.count(v) || st.drots.count(v) || st.prods.count(v) || st.prodrel.count(v) || st.prods2.count(v) || st.prodres.count(v)) return false;
+      if (st.sums.count(v) || st.relins.count(v) || st.drots.count(v) || st.prods.count(v) || st.prodrel.count(v) || st.prods2.count(v) || st.prodres.count(v) || st.resrel.count(v)) return false;
       if (tab[v].kind == EVAH_VAL_CT && tab[v].h) {
         x.kind = 1; x.ct = static_cast<evah_ct *>(tab[v].h);
         x.size = x.ct->size; x.limbs = x.ct->limbs; x.batch = x.ct->batch; x.scale = x.ct->scale;
@@ -513,7 +517,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
     std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> mulps; // ct x pt products by (size, limbs)
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<uint32_t>> rescales;
     std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> fused, fused3;
-    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<uint32_t>> fused3b; // (limbs, divisor, instances per handle)
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<uint32_t>> fused3b, fused_rr; // (limbs, divisor, instances per handle)
     // ---- one op through the ordinary entry points (seal_executor.h:114-215)
     auto single = [&](const evah_op &o) {
       evah_ct *out = nullptr;
@@ -606,6 +610,19 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         return true;
       };
       if (batched && defer_chain2()) continue;
+      // Rescale of a size-3 ciphertext read only by a Relinearize (r6): nothing is computed here either
+      auto defer_resrel = [&]() {
+        if (!(o.op == 22 && is_ct(o.src0) && !st.relins.count(o.src0) && c->tun.fuse_mac && c->tun.fuse_mul2 && c->tun.chain_step &&
+              c->sh->relin.d && feeds_only(o.dst, 20)))
+          return false;
+        evah_ct *x = ct_of(o.src0);
+        if (!(x->size == 3 && x->limbs >= 2 && x->batch <= (uint32_t)KS_BATCH_MAX)) return false;
+        if (x->batch > 1 && !c->tun.chain_batched) return false;
+        st.resrel[o.dst] = alias_ct(x);
+        st.resdiv[o.dst] = (uint32_t)o.imm;
+        return true;
+      };
+      if (batched && defer_resrel()) continue;
       if (batched && (o.op == 22 || (o.op == 20 && !feeds_only(o.dst, 22)) || (o.op == 13 && o.src0 != o.src1 && is_ct(o.src0) && is_ct(o.src1)))) {
         if (o.op == 13 && try_defer_ew(o)) continue; // a product of batched handles inside an elementwise expression
         if (o.op == 22 && st.relins.count(o.src0)) { // deferred relinearize + this rescale, on the batched handle
@@ -623,6 +640,8 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
         st.prodres[o.dst] = st.prods2[o.src0];
         st.resdiv[o.dst] = (uint32_t)o.imm;
         st.prods2.erase(o.src0);
+      } else if (o.op == 20 && st.resrel.count(o.src0)) {
+        fused_rr[{st.resrel[o.src0]->limbs, st.resdiv[o.src0], st.resrel[o.src0]->batch}].push_back(i);
       } else if (o.op == 20 && st.prodres.count(o.src0)) {
         fused3b[{st.prodres[o.src0].first->limbs, st.resdiv[o.src0], st.prodres[o.src0].first->batch}].push_back(i);
       } else if (o.op == 20 && st.prods.count(o.src0)) { // Relinearize of a deferred product: still deferred
@@ -636,6 +655,7 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
       } else if (o.op == 22 && st.relins.count(o.src0)) {
         chk(evah_ct_info(st.relins[o.src0], &size, &limbs, &scale));
         fused[{limbs, (uint32_t)o.imm}].push_back(i);
+      } else if (!batched && defer_resrel()) {
       } else if (o.op == 22 && is_ct(o.src0)) {
         shape(o.src0, size, limbs, scale);
         rescales[{size, limbs, (uint32_t)o.imm}].push_back(i);
@@ -826,6 +846,23 @@ int evah_execute(evah_ctx *c, const evah_op *ops, uint32_t n_ops, evah_val *tab,
           evah_ct_free(c, const_cast<evah_ct *>(ia[j]));
           evah_ct_free(c, const_cast<evah_ct *>(ib[j]));
           st.prodres.erase(ops[is[j]].src0);
+          st.resdiv.erase(ops[is[j]].src0);
+        }
+        store(is, n, outs);
+      }
+    }
+    for (auto &kv : fused_rr) {
+      const size_t per_call = std::max<size_t>(1, (size_t)KS_BATCH_MAX / std::max<uint32_t>(1, std::get<2>(kv.first)));
+      for (size_t i0 = 0; i0 < kv.second.size(); i0 += per_call) {
+        const uint32_t n = (uint32_t)std::min<size_t>(per_call, kv.second.size() - i0);
+        const uint32_t *is = kv.second.data() + i0;
+        std::vector<const evah_ct *> in(n);
+        std::vector<evah_ct *> outs(n, nullptr);
+        for (uint32_t j = 0; j < n; j++) in[j] = st.resrel[ops[is[j]].src0];
+        chk(evah_rescale_relinearize_many(c, in.data(), n, std::get<1>(kv.first), outs.data()));
+        for (uint32_t j = 0; j < n; j++) {
+          evah_ct_free(c, const_cast<evah_ct *>(in[j]));
+          st.resrel.erase(ops[is[j]].src0);
           st.resdiv.erase(ops[is[j]].src0);
         }
         store(is, n, outs);

@@ -227,6 +227,13 @@ int evah_multiply_rescale_relinearize(evah_ctx *ctx, const evah_ct *a, const eva
 /* the same for n independent pairs at one level as one launch set (n x instances per handle <= 64) */
 int evah_multiply_rescale_relinearize_many(evah_ctx *ctx, const evah_ct *const *as, const evah_ct *const *bs, uint32_t n,
                                            uint32_t divisor_bits, evah_ct **outs);
+/* evaluator.rescale_to_next + scale fix-up (seal_executor.h:213-214) of a size-3 ciphertext followed by evaluator.relinearize
+ * (:200): what lazy relinearization (eva/ckks/lazy_relinearizer.h:73-80) leaves after a SUM of products.  Evaluated together
+ * like evah_multiply_rescale_relinearize, on the stored polynomials.  Identical ciphertext to the two calls.  Batched handles
+ * keep their instance count. */
+int evah_rescale_relinearize(evah_ctx *ctx, const evah_ct *a, uint32_t divisor_bits, evah_ct **out);
+/* the same for n size-3 ciphertexts at one level as one launch set (n x instances per handle <= 64) */
+int evah_rescale_relinearize_many(evah_ctx *ctx, const evah_ct *const *as, uint32_t n, uint32_t divisor_bits, evah_ct **outs);
 /* evaluator.rotate_vector(a, steps) (seal_executor.h:181; rightRotate passes -steps, :188);
  * steps == 0 copies; needs the Galois key for exactly this step's element */
 int evah_rotate(evah_ctx *ctx, const evah_ct *a, int32_t steps, evah_ct **out);

@@ -82,6 +82,8 @@ def test_random_parameters(seed):
         sq = e.g.multiply_rescale_relinearize_many([A2, B2], [A2, B2], 3)
         assert np.array_equal(sq[0].download(), e.o.relinearize(e.o.rescale(e.o.square(a2)), key))
         assert np.array_equal(sq[1].download(), e.o.relinearize(e.o.rescale(e.o.square(b2)), key))
+        # r6: Rescale -> Relinearize of a stored size-3 ciphertext as one call
+        assert np.array_equal(e.g.rescale_relinearize(A3, 3).download(), e.o.relinearize(e.o.rescale(a3), key))
     outs = e.g.relinearize_many([A3, up(a3f)])
     assert all(np.array_equal(m.download(), relin) for m in outs)
     outs = e.g.rotate_pairs([A2, B2], [steps, steps])

@@ -242,6 +242,47 @@ def test_multiply_rescale_relinearize_batched_handles_bit_exact(cfg, chain, monk
     e.g.close()
 
 
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"N{c[0]}")
+@pytest.mark.parametrize("chain", ["1", "0"])
+def test_rescale_relinearize_of_stored_size3_bit_exact(cfg, chain, monkeypatch):
+    """r6: evah_rescale_relinearize(_many) — rescale_to_next of a size-3 ciphertext, then relinearize (what lazy relinearization
+    leaves after a SUM of products: Sobel's Ix^2 + Iy^2, Harris' response), as the chain step on the stored polynomials — ==
+    the oracle's two calls; every level down to the last key switch, a mod-switched view, several handles in one call,
+    batched handles; EVAH_CHAIN_STEP=0 is the two separate calls behind the same entry point"""
+    monkeypatch.setenv("EVAH_CHAIN_STEP", chain)
+    e = Env(*cfg)
+    key = e.rand_key()
+    e.g.upload_relin_key(key)
+    for l in sorted({e.k - 1, max(2, e.k - 2), 2}):
+        hosts = [e.rand(3, l) for _ in range(3)]
+        H = [e.g.upload_ct(h, 2.0 ** 40) for h in hosts]
+        want = [e.o.relinearize(e.o.rescale(h), key) for h in hosts]
+        one = e.g.rescale_relinearize(H[0], 30)
+        assert one.info() == (2, l - 1, 2.0 ** 10)
+        assert np.array_equal(one.download(), want[0]), f"rescale+relinearize mismatch at l={l}"
+        outs = e.g.rescale_relinearize_many(H + [H[1]], 30)
+        for o, w in zip(outs, want + [want[1]]):
+            assert np.array_equal(o.download(), w)
+        assert np.array_equal(e.g.relinearize(e.g.rescale(H[2], 30)).download(), want[2])  # the two calls of this library
+        if l + 1 <= e.k - 1:
+            big = e.rand(3, l + 1)
+            V = e.g.mod_switch(e.g.upload_ct(big, 2.0 ** 40))
+            assert np.array_equal(e.g.rescale_relinearize(V, 30).download(), e.o.relinearize(e.o.rescale(e.o.mod_switch(big)), key))
+        if e.N >= 4096:
+            B = 3
+            xs = np.stack([e.rand(3, l) for _ in range(B)])
+            got = e.g.rescale_relinearize(e.g.upload_ct_batch(xs, 2.0 ** 40), 30)
+            assert got.batch == B
+            d = got.download()
+            for b in range(B):
+                assert np.array_equal(d[b], e.o.relinearize(e.o.rescale(xs[b]), key)), f"instance {b} at l={l}"
+    with pytest.raises(backend.EvaHipError, match="size-3"):
+        e.g.rescale_relinearize(e.g.upload_ct(e.rand(2, e.k - 1), 2.0 ** 40), 30)
+    with pytest.raises(backend.EvaHipError, match="end of modulus switching chain"):
+        e.g.rescale_relinearize(e.g.upload_ct(e.rand(3, 1), 2.0 ** 10), 10)
+    e.g.close()
+
+
 @pytest.mark.parametrize("chain", ["1", "0"])
 def test_multiply_rescale_relinearize_config5_shape_bit_exact(chain, monkeypatch):
     """the shape it was built for: one square at N = 2^16, l = 12 of 13 primes (BASELINE config 5's chain step), eager and
