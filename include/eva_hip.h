@@ -221,7 +221,7 @@ int evah_multiply_relinearize_rescale_many(evah_ctx *ctx, const evah_ct *const *
  * (:213-214) on the size-3 product and evaluator.relinearize (:200) — the order lazy relinearization
  * (eva/ckks/lazy_relinearizer.h:73-80) gives a product under the waterline rescalers — evaluated together: the
  * size-3 product is never written; the rescaled d2 is formed in coefficient form where the digit decomposition reads it, and
- * the rescale of d0 / d1 shares the forward transform of the key switch's mod-down (six dependent launches; DESIGN.md 4.3).
+ * the rescale of d0 / d1 shares the forward transform of the key switch's mod-down (six dependent launches; DESIGN.md 4.4).
  * Identical ciphertext to the three calls.  Batched handles: a and b hold the same number of instances, so does *out. */
 int evah_multiply_rescale_relinearize(evah_ctx *ctx, const evah_ct *a, const evah_ct *b, uint32_t divisor_bits, evah_ct **out);
 /* the same for n independent pairs at one level as one launch set (n x instances per handle <= 64) */
