@@ -691,6 +691,30 @@ def subdag_leg(args, dist):
     dist.close()
 
 
+def _mem(tag, dev=0):
+    """EVA_BENCH_MEMDEBUG=1: HBM in use at a point of the run (stderr)"""
+    if os.environ.get("EVA_BENCH_MEMDEBUG") == "1":
+        import torch
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        print(f"[mem] {tag}: {(total_b - free_b) / 1e9:.2f} GB in use", file=sys.stderr, flush=True)
+
+
+def run_dag_legs(args):
+    """the four DAG legs of the line (Harris latency, Harris batch, config 4, C1 / C2 / C5); a leg must not cost the line"""
+    import gc
+    legs = {}
+    for name, fn in (("dag", lambda: dag_leg(15, host_cores())),
+                     ("dag_harris_batch", lambda: dag_batch_leg(args.harris_batch, 5, workload="harris", chunk=args.harris_chunk or None)),
+                     ("dag_batch", lambda: dag_batch_leg(args.dag_batch, 7)),
+                     ("dag_configs", lambda: dag_configs_leg(9))):
+        try:
+            legs[name] = fn()
+        except Exception as e:  # noqa: BLE001
+            legs[name] = {"error": repr(e)}
+        gc.collect()
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -711,6 +735,7 @@ def main():
     ap.add_argument("--dag-batch", type=int, default=256, help="--shard dag / the dag_batch leg: independent Sobel DAGs in the batch")
     ap.add_argument("--harris-batch", type=int, default=64, help="the dag_harris_batch leg: independent Harris DAGs (N=2^15, L=8) in the batch")
     ap.add_argument("--harris-chunk", type=int, default=0, help="instances per batched device handle of the dag_harris_batch leg (0: the leg's default)")
+    ap.add_argument("--legs-first", action="store_true", help="run the DAG legs before the headline (EVA_BENCH_LEGS_FIRST=1)")
     ap.add_argument("--only-leg", default="", help="run only this leg (dag | dag_batch | dag_harris_batch | dag_configs) and print its dict")
     ap.add_argument("--shard", choices=["ciphertexts", "limb", "subdag", "dag"], default="ciphertexts",
                     help="ciphertexts: independent triples per GPU, no collective (default, weak scaling); "
@@ -771,12 +796,23 @@ def main():
 
     from eva.seal import generate_keys
 
+    # --legs-first / EVA_BENCH_LEGS_FIRST=1: the DAG legs before the headline's state exists (each leg builds and frees its
+    # own key pair and valuations; the order of the legs inside one process is not part of any number's definition)
+    dag_legs_first = None
+    if (args.legs_first or os.environ.get("EVA_BENCH_LEGS_FIRST") == "1") and world == 1 and not args.no_legs:
+        hold = None
+        if os.environ.get("EVA_BENCH_HOLD_GB"):  # experiment: other allocations of the process alive during the legs
+            hold = [torch.empty(1 << 28, dtype=torch.uint8, device=f"cuda:{dev}") for _ in range(4 * int(os.environ["EVA_BENCH_HOLD_GB"]))]
+        dag_legs_first = run_dag_legs(args)
+        hold = None
+
     N, l = 1 << args.logn, args.limbs
     k = l + 1
     G = max(1, min(args.group, 64, args.batch))
     n_calls = max(1, args.batch // G)          # execute() calls per step
     batch = n_calls * G                        # triples per step
     compiled, params, sig = triple_program(G, N, l)
+    _mem("before the headline's keys", dev)
     pub, sec = generate_keys(params, 17 + rank)
     pub.device = dev
     sec.device = dev
@@ -954,27 +990,19 @@ def main():
             except Exception as e:  # noqa: BLE001
                 legs["execute_path"] = {"error": repr(e)}
             # the headline's key pair, valuations (2.7 GB of operands) and outputs are not needed past this point
-            outs = vals = pub = sec = None
+            _mem("after the headline and its side legs", dev)
+            # (the verification loop's variables hold valuations too — device handles that keep the key pair's pools alive:
+            # 5.9 GB stayed allocated through the DAG legs until r6, and config 4 ran 9 % slower beside them)
+            outs = vals = pub = sec = v = out = dec = None
             import gc
             gc.collect()
+            _mem("after dropping the headline's state", dev)
             try:
-                legs["dag"] = dag_leg(15, host_cores())
-            except Exception as e:  # noqa: BLE001
-                legs["dag"] = {"error": repr(e)}
-            try:
-                legs["dag_harris_batch"] = dag_batch_leg(args.harris_batch, 5, workload="harris", chunk=args.harris_chunk or None)
-            except Exception as e:  # noqa: BLE001
-                legs["dag_harris_batch"] = {"error": repr(e)}
-            gc.collect()
-            try:
-                legs["dag_batch"] = dag_batch_leg(args.dag_batch, 7)
-            except Exception as e:  # noqa: BLE001
-                legs["dag_batch"] = {"error": repr(e)}
-            gc.collect()
-            try:
-                legs["dag_configs"] = dag_configs_leg(9)
-            except Exception as e:  # noqa: BLE001
-                legs["dag_configs"] = {"error": repr(e)}
+                free_b, total_b = torch.cuda.mem_get_info(dev)
+                legs["hbm_in_use_before_dag_legs_gb"] = round((total_b - free_b) / 1e9, 2)
+            except Exception:  # noqa: BLE001
+                pass
+            legs.update(dag_legs_first if dag_legs_first is not None else run_dag_legs(args))
         if dag_batch_multi is not None:
             legs["dag_batch"] = dag_batch_multi
 

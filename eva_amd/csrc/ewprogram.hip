@@ -385,6 +385,13 @@ int evah_elementwise_program(evah_ctx *c, const evah_val *in, uint32_t n_in, con
       }
     } else {
       pg.n_ins = (uint32_t)live.size();
+      static const bool ew_debug = std::getenv("EVAH_EW_DEBUG") != nullptr; // what each launch holds (scripts/ew_debug_probe.py)
+      if (ew_debug) {
+        std::string ops_s;
+        for (uint32_t j = 0; j < n_ops; j++) ops_s += std::to_string(ops[j].op) + (j + 1 < n_ops ? "," : "");
+        std::fprintf(stderr, "EVAH ew program: %u inputs, ops [%s], %u outputs -> %zu instructions, %d registers, %u scalars, limbs %u batch %u\n",
+                     n_in, ops_s.c_str(), n_out, live.size(), n_regs, pg.n_sc, limbs, batch);
+      }
       for (size_t q = 0; q < ptr_used.size(); q++) { pg.ptr[q] = ptr_used[q].p; pg.bstride[q] = ptr_used[q].bstride; }
       // throughput-sized launches: two coefficients per thread, 256 threads when the registers fit (else 128); small ones
       // (bound by the latency of one wave's instruction stream): one coefficient per thread, 256 threads

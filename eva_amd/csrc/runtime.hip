@@ -149,7 +149,11 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
       }
     }
     c->all_tb = true;
+#if defined(EVAH_TBMUL) && EVAH_TBMUL // (the build-time experiment multiplies by c = 2^b - q in every top-bit butterfly: strict shape)
+    for (uint32_t i = 0; i < k; i++) c->all_tb = c->all_tb && hp[i].tb_c != 0;
+#else
     for (uint32_t i = 0; i < k; i++) c->all_tb = c->all_tb && (hp[i].tb_c != 0 || hp[i].q < ((u64)1 << 54));
+#endif
     c->sh = std::make_shared<SharedDev>();
     c->sh->device = device;
     HIPCHK(hipMalloc(&c->sh->d_tables, total));
