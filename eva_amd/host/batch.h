@@ -10,16 +10,27 @@ inline std::vector<HipValuation> HipPublic::execute_batch(Program &program, cons
   ensure_device();
   if (batch_chunk < 1 || batch_chunk > 64) throw std::runtime_error("batch_chunk must be 1..64");
   std::vector<HipValuation> all(inputs.size());
-  // Groups rotate over batch_depth issue queues (default three, r6: +9 % over four and +11 % over two on config 4) and nothing waits in between: each group's uploads,
+  // Groups rotate over batch_depth issue queues (r6 default: three on resident valuations — +9 % over four and +11 % over two on
+  // config 4 — four when the call moves host words over PCIe) and nothing waits in between: each group's uploads,
   // launches and downloads are enqueued in queue order (evah_ct_*_instances_async), so the copies
   // of one group overlap the kernels of the other and the host never idles the device.  Device
   // memory stays at two groups' working sets (the pools recycle in queue order); the inputs belong
   // to the caller and the outputs are allocated up front, so both outlive the final synchronisation.
   if (devices.size() > 1 && shard_mode == "dag") return execute_batch_multi(program, inputs);
-  if (batch_depth < 2 || batch_depth > 8) throw std::runtime_error("batch_depth must be 2..8");
-  while (batch_forks.size() + 1 < batch_depth) batch_forks.push_back(std::make_shared<Fork>(dev));
+  uint32_t depth = batch_depth;
+  if (depth == 0) { // auto: do the call's ciphertexts live in HBM already?
+    bool in_hbm = resident && !inputs.empty();
+    if (in_hbm) {
+      in_hbm = false;
+      for (auto &kv : inputs[0]->values)
+        if (auto *c0 = std::get_if<HostCipher>(&kv.second)) { in_hbm = (bool)c0->dev; break; }
+    }
+    depth = in_hbm ? 3 : 4;
+  }
+  if (depth < 2 || depth > 8) throw std::runtime_error("batch_depth must be 2..8 (0: chosen by the call's valuations)");
+  while (batch_forks.size() + 1 < depth) batch_forks.push_back(std::make_shared<Fork>(dev));
   std::vector<evah_ctx *> qs{dev->h};
-  for (uint32_t i = 0; i + 1 < batch_depth; i++) qs.push_back(batch_forks[i]->h);
+  for (uint32_t i = 0; i + 1 < depth; i++) qs.push_back(batch_forks[i]->h);
   const size_t Q = qs.size();
   // constants (Constant / Encode nodes and raw arithmetic on them) are evaluated once per PROGRAM — by the first group
   // of the first call, or by an earlier execute() of the same program (const_cache) — and shared by all groups of all
@@ -108,8 +119,8 @@ inline std::vector<HipValuation> HipPublic::execute_batch_multi(Program &program
   if (batch_chunk < 1 || batch_chunk > 64) throw std::runtime_error("batch_chunk must be 1..64");
   ensure_group(false);
   const size_t G = group->size();
-  if (batch_depth < 2 || batch_depth > 8) throw std::runtime_error("batch_depth must be 2..8");
-  const size_t D = batch_depth;
+  if (batch_depth != 0 && (batch_depth < 2 || batch_depth > 8)) throw std::runtime_error("batch_depth must be 2..8 (0: chosen by the call's valuations)");
+  const size_t D = batch_depth ? batch_depth : 4; // (dag mode deals host valuations over its members)
   if (batch_queues.size() != D * G) {
     batch_queues.clear();
     for (size_t m = 0; m < G; m++)

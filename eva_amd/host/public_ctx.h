@@ -280,7 +280,9 @@ public:
   // overlap the kernels of the others; device memory = batch_depth groups' working sets
   // (r6 sweep, profiles/r06_tuning_notes.md: three queues — config 4 22.0 k -> 24.1 k DAGs/s against four, Harris batch +1 %;
   // two and four to seven queues all measured lower)
-  uint32_t batch_depth = std::getenv("EVA_BATCH_DEPTH") ? (uint32_t)std::atoi(std::getenv("EVA_BATCH_DEPTH")) : 3;
+  // 0 (the default) = by the valuations of the call: three queues when they are resident, four when the call uploads and
+  // downloads host words (config 4: 25.8 k against 23.8 k DAGs/s resident, 17.5 k against 20.0 k with host valuations)
+  uint32_t batch_depth = std::getenv("EVA_BATCH_DEPTH") ? (uint32_t)std::atoi(std::getenv("EVA_BATCH_DEPTH")) : 0;
   // smaller groups at both ends of a batch (batch.h; EVA_BATCH_RAMP=1).  Off by default: measured on config 4
   // (profiles/r05_tuning_notes.md) the shorter fill / drain is real — the best calls are the same 16.8 ms — but the odd
   // group sizes make some calls 3-6 ms longer (pool misses), so the median is no better

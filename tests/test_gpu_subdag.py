@@ -171,7 +171,7 @@ def test_dag_mode_deals_a_batch_over_the_members():
     assert np.array_equal(many[7].get('image')[4], ref['image'])
 
 
-@pytest.mark.parametrize("depth", [2, 3, 8])
+@pytest.mark.parametrize("depth", [0, 2, 3, 8])
 def test_groups_in_flight_do_not_change_a_batch(depth):
     """execute_batch rotates its groups over `batch_depth` issue queues (copies of one group against kernels of the
     others): any depth gives the ciphertexts of the one-by-one execute(), which equal the oracle walk"""
