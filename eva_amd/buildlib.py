@@ -80,12 +80,13 @@ def build_host(force=False, verbose=False):
         return out
     import pybind11
     cpps = [s for s in srcs if s.endswith(".cpp")]
+    # EVA_HOST_CXXFLAGS: extra flags for this one build (scripts/sanitize_cpu.sh: -fsanitize=address,undefined)
     # -ffp-contract=off: the FP64 encoder must round exactly like the device encoder (which is
     # compiled without FMA contraction too), so both give the same plaintext bit for bit
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-march=x86-64-v3", "-ffp-contract=off",
            "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
            "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", CSRC, "-I", hdir,
-           "-o", out] + cpps + ["-L", LIBDIR, "-leva_hip", "-Wl,-rpath,$ORIGIN/lib", "-lpthread", "-lz", "-ldl"]
+           "-o", out] + os.environ.get("EVA_HOST_CXXFLAGS", "").split() + cpps + ["-L", LIBDIR, "-leva_hip", "-Wl,-rpath,$ORIGIN/lib", "-lpthread", "-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
