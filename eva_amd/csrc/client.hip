@@ -144,7 +144,7 @@ int evah_client_key_upload(evah_ctx *c, int kind, const uint64_t *data) {
   kd.n_digits = 1;
   kd.bytes = sizeof(u64) * (size_t)(kind == EVAH_KEY_PUBLIC ? 2 : 1) * c->k * c->N;
   HIPCHK(hipMalloc(&kd.d, kd.bytes));
-  HIPCHK(hipMemcpy(kd.d, data, kd.bytes, hipMemcpyHostToDevice));
+  h2d_now(c, kd.d, data, kd.bytes);
   KeyDev &slot = kind == EVAH_KEY_PUBLIC ? c->sh->pk : c->sh->sk;
   if (slot.d) {
     if (kind == EVAH_KEY_SECRET) (void)hipMemset(slot.d, 0, slot.bytes); // no key material in freed HBM
@@ -206,7 +206,7 @@ int evah_decrypt_decode(evah_ctx *c, const evah_ct *ct, uint32_t n_out, double *
     std::vector<double> roots(2 * (size_t)N);
     for (uint32_t j = 0; j < N; j++) { roots[2 * j] = cr.fwd[j].real(); roots[2 * j + 1] = cr.fwd[j].imag(); }
     HIPCHK(hipMalloc(&c->sh->dec_roots, sizeof(double2) * N));
-    HIPCHK(hipMemcpy(c->sh->dec_roots, roots.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+    h2d_now(c, c->sh->dec_roots, roots.data(), sizeof(double2) * N);
   }
   // Garner tables of this level: [inv_prefix l][pre_mod l*l][prefix l*l][Q l][floor(Q/2) l]
   std::vector<u64> tab((size_t)2 * l * l + 3 * l, 0);

@@ -74,6 +74,33 @@ __device__ __forceinline__ void acc128(u128_t &acc, u64 a, u64 b) {
   acc.hi = (u64)(s >> 64);
 }
 
+// acc += a*b for CANONICAL operands (a, b < q <= 2^60: runtime.hip refuses larger primes) and sums of fewer than 2^7 terms —
+// the shape of the hoisted key inner products.  With both high words below 2^28 the cross terms a0 b1 + a1 b0 (+ the high
+// word of a0 b0 + lo) fit ONE 64-bit multiply-add chain, and a1 b1 + hi (< 2^56 + 2^63) cannot carry out, so the only carry
+// of the whole update is the one out of the first v_mad_u64_u32 (its scalar destination), added where the cross terms' high
+// word is added: 4 v_mad_u64_u32 + 2 v_addc_co_u32 + 2 moves, against the ~15 instructions the unsigned __int128 form
+// compiles to (r6: k_hoist_mac<4,2> 2 567 -> 1 700 VALU instructions per wave).  The result is the same 128-bit sum.
+#ifndef EVAH_MAC_ASM
+#define EVAH_MAC_ASM 1
+#endif
+__device__ __forceinline__ void acc128c(u128_t &acc, u64 a, u64 b) {
+#if EVAH_MAC_ASM
+  const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+  u64 t, c1, c2, c3;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t), "=s"(c1) : "v"(a0), "v"(b0), "v"(acc.lo));
+  u64 m = (u64)a0 * b1 + (t >> 32);       // < 2^60 + 2^32
+  m = (u64)a1 * b0 + m;                   // < 2^61 + 2^32
+  const u64 x = (u64)a1 * b1 + acc.hi;    // < 2^56 + acc.hi: no carry while the sum stays below 2^127
+  uint32_t x0, x1;
+  asm("v_addc_co_u32 %0, %1, %2, %3, %4" : "=v"(x0), "=s"(c2) : "v"((uint32_t)x), "v"((uint32_t)(m >> 32)), "s"(c1));
+  asm("v_addc_co_u32 %0, %1, %2, 0, %3" : "=v"(x1), "=s"(c3) : "v"((uint32_t)(x >> 32)), "s"(c2));
+  acc.lo = (m << 32) | (uint32_t)t;
+  acc.hi = ((u64)x1 << 32) | x0;
+#else
+  acc128(acc, a, b);
+#endif
+}
+
 __device__ __forceinline__ u64 addmod(u64 a, u64 b, u64 q) {
   u64 s = a + b;
   return s >= q ? s - q : s;

@@ -316,8 +316,8 @@ void enc_tables(evah_ctx *c) {
   c->sh->enc_last_root[1] = cr.inv_seq[N - 1].imag();
   HIPCHK(hipMalloc(&c->sh->enc_slot_map, sizeof(uint32_t) * N));
   HIPCHK(hipMalloc(&c->sh->enc_roots, sizeof(double2) * N));
-  HIPCHK(hipMemcpy(c->sh->enc_slot_map, map.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->sh->enc_roots, roots.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+  h2d_now(c, c->sh->enc_slot_map, map.data(), sizeof(uint32_t) * N);
+  h2d_now(c, c->sh->enc_roots, roots.data(), sizeof(double2) * N);
 }
 } // namespace evah
 extern "C" {

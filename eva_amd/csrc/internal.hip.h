@@ -450,6 +450,16 @@ inline Buffer *buf_new(evah_ctx *c, size_t elems) {
   b->ready_everywhere = false;
   return b;
 }
+// Host -> device copies of set-up data (keys, tables) that are COMPLETE when they return, whatever queue reads the words next.
+// hipMemcpy from pageable memory returns once the words are staged — the DMA into HBM may still be in flight — and only the
+// NULL stream is ordered behind it; this library's queues are non-blocking streams, so a kernel launched right after such
+// a copy (the split copy of a key, the first rotation through a new permutation table) could read the destination before
+// the words had landed.  Found by the r6 fuzz soak: ~3 of 10 000 parameter sets with 32 processes sharing the GPU, never
+// with the GPU to itself.  The copy goes on the queue's own stream and the queue is drained before returning.
+inline void h2d_now(evah_ctx *c, void *dst, const void *src, size_t bytes) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+}
 inline hipEvent_t sync_event(evah_ctx *c) {
   if (!c->capturing && !c->sync_events.empty()) {
     hipEvent_t e = c->sync_events.back();

@@ -47,7 +47,7 @@ const uint32_t *perm_table(evah_ctx *c, uint32_t elt) {
   }
   uint32_t *d = nullptr;
   HIPCHK(hipMalloc(&d, sizeof(uint32_t) * N));
-  HIPCHK(hipMemcpy(d, tab.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+  h2d_now(c, d, tab.data(), sizeof(uint32_t) * N);
   c->sh->perms.emplace(elt, d);
   return d;
 }

@@ -206,8 +206,8 @@ k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistMacTab tab, uint32_
       for (int s = 0; s < TS; s++)
 #pragma unroll
         for (int v = 0; v < V; v++) {
-          acc128(a0[s][r][v], d[s].v[v], k0[r].v[v]);
-          acc128(a1[s][r][v], d[s].v[v], k1[r].v[v]);
+          acc128c(a0[s][r][v], d[s].v[v], k0[r].v[v]);
+          acc128c(a1[s][r][v], d[s].v[v], k1[r].v[v]);
         }
   }
   if (fold_c0 && I < l) { // block-uniform
@@ -219,7 +219,7 @@ k_hoist_mac(DevCtx cx, const u64 *digits, size_t dg_bs, HoistMacTab tab, uint32_
 #pragma unroll
       for (int r = 0; r < TR; r++)
 #pragma unroll
-        for (int v = 0; v < V; v++) acc128(a0[s][r][v], c0v.v[v], pmod);
+        for (int v = 0; v < V; v++) acc128c(a0[s][r][v], c0v.v[v], pmod);
     }
   }
 #pragma unroll
@@ -306,7 +306,7 @@ static const uint32_t *perm_inv_table(evah_ctx *c, uint32_t elt) {
   }
   uint32_t *d = hoist_table_alloc<uint32_t>(sizeof(uint32_t) * N);
   if (!d) return nullptr;
-  HIPCHK(hipMemcpy(d, inv.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+  h2d_now(c, d, inv.data(), sizeof(uint32_t) * N);
   c->sh->perms_inv.emplace(elt, d);
   return d;
 }

@@ -157,7 +157,7 @@ int evah_ctx_create(uint32_t N, uint32_t k, const uint64_t *primes, int device, 
     c->sh = std::make_shared<SharedDev>();
     c->sh->device = device;
     HIPCHK(hipMalloc(&c->sh->d_tables, total));
-    HIPCHK(hipMemcpy(c->sh->d_tables, host.data(), total, hipMemcpyHostToDevice));
+    h2d_now(c, c->sh->d_tables, host.data(), total);
     auto *base = reinterpret_cast<unsigned char *>(c->sh->d_tables);
     c->dev.primes = reinterpret_cast<const DevPrime *>(base);
     c->dev.tw_fwd = reinterpret_cast<const ulonglong2 *>(base + sz_pr);
@@ -291,7 +291,7 @@ int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digit
   kd.bytes = sizeof(u64) * (size_t)n_digits * 2 * kd.rows * c->N;
   HIPCHK(hipMalloc(&kd.d, kd.bytes));
   if (!local_rows) {
-    HIPCHK(hipMemcpy(kd.d, data, kd.bytes, hipMemcpyHostToDevice));
+    h2d_now(c, kd.d, data, kd.bytes);
   } else {
     const size_t row = sizeof(u64) * c->N;
     hipError_t e = hipSuccess;
@@ -299,9 +299,11 @@ int evah_key_upload(evah_ctx *c, int kind, uint32_t galois_elt, uint32_t n_digit
       // rows s, s + G, ... of this (digit, polynomial): one strided copy; then the special prime's row
       const u64 *src = (const u64 *)data + (size_t)dk * c->k * c->N;
       u64 *dst = kd.d + (size_t)dk * kd.rows * c->N;
-      if (kd.rows > 1) e = hipMemcpy2D(dst, row, src + (size_t)s * c->N, row * G, row, kd.rows - 1, hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = hipMemcpy(dst + (size_t)(kd.rows - 1) * c->N, src + (size_t)(c->k - 1) * c->N, row, hipMemcpyHostToDevice);
+      for (uint32_t r = 0; r + 1 < kd.rows && e == hipSuccess; r++) // (linear copies: see evah_ct_download on 2-D copies and pageable memory)
+        e = hipMemcpyAsync(dst + (size_t)r * c->N, src + (size_t)(s + r * G) * c->N, row, hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(dst + (size_t)(kd.rows - 1) * c->N, src + (size_t)(c->k - 1) * c->N, row, hipMemcpyHostToDevice, c->stream);
     }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream); // complete before any queue reads the rows (h2d_now)
     if (e != hipSuccess) {
       (void)hipFree(kd.d);
       HIPCHK(e);
@@ -482,7 +484,11 @@ static void ct_download_instances(evah_ctx *c, const evah_ct *ct, uint64_t *cons
   io_copy(c, ct->batch, [&](uint32_t b, hipStream_t st) {
     const u64 *src = ct->d + (size_t)b * ct->size * ct->ps;
     if (dense) return hipMemcpyAsync(out[b], src, row * ct->size, hipMemcpyDeviceToHost, st);
-    return hipMemcpy2DAsync(out[b], row, src, sizeof(u64) * ct->ps, row, ct->size, hipMemcpyDeviceToHost, st);
+    // a mod-switched view: one linear copy per polynomial (not hipMemcpy2DAsync — see evah_ct_download)
+    hipError_t e = hipSuccess;
+    for (uint32_t p = 0; p < ct->size && e == hipSuccess; p++)
+      e = hipMemcpyAsync(reinterpret_cast<char *>(out[b]) + p * row, src + (size_t)p * ct->ps, row, hipMemcpyDeviceToHost, st);
+    return e;
   }, wait);
   count_d2h(c, row * ct->size * ct->batch);
 }
@@ -736,13 +742,17 @@ int evah_ct_download(evah_ctx *c, const evah_ct *ct, uint64_t *out) {
   if (c->capturing) throw std::logic_error("this call synchronises with the host and cannot be captured into a graph");
   acquire(c, ct->buf);
   const size_t row = sizeof(u64) * (size_t)ct->limbs * c->N;
-  // a batched handle downloads as [batch][size][limbs][N]; a dense handle (not a mod-switched
-  // view) is one linear copy — 2-D copies into pageable memory are several times slower
-  if (ct->ps == (size_t)ct->limbs * c->N)
+  // a batched handle downloads as [batch][size][limbs][N]; a dense handle (not a mod-switched view) is one linear copy,
+  // a view one linear copy per polynomial.  NOT hipMemcpy2DAsync: into pageable memory it is several times slower and —
+  // r6 fuzz soak, 32 processes sharing the GPU — hipStreamSynchronize returned before the LAST row of such a copy was in the
+  // caller's memory (4 of ~50 000 downloads of a view: the words of polynomial 1 arrived after the call had returned; the
+  // linear copies, tens of millions of them in the same runs, never did).
+  if (ct->ps == (size_t)ct->limbs * c->N) {
     HIPCHK(hipMemcpyAsync(out, ct->d, row * ct->size * ct->batch, hipMemcpyDeviceToHost, c->stream));
-  else
-    HIPCHK(hipMemcpy2DAsync(out, row, ct->d, sizeof(u64) * ct->ps, row, (size_t)ct->size * ct->batch, hipMemcpyDeviceToHost,
-                            c->stream));
+  } else {
+    for (size_t p = 0; p < (size_t)ct->size * ct->batch; p++)
+      HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(out) + p * row, ct->d + p * ct->ps, row, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   count_d2h(c, row * ct->size * ct->batch);
   API_END

@@ -104,7 +104,18 @@ def test_random_program_bit_exact(seed):
         params.poly_modulus_degree = max(params.poly_modulus_degree, 4096)
     pub, sec = generate_keys(params, seed + 1)
     enc = pub.encrypt(inputs, sig)
-    ref = oracle_execute(pub, compiled, enc)
+    try:
+        ref = oracle_execute(pub, compiled, enc)
+    except RuntimeError as ex:
+        # the generator can draw (unencrypted input) - (ciphertext): SEALExecutor::sub takes std::get<Ciphertext> of its first
+        # argument (seal_executor.h:139) and throws (std::bad_variant_access); the walk of the oracle refuses the program
+        # too, and so must execute() — as an exception, eager and on the call that would capture the graph
+        assert "Unsupported operation" in str(ex)
+        for graphs in (False, True, True):
+            pub.use_graphs = graphs
+            with pytest.raises(RuntimeError):
+                pub.execute(compiled, enc)
+        return
     pub.use_graphs = False
     _same(pub.execute(compiled, enc), ref, "eager walk")
     pub.use_graphs = True
