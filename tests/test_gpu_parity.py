@@ -96,6 +96,24 @@ def test_elementwise_bit_exact(cfg):
     assert np.array_equal(e.g.add(ms, ms2).download(), e.o.add(e.o.mod_switch(b3), e.o.mod_switch(a2)))
 
 
+def test_downloads_of_views_are_the_leading_limbs():
+    """A mod-switched handle is a view (poly stride > limbs * N): single and batched handles, one and two levels down,
+    download as the leading limbs of every polynomial — one linear copy per polynomial (r6: a 2-D copy into pageable
+    memory could return before its last row had arrived), also through the per-instance form."""
+    e = env(CONFIGS[4])
+    l = e.k - 1
+    for size in (2, 3):
+        one = e.rand(size, l)
+        many = np.stack([e.rand(size, l) for _ in range(3)])
+        V, VB = e.g.upload_ct(one, 2.0 ** 20), e.g.upload_ct_batch(many, 2.0 ** 20)
+        for drop in (1, 2):
+            V, VB = e.g.mod_switch(V), e.g.mod_switch(VB)
+            for _ in range(4):
+                assert np.array_equal(V.download(), one[:, :l - drop, :])
+                assert np.array_equal(VB.download(), many[:, :, :l - drop, :])
+            assert np.array_equal(VB.unstack(2).download(), many[2, :, :l - drop, :])
+
+
 @pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"N{c[0]}")
 def test_rescale_bit_exact(cfg):
     e = env(cfg)
