@@ -84,8 +84,8 @@ import os
 
 # default: 48 plain seeds plus a few of each richer family (unencrypted inputs / vector constants
 # from 2000, compiler configurations from 3000, other fixed-point formats and horizontal sums from
-# 4200); EVA_FUZZ_SEEDS=n runs seeds 0..n-1 instead
-_SEEDS = (range(int(os.environ["EVA_FUZZ_SEEDS"])) if "EVA_FUZZ_SEEDS" in os.environ else
+# 4200); EVA_FUZZ_SEEDS=n runs seeds 0..n-1 instead (EVA_FUZZ_FIRST=m: m..n-1)
+_SEEDS = (range(int(os.environ.get("EVA_FUZZ_FIRST", 0)), int(os.environ["EVA_FUZZ_SEEDS"])) if "EVA_FUZZ_SEEDS" in os.environ else
           list(range(48)) + list(range(2000, 2008)) + list(range(3000, 3008)) + list(range(4200, 4208)))
 
 

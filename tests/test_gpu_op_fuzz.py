@@ -15,7 +15,7 @@ from test_gpu_parity import Env
 pytestmark = pytest.mark.gpu
 
 
-_SEEDS = range(int(os.environ["EVA_FUZZ_SEEDS"])) if "EVA_FUZZ_SEEDS" in os.environ else list(range(32)) + list(range(1000, 1012))
+_SEEDS = range(int(os.environ.get("EVA_FUZZ_FIRST", 0)), int(os.environ["EVA_FUZZ_SEEDS"])) if "EVA_FUZZ_SEEDS" in os.environ else list(range(32)) + list(range(1000, 1012))
 
 
 def _same(handle, want):
