@@ -42,7 +42,16 @@ def test_random_parameters(seed):
     k = rng.randint(2, 7)
     bits = [rng.choice([20, 25, 30, 36, 40, 45, 50, 55, 58, 60]) for _ in range(k)]
     bits = [max(b, logn + 8) for b in bits]   # enough primes = 1 (mod 2N) of that size must exist
-    e = Env(N, bits)
+    try:
+        e = Env(N, bits)
+    except ValueError as ex:
+        # more primes of one small size than exist in [2^(b-1), 2^b) with q = 1 (mod 2N): CoeffModulus::Create throws
+        # "failed to find enough qualifying primes", the oracle's restatement and the host's both do
+        from eva_amd.hostref import coeff_modulus_create
+        assert "enough qualifying primes" in str(ex)
+        with pytest.raises(ValueError, match="enough qualifying primes"):
+            coeff_modulus_create(N, bits)
+        return
     l_top = k - 1
     drop = rng.randint(0, max(0, l_top - 1))          # work on a mod-switched view `drop` levels down
     l = l_top - drop
