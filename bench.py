@@ -446,6 +446,8 @@ def _dag_batch_run(state, batch, reps, dist, members, workload="sobel", check=8)
             "ms_calls": [round(t * 1e3, 2) for t in ts],
             "timing": f"median of {reps} calls" + (", barrier + max over ranks per call" if world > 1 else ""),
             "instances_per_device_handle": chunk, "instances_per_rank": len(mine), "ranks": world,
+            "group_sizes": ("balanced: %d groups of %d or %d instances" % (sets, len(mine) // sets, -(-len(mine) // sets))
+                            if getattr(pub, "batch_balance", False) and not pub.batch_ramp else "groups of %d and a remainder" % chunk),
             "members_per_rank": members, "shard_mode": "dag" if members > 1 else "",
             "partition": "instance b on rank b mod world (SURVEY.md 8(e) row 1), no data-path collective" if world > 1 else "one rank",
             "roofline": rl(nbytes * batch / world, med, compulsory=comp_rank),

@@ -62,6 +62,11 @@ inline std::vector<HipValuation> HipPublic::execute_batch(Program &program, cons
       for (size_t left = n - 2 * c; left > 0; left -= std::min(left, c)) sizes.push_back(std::min(left, c));
       sizes.push_back(c - q);
       sizes.push_back(q);
+    } else if (batch_balance) {
+      // the same number of groups, of (nearly) equal size: 64 instances in groups of at most 12 go as 11 11 11 11 10 10 instead
+      // of 12 12 12 12 12 4 — the queues the groups rotate over then finish together instead of one running dry early
+      const size_t G = (n + c - 1) / c, base = n / G, extra = n % G;
+      for (size_t i = 0; i < G; i++) sizes.push_back(base + (i < extra ? 1 : 0));
     } else {
       for (size_t left = n; left > 0; left -= std::min(left, c)) sizes.push_back(std::min(left, c));
     }

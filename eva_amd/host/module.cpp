@@ -343,6 +343,7 @@ PYBIND11_MODULE(_eva, m) {
       .def_readwrite("library_scheduler", &HipPublic::library_scheduler, "run the encrypted part of a program as one evah_execute (default) instead of the node-by-node host walk")
       .def_readwrite("batch_chunk", &HipPublic::batch_chunk, "instances per batched device handle in execute_batch (1..64)")
       .def_readwrite("batch_ramp", &HipPublic::batch_ramp, "execute_batch: quarter / three-quarter sized groups at both ends of the batch, so the pipeline fills and drains on small copies (EVA_BATCH_RAMP)")
+      .def_readwrite("batch_balance", &HipPublic::batch_balance, "execute_batch: groups of (nearly) equal size instead of full groups and a remainder (EVA_BATCH_BALANCE)")
       .def_readwrite("batch_depth", &HipPublic::batch_depth, "groups in flight in execute_batch = issue queues it rotates over (2..8; 0 = three on resident valuations, four on host valuations; EVA_BATCH_DEPTH)")
       .def_readwrite("device", &HipPublic::device)
       .def_readwrite("free_eagerly", &HipPublic::free_eagerly)

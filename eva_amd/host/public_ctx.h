@@ -283,6 +283,11 @@ public:
   // 0 (the default) = by the valuations of the call: three queues when they are resident, four when the call uploads and
   // downloads host words (config 4: 25.8 k against 23.8 k DAGs/s resident, 17.5 k against 20.0 k with host valuations)
   uint32_t batch_depth = std::getenv("EVA_BATCH_DEPTH") ? (uint32_t)std::atoi(std::getenv("EVA_BATCH_DEPTH")) : 0;
+  // groups of (nearly) equal size instead of full groups and a remainder (batch.h; EVA_BATCH_BALANCE=1).  Off by default: r6,
+  // seven A/B pairs over two calls — resident valuations Harris batch 2 971 against 2 953 DAGs/s, config 4 24 730 against 24 462
+  // (+0.6 % / +1.1 %, inside the noise), but host valuations of config 4 18 943 against 20 171 (-6 %, every pair: two group sizes
+  // are two sets of pool blocks and staging copies), and 10.2 k in one full bench run
+  bool batch_balance = std::getenv("EVA_BATCH_BALANCE") ? std::atoi(std::getenv("EVA_BATCH_BALANCE")) != 0 : false;
   // smaller groups at both ends of a batch (batch.h; EVA_BATCH_RAMP=1).  Off by default: measured on config 4
   // (profiles/r05_tuning_notes.md) the shorter fill / drain is real — the best calls are the same 16.8 ms — but the odd
   // group sizes make some calls 3-6 ms longer (pool misses), so the median is no better

@@ -194,6 +194,13 @@ def test_groups_in_flight_do_not_change_a_batch(depth):
         assert np.array_equal(o.get('image')[4], singles[(3 * i) % 4].get('image')[4]), i
     ref, _ = c_walk(pub, compiled, batch[5])
     assert np.array_equal(outs[5].get('image')[4], ref['image'])
+    # group sizes: full groups and a remainder (5 5 5 4 for 19 in groups of at most 5) or balanced (batch_balance, r6) — the same words
+    pub.batch_chunk = 5
+    for balance in (False, True):
+        pub.batch_balance = balance
+        again = pub.execute_batch(compiled, batch)
+        for i, o in enumerate(again):
+            assert np.array_equal(o.get('image')[4], outs[i].get('image')[4]), (balance, i)
     pub.batch_depth = 1
     with pytest.raises(RuntimeError, match="batch_depth"):
         pub.execute_batch(compiled, batch)
